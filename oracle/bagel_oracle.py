@@ -1,0 +1,606 @@
+"""CPU restatement of BAGEL's unified forward path (the ORACLE).
+
+TEST INFRASTRUCTURE ONLY -- never imported by ``bagel_amd`` (the product).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may use it, and only as the
+checker / reported baseline.
+
+Parity status: PINNED.  Every function below is checked bit-for-bit (torch CPU, bf16 weights,
+explicit casts == ``torch.autocast('cpu', bf16)``) against the unmodified reference imported from
+/root/reference by ``oracle/make_golden.py``; the resulting vectors are committed under
+``tests/golden/`` and re-checked by ``tests/test_oracle_golden.py`` on every box.
+(The reference itself ships no tests or golden vectors -- SURVEY.md section 4.)
+
+Style: functional, over a flat ``{state_dict_key: tensor}`` weight map ``W`` (reference key names,
+SURVEY.md Appendix B) and plain config dicts (oracle/configs.py).  All cast points follow the
+reference line by line; each function cites the lines it restates.
+"""
+import importlib.util
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BF16 = torch.bfloat16
+
+
+def _explicit_casts(fn):
+    """The oracle spells out every cast; make sure an ambient autocast region cannot add more."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with torch.no_grad(), torch.autocast("cpu", enabled=False):
+            return fn(*a, **k)
+    return wrapped
+
+_spec = importlib.util.spec_from_file_location(
+    "_oracle_flash_attn", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_shims", "flash_attn", "__init__.py"))
+_fa = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_fa)
+attn_varlen = _fa.flash_attn_varlen_func   # definition of flash_attn_varlen_func (qwen2_navit.py:579-588)
+
+
+# ----------------------------------------------------------------------------------------------
+# elementary ops
+# ----------------------------------------------------------------------------------------------
+@_explicit_casts
+def linear(x, w, b=None):
+    """F.linear under bf16 autocast: inputs cast to the (bf16) weight dtype, bf16 result."""
+    return F.linear(x.to(w.dtype), w, None if b is None else b.to(w.dtype))
+
+
+@_explicit_casts
+def rmsnorm(x, w, eps):
+    """Qwen2RMSNorm.forward, modeling_qwen2.py:54-59 (weight multiplies AFTER the cast back)."""
+    dt = x.dtype
+    h = x.to(torch.float32)
+    var = h.pow(2).mean(-1, keepdim=True)
+    h = h * torch.rsqrt(var + eps)
+    return w * h.to(dt)
+
+
+@_explicit_casts
+def rope_tables(position_ids, head_dim, theta, dtype):
+    """Qwen2RotaryEmbedding.forward, modeling_qwen2.py:130-150 ('default' rope, scaling 1.0)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    pos = position_ids[None, :]
+    inv = inv_freq[None, :, None].float().expand(pos.shape[0], -1, 1)
+    freqs = (inv.float() @ pos[:, None, :].float()).transpose(1, 2)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos() * 1.0, emb.sin() * 1.0
+    return cos.to(dtype).squeeze(0), sin.to(dtype).squeeze(0)
+
+
+def rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rope(q, k, cos, sin):
+    """apply_rotary_pos_emb, modeling_qwen2.py:162-186 with unsqueeze_dim=1."""
+    cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+    return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
+
+
+@_explicit_casts
+def silu_mlp(x, W, p):
+    """Qwen2MLP.forward, modeling_qwen2.py:200-201."""
+    return linear(F.silu(linear(x, W[p + ".gate_proj.weight"])) * linear(x, W[p + ".up_proj.weight"]),
+                  W[p + ".down_proj.weight"])
+
+
+def sincos_2d_table(embed_dim, grid_size):
+    """get_2d_sincos_pos_embed, modeling_utils.py:24-66 ('w goes first'); fp64 omega, fp32 table."""
+    gh = np.arange(grid_size, dtype=np.float32)
+    gw = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape([2, 1, grid_size, grid_size])
+
+    def one(dim, pos):
+        omega = np.arange(dim // 2, dtype=np.float64)
+        omega /= dim / 2.0
+        omega = 1.0 / 10000 ** omega
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    emb = np.concatenate([one(embed_dim // 2, grid[0]), one(embed_dim // 2, grid[1])], axis=1)
+    return torch.from_numpy(emb).float()
+
+
+@_explicit_casts
+def timestep_embed(t, W, freq_dim=256):
+    """TimestepEmbedder.forward, modeling_utils.py:88-110 (fp32 sinusoid, autocast MLP)."""
+    half = freq_dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    h = linear(emb, W["time_embedder.mlp.0.weight"], W["time_embedder.mlp.0.bias"])
+    h = F.silu(h)
+    return linear(h, W["time_embedder.mlp.2.weight"], W["time_embedder.mlp.2.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# KV cache (NaiveCache, qwen2_navit.py:207-221)
+# ----------------------------------------------------------------------------------------------
+class OracleCache:
+    def __init__(self, num_layers):
+        self.key_cache = {i: None for i in range(num_layers)}
+        self.value_cache = {i: None for i in range(num_layers)}
+
+    def clone(self):
+        c = OracleCache(len(self.key_cache))
+        for i in self.key_cache:
+            if self.key_cache[i] is not None:
+                c.key_cache[i] = self.key_cache[i].clone()
+                c.value_cache[i] = self.value_cache[i].clone()
+        return c
+
+
+# ----------------------------------------------------------------------------------------------
+# MoT backbone
+# ----------------------------------------------------------------------------------------------
+@_explicit_casts
+def mot_attention(W, pre, cfg, layer_idx, x, query_lens, cos_sin, q_idx, cache, kv_lens, kv_idx,
+                  update, causal, mode, vae_idx, text_idx):
+    """PackedAttentionMoT.forward_inference, qwen2_navit.py:499-600."""
+    nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    hd = cfg["hidden_size"] // nh
+    eps = cfg["rms_norm_eps"]
+    a = pre + ".self_attn."
+    if mode == "und":
+        q = linear(x, W[a + "q_proj.weight"], W[a + "q_proj.bias"]).view(-1, nh, hd)
+        k = linear(x, W[a + "k_proj.weight"], W[a + "k_proj.bias"]).view(-1, nkv, hd)
+        v = linear(x, W[a + "v_proj.weight"], W[a + "v_proj.bias"]).view(-1, nkv, hd)
+        q = rmsnorm(q, W[a + "q_norm.weight"], eps)
+        k = rmsnorm(k, W[a + "k_norm.weight"], eps)
+    else:
+        x = x.to(BF16)
+        q = x.new_zeros((x.shape[0], nh * hd))
+        k = x.new_zeros((x.shape[0], nkv * hd))
+        v = x.new_zeros((x.shape[0], nkv * hd))
+        xt, xv = x[text_idx], x[vae_idx]
+        q[text_idx] = linear(xt, W[a + "q_proj.weight"], W[a + "q_proj.bias"])
+        q[vae_idx] = linear(xv, W[a + "q_proj_moe_gen.weight"], W[a + "q_proj_moe_gen.bias"])
+        k[text_idx] = linear(xt, W[a + "k_proj.weight"], W[a + "k_proj.bias"])
+        k[vae_idx] = linear(xv, W[a + "k_proj_moe_gen.weight"], W[a + "k_proj_moe_gen.bias"])
+        v[text_idx] = linear(xt, W[a + "v_proj.weight"], W[a + "v_proj.bias"])
+        v[vae_idx] = linear(xv, W[a + "v_proj_moe_gen.weight"], W[a + "v_proj_moe_gen.bias"])
+        q, k, v = q.view(-1, nh, hd), k.view(-1, nkv, hd), v.view(-1, nkv, hd)
+        q = q.to(torch.float32)
+        q[text_idx] = rmsnorm(q[text_idx], W[a + "q_norm.weight"], eps)
+        q[vae_idx] = rmsnorm(q[vae_idx], W[a + "q_norm_moe_gen.weight"], eps)
+        k = k.to(torch.float32)
+        k[text_idx] = rmsnorm(k[text_idx], W[a + "k_norm.weight"], eps)
+        k[vae_idx] = rmsnorm(k[vae_idx], W[a + "k_norm_moe_gen.weight"], eps)
+
+    cos, sin = cos_sin
+    q, k = apply_rope(q, k, cos, sin)
+    q, k, v = q.to(BF16), k.to(BF16), v.to(BF16)
+
+    if cache is not None and cache.key_cache[layer_idx] is not None:
+        pk, pv = cache.key_cache[layer_idx], cache.value_cache[layer_idx]
+        total = int(sum(query_lens)) + int(sum(kv_lens))
+        mk = pk.new_zeros((total, nkv, hd))
+        mv = pk.new_zeros((total, nkv, hd))
+        mk[q_idx] = k
+        mk[kv_idx] = pk
+        mv[q_idx] = v
+        mv[kv_idx] = pv
+        klens = kv_lens + query_lens
+    else:
+        mk, mv, klens = k, v, query_lens
+
+    cu_q = F.pad(torch.cumsum(query_lens, 0), (1, 0)).to(torch.int32)
+    cu_k = F.pad(torch.cumsum(klens, 0), (1, 0)).to(torch.int32)
+    o = attn_varlen(q, mk, mv, cu_q, cu_k, int(query_lens.max()), int(klens.max()), causal=causal)
+    o = o.reshape(-1, nh * hd)
+    if mode == "und":
+        o = linear(o, W[a + "o_proj.weight"])
+    else:
+        o[text_idx] = linear(o[text_idx], W[a + "o_proj.weight"])
+        o[vae_idx] = linear(o[vae_idx], W[a + "o_proj_moe_gen.weight"])
+    if update:
+        cache.key_cache[layer_idx] = mk
+        cache.value_cache[layer_idx] = mv
+    return o
+
+
+@_explicit_casts
+def mot_layer(W, cfg, layer_idx, x, query_lens, cos_sin, q_idx, cache, kv_lens, kv_idx, update, causal,
+              mode, vae_idx, text_idx):
+    """Qwen2MoTDecoderLayer.forward_inference, qwen2_navit.py:757-831 (TaylorSeer off)."""
+    pre = f"language_model.model.layers.{layer_idx}"
+    eps = cfg["rms_norm_eps"]
+    res = x
+    if mode == "und":
+        h = rmsnorm(x, W[pre + ".input_layernorm.weight"], eps)
+    else:
+        h = torch.zeros_like(x)
+        h[text_idx] = rmsnorm(x[text_idx], W[pre + ".input_layernorm.weight"], eps)
+        h[vae_idx] = rmsnorm(x[vae_idx], W[pre + ".input_layernorm_moe_gen.weight"], eps)
+    h = mot_attention(W, pre, cfg, layer_idx, h, query_lens, cos_sin, q_idx, cache, kv_lens, kv_idx,
+                      update, causal, mode, vae_idx, text_idx)
+    x = res + h
+    res = x
+    if mode == "und":
+        h = rmsnorm(x, W[pre + ".post_attention_layernorm.weight"], eps)
+        h = silu_mlp(h, W, pre + ".mlp")
+    else:
+        ht = rmsnorm(x[text_idx], W[pre + ".post_attention_layernorm.weight"], eps).to(BF16)
+        hv = rmsnorm(x[vae_idx], W[pre + ".post_attention_layernorm_moe_gen.weight"], eps).to(BF16)
+        h = torch.zeros_like(x).to(BF16)
+        h[text_idx] = silu_mlp(ht, W, pre + ".mlp")
+        h[vae_idx] = silu_mlp(hv, W, pre + ".mlp_moe_gen")
+    return res + h
+
+
+@_explicit_casts
+def llm_forward(W, cfg, x, query_lens, position_ids, q_idx, cache, kv_lens, kv_idx, update, causal,
+                mode="und", vae_idx=None, text_idx=None, num_layers=None):
+    """Qwen2Model.forward_inference, qwen2_navit.py:1018-1092."""
+    hd = cfg["hidden_size"] // cfg["num_attention_heads"]
+    cos_sin = rope_tables(position_ids, hd, cfg["rope_theta"], x.dtype)
+    L = cfg["num_hidden_layers"] if num_layers is None else num_layers
+    for i in range(L):
+        x = mot_layer(W, cfg, i, x, query_lens, cos_sin, q_idx, cache, kv_lens, kv_idx, update, causal,
+                      mode, vae_idx, text_idx)
+    eps = cfg["rms_norm_eps"]
+    if mode == "und":
+        x = rmsnorm(x, W["language_model.model.norm.weight"], eps)
+    else:
+        y = torch.zeros_like(x)
+        y[text_idx] = rmsnorm(x[text_idx], W["language_model.model.norm.weight"], eps)
+        y[vae_idx] = rmsnorm(x[vae_idx], W["language_model.model.norm_moe_gen.weight"], eps)
+        x = y
+    return x
+
+
+def embed_tokens(W, ids):
+    return F.embedding(ids, W["language_model.model.embed_tokens.weight"])
+
+
+# ----------------------------------------------------------------------------------------------
+# prefill entry points (bagel.py:267-297, 362-415, 491-550)
+# ----------------------------------------------------------------------------------------------
+@_explicit_casts
+def forward_cache_update_text(W, cfg, cache, packed_text_ids, packed_text_position_ids, text_token_lens,
+                              packed_text_indexes, packed_key_value_indexes, key_values_lens):
+    x = embed_tokens(W, packed_text_ids)
+    llm_forward(W, cfg["llm"], x, text_token_lens, packed_text_position_ids, packed_text_indexes, cache,
+                key_values_lens, packed_key_value_indexes, True, True, "und")
+    return cache
+
+
+@_explicit_casts
+def connector(W, x):
+    """MLPconnector, modeling_utils.py:113-124 (gelu_pytorch_tanh)."""
+    h = linear(x, W["connector.fc1.weight"], W["connector.fc1.bias"])
+    h = F.gelu(h, approximate="tanh")
+    return linear(h, W["connector.fc2.weight"], W["connector.fc2.bias"])
+
+
+@_explicit_casts
+def forward_cache_update_vit(W, cfg, cache, packed_text_ids, packed_text_indexes, packed_vit_tokens,
+                             packed_vit_token_indexes, packed_vit_position_ids, vit_token_seqlens,
+                             packed_position_ids, packed_seqlens, packed_indexes, packed_key_value_indexes,
+                             key_values_lens):
+    H = cfg["llm"]["hidden_size"]
+    te = embed_tokens(W, packed_text_ids)
+    seq = te.new_zeros((int(sum(packed_seqlens)), H))
+    seq[packed_text_indexes] = te
+    cu = F.pad(torch.cumsum(vit_token_seqlens, 0), (1, 0)).to(torch.int32)
+    vt = siglip_forward(W, cfg["vit"], packed_vit_tokens, packed_vit_position_ids, cu,
+                        int(vit_token_seqlens.max()))
+    vt = connector(W, vt)
+    vt = vt + W["vit_pos_embed.pos_embed"][packed_vit_position_ids]
+    if vt.dtype != seq.dtype:
+        vt = vt.to(seq.dtype)
+    seq[packed_vit_token_indexes] = vt
+    llm_forward(W, cfg["llm"], seq, packed_seqlens, packed_position_ids, packed_indexes, cache,
+                key_values_lens, packed_key_value_indexes, True, False, "und")
+    return cache
+
+
+def patchify_latent(latent, h, w, p, C):
+    """bagel.py:516-519."""
+    lat = latent[:, : h * p, : w * p].reshape(C, h, p, w, p)
+    return torch.einsum("chpwq->hwpqc", lat).reshape(-1, p * p * C)
+
+
+@_explicit_casts
+def forward_cache_update_vae(W, cfg, vae_W, cache, padded_images, patchified_vae_latent_shapes,
+                             packed_vae_position_ids, packed_timesteps, packed_vae_token_indexes,
+                             packed_text_ids, packed_text_indexes, packed_position_ids, packed_seqlens,
+                             packed_indexes, key_values_lens, packed_key_value_indexes, sample_noise=None):
+    H = cfg["llm"]["hidden_size"]
+    p, C = cfg["bagel"]["latent_patch_size"], cfg["vae"]["z_channels"]
+    te = embed_tokens(W, packed_text_ids)
+    seq = te.new_zeros((int(sum(packed_seqlens)), H))
+    seq[packed_text_indexes] = te
+    lat = vae_encode(vae_W, cfg["vae"], padded_images, sample_noise)
+    packed = torch.cat([patchify_latent(l, h, w, p, C) for l, (h, w) in zip(lat, patchified_vae_latent_shapes)], 0)
+    pos = W["latent_pos_embed.pos_embed"][packed_vae_position_ids]
+    temb = timestep_embed(packed_timesteps, W)
+    packed = linear(packed, W["vae2llm.weight"], W["vae2llm.bias"]) + temb + pos
+    if packed.dtype != seq.dtype:
+        packed = packed.to(seq.dtype)
+    seq[packed_vae_token_indexes] = packed
+    llm_forward(W, cfg["llm"], seq, packed_seqlens, packed_position_ids, packed_indexes, cache,
+                key_values_lens, packed_key_value_indexes, True, False, "gen",
+                packed_vae_token_indexes, packed_text_indexes)
+    return cache
+
+
+# ----------------------------------------------------------------------------------------------
+# rectified-flow sampler (bagel.py:644-907)
+# ----------------------------------------------------------------------------------------------
+def flow_schedule(num_timesteps, shift):
+    """bagel.py:693-696: T points, T-1 Euler steps."""
+    t = torch.linspace(1, 0, num_timesteps)
+    t = shift * t / (1 + (shift - 1) * t)
+    return t[:-1], t[:-1] - t[1:]
+
+
+@_explicit_casts
+def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, cfg_text_scale=1.0,
+                 cfg_img_scale=1.0, cfg_renorm_min=0.0, cfg_renorm_type="global"):
+    """Bagel._forward_flow, bagel.py:757-907.  ``cfg_text``/``cfg_img`` = dict(cache, position_ids,
+    query_indexes, key_values_lens, key_value_indexes) or None."""
+    H = cfg["llm"]["hidden_size"]
+    te = embed_tokens(W, gi["packed_text_ids"])
+    seq = te.new_zeros((int(sum(gi["packed_seqlens"])), H))
+    seq[gi["packed_text_indexes"]] = te
+    assert timestep.unique().shape[0] == 1
+    pos = W["latent_pos_embed.pos_embed"][gi["packed_vae_position_ids"]]
+    temb = timestep_embed(timestep, W)
+    h = linear(x_t, W["vae2llm.weight"], W["vae2llm.bias"]) + temb + pos
+    if h.dtype != seq.dtype:
+        h = h.to(seq.dtype)
+    seq[gi["packed_vae_token_indexes"]] = h
+    vae_idx, text_idx = gi["packed_vae_token_indexes"], gi["packed_text_indexes"]
+
+    def run(cache_, pos_ids, q_idx, kv_lens, kv_idx):
+        out = llm_forward(W, cfg["llm"], seq, gi["packed_seqlens"], pos_ids, q_idx, cache_, kv_lens, kv_idx,
+                          False, False, "gen", vae_idx, text_idx)
+        v = linear(out, W["llm2vae.weight"], W["llm2vae.bias"])
+        return v[vae_idx]
+
+    v_t = run(cache, gi["packed_position_ids"], gi["packed_indexes"], gi["key_values_lens"],
+              gi["packed_key_value_indexes"])
+    if cfg_text_scale > 1.0:
+        c = cfg_text
+        v_ct = run(c["cache"], c["position_ids"], c["query_indexes"], c["key_values_lens"], c["key_value_indexes"])
+    if cfg_img_scale > 1.0:
+        c = cfg_img
+        v_ci = run(c["cache"], c["position_ids"], c["query_indexes"], c["key_values_lens"], c["key_value_indexes"])
+
+    if cfg_text_scale > 1.0:
+        if cfg_renorm_type == "text_channel":
+            v_text_ = v_ct + cfg_text_scale * (v_t - v_ct)
+            n0 = torch.norm(v_t, dim=-1, keepdim=True)
+            n1 = torch.norm(v_text_, dim=-1, keepdim=True)
+            scale = (n0 / (n1 + 1e-8)).clamp(min=cfg_renorm_min, max=1.0)
+            v_text = v_text_ * scale
+            v_t = v_ci + cfg_img_scale * (v_text - v_ci) if cfg_img_scale > 1.0 else v_text
+        else:
+            v_text_ = v_ct + cfg_text_scale * (v_t - v_ct)
+            v_ = v_ci + cfg_img_scale * (v_text_ - v_ci) if cfg_img_scale > 1.0 else v_text_
+            if cfg_renorm_type == "global":
+                n0, n1 = torch.norm(v_t), torch.norm(v_)
+            elif cfg_renorm_type == "channel":
+                n0, n1 = torch.norm(v_t, dim=-1, keepdim=True), torch.norm(v_, dim=-1, keepdim=True)
+            else:
+                raise NotImplementedError(cfg_renorm_type)
+            scale = (n0 / (n1 + 1e-8)).clamp(min=cfg_renorm_min, max=1.0)
+            v_t = v_ * scale
+    return v_t
+
+
+@_explicit_casts
+def generate_image(W, cfg, gi, cache, cfg_text=None, cfg_img=None, num_timesteps=24, timestep_shift=1.0,
+                   cfg_renorm_min=0.0, cfg_renorm_type="global", cfg_interval=(0, 1), cfg_text_scale=1.0,
+                   cfg_img_scale=1.0, max_steps=None):
+    """Bagel.generate_image, bagel.py:644-754."""
+    x_t = gi["packed_init_noises"]
+    ts, dts = flow_schedule(num_timesteps, timestep_shift)
+    for i, t in enumerate(ts):
+        if max_steps is not None and i >= max_steps:
+            break
+        timestep = torch.tensor([t] * x_t.shape[0])
+        if t > cfg_interval[0] and t <= cfg_interval[1]:
+            s_t, s_i = cfg_text_scale, cfg_img_scale
+        else:
+            s_t, s_i = 1.0, 1.0
+        v_t = forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text, cfg_img, s_t, s_i, cfg_renorm_min,
+                           cfg_renorm_type)
+        x_t = x_t - v_t.to(x_t.device) * dts[i]
+    return x_t.split((gi["packed_seqlens"] - 2).tolist())
+
+
+# ----------------------------------------------------------------------------------------------
+# autoregressive text decode (bagel.py:930-1000)
+# ----------------------------------------------------------------------------------------------
+@_explicit_casts
+def generate_text(W, cfg, cache, packed_key_value_indexes, key_values_lens, packed_start_tokens,
+                  packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None,
+                  return_logits=False):
+    step, seq, logits_all = 0, [], []
+    curr = packed_start_tokens
+    kv_idx, kv_lens, pos = packed_key_value_indexes, key_values_lens, packed_query_position_ids
+    while step < max_length:
+        seq.append(curr)
+        x = embed_tokens(W, curr)
+        qlens = torch.ones_like(curr)
+        q_idx = torch.cumsum(kv_lens, 0) + torch.arange(0, len(kv_lens), dtype=kv_lens.dtype)
+        parts = list(kv_idx.split(kv_lens.tolist(), 0))
+        for i in range(len(parts)):
+            parts[i] = parts[i] + i
+        kv_idx = torch.cat(parts, 0)
+        out = llm_forward(W, cfg["llm"], x, qlens, pos, q_idx, cache, kv_lens, kv_idx, True, True, "und")
+        logits = linear(out, W["language_model.lm_head.weight"])
+        if return_logits:
+            logits_all.append(logits)
+        if do_sample:
+            probs = F.softmax(logits / temperature, dim=-1)
+            curr = torch.multinomial(probs, num_samples=1).squeeze(1)
+        else:
+            curr = torch.argmax(logits, dim=-1)
+        parts = list(kv_idx.split(kv_lens.tolist(), 0))
+        for i in range(len(parts)):
+            parts[i] = torch.cat([parts[i], torch.tensor([parts[i][-1] + 1])], 0)
+        kv_idx = torch.cat(parts, 0)
+        kv_lens = kv_lens + 1
+        pos = pos + 1
+        step += 1
+        if end_token_id is not None and curr[0] == end_token_id:
+            break
+    toks = torch.stack(seq, 0)
+    return (toks, torch.stack(logits_all, 0)) if return_logits else toks
+
+
+# ----------------------------------------------------------------------------------------------
+# SigLIP NaViT encoder (siglip_navit.py:145-402), rope=False path + optional 2-D rope
+# ----------------------------------------------------------------------------------------------
+def rope2d_tables(dim, max_h, max_w, base=10000):
+    """RotaryEmbedding2D, siglip_navit.py:102-133."""
+    freq = torch.arange(0, dim, 2, dtype=torch.int64).float() / dim
+    inv = 1.0 / (base ** freq)
+    gh = torch.arange(0, max_h).to(inv.dtype)[:, None].repeat(1, max_w)
+    gw = torch.arange(0, max_w).to(inv.dtype)[None, :].repeat(max_h, 1)
+
+    def side(g):
+        fr = g[..., None] * inv[None, None, :]
+        e = torch.cat((fr, fr), -1).flatten(0, 1)
+        return e.cos(), e.sin()
+
+    return side(gh) + side(gw)   # cos_h, sin_h, cos_w, sin_w
+
+
+@_explicit_casts
+def siglip_forward(W, vcfg, pixels, pos_ids, cu_seqlens, max_seqlen):
+    pre = "vit_model.vision_model."
+    nh = vcfg["num_attention_heads"]
+    D = vcfg["hidden_size"]
+    hd = D // nh
+    eps = vcfg.get("layer_norm_eps", 1e-6)
+    x = linear(pixels, W[pre + "embeddings.patch_embedding.weight"], W[pre + "embeddings.patch_embedding.bias"])
+    use_rope = vcfg.get("rope", False)
+    if not use_rope:
+        x = x + F.embedding(pos_ids, W[pre + "embeddings.position_embedding.weight"])
+    else:
+        ms = vcfg["image_size"] // vcfg["patch_size"]
+        ch, sh, cw, sw = [t[pos_ids] for t in rope2d_tables(hd // 2, ms, ms)]
+    for i in range(vcfg["num_hidden_layers"]):
+        lp = f"{pre}encoder.layers.{i}."
+        res = x
+        h = F.layer_norm(x, (D,), W[lp + "layer_norm1.weight"], W[lp + "layer_norm1.bias"], eps)
+        q = linear(h, W[lp + "self_attn.q_proj.weight"], W[lp + "self_attn.q_proj.bias"]).view(-1, nh, hd)
+        k = linear(h, W[lp + "self_attn.k_proj.weight"], W[lp + "self_attn.k_proj.bias"]).view(-1, nh, hd)
+        v = linear(h, W[lp + "self_attn.v_proj.weight"], W[lp + "self_attn.v_proj.bias"]).view(-1, nh, hd)
+        if use_rope:
+            def rot(a, b, c, s):
+                c, s = c.unsqueeze(1), s.unsqueeze(1)
+                return (a * c) + (rotate_half(a) * s), (b * c) + (rotate_half(b) * s)
+            qh, kh = rot(q[:, :, : hd // 2], k[:, :, : hd // 2], ch, sh)
+            qw, kw = rot(q[:, :, hd // 2:], k[:, :, hd // 2:], cw, sw)
+            q, k = torch.cat([qh, qw], -1), torch.cat([kh, kw], -1)
+        o = attn_varlen(q.to(BF16), k.to(BF16), v.to(BF16), cu_seqlens, cu_seqlens, max_seqlen, max_seqlen,
+                        causal=False)
+        o = linear(o.reshape(-1, D), W[lp + "self_attn.out_proj.weight"], W[lp + "self_attn.out_proj.bias"])
+        x = res + o
+        res = x
+        h = F.layer_norm(x, (D,), W[lp + "layer_norm2.weight"], W[lp + "layer_norm2.bias"], eps)
+        h = linear(h, W[lp + "mlp.fc1.weight"], W[lp + "mlp.fc1.bias"])
+        h = F.gelu(h, approximate="tanh")
+        h = linear(h, W[lp + "mlp.fc2.weight"], W[lp + "mlp.fc2.bias"])
+        x = res + h
+    return F.layer_norm(x, (D,), W[pre + "post_layernorm.weight"], W[pre + "post_layernorm.bias"], eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# FLUX-style VAE (modeling/autoencoder.py), fp32
+# ----------------------------------------------------------------------------------------------
+def _gn(x, W, p):
+    return F.group_norm(x, 32, W[p + ".weight"], W[p + ".bias"], 1e-6)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _conv(x, W, p, stride=1, padding=1):
+    return F.conv2d(x, W[p + ".weight"], W[p + ".bias"], stride=stride, padding=padding)
+
+
+def _resblock(x, W, p):
+    """ResnetBlock.forward, autoencoder.py:83-95."""
+    h = _conv(_swish(_gn(x, W, p + ".norm1")), W, p + ".conv1")
+    h = _conv(_swish(_gn(h, W, p + ".norm2")), W, p + ".conv2")
+    if (p + ".nin_shortcut.weight") in W:
+        x = _conv(x, W, p + ".nin_shortcut", padding=0)
+    return x + h
+
+
+def _attnblock(x, W, p):
+    """AttnBlock.forward, autoencoder.py:49-65 (single head, head_dim = C)."""
+    h = _gn(x, W, p + ".norm")
+    q, k, v = (_conv(h, W, p + "." + n, padding=0) for n in ("q", "k", "v"))
+    b, c, hh, ww = q.shape
+    from einops import rearrange   # same view/stride pattern as the reference => same conv kernel choice
+    q, k, v = (rearrange(t, "b c h w -> b 1 (h w) c").contiguous() for t in (q, k, v))
+    o = F.scaled_dot_product_attention(q, k, v)
+    o = rearrange(o, "b 1 (h w) c -> b c h w", h=hh, w=ww, c=c, b=b)
+    return x + _conv(o, W, p + ".proj_out", padding=0)
+
+
+@_explicit_casts
+def vae_encode(W, vcfg, x, sample_noise=None):
+    """AutoEncoder.encode, autoencoder.py:315-318; Encoder.forward :172-193; DiagonalGaussian :280-287.
+    ``sample_noise``: the randn_like draw (None -> draw from the global CPU generator like the reference)."""
+    nres, nb = len(vcfg["ch_mult"]), vcfg["num_res_blocks"]
+    h = _conv(x, W, "encoder.conv_in")
+    for lvl in range(nres):
+        for b in range(nb):
+            h = _resblock(h, W, f"encoder.down.{lvl}.block.{b}")
+        if lvl != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = _conv(h, W, f"encoder.down.{lvl}.downsample.conv", stride=2, padding=0)
+    h = _resblock(h, W, "encoder.mid.block_1")
+    h = _attnblock(h, W, "encoder.mid.attn_1")
+    h = _resblock(h, W, "encoder.mid.block_2")
+    h = _conv(_swish(_gn(h, W, "encoder.norm_out")), W, "encoder.conv_out")
+    mean, logvar = torch.chunk(h, 2, dim=1)
+    std = torch.exp(0.5 * logvar)
+    noise = torch.randn_like(mean) if sample_noise is None else sample_noise
+    z = mean + std * noise
+    return vcfg["scale_factor"] * (z - vcfg["shift_factor"])
+
+
+@_explicit_casts
+def vae_decode(W, vcfg, z):
+    """AutoEncoder.decode, autoencoder.py:320-322; Decoder.forward :250-272."""
+    nres, nb = len(vcfg["ch_mult"]), vcfg["num_res_blocks"]
+    z = z / vcfg["scale_factor"] + vcfg["shift_factor"]
+    h = _conv(z, W, "decoder.conv_in")
+    h = _resblock(h, W, "decoder.mid.block_1")
+    h = _attnblock(h, W, "decoder.mid.attn_1")
+    h = _resblock(h, W, "decoder.mid.block_2")
+    for lvl in reversed(range(nres)):
+        for b in range(nb + 1):
+            h = _resblock(h, W, f"decoder.up.{lvl}.block.{b}")
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = _conv(h, W, f"decoder.up.{lvl}.upsample.conv")
+    return _conv(_swish(_gn(h, W, "decoder.norm_out")), W, "decoder.conv_out")
+
+
+@_explicit_casts
+def latent_to_image_uint8(vae_W, vcfg, latent, H, W_, downsample, p, C):
+    """InterleaveInferencer.decode_image, inferencer.py:174-185 (truncating uint8 cast)."""
+    h, w = H // downsample, W_ // downsample
+    lat = latent.reshape(1, h, w, p, p, C)
+    lat = torch.einsum("nhwpqc->nchpwq", lat).reshape(1, C, h * p, w * p)
+    img = vae_decode(vae_W, vcfg, lat)
+    img = (img * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255
+    return img.to(torch.uint8)

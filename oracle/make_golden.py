@@ -1,0 +1,325 @@
+"""Generate tests/golden/*.pt from the UNMODIFIED reference and pin the oracle against it.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference):
+
+    python -m oracle.make_golden            # writes tests/golden/<cfg>_<scenario>.pt
+
+For every scenario the reference classes (modeling.bagel.Bagel, modeling.autoencoder.AutoEncoder;
+bf16 weights + torch.autocast('cpu', bf16), VAE in fp32 as in app.py:48,138) are run on seeded
+synthetic inputs, the oracle restatement (oracle/bagel_oracle.py, oracle/packers.py) is run on the
+same inputs, and the two must agree BIT-FOR-BIT before anything is written.  Fixtures hold inputs and
+reference outputs only; weights are re-synthesised from (key, shape, seed) by oracle/weights.py.
+"""
+import argparse
+import copy
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import bagel_oracle as O          # noqa: E402
+from oracle import packers as P               # noqa: E402
+from oracle import ref_env                    # noqa: E402
+from oracle.configs import TINY, TINY_D128, NEW_TOKEN_IDS_TINY, StubTokenizer  # noqa: E402
+from oracle.weights import load_synth         # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 0
+
+
+class _Fp32Vae:
+    """VAE stays fp32 / outside the LLM's autocast region (app.py:48,138: VAE lives on the CPU)."""
+
+    def __init__(self, vae):
+        self.vae = vae
+
+    def encode(self, x):
+        with torch.autocast("cpu", enabled=False):
+            return self.vae.encode(x.float())
+
+    def decode(self, z):
+        with torch.autocast("cpu", enabled=False):
+            return self.vae.decode(z.float())
+
+
+def build(cfg):
+    ref_env.activate()
+    import modeling.bagel  # noqa: F401
+    from modeling.bagel import (BagelConfig, Bagel, Qwen2Config, Qwen2ForCausalLM, SiglipVisionConfig,
+                                SiglipVisionModel)
+    from modeling.autoencoder import AutoEncoder, AutoEncoderParams
+    llm_config = Qwen2Config(pad_token_id=None, **cfg["llm"])
+    vit_config = SiglipVisionConfig(**cfg["vit"])
+    vae_params = AutoEncoderParams(**cfg["vae"])
+    bc = BagelConfig(visual_gen=True, visual_und=True, llm_config=llm_config, vit_config=vit_config,
+                     vae_config=vae_params, **cfg["bagel"])
+    model = Bagel(Qwen2ForCausalLM(llm_config), SiglipVisionModel(vit_config), bc)
+    model.vit_model.vision_model.embeddings.convert_conv2d_to_linear(vit_config)
+    vae = AutoEncoder(vae_params)
+    load_synth(model, WEIGHT_SEED)
+    load_synth(vae, WEIGHT_SEED)
+    model = model.to(torch.bfloat16).eval()
+    # ``inv_freq`` is a NON-persistent buffer: app.py:105-113 (accelerate load, dtype=bf16) converts only
+    # checkpoint tensors, so the deployed model keeps it fp32.  ``.to(bfloat16)`` above would round it
+    # (a harness artefact that changes RoPE angles by up to 0.4 %); restore the fp32 buffer.
+    rot = model.language_model.model.rotary_emb
+    rot.inv_freq = rot.original_inv_freq.clone().float()
+    vae = vae.eval()
+    W = {k: v for k, v in model.state_dict().items()}
+    VW = {k: v for k, v in vae.state_dict().items()}
+    return model, vae, W, VW
+
+
+def same(a, b, what):
+    if isinstance(a, (list, tuple)):
+        assert len(a) == len(b), what
+        for i, (x, y) in enumerate(zip(a, b)):
+            same(x, y, f"{what}[{i}]")
+        return
+    if torch.is_tensor(a):
+        assert a.dtype == b.dtype and a.shape == b.shape, (what, a.dtype, b.dtype, a.shape, b.shape)
+        if not torch.equal(a, b):
+            d = (a.float() - b.float()).abs().max().item()
+            raise AssertionError(f"oracle != reference at {what}: max|d|={d}")
+    else:
+        assert a == b, (what, a, b)
+
+
+def same_dict(a, b, what):
+    assert set(a) == set(b), (what, set(a) ^ set(b))
+    for k in a:
+        same(a[k], b[k], f"{what}.{k}")
+
+
+def cache_to_lists(c, L):
+    return [c.key_cache[i] for i in range(L)], [c.value_cache[i] for i in range(L)]
+
+
+def scenario_t2i(cfg, model, vae, W, VW):
+    from modeling.bagel.qwen2_navit import NaiveCache
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    prompts = ["a tiny red cube", "sky"]
+    sizes = [(64, 64), (32, 64)]
+    out = {}
+    ds = cfg["vae"]["downsample"] * cfg["bagel"]["latent_patch_size"]
+    pdim = cfg["bagel"]["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"]
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        gi, newlens, newrope = model.prepare_prompts([0, 0], [0, 0], prompts, tok, NEW_TOKEN_IDS_TINY)
+        ogi, onl, onr = P.prepare_prompts([0, 0], [0, 0], prompts, tok, NEW_TOKEN_IDS_TINY)
+        same_dict(gi, ogi, "prepare_prompts")
+        assert (newlens, newrope) == (onl, onr)
+        cache = model.forward_cache_update_text(NaiveCache(L), **gi)
+        ocache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **ogi)
+        same(cache_to_lists(cache, L), cache_to_lists(ocache, L), "text prefill cache")
+        torch.manual_seed(42)
+        li = model.prepare_vae_latent(newlens, newrope, sizes, NEW_TOKEN_IDS_TINY)
+        torch.manual_seed(42)
+        oli = P.prepare_vae_latent(newlens, newrope, sizes, NEW_TOKEN_IDS_TINY, ds,
+                                   cfg["bagel"]["max_latent_size"], pdim)
+        same_dict(li, oli, "prepare_vae_latent")
+        ci = model.prepare_vae_latent_cfg([0, 0], [0, 0], sizes)
+        oci = P.prepare_vae_latent_cfg([0, 0], [0, 0], sizes, ds)
+        same_dict(ci, oci, "prepare_vae_latent_cfg")
+        kw = dict(num_timesteps=5, timestep_shift=3.0, cfg_renorm_min=0.0, cfg_renorm_type="global",
+                  cfg_interval=[0.4, 1.0], cfg_text_scale=4.0)
+        lat = model.generate_image(
+            past_key_values=cache, cfg_text_past_key_values=NaiveCache(L),
+            cfg_text_packed_position_ids=ci["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=ci["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"], **kw, **li)
+        ocfg = dict(cache=O.OracleCache(L), position_ids=oci["cfg_packed_position_ids"],
+                    query_indexes=oci["cfg_packed_query_indexes"], key_values_lens=oci["cfg_key_values_lens"],
+                    key_value_indexes=oci["cfg_packed_key_value_indexes"])
+        olat = O.generate_image(W, cfg, oli, ocache, cfg_text=ocfg, **kw)
+        same(list(lat), list(olat), "generate_image latents")
+        # first-step velocity (intermediate, for debugging a failing GPU run)
+        model.language_model.model.enable_taylorseer = False
+        ts, _ = O.flow_schedule(5, 3.0)
+        timestep = torch.tensor([ts[0]] * li["packed_init_noises"].shape[0])
+        v0 = O.forward_flow(W, cfg, oli["packed_init_noises"], timestep, oli, ocache, ocfg, None, 4.0, 1.0, 0.0, "global")
+        # "channel" renorm variant, CFG on the whole interval
+        kw2 = dict(kw, cfg_renorm_type="channel", cfg_interval=[0.0, 1.0], cfg_renorm_min=0.3)
+        lat2 = model.generate_image(
+            past_key_values=cache, cfg_text_past_key_values=NaiveCache(L),
+            cfg_text_packed_position_ids=ci["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=ci["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"], **kw2, **li)
+        olat2 = O.generate_image(W, cfg, oli, ocache, cfg_text=ocfg, **kw2)
+        same(list(lat2), list(olat2), "generate_image latents (channel)")
+    kc, vc = cache_to_lists(cache, L)
+    out.update(prompts=prompts, image_sizes=sizes, prompt_inputs=gi, newlens=newlens, newrope=newrope,
+               key_cache=kc, value_cache=vc, latent_inputs=li, cfg_inputs=ci, gen_kwargs=kw,
+               latents=list(lat), v_first_step=v0, gen_kwargs_channel=kw2, latents_channel=list(lat2))
+    return out
+
+
+def scenario_edit_und(cfg, model, vae, W, VW):
+    """image(VAE+ViT) + text context -> (a) 3-forward edit sampling, (b) greedy text decode."""
+    from modeling.bagel.qwen2_navit import NaiveCache
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ds = cfg["vae"]["downsample"] * cfg["bagel"]["latent_patch_size"]
+    pdim = cfg["bagel"]["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"]
+    g = torch.Generator().manual_seed(7)
+    img_vae = torch.rand(3, 64, 96, generator=g) * 2 - 1      # "vae_transform(image)" output
+    img_vit = torch.rand(3, 56, 84, generator=g) * 2 - 1      # "vit_transform(image)" output (14-px patches)
+    ident = lambda t: t  # noqa: E731
+    fvae = _Fp32Vae(vae)
+    out = {}
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        # --- context: VAE tokens, ViT tokens (inferencer.py:62-97)
+        vi, l1, r1 = model.prepare_vae_images([0], [0], [img_vae], ident, NEW_TOKEN_IDS_TINY)
+        ovi, ol1, or1 = P.prepare_vae_images([0], [0], [img_vae], ident, NEW_TOKEN_IDS_TINY, ds,
+                                             cfg["bagel"]["max_latent_size"])
+        same_dict(vi, ovi, "prepare_vae_images")
+        assert (l1, r1) == (ol1, or1)
+        torch.manual_seed(43)
+        cache = model.forward_cache_update_vae(fvae, NaiveCache(L), **vi)
+        torch.manual_seed(43)
+        zshape = (1, cfg["vae"]["z_channels"], 64 // 8, 96 // 8)
+        enc_noise = torch.randn(zshape)
+        ocache = O.forward_cache_update_vae(W, cfg, VW, O.OracleCache(L), sample_noise=enc_noise, **ovi)
+        same(cache_to_lists(cache, L), cache_to_lists(ocache, L), "vae prefill cache")
+
+        ti, l2, r2 = model.prepare_vit_images(l1, r1, [img_vit], ident, NEW_TOKEN_IDS_TINY)
+        oti, ol2, or2 = P.prepare_vit_images(l1, r1, [img_vit], ident, NEW_TOKEN_IDS_TINY,
+                                             cfg["vit"]["patch_size"], cfg["bagel"]["vit_max_num_patch_per_side"])
+        same_dict(ti, oti, "prepare_vit_images")
+        assert (l2, r2) == (ol2, or2)
+        cache = model.forward_cache_update_vit(cache, **ti)
+        ocache = O.forward_cache_update_vit(W, cfg, ocache, **oti)
+        same(cache_to_lists(cache, L), cache_to_lists(ocache, L), "vit prefill cache")
+        cfg_text_cache, ocfg_text_cache = copy.deepcopy(cache), ocache.clone()
+        kc_img, vc_img = cache_to_lists(cfg_text_cache, L)
+
+        # --- text on top of the image (gen context) and text alone (cfg_img context)
+        prompt = "make it blue"
+        pi, l3, r3 = model.prepare_prompts(l2, r2, [prompt], tok, NEW_TOKEN_IDS_TINY)
+        cache = model.forward_cache_update_text(cache, **pi)
+        ocache = O.forward_cache_update_text(W, cfg, ocache, **P.prepare_prompts(l2, r2, [prompt], tok, NEW_TOKEN_IDS_TINY)[0])
+        same(cache_to_lists(cache, L), cache_to_lists(ocache, L), "img+text prefill cache")
+        pi2, l4, r4 = model.prepare_prompts([0], [0], [prompt], tok, NEW_TOKEN_IDS_TINY)
+        cimg_cache = model.forward_cache_update_text(NaiveCache(L), **pi2)
+        ocimg_cache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **pi2)
+
+        # --- (a) edit sampling: 3 forwards / step, text_channel renorm (app.py:224-228)
+        size = [(64, 96)]
+        torch.manual_seed(44)
+        li = model.prepare_vae_latent(l3, r3, size, NEW_TOKEN_IDS_TINY)
+        ct = model.prepare_vae_latent_cfg(l2, r2, size)
+        cim = model.prepare_vae_latent_cfg(l4, r4, size)
+        kw = dict(num_timesteps=4, timestep_shift=3.0, cfg_renorm_min=0.0, cfg_renorm_type="text_channel",
+                  cfg_interval=[0.0, 1.0], cfg_text_scale=4.0, cfg_img_scale=2.0)
+        lat = model.generate_image(
+            past_key_values=cache, cfg_text_past_key_values=cfg_text_cache, cfg_img_past_key_values=cimg_cache,
+            cfg_text_packed_position_ids=ct["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=ct["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=ct["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=ct["cfg_packed_key_value_indexes"],
+            cfg_img_packed_position_ids=cim["cfg_packed_position_ids"],
+            cfg_img_packed_query_indexes=cim["cfg_packed_query_indexes"],
+            cfg_img_key_values_lens=cim["cfg_key_values_lens"],
+            cfg_img_packed_key_value_indexes=cim["cfg_packed_key_value_indexes"], **kw, **li)
+
+        def oc(c, d):
+            return dict(cache=c, position_ids=d["cfg_packed_position_ids"], query_indexes=d["cfg_packed_query_indexes"],
+                        key_values_lens=d["cfg_key_values_lens"], key_value_indexes=d["cfg_packed_key_value_indexes"])
+        olat = O.generate_image(W, cfg, li, ocache, cfg_text=oc(ocfg_text_cache, ct), cfg_img=oc(ocimg_cache, cim), **kw)
+        same(list(lat), list(olat), "edit latents")
+        # global renorm with both CFG branches
+        kwg = dict(kw, cfg_renorm_type="global")
+        latg = model.generate_image(
+            past_key_values=cache, cfg_text_past_key_values=cfg_text_cache, cfg_img_past_key_values=cimg_cache,
+            cfg_text_packed_position_ids=ct["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=ct["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=ct["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=ct["cfg_packed_key_value_indexes"],
+            cfg_img_packed_position_ids=cim["cfg_packed_position_ids"],
+            cfg_img_packed_query_indexes=cim["cfg_packed_query_indexes"],
+            cfg_img_key_values_lens=cim["cfg_key_values_lens"],
+            cfg_img_packed_key_value_indexes=cim["cfg_packed_key_value_indexes"], **kwg, **li)
+        olatg = O.generate_image(W, cfg, li, ocache, cfg_text=oc(ocfg_text_cache, ct), cfg_img=oc(ocimg_cache, cim), **kwg)
+        same(list(latg), list(olatg), "edit latents (global)")
+
+        # --- (b) understanding: greedy decode on a deep copy of the gen context (inferencer.py:188-205)
+        si = model.prepare_start_tokens(l3, r3, NEW_TOKEN_IDS_TINY)
+        same_dict(si, P.prepare_start_tokens(l3, r3, NEW_TOKEN_IDS_TINY), "prepare_start_tokens")
+        toks = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=8, do_sample=False,
+                                   end_token_id=None, **si)
+        otoks, ologits = O.generate_text(W, cfg, ocache.clone(), si["packed_key_value_indexes"], si["key_values_lens"],
+                                         si["packed_start_tokens"], si["packed_query_position_ids"], 8,
+                                         return_logits=True)
+        same(toks, otoks, "greedy tokens")
+    kc, vc = cache_to_lists(cache, L)
+    out.update(img_vae=img_vae, img_vit=img_vit, enc_noise=enc_noise, prompt=prompt, vae_inputs=vi, vit_inputs=ti,
+               key_cache_img=kc_img, value_cache_img=vc_img, key_cache=kc, value_cache=vc,
+               lens=[l1, l2, l3, l4], ropes=[r1, r2, r3, r4], image_size=size, latent_inputs=li,
+               cfg_text_inputs=ct, cfg_img_inputs=cim, gen_kwargs=kw, latents=list(lat),
+               gen_kwargs_global=kwg, latents_global=list(latg), start_inputs=si, tokens=toks, logits=ologits)
+    return out
+
+
+def scenario_vae(cfg, model, vae, W, VW):
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(1, cfg["vae"]["z_channels"], 16, 24, generator=g)
+    x = torch.rand(2, 3, 64, 96, generator=g) * 2 - 1
+    with torch.no_grad():
+        dec = vae.decode(z)
+        same(dec, O.vae_decode(VW, cfg["vae"], z), "vae.decode")
+        torch.manual_seed(45)
+        enc = vae.encode(x)
+        torch.manual_seed(45)
+        noise = torch.randn(2, cfg["vae"]["z_channels"], 8, 12)
+        same(enc, O.vae_encode(VW, cfg["vae"], x, noise), "vae.encode")
+        h = 16 // cfg["bagel"]["latent_patch_size"]
+        w = 24 // cfg["bagel"]["latent_patch_size"]
+        lat = torch.randn(h * w, 64, generator=g)
+        img = O.latent_to_image_uint8(VW, cfg["vae"], lat, h * 16, w * 16, 16, 2, 16)
+    return dict(z=z, decoded=dec, x=x, enc_noise=noise, encoded=enc, packed_latent=lat, image_u8=img)
+
+
+def scenario_siglip(cfg, model, vae, W, VW):
+    g = torch.Generator().manual_seed(13)
+    ps = cfg["vit"]["patch_size"]
+    imgs = [torch.rand(3, 5 * ps, 7 * ps, generator=g) * 2 - 1, torch.rand(3, 3 * ps, 3 * ps, generator=g) * 2 - 1]
+    toks = torch.cat([P.patchify(i, ps) for i in imgs], 0)
+    side = cfg["bagel"]["vit_max_num_patch_per_side"]
+    pos = torch.cat([P.position_ids_extrapolate(i.shape[1], i.shape[2], ps, side) for i in imgs], 0)
+    lens = torch.tensor([35, 9], dtype=torch.int)
+    cu = torch.nn.functional.pad(torch.cumsum(lens, 0), (1, 0)).to(torch.int32)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ref = model.vit_model(packed_pixel_values=toks, packed_flattened_position_ids=pos, cu_seqlens=cu, max_seqlen=35)
+        same(ref, O.siglip_forward(W, cfg["vit"], toks, pos, cu, 35), "siglip")
+        conn = model.connector(ref)
+        same(conn, O.connector(W, ref), "connector")
+    return dict(tokens=toks, pos=pos, cu=cu, out=ref, connector_out=conn)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    for cfg in (TINY, TINY_D128):
+        model, vae, W, VW = build(cfg)
+        for name, fn in (("t2i", scenario_t2i), ("editund", scenario_edit_und), ("vae", scenario_vae),
+                         ("siglip", scenario_siglip)):
+            if args.only and args.only != name:
+                continue
+            if name == "vae" and cfg is not TINY:
+                continue   # VAE config is shared
+            data = fn(cfg, model, vae, W, VW)
+            path = os.path.join(GOLD, f"{cfg['name']}_{name}.pt")
+            torch.save(data, path)
+            print(f"[golden] {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  oracle == reference bit-exact")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,27 @@
+"""Shared helpers for tests: synthetic weights for the oracle (no reference tree needed)."""
+import functools
+
+import torch
+
+from oracle import bagel_oracle as O
+from oracle.shapes import bagel_shapes, vae_shapes
+from oracle.weights import synth_state_dict
+
+WEIGHT_SEED = 0
+
+
+@functools.lru_cache(maxsize=4)
+def _weights(name):
+    from oracle import configs
+    cfg = {"tiny": configs.TINY, "tiny_d128": configs.TINY_D128}[name]
+    W = {k: v.to(torch.bfloat16) for k, v in synth_state_dict(bagel_shapes(cfg), WEIGHT_SEED).items()}
+    H = cfg["llm"]["hidden_size"]
+    W["latent_pos_embed.pos_embed"] = O.sincos_2d_table(H, cfg["bagel"]["max_latent_size"]).to(torch.bfloat16)
+    W["vit_pos_embed.pos_embed"] = O.sincos_2d_table(H, cfg["bagel"]["vit_max_num_patch_per_side"]).to(torch.bfloat16)
+    VW = synth_state_dict(vae_shapes(cfg["vae"]), WEIGHT_SEED)
+    return W, VW
+
+
+def oracle_weights(cfg):
+    """(W, VW): bf16 Bagel weights and fp32 VAE weights, as the golden generator built them."""
+    return _weights(cfg["name"])
