@@ -1,0 +1,331 @@
+// Packed (NaViT / varlen) flash-style attention forward for gfx950, head_dim 64 or 128, GQA.
+//
+// Replaces flash_attn.flash_attn_varlen_func at its three call sites (qwen2_navit.py:361-370, 579-588;
+// siglip_navit.py:232-241): per sample  softmax(q k^T * scale [+ bottom-right causal]) v, fp32 softmax,
+// bf16 in/out.  Differences from the reference call that are deliberate MI355X design:
+//   * K/V come from TWO segments per sample -- the immutable context cache and the freshly projected rows of
+//     this forward -- so the per-layer "merge" copy of qwen2_navit.py:563-570 never happens;
+//   * V is consumed TRANSPOSED ([kv_head][d][key], written once by bagel_v_transpose): the PV product contracts
+//     over keys, so a [d][key] image lets both operands be fetched with conflict-free ds_read_b128.
+//
+// Kernel shape: one workgroup = 4 waves = 128 query rows of one (sample, head); each wave owns 32 rows.
+//   S^T = K Q^T   with mfma_f32_32x32x16_bf16 (A = K tile from LDS, B = Q fragments held in registers), so every
+//                 lane holds 32 of the 64 scores of ONE query row: the row max / row sum need a single
+//                 cross-lane exchange (lane ^ 32).
+//   O^T = V^T P^T with the SAME instruction: P (bf16) is used straight from the score registers as the B
+//                 operand.  The MFMA row -> key assignment inside each 32-key block is permuted (quads 1<->2 of
+//                 every 16) when K fragments are read, which makes each lane's 8 k-slots 8 CONSECUTIVE keys, so
+//                 the V^T fragment is one ds_read_b128.
+//   K / V^T tiles (64 keys) stream HBM -> LDS by global_load_lds_dwordx4, double buffered, XOR-swizzled on the
+//   source side; counted vmcnt keeps the next tile in flight across the barrier.
+#include "common.h"
+
+struct AttnParams {
+    const bf16_t* q; long ldq;
+    const bf16_t* k_new; long ldk_new;
+    const bf16_t* vt_new; long ldvt_new;
+    const bf16_t* k_ctx; long ldk_ctx;
+    const bf16_t* vt_ctx; long ldvt_ctx;
+    bf16_t* out; long ldo;
+    const int* cu_q;
+    const int* cu_ctx;
+    const int* vt_new_col;
+    const int* vt_ctx_col;
+    int nq, nkv, causal;
+    float scale_log2;
+};
+
+__device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int KS = D / 16;              // k-steps of the QK^T contraction
+    constexpr int DB = D / 32;              // 32-row blocks of O^T
+    constexpr int KROW = D * 2;             // bytes per K row in LDS
+    constexpr int KT_BYTES = 64 * KROW;
+    constexpr int VT_BYTES = D * 128;
+    constexpr int STAGE = KT_BYTES + VT_BYTES;
+    constexpr int NLK = KT_BYTES / 1024 / 4;   // glds per wave for K   (4 @128, 2 @64)
+    constexpr int NLV = VT_BYTES / 1024 / 4;   // glds per wave for V^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    const int g = h / (p.nq / p.nkv);
+    const int q0 = p.cu_q[b];
+    const int Lq = p.cu_q[b + 1] - q0;
+    if (qt * 128 >= Lq) return;
+    const int c0 = p.cu_ctx ? p.cu_ctx[b] : 0;
+    const int C = p.cu_ctx ? p.cu_ctx[b + 1] - c0 : 0;
+    const int vcol_new = p.vt_new_col[b];
+    const int vcol_ctx = C > 0 ? p.vt_ctx_col[b] : 0;
+
+    const int qi = lane & 31, hi = lane >> 5;
+    const int qrow = qt * 128 + wave * 32 + qi;            // row inside the sample (may exceed Lq-1: padding row)
+    const int qrow_c = qrow < Lq ? qrow : Lq - 1;
+
+    // ---- Q fragments (B operand): Q[qrow][16*ks + 8*hi .. +8) ----
+    bf16x8_t qf[KS];
+    {
+        const bf16_t* qp = p.q + (long)(q0 + qrow_c) * p.ldq + (long)h * D + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qp + 16 * ks);
+    }
+
+    // ---- tile schedule: ctx tiles then new tiles ----
+    const int nt_ctx = (C + 63) >> 6;
+    const int qlast = min(Lq, qt * 128 + 128) - 1;
+    const int new_needed = p.causal ? (qlast + 1) : Lq;
+    const int nt_new = (new_needed + 63) >> 6;
+    const int T = nt_ctx + nt_new;
+
+    // ---- per-lane constants for the DMA issue ----
+    // K tile: D=128: 256-B rows, instr j -> rows 4j + lane/16, chunk lane%16 ^ (row&15)
+    //         D=64 : 128-B rows, instr j -> rows 8j + lane/8 , chunk lane%8  ^ ((row>>1)&7)
+    // V^T tile: 128-B rows (64 keys), instr j -> d rows 8j + lane/8, chunk lane%8 ^ ((d>>1)&7)
+    auto issue = [&](int stage, int t) {
+        char* sb = smem + stage * STAGE;
+        const bool is_ctx = t < nt_ctx;
+        const int ti = is_ctx ? t : t - nt_ctx;
+        const int seglen = is_ctx ? C : Lq;
+        const bf16_t* kbase = is_ctx ? p.k_ctx + (long)c0 * p.ldk_ctx : p.k_new + (long)q0 * p.ldk_new;
+        const long ldk = is_ctx ? p.ldk_ctx : p.ldk_new;
+        const bf16_t* vbase = is_ctx ? p.vt_ctx : p.vt_new;
+        const long ldvt = is_ctx ? p.ldvt_ctx : p.ldvt_new;
+        const int vcol = (is_ctx ? vcol_ctx : vcol_new) + ti * 64;
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) {
+            const int j = wave + 4 * i;
+            int row, gch;
+            if (D == 128) { row = 4 * j + (lane >> 4); gch = (lane & 15) ^ (row & 15); }
+            else          { row = 8 * j + (lane >> 3); gch = (lane & 7) ^ ((row >> 1) & 7); }
+            int key = ti * 64 + row;
+            key = key < seglen ? key : seglen - 1;
+            glds16a(kbase + (long)key * ldk + (long)g * D + gch * 8, sb + j * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NLV; ++i) {
+            const int j = wave + 4 * i;
+            const int d = 8 * j + (lane >> 3);
+            const int gch = (lane & 7) ^ ((d >> 1) & 7);
+            glds16a(vbase + ((long)g * D + d) * ldvt + vcol + gch * 8, sb + KT_BYTES + j * 1024);
+        }
+    };
+
+    // ---- per-lane constants for fragment reads ----
+    // MFMA row i = lane&31 reads key pi(i): swap quads 1<->2 inside each 16
+    const int quad = (qi >> 2) & 3;
+    const int pkey = (qi & 16) | ((((quad & 1) << 1) | (quad >> 1)) << 2) | (qi & 3);
+    int koff[2];   // byte offset of this lane's K row for key block kb, swizzle folded in for chunk 0
+    int kswz;      // XOR mask applied to the chunk index
+    if (D == 128) { kswz = pkey & 15; }          // (32*kb + pkey) & 15 == pkey & 15
+    else          { kswz = (pkey >> 1) & 7; }    // ((32*kb + pkey) >> 1) & 7
+    koff[0] = pkey * KROW;
+    koff[1] = (32 + pkey) * KROW;
+    const int vswz = (qi >> 1) & 7;   // d = 32*db + qi  ->  ((d>>1)&7) == ((qi>>1)&7)
+    const int voff = KT_BYTES + qi * 128;
+
+    f32x16_t o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (T > 0) issue(0, 0);
+    for (int t = 0; t < T; ++t) {
+        const int st = t & 1;
+        if (t + 1 < T) {
+            issue(st ^ 1, t + 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLK + NLV) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        const char* sb = smem + st * STAGE;
+
+        // ---- S^T = K Q^T ----
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ch = (2 * ks + hi) ^ kswz;
+                const bf16x8_t kf = *(const bf16x8_t*)(sb + koff[kb] + ch * 16);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+
+        // ---- scale, mask, online softmax ----
+        const bool is_ctx = t < nt_ctx;
+        const int ti = is_ctx ? t : t - nt_ctx;
+        const int seglen = is_ctx ? C : Lq;
+        const int kbase = ti * 64;
+        const bool need_mask = (kbase + 64 > seglen) || (p.causal && !is_ctx && (kbase + 63 > qt * 128 + wave * 32));
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = s[kb][r] * p.scale_log2;
+                if (need_mask) {
+                    const int key = kbase + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    const bool ok = key < seglen && (!p.causal || is_ctx || key <= qrow);
+                    x = ok ? x : -INFINITY;
+                }
+                s[kb][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        // m_new is finite for every real query row (its first tile always holds >= 1 visible key);
+        // padding rows are clamped copies of real rows.  Guard anyway so a fully masked tile cannot make NaN.
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p0 = exp2f(s[kb][8 * c + 2 * e] - m_use);
+                    const float p1 = exp2f(s[kb][8 * c + 2 * e + 1] - m_use);
+                    psum += p0 + p1;
+                    w[e] = pack2bf(p0, p1);
+                }
+                u32x4_t wv = {w[0], w[1], w[2], w[3]};
+                pf[kb][c] = __builtin_bit_cast(bf16x8_t, wv);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int ch = (4 * kb + 2 * c + hi) ^ vswz;
+                    const bf16x8_t vf = *(const bf16x8_t*)(sb + voff + db * 4096 + ch * 16);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][c], o[db], 0, 0, 0);
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue: O[q][d] = O^T / l ; lane owns d = 32*db + 8*u + 4*hi + (0..3) ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < Lq) {
+        bf16_t* op = p.out + (long)(q0 + qrow) * p.ldo + (long)h * D + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                u32x2_t v = {pack2bf(o[db][4 * u] * inv, o[db][4 * u + 1] * inv),
+                             pack2bf(o[db][4 * u + 2] * inv, o[db][4 * u + 3] * inv)};
+                *(u32x2_t*)(op + 32 * db + 8 * u) = v;
+            }
+    }
+}
+
+extern "C" int bagel_attn_varlen_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
+                                      int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
+                                      int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* cu_q, const int32_t* cu_ctx,
+                                      const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t max_lq,
+                                      int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale,
+                                      hipStream_t stream) {
+    BAGEL_REQUIRE(q && k_new && vt_new && out && cu_q && vt_new_col, "attn: null pointer");
+    BAGEL_REQUIRE(!cu_ctx || (k_ctx && vt_ctx && vt_ctx_col), "attn: context segment incomplete");
+    BAGEL_REQUIRE(nq > 0 && nkv > 0 && nq % nkv == 0, "attn: bad head counts %d/%d", nq, nkv);
+    BAGEL_REQUIRE(ldq % 8 == 0 && ldk_new % 8 == 0 && ldvt_new % 8 == 0 && ldo % 4 == 0 && ldk_ctx % 8 == 0 && ldvt_ctx % 8 == 0,
+                  "attn: leading dims must keep 16-byte alignment");
+    if (batch <= 0 || max_lq <= 0) return BAGEL_OK;
+    AttnParams p;
+    p.q = (const bf16_t*)q; p.ldq = ldq;
+    p.k_new = (const bf16_t*)k_new; p.ldk_new = ldk_new;
+    p.vt_new = (const bf16_t*)vt_new; p.ldvt_new = ldvt_new;
+    p.k_ctx = (const bf16_t*)k_ctx; p.ldk_ctx = ldk_ctx;
+    p.vt_ctx = (const bf16_t*)vt_ctx; p.ldvt_ctx = ldvt_ctx;
+    p.out = (bf16_t*)out; p.ldo = ldo;
+    p.cu_q = cu_q; p.cu_ctx = cu_ctx; p.vt_new_col = vt_new_col; p.vt_ctx_col = vt_ctx_col;
+    p.nq = nq; p.nkv = nkv; p.causal = causal;
+    p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    const dim3 grid(ceil_div(max_lq, 128), nq, batch), block(256);
+    if (head_dim == 128) {
+        constexpr int smem = 2 * (64 * 256 + 128 * 128);
+        static bool set = false;
+        if (!set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set = true; }
+        hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, smem, stream, p);
+    } else if (head_dim == 64) {
+        constexpr int smem = 2 * (64 * 128 + 64 * 128);
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, smem, stream, p);
+    } else {
+        return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn: head_dim %d not in {64,128} (pad the head)", head_dim);
+    }
+    return bagel_check_launch("attn_fwd_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// V -> V^T :  src rows [cu[b], cu[b+1]) x [nkv][D]  ->  dst[(g*D + d) * ld_dst + col0[b] + (row - cu[b])]
+// One block = 64 rows x one kv head; 16-byte loads, LDS transpose, 16-byte stores (8 consecutive keys of one d).
+// Columns past the sample's end inside the last 64-block are zero-filled so the PV MFMA never sees stale NaNs.
+// ---------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ dst,
+                                                          long ld_dst, const int* __restrict__ cu, const int* __restrict__ col0,
+                                                          int nkv) {
+    __shared__ bf16_t tile[64][D + 2];
+    const int b = blockIdx.z, g = blockIdx.y, rt = blockIdx.x;
+    const int r0 = cu[b], L = cu[b + 1] - r0;
+    if (rt * 64 >= L) return;
+    const int tid = threadIdx.x;
+    constexpr int CPR = D / 8;   // 16-byte chunks per row
+    for (int i = tid; i < 64 * CPR; i += 256) {
+        const int r = i / CPR, c = i % CPR;
+        const int row = rt * 64 + r;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *(const u32x4_t*)(src + (long)(r0 + row) * ld_src + (long)g * D + c * 8);
+        unsigned* t = (unsigned*)&tile[r][c * 8];   // (D+2)*2 bytes per row keeps 4-byte alignment
+        t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+    }
+    __syncthreads();
+    for (int i = tid; i < D * 8; i += 256) {
+        const int d = i >> 3, kc = i & 7;
+        bf16_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = tile[kc * 8 + k][d];
+        u32x4_t v = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                     (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+        *(u32x4_t*)(dst + ((long)g * D + d) * ld_dst + col0[b] + rt * 64 + kc * 8) = v;
+    }
+}
+
+extern "C" int bagel_v_transpose_bf16(const void* v, int64_t ld_src, void* vt, int64_t ld_dst, const int32_t* cu_rows,
+                                      const int32_t* col_start, int32_t batch, int32_t max_len, int32_t nkv, int32_t head_dim,
+                                      hipStream_t stream) {
+    BAGEL_REQUIRE(v && vt && cu_rows && col_start, "v_transpose: null pointer");
+    BAGEL_REQUIRE(ld_src % 8 == 0 && ld_dst % 8 == 0, "v_transpose: leading dims must be multiples of 8");
+    if (batch <= 0 || max_len <= 0) return BAGEL_OK;
+    const dim3 grid(ceil_div(max_len, 64), nkv, batch), block(256);
+    if (head_dim == 128)
+        hipLaunchKernelGGL(v_transpose_kernel<128>, grid, block, 0, stream, (const bf16_t*)v, (long)ld_src, (bf16_t*)vt, (long)ld_dst, cu_rows, col_start, nkv);
+    else if (head_dim == 64)
+        hipLaunchKernelGGL(v_transpose_kernel<64>, grid, block, 0, stream, (const bf16_t*)v, (long)ld_src, (bf16_t*)vt, (long)ld_dst, cu_rows, col_start, nkv);
+    else
+        return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "v_transpose: head_dim %d not in {64,128}", head_dim);
+    return bagel_check_launch("v_transpose_kernel");
+}

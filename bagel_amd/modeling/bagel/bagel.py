@@ -1,0 +1,535 @@
+"""Bagel: packs text / ViT / VAE-latent tokens into NaViT sequences and drives the MoT backbone, the rectified-flow
+sampler (CFG + renorm) and the autoregressive text decode -- the reference's ``modeling.bagel.Bagel`` surface
+(bagel.py:27-1074: same method names, keyword names, returned dict keys, state-dict keys), executed on MI355X
+through the kernels in ``bagel_amd/csrc`` (no eager torch arithmetic, no CPU path).
+
+Host/device split: every ``prepare_*`` packer runs on the host and returns the reference's CPU index tensors
+(bit-exact contract); ``generate_image`` digests them ONCE into ForwardPlans, uploads the noise, and then the whole
+T-1 step Euler loop only launches kernels (the reference re-derives lengths and syncs the host several times per
+layer per step).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from ... import ops
+from ...data.data_utils import (get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
+from .modeling_utils import MLPconnector, PositionEmbedding, TimestepEmbedder
+from .qwen2_navit import NaiveCache, _Linear
+
+BF16 = torch.bfloat16
+
+
+class BagelConfig:
+    """Field names of bagel.py:27-54."""
+
+    def __init__(self, visual_gen=True, visual_und=True, llm_config=None, vit_config=None, vae_config=None,
+                 latent_patch_size=2, max_latent_size=32, vit_max_num_patch_per_side=70,
+                 connector_act="gelu_pytorch_tanh", interpolate_pos=False, timestep_shift=1.0, **kwargs):
+        self.visual_gen = visual_gen
+        self.visual_und = visual_und
+        self.llm_config = llm_config
+        self.vit_config = vit_config
+        self.vae_config = vae_config
+        self.latent_patch_size = latent_patch_size
+        self.max_latent_size = max_latent_size
+        self.vit_max_num_patch_per_side = vit_max_num_patch_per_side
+        self.connector_act = connector_act
+        self.interpolate_pos = interpolate_pos
+        self.timestep_shift = timestep_shift
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# packed-layout arithmetic shared by all packers
+# ------------------------------------------------------------------------------------------------------------
+def _merged_layout(ctx_lens, new_lens):
+    """Row numbers inside the merged KV layout [ctx_0 | new_0 | ctx_1 | new_1 | ...].
+    Returns (rows of the cached tokens, rows of the new tokens, start row of each sample's new block)."""
+    ctx = np.asarray(ctx_lens, dtype=np.int64)
+    new = np.asarray(new_lens, dtype=np.int64)
+    block_start = np.concatenate([[0], np.cumsum(ctx + new)[:-1]]) if len(ctx) else np.zeros(0, np.int64)
+    kv_rows = np.concatenate([np.arange(s, s + c) for s, c in zip(block_start, ctx)]) if len(ctx) else np.zeros(0, np.int64)
+    new_start = block_start + ctx
+    new_rows = np.concatenate([np.arange(s, s + n) for s, n in zip(new_start, new)]) if len(ctx) else np.zeros(0, np.int64)
+    return kv_rows.astype(np.int64), new_rows.astype(np.int64), new_start
+
+
+def _framed_image_layout(n_tokens):
+    """Query-sequence rows when every sample is <start> n_b image tokens <end>:
+    (rows of the two marker tokens, rows of the image tokens)."""
+    n = np.asarray(n_tokens, dtype=np.int64)
+    first = np.concatenate([[0], np.cumsum(n + 2)[:-1]])
+    marker_rows = np.stack([first, first + n + 1], axis=1).reshape(-1)
+    token_rows = np.concatenate([np.arange(f + 1, f + 1 + k) for f, k in zip(first, n)]) if len(n) else np.zeros(0, np.int64)
+    return marker_rows, token_rows
+
+
+def _lt(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int64))
+
+
+def _it(x):
+    return torch.tensor([int(v) for v in x], dtype=torch.int)
+
+
+class Bagel(nn.Module):
+    """Drop-in for ``modeling.bagel.Bagel`` (inference methods)."""
+
+    def __init__(self, language_model, vit_model, config: BagelConfig):
+        super().__init__()
+        self.language_model = language_model
+        llm = config.llm_config
+        self.hidden_size = llm.hidden_size
+        self.use_moe = "Mo" in llm.layer_module
+        self.num_heads = llm.num_attention_heads
+        if config.visual_gen:
+            self.latent_patch_size = config.latent_patch_size
+            self.timestep_shift = config.timestep_shift
+            self.latent_downsample = config.vae_config.downsample * config.latent_patch_size
+            self.max_latent_size = config.max_latent_size
+            self.latent_channel = config.vae_config.z_channels
+            self.patch_latent_dim = self.latent_patch_size ** 2 * self.latent_channel
+            self.time_embedder = TimestepEmbedder(self.hidden_size)
+            self.vae2llm = _Linear(self.patch_latent_dim, self.hidden_size, True)
+            self.llm2vae = _Linear(self.hidden_size, self.patch_latent_dim, True)
+            self.latent_pos_embed = PositionEmbedding(self.max_latent_size, self.hidden_size)
+        if config.visual_und:
+            self.vit_model = vit_model
+            self.vit_patch_size = config.vit_config.patch_size
+            self.vit_max_num_patch_per_side = config.vit_max_num_patch_per_side
+            self.vit_hidden_size = config.vit_config.hidden_size
+            self.connector = MLPconnector(self.vit_hidden_size, self.hidden_size, config.connector_act)
+            self.vit_pos_embed = PositionEmbedding(self.vit_max_num_patch_per_side, self.hidden_size)
+        self.get_flattened_position_ids = (get_flattened_position_ids_interpolate if config.interpolate_pos
+                                           else get_flattened_position_ids_extrapolate)
+        self.config = config
+        if config.visual_gen:   # bagel.py:96-99
+            nn.init.constant_(self.llm2vae.weight, 0)
+            nn.init.constant_(self.llm2vae.bias, 0)
+        self._k64 = {}
+
+    # ------------------------------------------------------------------------------------------------
+    # helpers
+    # ------------------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.language_model.model.embed_tokens.weight.device
+
+    def _dev(self, t, dtype=None):
+        if t is None:
+            return None
+        if not torch.is_tensor(t):
+            t = torch.tensor(t)
+        return t.to(device=self.device, dtype=dtype if dtype is not None else t.dtype).contiguous()
+
+    def _embed_into(self, seq, token_ids, rows):
+        """seq[rows] = embed_tokens[token_ids]  (bagel.py:277/377/508/796-798)."""
+        table = self.language_model.model.embed_tokens.weight.data
+        ids = self._dev(token_ids, torch.int32)
+        ops.copy_rows(table, seq, ids.numel(), self.hidden_size, src_rows=ids, dst_rows=rows)
+
+    def _timestep_embedding(self, t):
+        """time_embedder(t) for one scalar timestep -> (1, H) bf16  (modeling_utils.py:106-110).  The reference
+        recomputes this MLP for every latent token although ``timestep.unique()`` is asserted to be a single value
+        (bagel.py:800-802); one row is the same bits."""
+        te, dev = self.time_embedder, self.device
+        fe = te.frequency_embedding_size
+        sinus = torch.empty((1, fe), dtype=BF16, device=dev)
+        ops.timestep_sinusoid(float(t), te.freqs(dev), sinus)
+        h = torch.empty((1, self.hidden_size), dtype=BF16, device=dev)
+        ops.gemm(sinus, te.mlp[0].weight.data, h, bias0=te.mlp[0].bias.data, M0=1, epilogue=ops.EPI_SILU)
+        out = torch.empty_like(h)
+        ops.gemm(h, te.mlp[2].weight.data, out, bias0=te.mlp[2].bias.data, M0=1)
+        return out
+
+    def _latent_tokens_into(self, seq, latent_f32, vae_rows, vae_pos_ids, t):
+        """seq[vae_rows] = bf16(bf16(vae2llm(x) + t_emb) + latent_pos_embed[ids])  (bagel.py:521-526, 801-806)."""
+        x16 = ops.f32_to_bf16(latent_f32)
+        ops.gemm(x16, self.vae2llm.weight.data, seq, bias0=self.vae2llm.bias.data, c_rows0=vae_rows, M0=x16.shape[0])
+        ops.flow_add(seq, vae_rows, self._timestep_embedding(t), self.latent_pos_embed.pos_embed.data, vae_pos_ids)
+
+    # ------------------------------------------------------------------------------------------------
+    # host-side packers (integer outputs are bit-exact with the reference)
+    # ------------------------------------------------------------------------------------------------
+    def prepare_prompts(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
+        bos, eos = new_token_ids["bos_token_id"], new_token_ids["eos_token_id"]
+        toks = [[bos] + list(tokenizer.encode(p)) + [eos] for p in prompts]
+        lens = [len(t) for t in toks]
+        kv_rows, new_rows, _ = _merged_layout(curr_kvlens, lens)
+        pos = np.concatenate([np.arange(r, r + n) for r, n in zip(curr_rope, lens)]) if lens else np.zeros(0, np.int64)
+        generation_input = {
+            "text_token_lens": _it(lens),
+            "packed_text_ids": torch.tensor([i for t in toks for i in t], dtype=torch.long),
+            "packed_text_position_ids": _lt(pos),
+            "packed_text_indexes": _lt(new_rows),
+            "packed_key_value_indexes": _lt(kv_rows),
+            "key_values_lens": _it(curr_kvlens),
+        }
+        return generation_input, [c + n for c, n in zip(curr_kvlens, lens)], [r + n for r, n in zip(curr_rope, lens)]
+
+    def _image_block_inputs(self, curr_kvlens, curr_rope, n_tokens, new_token_ids):
+        """Index tensors common to the three '<start> tokens <end>' packers."""
+        qlens = [n + 2 for n in n_tokens]
+        kv_rows, new_rows, _ = _merged_layout(curr_kvlens, qlens)
+        marker_rows, token_rows = _framed_image_layout(n_tokens)
+        B = len(n_tokens)
+        return dict(
+            text_ids=torch.tensor([new_token_ids["start_of_image"], new_token_ids["end_of_image"]] * B, dtype=torch.long)
+            if new_token_ids is not None else None,
+            text_rows=_lt(marker_rows), token_rows=_lt(token_rows),
+            position_ids=_lt(np.repeat(np.asarray(curr_rope, dtype=np.int64), qlens)),
+            seqlens=_it(qlens), indexes=_lt(new_rows), kv_indexes=_lt(kv_rows), kv_lens=_it(curr_kvlens))
+
+    def prepare_vit_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids):
+        tensors = [transforms(im) for im in images]
+        tokens = [patchify(t, self.vit_patch_size) for t in tensors]
+        n = [t.shape[0] for t in tokens]
+        pos = [self.get_flattened_position_ids(t.size(1), t.size(2), self.vit_patch_size,
+                                               max_num_patches_per_side=self.vit_max_num_patch_per_side) for t in tensors]
+        L = self._image_block_inputs(curr_kvlens, curr_rope, n, new_token_ids)
+        generation_input = {
+            "packed_text_ids": L["text_ids"],
+            "packed_text_indexes": L["text_rows"],
+            "vit_token_seqlens": _it(n),
+            "packed_vit_tokens": torch.cat(tokens, dim=0),
+            "packed_vit_position_ids": torch.cat(pos, dim=0),
+            "packed_vit_token_indexes": L["token_rows"],
+            "packed_position_ids": L["position_ids"],
+            "packed_seqlens": L["seqlens"],
+            "packed_indexes": L["indexes"],
+            "packed_key_value_indexes": L["kv_indexes"],
+            "key_values_lens": L["kv_lens"],
+        }
+        return generation_input, [c + k + 2 for c, k in zip(curr_kvlens, n)], [r + 1 for r in curr_rope]
+
+    def prepare_vae_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids, timestep=0):
+        tensors = [transforms(im) for im in images]
+        ds = self.latent_downsample
+        shapes = [(t.shape[1] // ds, t.shape[2] // ds) for t in tensors]
+        n = [h * w for h, w in shapes]
+        pos = [self.get_flattened_position_ids(t.size(1), t.size(2), ds, max_num_patches_per_side=self.max_latent_size)
+               for t in tensors]
+        L = self._image_block_inputs(curr_kvlens, curr_rope, n, new_token_ids)
+        Hm = max(t.shape[1] for t in tensors)
+        Wm = max(t.shape[2] for t in tensors)
+        Cm = max(t.shape[0] for t in tensors)
+        padded = torch.zeros(size=(len(tensors), Cm, Hm, Wm))
+        for i, t in enumerate(tensors):
+            padded[i, :, : t.shape[1], : t.shape[2]] = t
+        generation_input = {
+            "padded_images": padded,
+            "patchified_vae_latent_shapes": shapes,
+            "packed_vae_position_ids": torch.cat(pos, dim=0),
+            "packed_timesteps": torch.tensor([timestep]),
+            "packed_vae_token_indexes": L["token_rows"],
+            "packed_text_ids": L["text_ids"],
+            "packed_text_indexes": L["text_rows"],
+            "packed_position_ids": L["position_ids"],
+            "packed_seqlens": L["seqlens"],
+            "packed_indexes": L["indexes"],
+            "packed_key_value_indexes": L["kv_indexes"],
+            "key_values_lens": L["kv_lens"],
+        }
+        return generation_input, [c + k + 2 for c, k in zip(curr_kvlens, n)], [r + 1 for r in curr_rope]
+
+    def prepare_vae_latent(self, curr_kvlens, curr_rope, image_sizes, new_token_ids):
+        ds = self.latent_downsample
+        n = [(H // ds) * (W // ds) for H, W in image_sizes]
+        pos = [self.get_flattened_position_ids(H, W, ds, max_num_patches_per_side=self.max_latent_size) for H, W in image_sizes]
+        # initial noise: CPU generator, one draw per image in sample order (bagel.py:578-580) -- RNG parity
+        noises = [torch.randn(k, self.latent_channel * self.latent_patch_size ** 2) for k in n]
+        L = self._image_block_inputs(curr_kvlens, curr_rope, n, new_token_ids)
+        return {
+            "packed_text_ids": L["text_ids"],
+            "packed_text_indexes": L["text_rows"],
+            "packed_init_noises": torch.cat(noises, dim=0),
+            "packed_vae_position_ids": torch.cat(pos, dim=0),
+            "packed_vae_token_indexes": L["token_rows"],
+            "packed_seqlens": L["seqlens"],
+            "packed_position_ids": L["position_ids"],
+            "key_values_lens": L["kv_lens"],
+            "packed_indexes": L["indexes"],
+            "packed_key_value_indexes": L["kv_indexes"],
+        }
+
+    def prepare_vae_latent_cfg(self, curr_kvlens, curr_rope, image_sizes):
+        ds = self.latent_downsample
+        n = [(H // ds) * (W // ds) for H, W in image_sizes]
+        L = self._image_block_inputs(curr_kvlens, curr_rope, n, None)
+        return {
+            "cfg_packed_position_ids": L["position_ids"],
+            "cfg_key_values_lens": L["kv_lens"],
+            "cfg_packed_query_indexes": L["indexes"],
+            "cfg_packed_key_value_indexes": L["kv_indexes"],
+        }
+
+    def prepare_start_tokens(self, curr_kvlens, curr_rope, new_token_ids):
+        kv_rows = np.arange(int(sum(curr_kvlens)), dtype=np.int64)   # bagel.py:913-918: no gaps yet
+        return {
+            "packed_start_tokens": torch.tensor([new_token_ids["bos_token_id"]] * len(curr_kvlens), dtype=torch.long),
+            "packed_query_position_ids": torch.tensor(list(curr_rope), dtype=torch.long),
+            "key_values_lens": _it(curr_kvlens),
+            "packed_key_value_indexes": _lt(kv_rows),
+        }
+
+    # ------------------------------------------------------------------------------------------------
+    # prefill
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_cache_update_text(self, past_key_values, packed_text_ids, packed_text_position_ids, text_token_lens,
+                                  packed_text_indexes, packed_key_value_indexes, key_values_lens):
+        lm = self.language_model
+        n = packed_text_ids.numel()
+        seq = torch.empty((n, self.hidden_size), dtype=BF16, device=self.device)
+        self._embed_into(seq, packed_text_ids, None)
+        out = lm.forward_inference(
+            packed_query_sequence=seq, query_lens=text_token_lens, packed_query_position_ids=packed_text_position_ids,
+            packed_query_indexes=packed_text_indexes, past_key_values=past_key_values,
+            packed_key_value_indexes=packed_key_value_indexes, key_values_lens=key_values_lens,
+            update_past_key_values=True, is_causal=True, mode="und")
+        return out.past_key_values
+
+    @torch.no_grad()
+    def forward_cache_update_vit(self, past_key_values, packed_text_ids, packed_text_indexes, packed_vit_tokens,
+                                 packed_vit_token_indexes, packed_vit_position_ids, vit_token_seqlens, packed_position_ids,
+                                 packed_seqlens, packed_indexes, packed_key_value_indexes, key_values_lens):
+        dev = self.device
+        total = int(sum(int(x) for x in packed_seqlens.tolist()))
+        seq = torch.empty((total, self.hidden_size), dtype=BF16, device=dev)
+        self._embed_into(seq, packed_text_ids, self._dev(packed_text_indexes, torch.int32))
+        lens = [int(x) for x in vit_token_seqlens.tolist()]
+        cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+        feats = self.vit_model(packed_pixel_values=packed_vit_tokens, packed_flattened_position_ids=packed_vit_position_ids,
+                               cu_seqlens=cu, max_seqlen=max(lens))
+        # connector (fc1 - gelu_tanh - fc2) + vit_pos_embed, scattered into the packed sequence (bagel.py:390-395)
+        c = self.connector
+        n = feats.shape[0]
+        hmid = torch.empty((n, self.hidden_size), dtype=BF16, device=dev)
+        ops.gemm(feats, c.fc1.weight.data, hmid, bias0=c.fc1.bias.data, epilogue=ops.EPI_GELU_TANH)
+        emb = torch.empty_like(hmid)
+        ops.gemm(hmid, c.fc2.weight.data, emb, bias0=c.fc2.bias.data)
+        ops.add_table_rows(emb, self.vit_pos_embed.pos_embed.data, self._dev(packed_vit_position_ids, torch.long))
+        ops.copy_rows(emb, seq, n, self.hidden_size, dst_rows=self._dev(packed_vit_token_indexes, torch.int32))
+        out = self.language_model.forward_inference(
+            packed_query_sequence=seq, query_lens=packed_seqlens, packed_query_position_ids=packed_position_ids,
+            packed_query_indexes=packed_indexes, past_key_values=past_key_values,
+            packed_key_value_indexes=packed_key_value_indexes, key_values_lens=key_values_lens,
+            update_past_key_values=True, is_causal=False, mode="und")
+        return out.past_key_values
+
+    @torch.no_grad()
+    def forward_cache_update_vae(self, vae_model, past_key_values, padded_images, patchified_vae_latent_shapes,
+                                 packed_vae_position_ids, packed_timesteps, packed_vae_token_indexes, packed_text_ids,
+                                 packed_text_indexes, packed_position_ids, packed_seqlens, packed_indexes, key_values_lens,
+                                 packed_key_value_indexes):
+        dev = self.device
+        total = int(sum(int(x) for x in packed_seqlens.tolist()))
+        seq = torch.empty((total, self.hidden_size), dtype=BF16, device=dev)
+        self._embed_into(seq, packed_text_ids, self._dev(packed_text_indexes, torch.int32))
+        padded_latent = vae_model.encode(padded_images)
+        p, C = self.latent_patch_size, self.latent_channel
+        pieces = []
+        for latent, (h, w) in zip(padded_latent, patchified_vae_latent_shapes):
+            lat = latent[:, : h * p, : w * p].reshape(C, h, p, w, p)
+            pieces.append(lat.permute(1, 3, 2, 4, 0).reshape(h * w, p * p * C))   # "chpwq->hwpqc"
+        packed_latent = torch.cat(pieces, dim=0).to(device=dev, dtype=torch.float32)
+        ts = packed_timesteps.reshape(-1)
+        if ts.numel() != 1:
+            raise NotImplementedError("one shared timestep per call (bagel.py:477 always passes tensor([t]))")
+        self._latent_tokens_into(seq, packed_latent, self._dev(packed_vae_token_indexes, torch.int32),
+                                 self._dev(packed_vae_position_ids, torch.long), float(ts[0]))
+        out = self.language_model.forward_inference(
+            packed_query_sequence=seq, query_lens=packed_seqlens, packed_query_position_ids=packed_position_ids,
+            packed_query_indexes=packed_indexes, past_key_values=past_key_values, key_values_lens=key_values_lens,
+            packed_key_value_indexes=packed_key_value_indexes, update_past_key_values=True, is_causal=False,
+            mode="gen", packed_vae_token_indexes=packed_vae_token_indexes, packed_text_indexes=packed_text_indexes)
+        return out.past_key_values
+
+    # ------------------------------------------------------------------------------------------------
+    # rectified-flow sampler
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def flow_schedule(num_timesteps, timestep_shift):
+        """(timesteps[:-1], dts) exactly as bagel.py:693-696, evaluated on the host in fp32."""
+        t = torch.linspace(1, 0, num_timesteps)
+        t = timestep_shift * t / (1 + (timestep_shift - 1) * t)
+        return t[:-1], t[:-1] - t[1:]
+
+    @torch.no_grad()
+    def generate_image(self, packed_text_ids, packed_text_indexes, packed_init_noises, packed_vae_position_ids,
+                       packed_vae_token_indexes, packed_seqlens, packed_position_ids, packed_indexes, past_key_values,
+                       key_values_lens, packed_key_value_indexes, num_timesteps=24, timestep_shift=1.0,
+                       cfg_renorm_min=0.0, cfg_renorm_type="global", cfg_interval=[0, 1],
+                       cfg_text_scale=1.0, cfg_text_packed_query_indexes=None, cfg_text_packed_position_ids=None,
+                       cfg_text_past_key_values=None, cfg_text_key_values_lens=None, cfg_text_packed_key_value_indexes=None,
+                       cfg_img_scale=1.0, cfg_img_packed_query_indexes=None, cfg_img_packed_position_ids=None,
+                       cfg_img_past_key_values=None, cfg_img_key_values_lens=None, cfg_img_packed_key_value_indexes=None,
+                       cfg_type="parallel", enable_taylorseer=False):
+        if enable_taylorseer:
+            raise NotImplementedError("enable_taylorseer=True: TaylorSeer is out of scope for this build (SURVEY.md 8f)")
+        self.language_model.model.enable_taylorseer = False
+        if cfg_renorm_type not in ops.RENORM_MODES:
+            raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
+        st = self._flow_state(packed_text_ids, packed_text_indexes, packed_vae_position_ids, packed_vae_token_indexes,
+                              packed_seqlens)
+        lm = self.language_model
+        mk = lambda pos, qidx, kvlens, kvidx: lm.make_plan(  # noqa: E731
+            packed_seqlens, pos, qidx, kvlens, kvidx, packed_vae_token_indexes, packed_text_indexes)
+        plan = mk(packed_position_ids, packed_indexes, key_values_lens, packed_key_value_indexes)
+        plan_t = plan_i = None
+        if cfg_text_scale > 1.0:
+            plan_t = mk(cfg_text_packed_position_ids, cfg_text_packed_query_indexes, cfg_text_key_values_lens,
+                        cfg_text_packed_key_value_indexes)
+            if cfg_img_scale > 1.0:
+                # the reference also runs this forward when cfg_text_scale <= 1 but discards it (bagel.py:854-905)
+                plan_i = mk(cfg_img_packed_position_ids, cfg_img_packed_query_indexes, cfg_img_key_values_lens,
+                            cfg_img_packed_key_value_indexes)
+        x_t = packed_init_noises.to(device=self.device, dtype=torch.float32).contiguous().clone()
+        timesteps, dts = self.flow_schedule(num_timesteps, timestep_shift)
+        mode = ops.RENORM_MODES[cfg_renorm_type]
+        for i, t in enumerate(timesteps):
+            use_cfg = bool(t > cfg_interval[0] and t <= cfg_interval[1])   # fp32 tensor vs python float, as bagel.py:701
+            s_t = cfg_text_scale if use_cfg else 1.0
+            s_i = cfg_img_scale if use_cfg else 1.0
+            self._flow_step(st, x_t, float(t), float(dts[i]), plan, past_key_values,
+                            plan_t if s_t > 1.0 else None, cfg_text_past_key_values,
+                            plan_i if (s_t > 1.0 and s_i > 1.0) else None, cfg_img_past_key_values,
+                            s_t, s_i, cfg_renorm_min, mode)
+        return x_t.split([int(n) - 2 for n in packed_seqlens.tolist()])
+
+    def _flow_state(self, packed_text_ids, packed_text_indexes, packed_vae_position_ids, packed_vae_token_indexes,
+                    packed_seqlens):
+        dev = self.device
+        total = int(sum(int(x) for x in packed_seqlens.tolist()))
+        nv = packed_vae_token_indexes.numel()
+        return dict(
+            seq=torch.empty((total, self.hidden_size), dtype=BF16, device=dev),
+            text_ids=packed_text_ids, text_rows=self._dev(packed_text_indexes, torch.int32),
+            vae_rows=self._dev(packed_vae_token_indexes, torch.int32),
+            vae_pos=self._dev(packed_vae_position_ids, torch.long),
+            v=[torch.empty((nv, self.patch_latent_dim), dtype=BF16, device=dev) for _ in range(3)],
+            tmp=torch.empty((nv, self.patch_latent_dim), dtype=BF16, device=dev),
+            partials=torch.empty((2 * 256,), dtype=torch.float32, device=dev), embedded=False)
+
+    def _velocity(self, st, plan, cache, out):
+        """llm2vae(backbone(seq))[latent rows] -> out (bagel.py:820-833)."""
+        h = self.language_model.engine().forward(st["seq"], plan, "gen" if self.use_moe else "und", cache, update=False,
+                                                 causal=False)
+        ops.gemm(h, self.llm2vae.weight.data, out, bias0=self.llm2vae.bias.data, a_rows0=st["vae_rows"], M0=out.shape[0])
+        return out
+
+    def _flow_step(self, st, x_t, t, dt, plan, cache, plan_t, cache_t, plan_i, cache_i, s_t, s_i, renorm_min, mode):
+        """One Euler step of bagel.py:698-746 (= _forward_flow + the update), all on the current stream."""
+        seq = st["seq"]
+        if not st["embedded"]:      # marker-token rows never change across steps
+            self._embed_into(seq, st["text_ids"], st["text_rows"])
+            st["embedded"] = True
+        self._latent_tokens_into(seq, x_t, st["vae_rows"], st["vae_pos"], t)
+        v = self._velocity(st, plan, cache, st["v"][0])
+        if plan_t is not None:
+            v_ct = self._velocity(st, plan_t, cache_t, st["v"][1])
+            v_ci = self._velocity(st, plan_i, cache_i, st["v"][2]) if plan_i is not None else None
+            nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
+            ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
+        else:
+            ops.cfg_stage2_euler(x_t, v, None, 0, renorm_min, dt, use_global_scale=False)
+
+    @torch.no_grad()
+    def _forward_flow(self, x_t, timestep, packed_vae_token_indexes, packed_vae_position_ids, packed_text_ids,
+                      packed_text_indexes, packed_indexes, packed_position_ids, packed_seqlens, key_values_lens,
+                      past_key_values, packed_key_value_indexes, cfg_renorm_min=0.0, cfg_renorm_type="global",
+                      cfg_text_scale=1.0, cfg_text_packed_position_ids=None, cfg_text_packed_query_indexes=None,
+                      cfg_text_key_values_lens=None, cfg_text_past_key_values=None, cfg_text_packed_key_value_indexes=None,
+                      cfg_img_scale=1.0, cfg_img_packed_position_ids=None, cfg_img_packed_query_indexes=None,
+                      cfg_img_key_values_lens=None, cfg_img_past_key_values=None, cfg_img_packed_key_value_indexes=None,
+                      cfg_type="parallel", **taylorseer_kwargs):
+        """Velocity for one timestep (bagel.py:757-907), kept for callers that drive the sampler themselves.
+        Returns v_t (bf16, on the GPU); does not touch x_t."""
+        tvals = timestep.reshape(-1)
+        if tvals.unique().shape[0] != 1:
+            raise AssertionError("all latent tokens must share one timestep")   # bagel.py:800
+        st = self._flow_state(packed_text_ids, packed_text_indexes, packed_vae_position_ids, packed_vae_token_indexes,
+                              packed_seqlens)
+        lm = self.language_model
+        mk = lambda pos, qidx, kvlens, kvidx: lm.make_plan(  # noqa: E731
+            packed_seqlens, pos, qidx, kvlens, kvidx, packed_vae_token_indexes, packed_text_indexes)
+        x_dev = x_t.to(device=self.device, dtype=torch.float32).contiguous()
+        self._embed_into(st["seq"], st["text_ids"], st["text_rows"])
+        self._latent_tokens_into(st["seq"], x_dev, st["vae_rows"], st["vae_pos"], float(tvals[0]))
+        v = self._velocity(st, mk(packed_position_ids, packed_indexes, key_values_lens, packed_key_value_indexes),
+                           past_key_values, st["v"][0])
+        if cfg_text_scale > 1.0:
+            v_ct = self._velocity(st, mk(cfg_text_packed_position_ids, cfg_text_packed_query_indexes, cfg_text_key_values_lens,
+                                         cfg_text_packed_key_value_indexes), cfg_text_past_key_values, st["v"][1])
+            v_ci = None
+            if cfg_img_scale > 1.0:
+                v_ci = self._velocity(st, mk(cfg_img_packed_position_ids, cfg_img_packed_query_indexes, cfg_img_key_values_lens,
+                                             cfg_img_packed_key_value_indexes), cfg_img_past_key_values, st["v"][2])
+            mode = ops.RENORM_MODES[cfg_renorm_type]
+            nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], cfg_text_scale, cfg_img_scale, cfg_renorm_min, mode)
+            if mode == 0:   # apply the global scale without the Euler update: x = 0 - bf16(v*1) trick is not exact; do it directly
+                zero = torch.zeros(v.shape, dtype=torch.float32, device=self.device)
+                ops.cfg_stage2_euler(zero, st["tmp"], st["partials"], nparts, cfg_renorm_min, -1.0, use_global_scale=True)
+                return zero.to(BF16)
+            return st["tmp"].clone()
+        return v.clone()
+
+    # ------------------------------------------------------------------------------------------------
+    # autoregressive text
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_text(self, past_key_values, packed_key_value_indexes, key_values_lens, packed_start_tokens,
+                      packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None):
+        """bagel.py:930-1000.  Returns the INPUT token of every step, shape (steps, B) int64 (first row = bos)."""
+        lm = self.language_model
+        dev = self.device
+        eng = lm.engine()
+        kv_lens = [int(x) for x in key_values_lens.tolist()]
+        B = len(kv_lens)
+        pos = packed_query_position_ids.to(torch.long).clone()
+        curr = self._dev(packed_start_tokens, torch.long)
+        table = lm.model.embed_tokens.weight.data
+        head = lm.lm_head.weight.data
+        logits = torch.empty((B, head.shape[0]), dtype=BF16, device=dev)
+        x = torch.empty((B, self.hidden_size), dtype=BF16, device=dev)
+        generated = []
+        step = 0
+        while step < max_length:
+            generated.append(curr)
+            ops.copy_rows(table, x, B, self.hidden_size, src_rows=curr.to(torch.int32))
+            plan = eng.plan([1] * B, pos, key_values_lens=kv_lens)
+            h = eng.forward(x, plan, "und", past_key_values, update=True, causal=True)
+            ops.gemm(h, head, logits, M0=B)
+            if do_sample:
+                # sampling draws from torch's generator; an RNG stream cannot be matched across devices anyway
+                probs = torch.softmax(logits.float() / temperature, dim=-1)
+                curr = torch.multinomial(probs, num_samples=1).squeeze(1)
+            else:
+                curr = ops.argmax(logits)
+            kv_lens = [k + 1 for k in kv_lens]
+            pos = pos + 1
+            step += 1
+            if end_token_id is not None and int(curr[0]) == end_token_id:   # only support batch=1 (bagel.py:996)
+                break
+        return torch.stack(generated, dim=0)
+
+    @torch.no_grad()
+    def chat(self, tokenizer, new_token_ids, image_transform, images, prompt, max_length, do_sample=False, temperature=1.0):
+        """Evaluation entry point (bagel.py:1004-1074): ViT prefill per image, text prefill, greedy/sampled decode."""
+        cache = NaiveCache(self.config.llm_config.num_hidden_layers)
+        newlens, new_rope = [0], [0]
+        for image in images:
+            gi, newlens, new_rope = self.prepare_vit_images(newlens, new_rope, [image], image_transform, new_token_ids)
+            cache = self.forward_cache_update_vit(cache, **gi)
+        gi, newlens, new_rope = self.prepare_prompts(newlens, new_rope, [prompt], tokenizer, new_token_ids)
+        cache = self.forward_cache_update_text(cache, **gi)
+        gi = self.prepare_start_tokens(newlens, new_rope, new_token_ids)
+        toks = self.generate_text(past_key_values=cache, max_length=max_length, do_sample=do_sample, temperature=temperature,
+                                  end_token_id=new_token_ids["eos_token_id"], **gi)
+        output = tokenizer.decode(toks[:, 0])
+        return output.split("<|im_end|>")[0].split("<|im_start|>")[1]
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("the training forward (bagel.py:101-229) is outside this build's scope (SURVEY.md 8f)")

@@ -1,0 +1,673 @@
+"""MoT Qwen2 backbone on packed (NaViT) sequences -- MI355X execution plan behind the reference's API.
+
+Public surface mirrors modeling/bagel/qwen2_navit.py of the reference (Qwen2Config :46,152-204; NaiveCache :207-221;
+BaseNavitOutputWithPast :224-227; Qwen2ForCausalLM.forward_inference :1157-1188; state-dict keys of
+PackedAttentionMoT :381-398, Qwen2MoTDecoderLayer :687-705, Qwen2Model :943-959) so checkpoints and callers drop in.
+What is different is HOW a forward runs (MoTEngine below):
+
+  * q/k/v projections are ONE fused GEMM per layer, gate/up ONE GEMM with the SwiGLU product in its epilogue,
+    o_proj / down_proj fold the residual add into their epilogue;
+  * MoT routing (text rows -> und expert, latent rows -> gen expert) is a two-group GEMM launch with row index
+    lists -- the reference's ~32 gather/scatter kernels per layer (qwen2_navit.py:526-548,593-594,784-787,812-820)
+    do not exist here;
+  * attention reads the context KV cache and this forward's K/V as two segments (no merge copy, :563-570);
+  * every host-side scalar the reference syncs for (sum(query_lens), max(...).item(), :563,585-586) is computed
+    once per ForwardPlan on the host; the 28-layer loop launches kernels only.
+"""
+import copy
+import json
+import math
+
+import torch
+from torch import nn
+
+from ... import ops
+
+BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------------------------
+# config / small types
+# ------------------------------------------------------------------------------------------------------------
+class Qwen2Config:
+    """Attribute bag with the reference's field names (qwen2_navit.py:152-204)."""
+    model_type = "qwen2"
+
+    def __init__(self, vocab_size=151936, hidden_size=4096, intermediate_size=22016, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=32, hidden_act="silu", max_position_embeddings=32768,
+                 initializer_range=0.02, rms_norm_eps=1e-6, use_cache=True, tie_word_embeddings=False,
+                 rope_theta=10000.0, rope_scaling=None, use_sliding_window=False, sliding_window=4096,
+                 max_window_layers=28, attention_dropout=0.0, is_causal=True, _attn_implementation="flash_attention_2",
+                 qk_norm=True, layer_module="Qwen2DecoderLayer", freeze_und=False, pad_token_id=None, **kwargs):
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.num_key_value_heads = num_key_value_heads
+        self.hidden_act = hidden_act
+        self.max_position_embeddings = max_position_embeddings
+        self.initializer_range = initializer_range
+        self.rms_norm_eps = rms_norm_eps
+        self.use_cache = use_cache
+        self.tie_word_embeddings = tie_word_embeddings
+        self.rope_theta = rope_theta
+        self.rope_scaling = rope_scaling
+        self.use_sliding_window = use_sliding_window
+        self.sliding_window = sliding_window
+        self.max_window_layers = max_window_layers
+        self.attention_dropout = attention_dropout
+        self.is_causal = is_causal
+        self.qk_norm = qk_norm
+        self.layer_module = layer_module
+        self.freeze_und = freeze_und
+        self.pad_token_id = pad_token_id
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path) as f:
+            return cls(**json.load(f))
+
+    def to_dict(self):
+        return dict(self.__dict__)
+
+
+class BaseNavitOutputWithPast:
+    """(packed_query_sequence, past_key_values) -- qwen2_navit.py:224-227."""
+
+    def __init__(self, packed_query_sequence=None, past_key_values=None):
+        self.packed_query_sequence = packed_query_sequence
+        self.past_key_values = past_key_values
+
+    def __iter__(self):
+        return iter((self.packed_query_sequence, self.past_key_values))
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+def padded_head_dim(hd):
+    """Head dims the attention kernel runs natively; smaller heads are zero-padded in the packed weights."""
+    if hd <= 64:
+        return 64
+    if hd <= 128:
+        return 128
+    raise NotImplementedError(f"head_dim {hd} > 128 is not supported by the attention kernel")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# KV cache
+# ------------------------------------------------------------------------------------------------------------
+class _LayerView:
+    """dict-like ``cache.key_cache`` / ``cache.value_cache`` of the reference: layer -> (L, nkv, hd) tensor | None."""
+
+    def __init__(self, cache, which):
+        self._c, self._w = cache, which
+
+    def __len__(self):
+        return self._c._num_layers
+
+    def __iter__(self):
+        return iter(range(self._c._num_layers))
+
+    def keys(self):
+        return range(self._c._num_layers)
+
+    def __getitem__(self, layer):
+        store = self._c._k if self._w == "k" else self._c._v
+        t = store[layer]
+        if t is None:
+            return None
+        c = self._c
+        return t[: c._total].view(c._total, c._nkv, c._dp)[..., : c._hd]
+
+    def items(self):
+        return [(i, self[i]) for i in range(len(self))]
+
+    def values(self):
+        return [self[i] for i in range(len(self))]
+
+
+class NaiveCache:
+    """KV container with the reference's protocol (qwen2_navit.py:207-221): ``NaiveCache(num_layers)``,
+    ``.key_cache[layer]`` / ``.value_cache[layer]`` -> packed (sum L, nkv, hd) bf16 or None, ``.num_layers``,
+    ``.seq_lens``; survives ``copy.deepcopy`` (inferencer.py:189,230-231,244,253).
+
+    Storage is MI355X-oriented: per layer one (capacity, nkv*Dp) K buffer and V buffer that a single-sample context
+    appends to IN PLACE (the reference re-allocates and re-scatters the whole cache on every cached forward), plus a
+    lazily built transposed copy V^T[(g*Dp+d), col] that the MFMA attention kernel consumes."""
+
+    def __init__(self, num_layers):
+        self._num_layers = num_layers
+        self._k = {i: None for i in range(num_layers)}
+        self._v = {i: None for i in range(num_layers)}
+        self._vt = {i: None for i in range(num_layers)}
+        self._vt_ok = {i: False for i in range(num_layers)}
+        self._lens = {i: None for i in range(num_layers)}   # per-layer per-sample lens (layers fill in one by one)
+        self._total = 0
+        self._nkv = self._hd = self._dp = 0
+        self._dev_meta = {}
+
+    # -- reference protocol
+    @property
+    def key_cache(self):
+        return _LayerView(self, "k")
+
+    @property
+    def value_cache(self):
+        return _LayerView(self, "v")
+
+    @property
+    def num_layers(self):
+        return self._num_layers
+
+    @property
+    def seq_lens(self):
+        return self._total if self._k[0] is not None else 0
+
+    def __deepcopy__(self, memo):
+        c = NaiveCache(self._num_layers)
+        c._total, c._nkv, c._hd, c._dp = self._total, self._nkv, self._hd, self._dp
+        for i in range(self._num_layers):
+            if self._k[i] is not None:
+                n = int(sum(self._lens[i]))
+                c._k[i] = self._k[i][:n].clone()
+                c._v[i] = self._v[i][:n].clone()
+                c._lens[i] = list(self._lens[i])
+        return c
+
+    # -- engine side
+    def is_empty(self, layer):
+        return self._k[layer] is None
+
+    def lens(self, layer):
+        return self._lens[layer]
+
+    def _meta(self, layer, device):
+        """(cu_ctx int32[B+1], vt_col int32[B], vt_cols) for the current per-sample lens."""
+        lens = tuple(self._lens[layer])
+        m = self._dev_meta.get(lens)
+        if m is None:
+            cu = [0]
+            col = []
+            c = 0
+            for l in lens:
+                cu.append(cu[-1] + l)
+                col.append(c)
+                c += _ceil_to(max(l, 1), 64)
+            m = (torch.tensor(cu, dtype=torch.int32, device=device), torch.tensor(col, dtype=torch.int32, device=device), c,
+                 max(lens) if lens else 0)
+            self._dev_meta = {lens: m}
+        return m
+
+    def ctx_tensors(self, layer):
+        """(k, vt, cu_ctx, vt_col) for the attention kernel; builds V^T on first use after a change."""
+        k, v = self._k[layer], self._v[layer]
+        cu, col, cols, mx = self._meta(layer, k.device)
+        if not self._vt_ok[layer]:
+            vt = self._vt[layer]
+            if vt is None or vt.shape[1] < cols:
+                vt = torch.zeros((self._nkv * self._dp, _ceil_to(cols, 256)), dtype=BF16, device=k.device)
+                self._vt[layer] = vt
+            ops.v_transpose(v, vt, cu, col, len(self._lens[layer]), mx, self._nkv, self._dp)
+            self._vt_ok[layer] = True
+        return k, self._vt[layer], cu, col
+
+    def store(self, layer, k_rows, v_rows, q_lens, ctx_lens, nkv, hd, dp, new_dst=None, ctx_dst=None):
+        """Merge this forward's K/V rows (views into the fused projection buffer) into the cache.
+        Layout after the call is the reference's merged layout [ctx_0 | new_0 | ctx_1 | new_1 | ...]."""
+        self._nkv, self._hd, self._dp = nkv, hd, dp
+        width = nkv * dp
+        B = len(q_lens)
+        M = int(sum(q_lens))
+        dev = k_rows.device
+        if self._k[layer] is None:
+            k = torch.empty((_ceil_to(M, 64) if B > 1 else max(_ceil_to(2 * M, 256), 256), width), dtype=BF16, device=dev)
+            v = torch.empty_like(k)
+            ops.copy_rows(k_rows, k, M, width)
+            ops.copy_rows(v_rows, v, M, width)
+            self._k[layer], self._v[layer] = k, v
+            self._lens[layer] = [int(x) for x in q_lens]
+        elif B == 1:
+            old = int(self._lens[layer][0])
+            need = old + M
+            k, v = self._k[layer], self._v[layer]
+            if need > k.shape[0]:
+                cap = _ceil_to(max(need * 2, 256), 256)
+                k2 = torch.empty((cap, width), dtype=BF16, device=dev)
+                v2 = torch.empty_like(k2)
+                ops.copy_rows(k, k2, old, width)
+                ops.copy_rows(v, v2, old, width)
+                k, v = k2, v2
+                self._k[layer], self._v[layer] = k, v
+            ops.copy_rows(k_rows, k[old:], M, width)
+            ops.copy_rows(v_rows, v[old:], M, width)
+            self._lens[layer] = [need]
+        else:
+            old_total = int(sum(self._lens[layer]))
+            total = old_total + M
+            k2 = torch.empty((_ceil_to(total, 64), width), dtype=BF16, device=dev)
+            v2 = torch.empty_like(k2)
+            ops.copy_rows(self._k[layer], k2, old_total, width, dst_rows=ctx_dst)
+            ops.copy_rows(self._v[layer], v2, old_total, width, dst_rows=ctx_dst)
+            ops.copy_rows(k_rows, k2, M, width, dst_rows=new_dst)
+            ops.copy_rows(v_rows, v2, M, width, dst_rows=new_dst)
+            self._k[layer], self._v[layer] = k2, v2
+            self._lens[layer] = [int(a) + int(b) for a, b in zip(ctx_lens, q_lens)]
+        self._vt_ok[layer] = False
+        self._total = int(sum(self._lens[layer]))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# parameter holders (names/shapes == the reference's state dict)
+# ------------------------------------------------------------------------------------------------------------
+class _Linear(nn.Module):
+    def __init__(self, in_features, out_features, bias):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_features), requires_grad=False) if bias else None
+
+
+class _NormWeight(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim), requires_grad=False)
+        self.variance_epsilon = eps
+
+
+class _Embedding(nn.Module):
+    def __init__(self, n, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, dim), requires_grad=False)
+
+
+class _MLP(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.gate_proj = _Linear(cfg.hidden_size, cfg.intermediate_size, False)
+        self.up_proj = _Linear(cfg.hidden_size, cfg.intermediate_size, False)
+        self.down_proj = _Linear(cfg.intermediate_size, cfg.hidden_size, False)
+
+
+class _Attention(nn.Module):
+    def __init__(self, cfg, layer_idx, mot):
+        super().__init__()
+        H, nh, nkv = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads
+        hd = H // nh
+        self.layer_idx = layer_idx
+        sufs = ("", "_moe_gen") if mot else ("",)
+        for s in sufs:
+            setattr(self, "q_proj" + s, _Linear(H, nh * hd, True))
+            setattr(self, "k_proj" + s, _Linear(H, nkv * hd, True))
+            setattr(self, "v_proj" + s, _Linear(H, nkv * hd, True))
+            setattr(self, "o_proj" + s, _Linear(nh * hd, H, False))
+            if cfg.qk_norm:
+                setattr(self, "q_norm" + s, _NormWeight(hd, cfg.rms_norm_eps))
+                setattr(self, "k_norm" + s, _NormWeight(hd, cfg.rms_norm_eps))
+
+
+class _DecoderLayer(nn.Module):
+    """Qwen2DecoderLayer / Qwen2MoEDecoderLayer / Qwen2MoTDecoderLayer parameter sets (qwen2_navit.py:603-940)."""
+
+    def __init__(self, cfg, layer_idx):
+        super().__init__()
+        kind = cfg.layer_module
+        mot = kind == "Qwen2MoTDecoderLayer"
+        moe = kind == "Qwen2MoEDecoderLayer"
+        if kind not in ("Qwen2DecoderLayer", "Qwen2MoEDecoderLayer", "Qwen2MoTDecoderLayer"):
+            raise ValueError(f"unknown layer_module {kind}")
+        self.self_attn = _Attention(cfg, layer_idx, mot)
+        self.mlp = _MLP(cfg)
+        if mot or moe:
+            self.mlp_moe_gen = _MLP(cfg)
+        self.input_layernorm = _NormWeight(cfg.hidden_size, cfg.rms_norm_eps)
+        self.post_attention_layernorm = _NormWeight(cfg.hidden_size, cfg.rms_norm_eps)
+        if mot:
+            self.input_layernorm_moe_gen = _NormWeight(cfg.hidden_size, cfg.rms_norm_eps)
+            self.post_attention_layernorm_moe_gen = _NormWeight(cfg.hidden_size, cfg.rms_norm_eps)
+
+
+class _Rotary(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        hd = cfg.hidden_size // cfg.num_attention_heads
+        if getattr(cfg, "rope_scaling", None):
+            raise NotImplementedError("only the 'default' rope type is on BAGEL's path (modeling_qwen2.py:105)")
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float().cpu() / hd))
+        # fp32 on purpose, and immune to module.to(bf16): see DESIGN.md (non-persistent buffer, app.py:105-113)
+        self._inv_freq_cpu = inv
+        self._inv_freq_dev = {}
+
+    def inv_freq(self, device):
+        t = self._inv_freq_dev.get(device)
+        if t is None:
+            t = self._inv_freq_cpu.to(device)
+            self._inv_freq_dev[device] = t
+        return t
+
+
+class Qwen2Model(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.padding_idx = config.pad_token_id
+        self.vocab_size = config.vocab_size
+        self.use_moe = "Mo" in config.layer_module
+        self.embed_tokens = _Embedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([_DecoderLayer(config, i) for i in range(config.num_hidden_layers)])
+        self.norm = _NormWeight(config.hidden_size, config.rms_norm_eps)
+        if self.use_moe:
+            self.norm_moe_gen = _NormWeight(config.hidden_size, config.rms_norm_eps)
+        self.rotary_emb = _Rotary(config)
+        self.enable_taylorseer = False
+
+
+# ------------------------------------------------------------------------------------------------------------
+# per-forward plan (everything the reference recomputes / syncs for inside the layer loop)
+# ------------------------------------------------------------------------------------------------------------
+def _tolist(t):
+    if t is None:
+        return []
+    if torch.is_tensor(t):
+        return [int(x) for x in t.detach().cpu().tolist()]
+    return [int(x) for x in t]
+
+
+class ForwardPlan:
+    """Host-side digest of (query_lens, key_values_lens, packed_*_indexes, position ids, MoT index lists)."""
+
+    def __init__(self, device, query_lens, position_ids, packed_query_indexes=None, key_values_lens=None,
+                 packed_key_value_indexes=None, text_indexes=None, vae_indexes=None, inv_freq=None):
+        q = _tolist(query_lens)
+        B = len(q)
+        c = _tolist(key_values_lens) if key_values_lens is not None else [0] * B
+        if len(c) != B:
+            raise ValueError("key_values_lens and query_lens disagree on the batch size")
+        self.B, self.q_lens, self.ctx_lens = B, q, c
+        self.M = sum(q)
+        self.max_lq = max(q) if q else 0
+        cu_q, cu_c, vcol = [0], [0], []
+        col = 0
+        new_dst, ctx_dst = [], []
+        base = 0
+        for b in range(B):
+            cu_q.append(cu_q[-1] + q[b])
+            cu_c.append(cu_c[-1] + c[b])
+            vcol.append(col)
+            col += _ceil_to(max(q[b], 1), 64)
+            ctx_dst.extend(range(base, base + c[b]))
+            new_dst.extend(range(base + c[b], base + c[b] + q[b]))
+            base += c[b] + q[b]
+        self.vt_cols = col
+        self.has_ctx = any(x > 0 for x in c)
+        # the merged layout [ctx_0 | q_0 | ctx_1 | q_1 ...] is the only one the reference's packers produce
+        # (bagel.py:242-253, 309-338, 560-590); verify instead of silently assuming.
+        if packed_query_indexes is not None and _tolist(packed_query_indexes) != new_dst:
+            raise NotImplementedError("packed_query_indexes is not the [ctx_b | query_b] merged layout")
+        if packed_key_value_indexes is not None and self.has_ctx and _tolist(packed_key_value_indexes) != ctx_dst:
+            raise NotImplementedError("packed_key_value_indexes is not the [ctx_b | query_b] merged layout")
+
+        def i32(x):
+            return torch.tensor(x, dtype=torch.int32, device=device)
+
+        self.cu_q = i32(cu_q)
+        self.vt_new_col = i32(vcol)
+        self.new_dst = i32(new_dst) if B > 1 else None
+        self.ctx_dst = i32(ctx_dst) if (B > 1 and self.has_ctx) else None
+        pos = position_ids if torch.is_tensor(position_ids) else torch.tensor(position_ids, dtype=torch.long)
+        self.pos_ids = pos.to(device=device, dtype=torch.long).contiguous()
+        if self.pos_ids.numel() != self.M:
+            raise ValueError("position ids do not cover the packed query sequence")
+        self.cos, self.sin = ops.rope_table(self.pos_ids, inv_freq)
+        # MoT routing
+        self.text_idx = self.vae_idx = self.expert = None
+        if text_indexes is not None and vae_indexes is not None:
+            t, v = _tolist(text_indexes), _tolist(vae_indexes)
+            if len(t) + len(v) != self.M or len(set(t) | set(v)) != self.M:
+                raise NotImplementedError("gen mode expects text rows and latent rows to partition the sequence")
+            self.text_idx, self.vae_idx = i32(t), i32(v)
+            ex = torch.zeros(self.M, dtype=torch.int32)
+            ex[torch.tensor(v, dtype=torch.long)] = 1
+            self.expert = ex.to(device)
+            self.n_text, self.n_vae = len(t), len(v)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# engine: packed weights + workspaces + the layer loop
+# ------------------------------------------------------------------------------------------------------------
+def _pad_heads_rows(w, nheads, hd, dp):
+    """[nheads*hd, K] -> [nheads*dp, K] (zero rows for the padded head lanes)."""
+    if dp == hd:
+        return w
+    out = w.new_zeros((nheads, dp) + tuple(w.shape[1:]))
+    out[:, :hd] = w.view(nheads, hd, *w.shape[1:])
+    return out.view(nheads * dp, *w.shape[1:])
+
+
+def _pad_heads_cols(w, nheads, hd, dp):
+    """[N, nheads*hd] -> [N, nheads*dp]."""
+    if dp == hd:
+        return w
+    out = w.new_zeros((w.shape[0], nheads, dp))
+    out[:, :, :hd] = w.view(w.shape[0], nheads, hd)
+    return out.view(w.shape[0], nheads * dp)
+
+
+def interleave_gate_up(gate, up):
+    """[I,H],[I,H] -> [2I,H] in 16-row blocks g0..15,u0..15,g16..31,... (BAGEL_EPI_SWIGLU16 layout)."""
+    I, H = gate.shape
+    assert I % 16 == 0
+    return torch.stack((gate.view(I // 16, 16, H), up.view(I // 16, 16, H)), dim=1).reshape(2 * I, H).contiguous()
+
+
+class _PackedLayer:
+    __slots__ = ("wqkv", "bqkv", "wo", "wgu", "wd", "qn", "kn", "ln_in", "ln_post")
+
+
+class MoTEngine:
+    """Owns the MI355X-layout copies of a Qwen2Model's weights and runs forward_inference on them."""
+
+    def __init__(self, model: "Qwen2Model", lm_head: "_Linear"):
+        cfg = model.config
+        self.cfg = cfg
+        self.H, self.I = cfg.hidden_size, cfg.intermediate_size
+        self.nq, self.nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.hd = self.H // self.nq
+        self.dp = padded_head_dim(self.hd)
+        self.eps = cfg.rms_norm_eps
+        self.kind = cfg.layer_module
+        self.mot = self.kind == "Qwen2MoTDecoderLayer"
+        self.moe_mlp = self.kind in ("Qwen2MoTDecoderLayer", "Qwen2MoEDecoderLayer")
+        self.use_norm = bool(cfg.qk_norm)
+        if self.H % 64 or self.I % 64 or (self.nq * self.dp) % 64:
+            raise NotImplementedError("hidden/intermediate sizes must be multiples of 64 for the GEMM K loop")
+        p0 = model.embed_tokens.weight
+        if not p0.is_cuda or p0.dtype != BF16:
+            raise ops.BagelHipError("bagel_amd runs bf16 weights on an MI355X: call model.to('cuda', torch.bfloat16) first")
+        self.device = p0.device
+        self.model = model
+        self.lm_head = lm_head
+        self.layers = [self._pack_layer(l) for l in model.layers]
+        self._ws = {}
+
+    def _pack_layer(self, L):
+        nq, nkv, hd, dp = self.nq, self.nkv, self.hd, self.dp
+        a = L.self_attn
+        P = _PackedLayer()
+        P.wqkv, P.bqkv, P.wo, P.wgu, P.wd, P.qn, P.kn, P.ln_in, P.ln_post = [], [], [], [], [], [], [], [], []
+        attn_sufs = ("", "_moe_gen") if self.mot else ("",)
+        for s in attn_sufs:
+            q, k, v, o = (getattr(a, n + s) for n in ("q_proj", "k_proj", "v_proj", "o_proj"))
+            P.wqkv.append(torch.cat([_pad_heads_rows(q.weight.data, nq, hd, dp), _pad_heads_rows(k.weight.data, nkv, hd, dp),
+                                     _pad_heads_rows(v.weight.data, nkv, hd, dp)], 0).contiguous())
+            P.bqkv.append(torch.cat([_pad_heads_rows(q.bias.data, nq, hd, dp), _pad_heads_rows(k.bias.data, nkv, hd, dp),
+                                     _pad_heads_rows(v.bias.data, nkv, hd, dp)], 0).contiguous())
+            P.wo.append(_pad_heads_cols(o.weight.data, nq, hd, dp).contiguous())
+            if self.use_norm:
+                P.qn.append(getattr(a, "q_norm" + s).weight.data.contiguous())
+                P.kn.append(getattr(a, "k_norm" + s).weight.data.contiguous())
+            P.ln_in.append(getattr(L, "input_layernorm" + s).weight.data.contiguous())
+            P.ln_post.append(getattr(L, "post_attention_layernorm" + s).weight.data.contiguous())
+        for s in (("", "_moe_gen") if self.moe_mlp else ("",)):
+            m = getattr(L, "mlp" + s)
+            P.wgu.append(interleave_gate_up(m.gate_proj.weight.data, m.up_proj.weight.data))
+            P.wd.append(m.down_proj.weight.data.contiguous())
+        return P
+
+    # -- workspaces (cached per row count; everything stays resident in HBM)
+    def workspace(self, M, vt_cols):
+        key = (M, vt_cols)
+        ws = self._ws.get(key)
+        if ws is None:
+            dev = self.device
+            e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
+            ws = dict(x=e(M, self.H), h=e(M, self.H), qkv=e(M, (self.nq + 2 * self.nkv) * self.dp),
+                      attn=e(M, self.nq * self.dp), act=e(M, self.I),
+                      vt=torch.zeros((self.nkv * self.dp, _ceil_to(vt_cols, 256)), dtype=BF16, device=dev))
+            if len(self._ws) > 6:
+                self._ws.pop(next(iter(self._ws)))
+            self._ws[key] = ws
+        return ws
+
+    def plan(self, query_lens, position_ids, **kw):
+        return ForwardPlan(self.device, query_lens, position_ids, inv_freq=self.model.rotary_emb.inv_freq(self.device), **kw)
+
+    def forward(self, seq, plan: ForwardPlan, mode="und", cache: NaiveCache = None, update=True, causal=True,
+                num_layers=None):
+        """Qwen2Model.forward_inference (qwen2_navit.py:1018-1092).  ``seq`` is not modified."""
+        if seq.shape != (plan.M, self.H):
+            raise ValueError(f"packed sequence shape {tuple(seq.shape)} != ({plan.M}, {self.H})")
+        gen = mode == "gen" and self.moe_mlp
+        if gen and plan.expert is None:
+            raise AssertionError("gen mode needs packed_vae_token_indexes and packed_text_indexes")  # qwen2_navit.py:1049-1050
+        gen_attn = gen and self.mot
+        ws = self.workspace(plan.M, plan.vt_cols)
+        x, h, qkv, att, act, vt = ws["x"], ws["h"], ws["qkv"], ws["attn"], ws["act"], ws["vt"]
+        x.copy_(seq)
+        nq, nkv, dp, hd = self.nq, self.nkv, self.dp, self.hd
+        qw, kw_ = nq * dp, nkv * dp
+        q_v, k_v, v_v = qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
+        expert = plan.expert if gen else None
+        scale = hd ** -0.5
+
+        def groups(w, b=None, on=gen):
+            """kwargs selecting one (und) or two (und, gen) GEMM row groups."""
+            if on:
+                return dict(W0=w[0], bias0=None if b is None else b[0], a_rows0=plan.text_idx, c_rows0=plan.text_idx,
+                            M0=plan.n_text, W1=w[1], bias1=None if b is None else b[1], a_rows1=plan.vae_idx,
+                            c_rows1=plan.vae_idx, M1=plan.n_vae)
+            return dict(W0=w[0], bias0=None if b is None else b[0], M0=plan.M)
+
+        nl = len(self.layers) if num_layers is None else num_layers
+        for li in range(nl):
+            P = self.layers[li]
+            ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if gen_attn else None, expert=expert if gen_attn else None)
+            ops.gemm(h, C=qkv, **groups(P.wqkv, P.bqkv, gen_attn))
+            ops.qknorm_rope(qkv, plan.cos, plan.sin, P.qn[0] if self.use_norm else None, P.kn[0] if self.use_norm else None,
+                            P.qn[1] if (self.use_norm and gen_attn) else None, P.kn[1] if (self.use_norm and gen_attn) else None,
+                            expert if gen_attn else None, nq, nkv, hd, dp, self.eps, gen_mode=(mode == "gen" and self.mot),
+                            use_norm=self.use_norm)
+            ops.v_transpose(v_v, vt, plan.cu_q, plan.vt_new_col, plan.B, plan.max_lq, nkv, dp)
+            ctx = None
+            if cache is not None and not cache.is_empty(li) and plan.has_ctx:
+                if list(cache.lens(li)) != plan.ctx_lens:
+                    raise ValueError("key_values_lens does not match the KV cache contents")
+                ctx = cache.ctx_tensors(li)
+            ops.attn_varlen(q_v, k_v, vt, att, plan.cu_q, plan.vt_new_col, plan.B, plan.max_lq, nq, nkv, dp, causal, scale,
+                            k_ctx=None if ctx is None else ctx[0], vt_ctx=None if ctx is None else ctx[1],
+                            cu_ctx=None if ctx is None else ctx[2], vt_ctx_col=None if ctx is None else ctx[3])
+            if update:
+                if cache is None:
+                    raise ValueError("update_past_key_values=True needs a NaiveCache")
+                cache.store(li, k_v, v_v, plan.q_lens, plan.ctx_lens, nkv, hd, dp, plan.new_dst, plan.ctx_dst)
+            ops.gemm(att, C=x, residual=x, **groups(P.wo, None, gen_attn))
+            ops.rmsnorm(x, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if gen_attn else None, expert=expert if gen_attn else None)
+            ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu, None, gen))
+            ops.gemm(act, C=x, residual=x, **groups(P.wd, None, gen))
+        out = torch.empty_like(x)
+        m = self.model
+        if gen and self.mot or (gen and self.kind == "Qwen2MoEDecoderLayer"):
+            ops.rmsnorm(x, m.norm.weight.data, out, self.eps, w1=m.norm_moe_gen.weight.data, expert=expert)
+        else:
+            ops.rmsnorm(x, m.norm.weight.data, out, self.eps)
+        return out
+
+
+class Qwen2ForCausalLM(nn.Module):
+    """Same constructor, attribute names and ``forward_inference`` signature as qwen2_navit.py:1095-1188."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.model = Qwen2Model(config)
+        self.vocab_size = config.vocab_size
+        self.lm_head = _Linear(config.hidden_size, config.vocab_size, False)
+        self._engine = None
+        self._plans = {}
+
+    # ---- weight lifecycle -------------------------------------------------------------------------------
+    def init_moe(self):
+        """Copy every *_moe_gen parameter from its und twin (qwen2_navit.py:1107-1111)."""
+        sd = self.state_dict()
+        for name, param in self.named_parameters():
+            if "moe_gen" in name:
+                param.data.copy_(sd[name.replace("_moe_gen", "")].data)
+        self.invalidate_packed()
+
+    def invalidate_packed(self):
+        self._engine = None
+        self._plans = {}
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_packed()
+        return super().load_state_dict(*a, **k)
+
+    def engine(self) -> MoTEngine:
+        if self._engine is None:
+            self._engine = MoTEngine(self.model, self.lm_head)
+        return self._engine
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    # ---- inference --------------------------------------------------------------------------------------
+    def make_plan(self, query_lens, packed_query_position_ids, packed_query_indexes=None, key_values_lens=None,
+                  packed_key_value_indexes=None, packed_vae_token_indexes=None, packed_text_indexes=None):
+        return self.engine().plan(query_lens, packed_query_position_ids, packed_query_indexes=packed_query_indexes,
+                                  key_values_lens=key_values_lens, packed_key_value_indexes=packed_key_value_indexes,
+                                  text_indexes=packed_text_indexes, vae_indexes=packed_vae_token_indexes)
+
+    @torch.no_grad()
+    def forward_inference(self, packed_query_sequence, query_lens, packed_query_position_ids, packed_query_indexes,
+                          past_key_values=None, key_values_lens=None, packed_key_value_indexes=None,
+                          update_past_key_values=True, is_causal=True, mode="und", packed_vae_token_indexes=None,
+                          packed_text_indexes=None, plan=None):
+        if getattr(self.model, "enable_taylorseer", False):
+            raise NotImplementedError("TaylorSeer step skipping is out of scope for this build (SURVEY.md section 8f)")
+        eng = self.engine()
+        if plan is None:
+            gen = mode == "gen" and eng.moe_mlp
+            plan = self.make_plan(query_lens, packed_query_position_ids, packed_query_indexes, key_values_lens,
+                                  packed_key_value_indexes, packed_vae_token_indexes if gen else None,
+                                  packed_text_indexes if gen else None)
+        seq = packed_query_sequence
+        if seq.device != eng.device or seq.dtype != BF16:
+            seq = seq.to(device=eng.device, dtype=BF16)
+        out = eng.forward(seq, plan, mode, past_key_values, update_past_key_values, is_causal)
+        return BaseNavitOutputWithPast(packed_query_sequence=out, past_key_values=past_key_values)
+
+    def forward(self, *args, **kwargs):
+        if self.training:
+            raise NotImplementedError("training forward (forward_train) is outside this build's scope (SURVEY.md section 8f)")
+        return self.forward_inference(*args, **kwargs)

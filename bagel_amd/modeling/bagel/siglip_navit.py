@@ -1,0 +1,197 @@
+"""Packed (NaViT) SigLIP vision encoder on MI355X -- API and state-dict keys of modeling/bagel/siglip_navit.py
+(SiglipVisionConfig :21-99, SiglipVisionEmbeddings.convert_conv2d_to_linear :167-181, SiglipVisionModel :374-402).
+
+Execution: patch Linear + learned position rows, then per layer LayerNorm -> fused QKV GEMM -> varlen attention
+(non-causal, heads zero-padded 72 -> 128 inside the packed weights so the D=128 MFMA kernel applies; softmax scale
+stays 72^-1/2) -> out_proj with the residual in its epilogue -> LayerNorm -> fc1+GELU(tanh) epilogue -> fc2 +
+residual epilogue.  All bf16 with fp32 accumulation, rounding points as the reference under bf16 autocast.
+"""
+import json
+
+import torch
+from torch import nn
+
+from ... import ops
+from .qwen2_navit import _ceil_to, _pad_heads_cols, _pad_heads_rows, padded_head_dim
+
+BF16 = torch.bfloat16
+
+
+class SiglipVisionConfig:
+    model_type = "siglip_vision_model"
+
+    def __init__(self, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                 num_channels=3, image_size=224, patch_size=16, hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6,
+                 attention_dropout=0.0, rope=True, **kwargs):
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.num_channels = num_channels
+        self.image_size = image_size
+        self.patch_size = patch_size
+        self.hidden_act = hidden_act
+        self.layer_norm_eps = layer_norm_eps
+        self.attention_dropout = attention_dropout
+        self.rope = rope
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path) as f:
+            return cls(**json.load(f))
+
+
+class _P(nn.Module):
+    """weight(+bias) holder."""
+
+    def __init__(self, *wshape, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*wshape), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(wshape[0]), requires_grad=False) if bias else None
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embed_dim = config.hidden_size
+        self.patch_size = config.patch_size
+        # the checkpoint stores a Conv2d kernel; callers convert it to the Linear form (app.py:66)
+        self.patch_embedding = _P(config.hidden_size, config.num_channels, config.patch_size, config.patch_size)
+        self.num_patches_per_side = config.image_size // config.patch_size
+        self.num_positions = self.num_patches_per_side ** 2
+        if not config.rope:
+            self.position_embedding = _P(self.num_positions, config.hidden_size, bias=False)
+
+    def convert_conv2d_to_linear(self, config, meta=False):
+        """Conv2d(C,D,p,p) kernel -> Linear(p*p*C, D) with (p_h, p_w, c) column order == patchify's (siglip_navit.py:167-181)."""
+        conv = self.patch_embedding
+        lin = _P(self.embed_dim, config.num_channels * self.patch_size ** 2)
+        if not meta:
+            lin.weight.data = conv.weight.data.permute(0, 2, 3, 1).reshape(self.embed_dim, -1).contiguous()
+            lin.bias.data = conv.bias.data
+        del self.patch_embedding
+        self.patch_embedding = lin
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        D, I = config.hidden_size, config.intermediate_size
+        self.self_attn = nn.Module()
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            setattr(self.self_attn, n, _P(D, D))
+        self.layer_norm1 = _P(D)
+        self.layer_norm2 = _P(D)
+        self.mlp = nn.Module()
+        self.mlp.fc1 = _P(I, D)
+        self.mlp.fc2 = _P(D, I)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayer(config) for _ in range(config.num_hidden_layers)])
+
+
+class SiglipVisionTransformer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embeddings = _Embeddings(config)
+        self.encoder = _Encoder(config)
+        self.post_layernorm = _P(config.hidden_size)
+
+
+class SiglipVisionModel(nn.Module):
+    main_input_name = "packed_pixel_values"
+
+    def __init__(self, config: SiglipVisionConfig):
+        super().__init__()
+        self.config = config
+        self.vision_model = SiglipVisionTransformer(config)
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _pack(self):
+        cfg = self.config
+        vm = self.vision_model
+        pe = vm.embeddings.patch_embedding
+        if pe.weight.dim() != 2:
+            raise RuntimeError("call vision_model.embeddings.convert_conv2d_to_linear(vit_config) first (app.py:66)")
+        if not pe.weight.is_cuda or pe.weight.dtype != BF16:
+            raise ops.BagelHipError("bagel_amd runs bf16 weights on an MI355X: call model.to('cuda', torch.bfloat16) first")
+        if cfg.rope:
+            raise NotImplementedError("SigLIP 2-D RoPE (siglip_navit.py:102-142) is switched off for BAGEL (app.py:45); "
+                                      "not built in this round")
+        D, nh = cfg.hidden_size, cfg.num_attention_heads
+        hd = D // nh
+        dp = padded_head_dim(hd)
+        kin = pe.weight.shape[1]
+        kpad = _ceil_to(kin, 8)
+        w = pe.weight.data
+        if kpad != kin:
+            w = torch.cat([w, w.new_zeros((D, kpad - kin))], 1).contiguous()
+        layers = []
+        for L in vm.encoder.layers:
+            a = L.self_attn
+            layers.append(dict(
+                wqkv=torch.cat([_pad_heads_rows(getattr(a, n).weight.data, nh, hd, dp) for n in ("q_proj", "k_proj", "v_proj")], 0).contiguous(),
+                bqkv=torch.cat([_pad_heads_rows(getattr(a, n).bias.data, nh, hd, dp) for n in ("q_proj", "k_proj", "v_proj")], 0).contiguous(),
+                wo=_pad_heads_cols(a.out_proj.weight.data, nh, hd, dp).contiguous(), bo=a.out_proj.bias.data,
+                ln1=(L.layer_norm1.weight.data, L.layer_norm1.bias.data), ln2=(L.layer_norm2.weight.data, L.layer_norm2.bias.data),
+                fc1=(L.mlp.fc1.weight.data, L.mlp.fc1.bias.data), fc2=(L.mlp.fc2.weight.data, L.mlp.fc2.bias.data)))
+        self._packed = dict(wpatch=w, bpatch=pe.bias.data, kin=kin, kpad=kpad, layers=layers, hd=hd, dp=dp, nh=nh)
+        return self._packed
+
+    @torch.no_grad()
+    def forward(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
+        P = self._packed or self._pack()
+        cfg = self.config
+        dev = P["wpatch"].device
+        D, I, nh, dp = cfg.hidden_size, cfg.intermediate_size, P["nh"], P["dp"]
+        eps = cfg.layer_norm_eps
+        pix = packed_pixel_values.to(device=dev, dtype=torch.float32)
+        n = pix.shape[0]
+        pos = packed_flattened_position_ids.to(device=dev, dtype=torch.long).contiguous()
+        lens = (cu_seqlens[1:] - cu_seqlens[:-1]).tolist()
+        B = len(lens)
+        cu = cu_seqlens.to(device=dev, dtype=torch.int32).contiguous()
+        cols, c = [], 0
+        for l in lens:
+            cols.append(c)
+            c += _ceil_to(max(int(l), 1), 64)
+        vcol = torch.tensor(cols, dtype=torch.int32, device=dev)
+        e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
+        x, h, qkv, att, mid = e(n, D), e(n, D), e(n, 3 * nh * dp), e(n, nh * dp), e(n, I)
+        vt = torch.zeros((nh * dp, _ceil_to(c, 256)), dtype=BF16, device=dev)
+        a16 = ops.f32_to_bf16(pix, cols_padded=P["kpad"])
+        ops.gemm(a16, P["wpatch"], x, bias0=P["bpatch"])
+        ops.add_table_rows(x, self.vision_model.embeddings.position_embedding.weight.data, pos)
+        qw = nh * dp
+        scale = P["hd"] ** -0.5
+        for L in P["layers"]:
+            ops.layernorm(x, L["ln1"][0], L["ln1"][1], h, eps)
+            ops.gemm(h, L["wqkv"], qkv, bias0=L["bqkv"])
+            ops.v_transpose(qkv[:, 2 * qw:], vt, cu, vcol, B, int(max_seqlen), nh, dp)
+            ops.attn_varlen(qkv[:, :qw], qkv[:, qw:2 * qw], vt, att, cu, vcol, B, int(max_seqlen), nh, nh, dp, False, scale)
+            ops.gemm(att, L["wo"], x, bias0=L["bo"], residual=x)
+            ops.layernorm(x, L["ln2"][0], L["ln2"][1], h, eps)
+            ops.gemm(h, L["fc1"][0], mid, bias0=L["fc1"][1], epilogue=ops.EPI_GELU_TANH)
+            ops.gemm(mid, L["fc2"][0], x, bias0=L["fc2"][1], residual=x)
+        out = torch.empty_like(x)
+        pl = self.vision_model.post_layernorm
+        ops.layernorm(x, pl.weight.data, pl.bias.data, out, eps)
+        return out

@@ -1,0 +1,190 @@
+"""Tensor-level wrappers over the C ABI (include/bagel_hip.h).  PyTorch is used for device memory and the
+current HIP stream only; every op below is one or two launches of a hand-written gfx950 kernel.
+
+All tensors must live on the GPU; there is no CPU path (see _lib.py)."""
+import ctypes
+import os
+
+import torch
+
+from ._lib import BagelHipError, check, lib
+
+BF16 = torch.bfloat16
+
+EPI_NONE, EPI_GELU_TANH, EPI_SILU, EPI_SWIGLU16 = 0, 1, 2, 3
+RENORM_MODES = {"global": 0, "channel": 1, "text_channel": 2}
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise BagelHipError(f"{name}: expected a GPU tensor (bagel_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise BagelHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise BagelHipError(f"{name}: innermost dimension must be contiguous")
+
+
+def _ld(t):
+    return t.stride(0) if t.dim() == 2 else t.shape[-1]
+
+
+def default_gemm_variant(M, N, K):
+    v = os.environ.get("BAGEL_GEMM_VARIANT")
+    if v is not None:
+        return int(v)
+    return 0
+
+
+def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, bias1=None, a_rows1=None, c_rows1=None,
+         M1=0, residual=None, epilogue=EPI_NONE, variant=None):
+    """C = A @ W^T (+bias)(act)(+residual); see bagel_gemm_bf16.  A:[*,K] W:[N,K] C:[*,N or N/2]."""
+    _req(A, BF16, "gemm.A"); _req(W0, BF16, "gemm.W0"); _req(C, BF16, "gemm.C")
+    N, K = W0.shape
+    if A.shape[-1] != K:
+        raise BagelHipError(f"gemm: A has K={A.shape[-1]}, W has K={K}")
+    if M0 is None:
+        M0 = a_rows0.numel() if a_rows0 is not None else A.shape[0]
+    if W1 is not None:
+        _req(W1, BF16, "gemm.W1")
+        assert W1.shape == W0.shape and W1.stride(0) == W0.stride(0)
+    for r in (a_rows0, c_rows0, a_rows1, c_rows1):
+        if r is not None:
+            _req(r, torch.int32, "gemm.rows")
+    if residual is not None:
+        _req(residual, BF16, "gemm.residual")
+    if variant is None:
+        variant = default_gemm_variant(M0 + M1, N, K)
+    check(lib().bagel_gemm_bf16(_ptr(A), _ld(A), _ptr(W0), _ptr(bias0), _ptr(a_rows0), _ptr(c_rows0), M0,
+                                _ptr(W1), _ptr(bias1), _ptr(a_rows1), _ptr(c_rows1), M1, W0.stride(0),
+                                _ptr(residual), _ld(residual) if residual is not None else 0, _ptr(C), _ld(C),
+                                N, K, epilogue, variant, _stream()), "bagel_gemm_bf16")
+    return C
+
+
+def rmsnorm(x, w0, out, eps, w1=None, expert=None):
+    _req(x, BF16, "rmsnorm.x"); _req(out, BF16, "rmsnorm.out"); _req(w0, BF16, "rmsnorm.w0")
+    rows, cols = x.shape
+    check(lib().bagel_rmsnorm_bf16(_ptr(x), _ld(x), _ptr(w0), _ptr(w1), _ptr(expert), _ptr(out), _ld(out), rows, cols,
+                                   float(eps), _stream()), "bagel_rmsnorm_bf16")
+    return out
+
+
+def layernorm(x, w, b, out, eps):
+    _req(x, BF16, "layernorm.x"); _req(out, BF16, "layernorm.out")
+    rows, cols = x.shape
+    check(lib().bagel_layernorm_bf16(_ptr(x), _ld(x), _ptr(w), _ptr(b), _ptr(out), _ld(out), rows, cols, float(eps),
+                                     _stream()), "bagel_layernorm_bf16")
+    return out
+
+
+def rope_table(position_ids, inv_freq):
+    _req(position_ids, torch.int64, "rope_table.position_ids"); _req(inv_freq, torch.float32, "rope_table.inv_freq")
+    rows, half = position_ids.numel(), inv_freq.numel()
+    cos = torch.empty((rows, half), dtype=BF16, device=position_ids.device)
+    sin = torch.empty_like(cos)
+    check(lib().bagel_rope_table(_ptr(position_ids), _ptr(inv_freq), _ptr(cos), _ptr(sin), rows, half, _stream()),
+          "bagel_rope_table")
+    return cos, sin
+
+
+def qknorm_rope(qkv, cos, sin, q_w0, k_w0, q_w1, k_w1, expert, nq, nkv, head_dim, head_dim_padded, eps, gen_mode, use_norm):
+    _req(qkv, BF16, "qknorm_rope.qkv")
+    check(lib().bagel_qknorm_rope_bf16(_ptr(qkv), _ld(qkv), _ptr(cos), _ptr(sin), _ptr(q_w0), _ptr(k_w0), _ptr(q_w1),
+                                       _ptr(k_w1), _ptr(expert), qkv.shape[0], nq, nkv, head_dim, head_dim_padded,
+                                       float(eps), int(gen_mode), int(use_norm), _stream()), "bagel_qknorm_rope_bf16")
+    return qkv
+
+
+def attn_varlen(q, k_new, vt_new, out, cu_q, vt_new_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale,
+                k_ctx=None, vt_ctx=None, cu_ctx=None, vt_ctx_col=None):
+    """q:[M, >=nq*D] rows with stride; k_new likewise; vt_new:[nkv*D, cols]; ctx triple optional."""
+    for t, n in ((q, "q"), (k_new, "k_new"), (vt_new, "vt_new"), (out, "out")):
+        _req(t, BF16, "attn." + n)
+    check(lib().bagel_attn_varlen_bf16(
+        _ptr(q), q.stride(0), _ptr(k_new), k_new.stride(0), _ptr(vt_new), vt_new.stride(0),
+        _ptr(k_ctx), k_ctx.stride(0) if k_ctx is not None else 0, _ptr(vt_ctx), vt_ctx.stride(0) if vt_ctx is not None else 0,
+        _ptr(out), out.stride(0), _ptr(cu_q), _ptr(cu_ctx), _ptr(vt_new_col), _ptr(vt_ctx_col), batch, max_lq, nq, nkv,
+        head_dim, int(causal), float(softmax_scale), _stream()), "bagel_attn_varlen_bf16")
+    return out
+
+
+def v_transpose(v, vt, cu_rows, col_start, batch, max_len, nkv, head_dim):
+    _req(v, BF16, "v_transpose.v"); _req(vt, BF16, "v_transpose.vt")
+    check(lib().bagel_v_transpose_bf16(_ptr(v), v.stride(0), _ptr(vt), vt.stride(0), _ptr(cu_rows), _ptr(col_start), batch,
+                                       max_len, nkv, head_dim, _stream()), "bagel_v_transpose_bf16")
+    return vt
+
+
+def copy_rows(src, dst, n, cols, src_rows=None, dst_rows=None):
+    _req(src, BF16, "copy_rows.src"); _req(dst, BF16, "copy_rows.dst")
+    check(lib().bagel_copy_rows_bf16(_ptr(src), src.stride(0), _ptr(src_rows), _ptr(dst), dst.stride(0), _ptr(dst_rows), n,
+                                     cols, _stream()), "bagel_copy_rows_bf16")
+    return dst
+
+
+def f32_to_bf16(src, dst=None, cols_padded=None):
+    """2-D fp32 -> bf16; optional zero padding of the row width (K padding for the GEMM)."""
+    _req(src, torch.float32, "f32_to_bf16.src")
+    if src.dim() != 2:
+        raise BagelHipError("f32_to_bf16 expects a 2-D tensor")
+    rows, cols = src.shape
+    cp = cols if cols_padded is None else cols_padded
+    if dst is None:
+        dst = torch.empty((rows, cp), dtype=BF16, device=src.device)
+    check(lib().bagel_f32_to_bf16(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), rows, cols, cp, _stream()),
+          "bagel_f32_to_bf16")
+    return dst
+
+
+def timestep_sinusoid(t, freqs, out):
+    check(lib().bagel_timestep_sinusoid(float(t), _ptr(freqs), _ptr(out), freqs.numel(), _stream()), "bagel_timestep_sinusoid")
+    return out
+
+
+def flow_add(seq, rows, temb, pos_table, pos_ids):
+    _req(seq, BF16, "flow_add.seq"); _req(rows, torch.int32, "flow_add.rows"); _req(pos_ids, torch.int64, "flow_add.pos_ids")
+    check(lib().bagel_flow_add_bf16(_ptr(seq), seq.stride(0), _ptr(rows), _ptr(temb), _ptr(pos_table), pos_table.stride(0),
+                                    _ptr(pos_ids), rows.numel(), seq.shape[1], _stream()), "bagel_flow_add_bf16")
+    return seq
+
+
+def add_table_rows(x, table, ids):
+    _req(x, BF16, "add_table_rows.x"); _req(ids, torch.int64, "add_table_rows.ids")
+    check(lib().bagel_add_table_rows_bf16(_ptr(x), x.stride(0), _ptr(table), table.stride(0), _ptr(ids), x.shape[0],
+                                          x.shape[1], _stream()), "bagel_add_table_rows_bf16")
+    return x
+
+
+_MAX_PARTIALS = 256
+
+
+def cfg_stage1(v, v_ct, v_ci, tmp, partials, text_scale, img_scale, renorm_min, mode):
+    n_rows, cols = v.shape
+    nparts = ctypes.c_int32(0)
+    check(lib().bagel_cfg_stage1(_ptr(v), _ptr(v_ct), _ptr(v_ci), _ptr(tmp), _ptr(partials), _MAX_PARTIALS, n_rows, cols,
+                                 float(text_scale), float(img_scale), float(renorm_min), mode,
+                                 ctypes.addressof(nparts), _stream()), "bagel_cfg_stage1")
+    return nparts.value
+
+
+def cfg_stage2_euler(x_t, v_or_tmp, partials, nparts, renorm_min, dt, use_global_scale):
+    _req(x_t, torch.float32, "cfg_stage2.x_t")
+    check(lib().bagel_cfg_stage2_euler(_ptr(x_t), _ptr(v_or_tmp), _ptr(partials), nparts, float(renorm_min), float(dt),
+                                       x_t.numel(), int(use_global_scale), _stream()), "bagel_cfg_stage2_euler")
+    return x_t
+
+
+def argmax(logits):
+    _req(logits, BF16, "argmax.logits")
+    out = torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)
+    check(lib().bagel_argmax_bf16(_ptr(logits), logits.stride(0), _ptr(out), logits.shape[0], logits.shape[1], _stream()),
+          "bagel_argmax_bf16")
+    return out

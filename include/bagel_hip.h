@@ -1,0 +1,115 @@
+/* libbagel_hip.so -- C ABI of the MI355X (gfx950) kernels behind BAGEL's unified multimodal forward path.
+ *
+ * The reference (ByteDance-Seed/Bagel) is pure Python; its only by-name native seam is
+ *   flash_attn.flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal)
+ * (modeling/bagel/qwen2_navit.py:24,361-370,579-588; modeling/bagel/siglip_navit.py:18,232-241); every other
+ * native op is reached through torch (cuBLAS F.linear, eager elementwise / index kernels, cuDNN).  Each entry
+ * point below names the reference call site(s) it replaces.  Conventions:
+ *   - plain device pointers + explicit sizes/strides (element units) + hipStream_t; no torch types;
+ *   - bf16 tensors are raw uint16 bit patterns; "ld*" are row strides in ELEMENTS;
+ *   - return 0 on success, <0 on error (bagel_hip_last_error() gives the thread-local message);
+ *   - ops never allocate, never synchronise, hold no global mutable state; async on `stream`.
+ */
+#ifndef BAGEL_HIP_H
+#define BAGEL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* bagel_stream_t; /* == hipStream_t */
+
+int bagel_hip_version(void);
+const char* bagel_hip_last_error(void);
+const char* bagel_hip_arch(void);
+
+/* epilogues of bagel_gemm_bf16 */
+#define BAGEL_EPI_NONE 0       /* C = bf16(A W^T + bias)                                              */
+#define BAGEL_EPI_GELU_TANH 1  /* C = bf16(gelu_tanh(bf16(A W^T + bias)))   siglip_navit.py:257, modeling_utils.py:122 */
+#define BAGEL_EPI_SILU 2       /* C = bf16(silu(bf16(...)))                 modeling_utils.py:82 (TimestepEmbedder)    */
+#define BAGEL_EPI_SWIGLU16 3   /* W rows interleaved [16 gate | 16 up]...;  C[:, N/2] = bf16(bf16(silu(g)) * u)       */
+                               /*                                           modeling_qwen2.py:201 (Qwen2MLP)           */
+
+/* C[M,N] = A[M,K] W[N,K]^T (+bias)(act)(+R), bf16 in/out, fp32 MFMA accumulate.  Up to two row groups, each with
+ * its own weights/bias and optional gather (a_rows) / scatter (c_rows, also used for R) index lists: the MoT
+ * expert routing of qwen2_navit.py:526-548,593-594,812-820 without gather/scatter kernels.
+ * Replaces F.linear at qwen2_navit.py:515-517,529-536,591-594; modeling_qwen2.py:200-201; bagel.py:803,832,978;
+ * modeling_utils.py:107-110,120-124; siglip_navit.py:190,216-218,243,256-258.
+ * variant: 0 = 128x128 tile/256 threads, 1 = 256x256/512, 2 = 256x128/256.  K % 8 == 0, N % 8 == 0. */
+int bagel_gemm_bf16(const void* A, int64_t lda,
+                    const void* W0, const void* bias0, const int32_t* a_rows0, const int32_t* c_rows0, int32_t M0,
+                    const void* W1, const void* bias1, const int32_t* a_rows1, const int32_t* c_rows1, int32_t M1,
+                    int64_t ldw, const void* R, int64_t ldr, void* C, int64_t ldc,
+                    int32_t N, int32_t K, int32_t epilogue, int32_t variant, bagel_stream_t stream);
+
+/* Qwen2RMSNorm (modeling_qwen2.py:54-59); expert_of_row (nullable) selects w1 for rows flagged 1
+ * (input_layernorm_moe_gen etc., qwen2_navit.py:784-787,812-815,1079-1082). */
+int bagel_rmsnorm_bf16(const void* x, int64_t ldx, const void* w0, const void* w1, const int32_t* expert_of_row,
+                       void* y, int64_t ldy, int32_t rows, int32_t cols, float eps, bagel_stream_t stream);
+
+/* nn.LayerNorm with affine (siglip_navit.py:266-269,342). */
+int bagel_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,
+                         int32_t rows, int32_t cols, float eps, bagel_stream_t stream);
+
+/* Qwen2RotaryEmbedding.forward (modeling_qwen2.py:130-150): cos/sin(pos * inv_freq) rounded to bf16, [rows, half]. */
+int bagel_rope_table(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out,
+                     int32_t rows, int32_t half_dim, bagel_stream_t stream);
+
+/* q_norm/k_norm + apply_rotary_pos_emb + bf16 casts of PackedAttentionMoT.forward_inference
+ * (qwen2_navit.py:518-557), in place on the fused [q|k|v] projection rows. gen_mode selects the fp32 pipeline. */
+int bagel_qknorm_rope_bf16(void* qkv, int64_t ld, const void* cos_tab, const void* sin_tab, const void* q_w0,
+                           const void* k_w0, const void* q_w1, const void* k_w1, const int32_t* expert_of_row,
+                           int32_t rows, int32_t nq, int32_t nkv, int32_t head_dim, int32_t head_dim_padded,
+                           float eps, int32_t gen_mode, int32_t use_norm, bagel_stream_t stream);
+
+/* flash_attn_varlen_func replacement (qwen2_navit.py:579-588 / 361-370, siglip_navit.py:232-241).
+ * Keys/values of sample b = [context rows cu_ctx[b]:cu_ctx[b+1] of (k_ctx, vt_ctx)] ++ [new rows cu_q[b]:cu_q[b+1] of
+ * (k_new, vt_new)]  -- the merged layout of qwen2_navit.py:563-570 without the copy.  V is passed transposed:
+ * vt[(g*head_dim + d) * ldvt + col_start[b] + key].  causal = bottom-right aligned (flash-attn >= 2.1). */
+int bagel_attn_varlen_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
+                           int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx, int64_t ldvt_ctx,
+                           void* out, int64_t ldo, const int32_t* cu_q, const int32_t* cu_ctx,
+                           const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t max_lq,
+                           int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale,
+                           bagel_stream_t stream);
+
+/* V[rows][nkv][D] -> V^T[nkv][D][cols] per sample (layout consumed by bagel_attn_varlen_bf16). */
+int bagel_v_transpose_bf16(const void* v, int64_t ld_src, void* vt, int64_t ld_dst, const int32_t* cu_rows,
+                           const int32_t* col_start, int32_t batch, int32_t max_len, int32_t nkv, int32_t head_dim,
+                           bagel_stream_t stream);
+
+/* Row gather/scatter copy: embed_tokens (bagel.py:277,377,508,796), KV-cache merge/append (qwen2_navit.py:563-570). */
+int bagel_copy_rows_bf16(const void* src, int64_t ld_src, const int32_t* src_rows, void* dst, int64_t ld_dst,
+                         const int32_t* dst_rows, int32_t n, int32_t cols, bagel_stream_t stream);
+
+/* fp32 -> bf16 with strides; dst columns [cols, cols_padded) are zero-filled (autocast input cast, bagel.py:803). */
+int bagel_f32_to_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t rows, int32_t cols,
+                      int32_t cols_padded, bagel_stream_t stream);
+
+/* TimestepEmbedder.timestep_embedding for one t (modeling_utils.py:88-104). */
+int bagel_timestep_sinusoid(float t, const float* freqs, void* out, int32_t half, bagel_stream_t stream);
+
+/* seq[rows[i]] = bf16(bf16(seq[rows[i]] + temb) + pos_table[pos_ids[i]])   (bagel.py:523,803-806). */
+int bagel_flow_add_bf16(void* seq, int64_t ld, const int32_t* rows, const void* temb, const void* pos_table,
+                        int64_t ld_pos, const int64_t* pos_ids, int32_t n, int32_t cols, bagel_stream_t stream);
+
+/* x[i] = bf16(x[i] + table[ids[i]])   (siglip_navit.py:192; bagel.py:391-392). */
+int bagel_add_table_rows_bf16(void* x, int64_t ld, const void* table, int64_t ld_table, const int64_t* ids, int32_t n,
+                              int32_t cols, bagel_stream_t stream);
+
+/* CFG combine + renorm (bagel.py:873-905).  mode 0 global / 1 channel / 2 text_channel.  Stage 1 writes the
+ * (un)scaled velocity to tmp and, for mode 0, per-block partial sums; stage 2 applies the global scale (mode 0)
+ * and the Euler update x_t -= bf16(v_t * dt) (bagel.py:746). */
+int bagel_cfg_stage1(const void* v, const void* v_cfg_text, const void* v_cfg_img, void* tmp, float* partials,
+                     int32_t max_partials, int32_t n_rows, int32_t cols, float text_scale, float img_scale,
+                     float renorm_min, int32_t mode, int32_t* nparts_out, bagel_stream_t stream);
+int bagel_cfg_stage2_euler(float* x_t, const void* v_or_tmp, const float* partials, int32_t nparts, float renorm_min,
+                           float dt, int64_t n_elems, int32_t use_global_scale, bagel_stream_t stream);
+
+/* torch.argmax(logits, -1) (bagel.py:984). */
+int bagel_argmax_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows, int32_t cols, bagel_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

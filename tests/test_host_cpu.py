@@ -1,0 +1,101 @@
+"""CPU-only checks of the product's host logic: C-ABI exports, state-dict compatibility, bit-exact packers."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from bagel_amd import _lib
+from bagel_amd.factory import build_bagel
+from oracle import packers as P
+from oracle.configs import TINY, TINY_D128, NEW_TOKEN_IDS_TINY, StubTokenizer
+from oracle.shapes import bagel_shapes, vae_shapes
+
+
+def test_library_exports_every_declared_symbol():
+    protos = _lib.parse_header()
+    assert len(protos) >= 15
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m bagel_amd.build` (done by __graft_entry__.build())"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(L, name), f"{name} declared in include/bagel_hip.h but not exported"
+    L.bagel_hip_version.restype = ctypes.c_int
+    assert L.bagel_hip_version() >= 100
+    L.bagel_hip_arch.restype = ctypes.c_char_p
+    assert L.bagel_hip_arch() == b"gfx950"
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host before any launch (no GPU needed)."""
+    L = _lib.lib()
+    rc = L.bagel_gemm_bf16(None, 0, None, None, None, None, 0, None, None, None, None, 0, 0, None, 0, None, 0, 8, 64, 0, 0, None)
+    assert rc < 0 and b"null" in L.bagel_hip_last_error()
+    rc = L.bagel_rmsnorm_bf16(1, 8, 1, None, None, 1, 8, 4, 7, 1e-6, None)
+    assert rc < 0 and b"multiples of 8" in L.bagel_hip_last_error()
+
+
+def test_no_cpu_fallback():
+    from bagel_amd import ops
+    with pytest.raises(_lib.BagelHipError):
+        ops.rmsnorm(torch.zeros(4, 8, dtype=torch.bfloat16), torch.ones(8, dtype=torch.bfloat16),
+                    torch.zeros(4, 8, dtype=torch.bfloat16), 1e-6)
+
+
+@pytest.mark.parametrize("cfg", [TINY, TINY_D128], ids=lambda c: c["name"])
+def test_state_dict_keys_and_shapes(cfg):
+    model, vae = build_bagel(cfg, device="cpu")
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == bagel_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in vae.state_dict().items()} == vae_shapes(cfg["vae"])
+
+
+def _eq(a, b):
+    assert set(a) == set(b), set(a) ^ set(b)
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+
+
+def test_packers_bit_exact(golden):
+    cfg = TINY
+    model, _ = build_bagel(cfg, device="cpu")
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ids = NEW_TOKEN_IDS_TINY
+    ds, pdim = 16, 64
+    g = golden("tiny_t2i")
+    for kv, rope, prompts in (([0, 0], [0, 0], g["prompts"]), ([5, 0, 9], [3, 0, 2], ["x", "hello world", ""])):
+        a = model.prepare_prompts(kv, rope, prompts, tok, ids)
+        b = P.prepare_prompts(kv, rope, prompts, tok, ids)
+        _eq(a[0], b[0]); assert a[1:] == b[1:]
+    _eq(model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, ids)[0], g["prompt_inputs"])   # vs the reference itself
+    for kv, rope, sizes in ((g["newlens"], g["newrope"], g["image_sizes"]), ([0], [0], [(1024, 1024)]), ([7, 0], [2, 5], [(48, 80), (16, 16)])):
+        torch.manual_seed(42); a = model.prepare_vae_latent(kv, rope, sizes, ids)
+        torch.manual_seed(42); b = P.prepare_vae_latent(kv, rope, sizes, ids, ds, 64, pdim)
+        _eq(a, b)
+        _eq(model.prepare_vae_latent_cfg(kv, rope, sizes), P.prepare_vae_latent_cfg(kv, rope, sizes, ds))
+        _eq(model.prepare_start_tokens(kv, rope, ids), P.prepare_start_tokens(kv, rope, ids))
+    torch.manual_seed(42)
+    _eq(model.prepare_vae_latent(g["newlens"], g["newrope"], g["image_sizes"], ids), g["latent_inputs"])
+    _eq(model.prepare_vae_latent_cfg([0, 0], [0, 0], g["image_sizes"]), g["cfg_inputs"])
+    e = golden("tiny_editund")
+    ident = lambda t: t  # noqa: E731
+    a = model.prepare_vae_images([0], [0], [e["img_vae"]], ident, ids)
+    _eq(a[0], e["vae_inputs"])
+    b = model.prepare_vit_images(a[1], a[2], [e["img_vit"]], ident, ids)
+    _eq(b[0], e["vit_inputs"])
+    assert [a[1], b[1]] == e["lens"][:2] and [a[2], b[2]] == e["ropes"][:2]
+    imgs = [torch.randn(3, 32, 48), torch.randn(3, 64, 16)]
+    _eq(model.prepare_vae_images([3, 1], [1, 4], imgs, ident, ids, timestep=0)[0],
+        P.prepare_vae_images([3, 1], [1, 4], imgs, ident, ids, ds, 64)[0])
+    imgs = [torch.randn(3, 28, 42), torch.randn(3, 14, 14)]
+    _eq(model.prepare_vit_images([3, 1], [1, 4], imgs, ident, ids)[0], P.prepare_vit_images([3, 1], [1, 4], imgs, ident, ids, 14, 10)[0])
+    _eq(model.prepare_start_tokens(e["lens"][2], e["ropes"][2], ids), e["start_inputs"])
+
+
+def test_flow_schedule_matches_reference_schedule():
+    from bagel_amd.modeling.bagel import Bagel
+    from oracle.bagel_oracle import flow_schedule
+    for T, s in ((5, 3.0), (50, 3.0), (24, 1.0)):
+        a, b = Bagel.flow_schedule(T, s), flow_schedule(T, s)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
