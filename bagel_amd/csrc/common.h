@@ -56,4 +56,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return 0.5f * x * (1.0f + tanhf(inner));
 }
 
+// 16 zero bytes a lane can DMA from when its chunk lies outside the operand (K tail, conv padding)
+static __device__ __attribute__((aligned(16), used)) unsigned int bagel_zero16[4] = {0u, 0u, 0u, 0u};
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

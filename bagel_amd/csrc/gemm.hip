@@ -44,9 +44,6 @@ struct GemmParams {
     GemmGroup g[2];
 };
 
-// 16 zero bytes every lane can DMA from when its k-chunk lies beyond K (K % 64 != 0 tail)
-__device__ __attribute__((aligned(16))) unsigned int bagel_zero16[4] = {0u, 0u, 0u, 0u};
-
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     // 16 bytes per lane, LDS destination = wave-uniform base + lane*16.
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -1,0 +1,365 @@
+// FLUX-style VAE kernels for gfx950, fp32 end to end (the reference keeps its VAE in fp32: app.py:48,138,
+// eval/gen/gen_images_mp.py:93).  Activations are NHWC so the contraction dimension (channels) is contiguous.
+//
+//   bagel_conv_gemm_f32     implicit-GEMM convolution / plain GEMM on the exact-fp32 MFMA
+//                           (v_mfma_f32_32x32x2_f32 == an fmaf chain, cdna_hip_programming.md section 3):
+//                           replaces F.conv2d 3x3 / 1x1 (autoencoder.py:76-78,102,114,139,170,221,248), the
+//                           stride-2 downsample with its asymmetric pad (:104-107), nearest-2x upsample + conv
+//                           (:116-118, fused: the loader reads in[(y+dy)>>1][(x+dx)>>1]) and the q k^T / p v
+//                           products of the single-head AttnBlock (:49-62).
+//   bagel_groupnorm_f32     GroupNorm(32, eps 1e-6, affine) (+ swish) (autoencoder.py:43,75,77,169,247)
+//   bagel_softmax_rows_f32  softmax(scale * s) in place
+//   bagel_vae_reparam_f32   DiagonalGaussian sample + latent scale/shift (autoencoder.py:280-287, 315-318)
+//   bagel_vae_unscale_f32   z / scale + shift (autoencoder.py:321)
+#include "common.h"
+
+__device__ __forceinline__ void glds16v(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct ConvParams {
+    const float* in;     // [B, Hin, Win, Cin] (mode 0: [M, K] rows with stride ld_in)
+    const float* w;      // [Cout, taps*Cin]
+    const float* bias;   // [Cout] or null
+    const float* res;    // residual, same layout as out, or null
+    float* out;          // [M, ld_out]
+    long ld_in, ld_w, ld_out;
+    int B, Hin, Win, Cin, Hout, Wout, Cout;
+    int M, K;            // M = B*Hout*Wout, K = taps*Cin
+    int mode;            // 0 rows, 1 conv3 s1 p1, 2 conv3 s2 pad(0,1,0,1), 3 nearest-2x upsample + conv3 s1 p1
+    int tiles_m, tiles_n;
+};
+
+// Tile: 128 (pixels) x 128 (cout) x 32 (k, fp32 = 128-byte rows), 4 waves (2x2), each wave 64x64 = 2x2 blocks of 32x32.
+// Operands are swapped (D = Wfrag * Afrag): a lane owns 4 consecutive cout of one pixel -> 16-byte stores.
+__global__ __launch_bounds__(256) void conv_gemm_f32_kernel(const ConvParams p) {
+    constexpr int BM = 128, BN = 128, A_BYTES = BM * 128, STAGE = (BM + BN) * 128, NW = 4, LA = BM / 8 / NW, LB = BN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;   // consecutive blocks share the A (pixel) panel
+    const int m0 = tm * BM, n0 = tn * BN;
+    const char* zsrc = (const char*)bagel_zero16;
+
+    // per-lane A rows (pixels): decode once
+    int ab[LA], ay[LA], ax[LA], ach[LA];
+    const char* arow[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int j = wave + i * NW;
+        const int row = j * 8 + (lane >> 3);
+        ach[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 4;   // channel offset (fp32 elements) of this lane's 16-byte chunk
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        if (p.mode == 0) {
+            arow[i] = (const char*)(p.in + (long)m * p.ld_in);
+            ab[i] = ay[i] = ax[i] = 0;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            ab[i] = m / hw;
+            const int r2 = m - ab[i] * hw;
+            ay[i] = r2 / p.Wout;
+            ax[i] = r2 - ay[i] * p.Wout;
+            arow[i] = nullptr;
+        }
+    }
+    const char* pb[LB];
+    int bch[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int j = wave + i * NW;
+        const int row = j * 8 + (lane >> 3);
+        bch[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 4;
+        int n = n0 + row;
+        n = n < p.Cout ? n : p.Cout - 1;
+        pb[i] = (const char*)(p.w + (long)n * p.ld_w);
+    }
+
+    const int nk = (p.K + 31) >> 5;
+    auto issue = [&](int stage, int kt) {
+        char* sb = smem + stage * STAGE;
+        const int k0 = kt * 32;
+        int dy = 0, dx = 0, c0 = k0;
+        if (p.mode != 0) {
+            const int tap = k0 / p.Cin;      // Cin % 32 == 0 -> a k-tile never straddles taps
+            c0 = k0 - tap * p.Cin;
+            dy = tap / 3;
+            dx = tap - dy * 3;
+        }
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const char* src;
+            if (p.mode == 0) {
+                src = (k0 + ach[i] < p.K) ? arow[i] + (long)(k0 + ach[i]) * 4 : zsrc;
+            } else {
+                int yy, xx;
+                bool ok;
+                if (p.mode == 1) { yy = ay[i] + dy - 1; xx = ax[i] + dx - 1; ok = yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win; }
+                else if (p.mode == 2) { yy = 2 * ay[i] + dy; xx = 2 * ax[i] + dx; ok = yy < p.Hin && xx < p.Win; }
+                else { yy = ay[i] + dy - 1; xx = ax[i] + dx - 1; ok = yy >= 0 && yy < p.Hout && xx >= 0 && xx < p.Wout; yy >>= 1; xx >>= 1; }
+                src = ok ? (const char*)(p.in + (((long)ab[i] * p.Hin + yy) * p.Win + xx) * p.Cin + c0 + ach[i]) : zsrc;
+            }
+            glds16v(src, sb + (wave + i * NW) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            glds16v((k0 + bch[i] < p.K) ? pb[i] + (long)(k0 + bch[i]) * 4 : zsrc, sb + A_BYTES + (wave + i * NW) * 1024);
+    };
+
+    // fragment reads: lane -> row (lane&31) of a 32-row block, 16-byte chunk 2*s + (lane>>5), s = 0..3
+    const int fr = lane & 31, hi = lane >> 5;
+    const int sw = (fr >> 1) & 7;
+    const int a_off = (wm * 64 + fr) * 128;
+    const int b_off = A_BYTES + (wn * 64 + fr) * 128;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nk) {
+            issue(st ^ 1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        const char* sb = smem + st * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ch = (2 * s + hi) ^ sw;
+            f32x4_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const f32x4_t*)(sb + a_off + i * 4096 + ch * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *(const f32x4_t*)(sb + b_off + j * 4096 + ch * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // epilogue: D row = cout (8*(r>>2) + 4*hi + (r&3)), D col = pixel (lane&31)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * u + 4 * hi;
+                if (n >= p.Cout) continue;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * u + e];
+                float* dst = p.out + (long)m * p.ld_out + n;
+                if (n + 3 < p.Cout) {
+                    if (p.bias) { const f32x4_t b = *(const f32x4_t*)(p.bias + n); o[0] += b[0]; o[1] += b[1]; o[2] += b[2]; o[3] += b[3]; }
+                    if (p.res) { const f32x4_t r = *(const f32x4_t*)(p.res + (long)m * p.ld_out + n); o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3]; }
+                    *(f32x4_t*)dst = (f32x4_t){o[0], o[1], o[2], o[3]};
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                        float x = o[e];
+                        if (p.bias) x += p.bias[n + e];
+                        if (p.res) x += p.res[(long)m * p.ld_out + n + e];
+                        dst[e] = x;
+                    }
+                }
+            }
+    }
+}
+
+extern "C" int bagel_conv_gemm_f32(const float* in, int64_t ld_in, const float* w, int64_t ld_w, const float* bias,
+                                   const float* residual, float* out, int64_t ld_out, int32_t B, int32_t Hin, int32_t Win,
+                                   int32_t Cin, int32_t Hout, int32_t Wout, int32_t Cout, int32_t mode, hipStream_t stream) {
+    BAGEL_REQUIRE(in && w && out, "conv_gemm: null pointer");
+    BAGEL_REQUIRE(mode >= 0 && mode <= 3, "conv_gemm: bad mode %d", mode);
+    BAGEL_REQUIRE(Cin % 4 == 0 && ld_w % 4 == 0 && ld_out % 4 == 0 && ld_in % 4 == 0, "conv_gemm: channel counts / strides must be multiples of 4");
+    BAGEL_REQUIRE(mode == 0 || Cin % 32 == 0, "conv_gemm: 3x3 modes need Cin %% 32 == 0 (pad the channels), got %d", Cin);
+    ConvParams p;
+    p.in = in; p.w = w; p.bias = bias; p.res = residual; p.out = out;
+    p.ld_in = ld_in; p.ld_w = ld_w; p.ld_out = ld_out;
+    p.B = B; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout; p.Cout = Cout;
+    p.M = B * Hout * Wout;
+    p.K = (mode == 0 ? 1 : 9) * Cin;
+    p.mode = mode;
+    if (p.M <= 0 || Cout <= 0) return BAGEL_OK;
+    p.tiles_m = ceil_div(p.M, 128);
+    p.tiles_n = ceil_div(Cout, 128);
+    constexpr int smem = 2 * 256 * 128;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)conv_gemm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set = true; }
+    hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, stream, p);
+    return bagel_check_launch("conv_gemm_f32_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GroupNorm over NHWC fp32: stats per (image, group) with a shifted two-moment accumulation (pivot = first element of
+// the group, common to every partial -> partials add exactly; no catastrophic cancellation), fixed-order reduction.
+// ---------------------------------------------------------------------------------------------------------
+#define GN_SLICES 64
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, int HW, int C, int G) {
+    const int b = blockIdx.z, g = blockIdx.y, sl = blockIdx.x;
+    const int cpg = C / G;
+    const float* xb = x + (long)b * HW * C + g * cpg;
+    const float pivot = xb[0];
+    const long n = (long)HW * cpg;
+    const long per = (n + GN_SLICES - 1) / GN_SLICES;
+    const long lo = sl * per, hi = min(n, lo + per);
+    float s1 = 0.f, s2 = 0.f;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const long pix = i / cpg;
+        const int c = (int)(i - pix * cpg);
+        const float d = xb[pix * C + c] - pivot;
+        s1 += d; s2 += d * d;
+    }
+    __shared__ float r1[256], r2[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float* o = partial + (((long)b * G + g) * GN_SLICES + sl) * 2;
+        o[0] = r1[0]; o[1] = r2[0];
+    }
+}
+
+// (mean, rstd) per (image, group) from the slice partials, fixed order.
+__global__ void gn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial, float* __restrict__ stats, int HW,
+                                   int C, int G, float eps, int BG) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BG) return;
+    const int b = i / G, g = i - b * G;
+    const int cpg = C / G;
+    const float* pp = partial + (long)i * GN_SLICES * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < GN_SLICES; ++k) { s1 += pp[2 * k]; s2 += pp[2 * k + 1]; }
+    const float n = (float)HW * (float)cpg;
+    const float pivot = x[(long)b * HW * C + g * cpg];
+    const float md = s1 / n;
+    const float var = fmaxf(s2 / n - md * md, 0.f);
+    stats[2 * i] = pivot + md;
+    stats[2 * i + 1] = rsqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int G,
+                                                       int swish) {
+    const int b = blockIdx.y;
+    const int cpg = C / G;
+    const long total4 = (long)HW * C / 4;
+    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * 256) {
+        const long i = i4 * 4;
+        const int c = (int)(i % C);
+        const long off = (long)b * HW * C + i;
+        const f32x4_t v = *(const f32x4_t*)(x + off);
+        f32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            const float mean = stats[2 * (b * G + g)], inv = stats[2 * (b * G + g) + 1];
+            float t = (v[e] - mean) * inv * gamma[c + e] + beta[c + e];
+            if (swish) t = t * (1.0f / (1.0f + __expf(-t)));
+            o[e] = t;
+        }
+        *(f32x4_t*)(y + off) = o;
+    }
+}
+
+extern "C" int bagel_groupnorm_f32(const float* x, float* y, float* partial_ws, const float* gamma, const float* beta, int32_t B,
+                                   int32_t HW, int32_t C, int32_t groups, float eps, int32_t swish, hipStream_t stream) {
+    BAGEL_REQUIRE(x && y && partial_ws && gamma && beta, "groupnorm: null pointer");
+    BAGEL_REQUIRE(C % groups == 0 && C % 4 == 0, "groupnorm: C=%d must divide into %d groups and be a multiple of 4", C, groups);
+    if (B <= 0 || HW <= 0) return BAGEL_OK;
+    // workspace: [B*G*GN_SLICES*2] partials followed by [B*G*2] stats
+    float* stats = partial_ws + (long)B * groups * GN_SLICES * 2;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(GN_SLICES, groups, B), dim3(256), 0, stream, x, partial_ws, HW, C, groups);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(B * groups, 64)), dim3(64), 0, stream, x, partial_ws, stats, HW, C, groups, eps, B * groups);
+    const long total4 = (long)HW * C / 4;
+    const int blocks = (int)min((long)ceil_div(total4, 256), 2048L);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, stream, x, y, stats, gamma, beta, HW, C, groups, swish);
+    return bagel_check_launch("groupnorm kernels");
+}
+
+// softmax over rows, in place: x = softmax(scale * x).  One block per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, long ld, int cols, float scale) {
+    float* r = x + (long)blockIdx.x * ld;
+    __shared__ float red[256];
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, r[c]);
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) { const float e = __expf((r[c] - mx) * scale); r[c] = e; sum += e; }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    const float inv = 1.0f / red[0];
+    for (int c = threadIdx.x; c < cols; c += 256) r[c] *= inv;
+}
+
+extern "C" int bagel_softmax_rows_f32(float* x, int64_t ld, int32_t rows, int32_t cols, float scale, hipStream_t stream) {
+    BAGEL_REQUIRE(x && cols > 0, "softmax_rows: bad arguments");
+    if (rows <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, (long)ld, cols, scale);
+    return bagel_check_launch("softmax_rows_kernel");
+}
+
+// z = scale * ((mean + exp(0.5 * logvar) * noise) - shift); moments NHWC [n_pix, 2*zc] (mean | logvar), noise/out [n_pix, zc]
+__global__ void vae_reparam_kernel(const float* __restrict__ mom, const float* __restrict__ noise, float* __restrict__ z, long n_pix,
+                                   int zc, float scale, float shift) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix * zc) return;
+    const long pix = i / zc;
+    const int c = (int)(i - pix * zc);
+    const float mean = mom[pix * 2 * zc + c], logvar = mom[pix * 2 * zc + zc + c];
+    const float stdv = expf(0.5f * logvar);
+    const float s = mean + stdv * (noise ? noise[i] : 0.f);
+    z[i] = scale * (s - shift);
+}
+
+extern "C" int bagel_vae_reparam_f32(const float* moments, const float* noise, float* z, int64_t n_pix, int32_t z_channels,
+                                     float scale, float shift, hipStream_t stream) {
+    BAGEL_REQUIRE(moments && z, "vae_reparam: null pointer");
+    const long n = n_pix * z_channels;
+    if (n <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(vae_reparam_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, moments, noise, z, (long)n_pix, z_channels, scale, shift);
+    return bagel_check_launch("vae_reparam_kernel");
+}
+
+__global__ void vae_unscale_kernel(const float* __restrict__ z, float* __restrict__ out, long n, float scale, float shift) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = z[i] / scale + shift;
+}
+
+extern "C" int bagel_vae_unscale_f32(const float* z, float* out, int64_t n, float scale, float shift, hipStream_t stream) {
+    BAGEL_REQUIRE(z && out, "vae_unscale: null pointer");
+    if (n <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(vae_unscale_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, z, out, (long)n, scale, shift);
+    return bagel_check_launch("vae_unscale_kernel");
+}

@@ -1,0 +1,158 @@
+"""Execution plan of the FLUX-style VAE on MI355X: NHWC fp32 activations, every conv an implicit GEMM on the exact-fp32
+MFMA, GroupNorm+swish fused, nearest-2x upsample folded into the following conv's loader, ResnetBlock / AttnBlock
+skip adds folded into conv epilogues.  Mirrors Encoder.forward / Decoder.forward of the reference
+(modeling/autoencoder.py:172-193, 250-272) block for block."""
+import torch
+
+from .. import ops
+from .._lib import check, lib
+
+F32 = torch.float32
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+def _pack3(w, cin_pad):
+    """[Cout, Cin, 3, 3] -> [Cout, 9 * cin_pad] tap-major (dy, dx, cin), zero-padded channels."""
+    cout, cin = w.shape[:2]
+    t = w.permute(0, 2, 3, 1)
+    if cin_pad != cin:
+        t = torch.cat([t, t.new_zeros((cout, 3, 3, cin_pad - cin))], 3)
+    return t.reshape(cout, 9 * cin_pad).contiguous()
+
+
+class VaeEngine:
+    def __init__(self, ae):
+        p0 = ae.encoder.conv_in.weight
+        if not p0.is_cuda or p0.dtype != F32:
+            raise ops.BagelHipError("the VAE runs in fp32 on an MI355X (as the reference): call vae.to('cuda') and keep it fp32")
+        self.ae = ae
+        self.dev = p0.device
+        self.P = ae.params
+        self._w = {}
+        self._ws = None
+
+    # -- packed weights, cached by module identity
+    def _conv_w(self, m):
+        w = self._w.get(id(m))
+        if w is None:
+            wt = m.weight.data
+            if wt.shape[-1] == 3:
+                cin_pad = _ceil_to(wt.shape[1], 32)
+                w = (_pack3(wt, cin_pad), cin_pad)
+            else:
+                w = (wt.reshape(wt.shape[0], wt.shape[1]).contiguous(), wt.shape[1])
+            self._w[id(m)] = w
+        return w
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def conv(self, x, m, mode, residual=None, out_hw=None):
+        """x: [B,H,W,C] NHWC fp32 -> [B,Ho,Wo,Cout]."""
+        B, H, W, C = x.shape
+        w, cin = self._conv_w(m)
+        if cin != C:
+            raise ValueError(f"conv expects {cin} (padded) input channels, got {C}")
+        Ho, Wo = (H, W) if mode in (0, 1) else ((H // 2, W // 2) if mode == 2 else (2 * H, 2 * W))
+        cout = w.shape[0]
+        ldo = _ceil_to(cout, 4)          # rows stay 16-byte aligned (conv_out has 3 channels)
+        if residual is not None and (ldo != cout or residual.shape[-1] != cout or not residual.is_contiguous()):
+            raise ValueError("residual must be a contiguous NHWC tensor with Cout % 4 == 0 channels")
+        out = torch.empty((B, Ho, Wo, ldo), dtype=F32, device=x.device)
+        check(lib().bagel_conv_gemm_f32(x.data_ptr(), C, w.data_ptr(), w.shape[1], m.bias.data.data_ptr(),
+                                        None if residual is None else residual.data_ptr(), out.data_ptr(), ldo, B, H, W, C, Ho, Wo,
+                                        cout, mode, self._stream()), "bagel_conv_gemm_f32")
+        return out if ldo == cout else out[..., :cout]
+
+    def gemm_nt(self, a, b):
+        """a:[M,K] b:[N,K] -> a @ b^T  (attention products)."""
+        M, K = a.shape
+        N = b.shape[0]
+        out = torch.empty((M, N), dtype=F32, device=a.device)
+        check(lib().bagel_conv_gemm_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), None, None, out.data_ptr(), N, 1, 1, M, K,
+                                        1, M, N, 0, self._stream()), "bagel_conv_gemm_f32")
+        return out
+
+    def gn(self, x, m, swish):
+        B, H, W, C = x.shape
+        need = B * 32 * (64 * 2 + 2)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=F32, device=x.device)
+        y = torch.empty_like(x)
+        check(lib().bagel_groupnorm_f32(x.data_ptr(), y.data_ptr(), self._ws.data_ptr(), m.weight.data.data_ptr(), m.bias.data.data_ptr(),
+                                        B, H * W, C, 32, 1e-6, int(swish), self._stream()), "bagel_groupnorm_f32")
+        return y
+
+    def res(self, x, m):
+        h = self.conv(self.gn(x, m.norm1, True), m.conv1, 1)
+        skip = self.conv(x, m.nin_shortcut, 0) if hasattr(m, "nin_shortcut") else x
+        return self.conv(self.gn(h, m.norm2, True), m.conv2, 1, residual=skip)
+
+    def attn(self, x, m):
+        B, H, W, C = x.shape
+        h = self.gn(x, m.norm, False)
+        q, k, v = self.conv(h, m.q, 0), self.conv(h, m.k, 0), self.conv(h, m.v, 0)
+        N = H * W
+        o = torch.empty((B, N, C), dtype=F32, device=x.device)
+        for b in range(B):
+            s = self.gemm_nt(q[b].view(N, C), k[b].view(N, C))
+            check(lib().bagel_softmax_rows_f32(s.data_ptr(), s.stride(0), N, N, float(C) ** -0.5, self._stream()), "bagel_softmax_rows_f32")
+            vt = v[b].view(N, C).t().contiguous()          # layout copy only
+            o[b] = self.gemm_nt(s, vt)
+        return self.conv(o.view(B, H, W, C), m.proj_out, 0, residual=x)
+
+    @staticmethod
+    def to_nhwc(x, cpad):
+        B, C, H, W = x.shape
+        out = torch.zeros((B, H, W, cpad), dtype=F32, device=x.device)
+        out[..., :C] = x.permute(0, 2, 3, 1)
+        return out
+
+    # -- public
+    def encode(self, x, sample_noise=None):
+        P, ae = self.P, self.ae
+        x = x.to(device=self.dev, dtype=F32)
+        B = x.shape[0]
+        e = ae.encoder
+        h = self.conv(self.to_nhwc(x, _ceil_to(x.shape[1], 32)), e.conv_in, 1)
+        nres = len(P.ch_mult)
+        for lvl in range(nres):
+            for blk in e.down[lvl].block:
+                h = self.res(h, blk)
+            if lvl != nres - 1:
+                h = self.conv(h, e.down[lvl].downsample.conv, 2)
+        h = self.res(h, e.mid.block_1)
+        h = self.attn(h, e.mid.attn_1)
+        h = self.res(h, e.mid.block_2)
+        mom = self.conv(self.gn(h, e.norm_out, True), e.conv_out, 1)          # [B,h,w,2z]
+        _, hh, ww, _ = mom.shape
+        zc = P.z_channels
+        if sample_noise is None:
+            sample_noise = torch.randn(B, zc, hh, ww)     # host generator: same draw as the reference's randn_like on CPU
+        noise = sample_noise.to(device=self.dev, dtype=F32).permute(0, 2, 3, 1).contiguous()
+        z = torch.empty((B, hh, ww, zc), dtype=F32, device=self.dev)
+        check(lib().bagel_vae_reparam_f32(mom.data_ptr(), noise.data_ptr(), z.data_ptr(), B * hh * ww, zc, float(P.scale_factor),
+                                          float(P.shift_factor), self._stream()), "bagel_vae_reparam_f32")
+        return z.permute(0, 3, 1, 2).contiguous()
+
+    def decode(self, z):
+        P, ae = self.P, self.ae
+        z = z.to(device=self.dev, dtype=F32).contiguous()
+        zz = torch.empty_like(z)
+        check(lib().bagel_vae_unscale_f32(z.data_ptr(), zz.data_ptr(), z.numel(), float(P.scale_factor), float(P.shift_factor),
+                                          self._stream()), "bagel_vae_unscale_f32")
+        d = ae.decoder
+        h = self.conv(self.to_nhwc(zz, _ceil_to(zz.shape[1], 32)), d.conv_in, 1)
+        h = self.res(h, d.mid.block_1)
+        h = self.attn(h, d.mid.attn_1)
+        h = self.res(h, d.mid.block_2)
+        for lvl in reversed(range(len(P.ch_mult))):
+            for blk in d.up[lvl].block:
+                h = self.res(h, blk)
+            if lvl != 0:
+                h = self.conv(h, d.up[lvl].upsample.conv, 3)
+        h = self.conv(self.gn(h, d.norm_out, True), d.conv_out, 1)            # [B,H,W,3]
+        return h.permute(0, 3, 1, 2).contiguous()

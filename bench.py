@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""bench.py -- BAGEL-7B-MoT text->image throughput on MI355X (BASELINE.json metric: images/sec, 1024^2, 50-step).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one complete pass of the hot path over one batch of synthetic input on every rank:
+  text prefill of the (shared) prompt -> [rank 0 computes, RCCL-broadcasts the conditioning KV] -> prepare_vae_latent ->
+  generate_image (T=50 -> 49 Euler steps x [cond + CFG-text] forwards of the 28-layer MoT backbone at 4098 tokens/sample)
+  -> VAE decode of every latent to a uint8 image.  Per-rank batch is fixed (weak scaling; config 3 = 4 samples/GPU,
+  config 4 = the same over 8 GPUs).  Weights are random-init bf16 of the BAGEL-7B-MoT architecture (no checkpoint
+  offline), inputs synthetic but resident in HBM before the timed region starts.
+
+Prints ONE JSON line (rank 0) with the contract's fields plus:
+  roofline      achieved MFMA TFLOP/s of the dominant kernel (gemm_tn_kernel): algorithmic 2*M*N*K FLOPs of every launch
+                in the timed region / their HIP-event durations (events on the launch stream), vs the 2.5 PFLOP/s bf16 peak;
+  cpu_baseline  the oracle (CPU restatement of the reference) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md:42
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="samples per GPU (config 3: 4)")
+    ap.add_argument("--resolution", type=int, default=1024)
+    ap.add_argument("--num-timesteps", type=int, default=50)
+    ap.add_argument("--prompt-tokens", type=int, default=30)
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer LLM layers (result flagged invalid)")
+    ap.add_argument("--no-vae", action="store_true", help="debug only: skip the VAE decode (result flagged invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-layers", type=int, default=1)
+    return ap.parse_args()
+
+
+class FixedTokenizer:
+    """The prompt is a fixed list of token ids (no vocabulary files offline)."""
+
+    def __init__(self, ids):
+        self.ids = ids
+
+    def encode(self, s):
+        return list(self.ids)
+
+
+def gemm_profile_hook():
+    """Wrap ops.gemm so every launch in the timed region is bracketed by HIP events on its own stream."""
+    from bagel_amd import ops
+    records = []
+    orig = ops.gemm
+
+    def timed(A, W0, C, **kw):
+        M = (kw.get("M0") if kw.get("M0") is not None else (kw["a_rows0"].numel() if kw.get("a_rows0") is not None else A.shape[0])) + kw.get("M1", 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(A, W0, C, **kw)
+        e1.record()
+        records.append((2.0 * M * W0.shape[0] * W0.shape[1], e0, e1))
+        return out
+    return records, orig, timed
+
+
+def cpu_baseline(args, cfg):
+    """Oracle MoT layer(s) at 7B shapes, one 1024^2 sample (4098 query tokens on a 32-token context), gen mode, on the
+    host cores; extrapolated to images/s as 1 / (steps * forwards * layers * t_layer)."""
+    from oracle import bagel_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    llm = cfg["llm"]
+    H, I, nh, nkv = llm["hidden_size"], llm["intermediate_size"], llm["num_attention_heads"], llm["num_key_value_heads"]
+    hd = H // nh
+    g = torch.Generator().manual_seed(0)
+    W = {}
+    nl = args.cpu_layers
+    for li in range(nl):
+        p = f"language_model.model.layers.{li}."
+        for suf in ("", "_moe_gen"):
+            for n, shp in (("q_proj", (nh * hd, H)), ("k_proj", (nkv * hd, H)), ("v_proj", (nkv * hd, H)), ("o_proj", (H, nh * hd))):
+                W[p + f"self_attn.{n}{suf}.weight"] = (torch.randn(shp, generator=g) * shp[1] ** -0.5).to(torch.bfloat16)
+                if n != "o_proj":
+                    W[p + f"self_attn.{n}{suf}.bias"] = (torch.randn(shp[0], generator=g) * 0.02).to(torch.bfloat16)
+            for n in ("q_norm", "k_norm"):
+                W[p + f"self_attn.{n}{suf}.weight"] = torch.ones(hd, dtype=torch.bfloat16)
+            for n, shp in (("gate_proj", (I, H)), ("up_proj", (I, H)), ("down_proj", (H, I))):
+                W[p + f"mlp{suf}.{n}.weight"] = (torch.randn(shp, generator=g) * shp[1] ** -0.5).to(torch.bfloat16)
+            for n in ("input_layernorm", "post_attention_layernorm"):
+                W[p + f"{n}{suf}.weight"] = torch.ones(H, dtype=torch.bfloat16)
+    n_img = (args.resolution // 16) ** 2
+    Lq, C = n_img + 2, args.prompt_tokens + 2
+    x = torch.randn(Lq, H, generator=g).to(torch.bfloat16)
+    cache = O.OracleCache(nl)
+    for li in range(nl):
+        cache.key_cache[li] = torch.randn(C, nkv, hd, generator=g).to(torch.bfloat16)
+        cache.value_cache[li] = torch.randn(C, nkv, hd, generator=g).to(torch.bfloat16)
+    text_idx = torch.tensor([0, Lq - 1])
+    vae_idx = torch.arange(1, Lq - 1)
+    cos_sin = O.rope_tables(torch.full((Lq,), C, dtype=torch.long), hd, llm["rope_theta"], torch.bfloat16)
+    qlens, kvlens = torch.tensor([Lq], dtype=torch.int), torch.tensor([C], dtype=torch.int)
+    q_idx, kv_idx = torch.arange(C, C + Lq), torch.arange(C)
+    t0 = time.time()
+    for li in range(nl):
+        x = O.mot_layer(W, llm, li, x, qlens, cos_sin, q_idx, cache, kvlens, kv_idx, False, False, "gen", vae_idx, text_idx)
+    dt = (time.time() - t0) / nl
+    steps = args.num_timesteps - 1
+    sec_per_image = steps * 2 * llm["num_hidden_layers"] * dt
+    return dict(value=1.0 / sec_per_image, unit="images/s", cores=os.cpu_count(), kind="port",
+                sample=f"oracle MoT decoder layer (gen mode, {Lq} query tokens on a {C}-token context, 7B shapes) x{nl}, "
+                       f"{dt:.2f} s/layer-forward on {os.cpu_count()} threads; extrapolated x{llm['num_hidden_layers']} layers "
+                       f"x2 forwards x{steps} Euler steps (glue, prefill and VAE excluded)")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bagel_amd import ops
+    from bagel_amd.factory import BAGEL_7B_MOT, NEW_TOKEN_IDS_QWEN25, build_bagel, init_random_
+    from bagel_amd.inferencer import InterleaveInferencer
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    from bagel_amd.parallel import broadcast_cache
+
+    cfg = BAGEL_7B_MOT
+    model, vae = build_bagel(cfg, device=dev, num_layers=args.layers)
+    init_random_(model, seed=0)
+    init_random_(vae, seed=0)
+    model.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device=dev).manual_seed(1))
+    L = model.config.llm_config.num_hidden_layers
+    B, R, T = args.batch, args.resolution, args.num_timesteps
+    g = torch.Generator().manual_seed(1)
+    prompt_ids = torch.randint(0, 151643, (args.prompt_tokens,), generator=g).tolist()
+    tok = FixedTokenizer(prompt_ids)
+    ids = NEW_TOKEN_IDS_QWEN25
+    inf = InterleaveInferencer(model, vae, tok, None, None, ids)
+    noise_gen = torch.Generator().manual_seed(42)
+    pdim = model.patch_latent_dim
+    n_img = (R // model.latent_downsample) ** 2
+    # global noise stream of the whole job; rank r takes rows [r*B, (r+1)*B)
+    all_noise = torch.randn(world * B * n_img, pdim, generator=noise_gen)
+    my_noise = all_noise[rank * B * n_img:(rank + 1) * B * n_img].to(dev)
+
+    def one_step():
+        # conditioning context: computed once (rank 0) and broadcast; every sample shares the prompt (gen_images_mp.py:43)
+        gi, newlens, newrope = model.prepare_prompts([0] * B, [0] * B, ["p"] * B, tok, ids)
+        if rank == 0:
+            cache = model.forward_cache_update_text(NaiveCache(L), **gi)
+        else:
+            cache = NaiveCache(L)
+        if world > 1:
+            cache = broadcast_cache(cache, src=0)
+        li = model.prepare_vae_latent(newlens, newrope, [(R, R)] * B, ids)
+        li["packed_init_noises"] = my_noise
+        ci = model.prepare_vae_latent_cfg([0] * B, [0] * B, [(R, R)] * B)
+        latents = model.generate_image(
+            past_key_values=cache, num_timesteps=T, cfg_text_scale=4.0, cfg_interval=[0, 1.0], cfg_renorm_min=0.0,
+            cfg_renorm_type="global", timestep_shift=3.0, cfg_text_past_key_values=NaiveCache(L),
+            cfg_text_packed_position_ids=ci["cfg_packed_position_ids"], cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=ci["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"], **li)
+        imgs = []
+        if not args.no_vae:
+            for lat in latents:
+                img = vae.decode(inf.latent_to_chw(lat, (R, R)))
+                imgs.append(((img * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8))
+        return latents, imgs
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    records, orig_gemm, timed_gemm = gemm_profile_hook()
+    ops.gemm = timed_gemm
+    import bagel_amd.modeling.bagel.qwen2_navit as qn
+    import bagel_amd.modeling.bagel.bagel as bg
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        latents, imgs = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.gemm = orig_gemm
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    finite = all(torch.isfinite(x).all().item() for x in latents)
+
+    if rank == 0:
+        flops = sum(r[0] for r in records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in records)
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        images = world * B * args.steps
+        out = {
+            "metric": "images/sec (1024^2, 50-step) + understanding tokens/sec, 7B-MoT, 1/2/4/8 GPU",
+            "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (random-init BAGEL-7B-MoT weights, random prompt ids, seed-42 CPU noise)",
+            "config": {"workload": f"BAGEL-7B-MoT text->image {R}x{R}, {T} timesteps ({T - 1} Euler steps x [cond + CFG-text 4.0]), "
+                                   f"global renorm, timestep_shift 3, prompt {args.prompt_tokens}+2 tokens, {B} samples/GPU, VAE decode included",
+                       "global_batch": world * B, "query_tokens_per_sample": n_img + 2, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                         "traffic": None, "kernel": "gemm_tn_kernel<128,128,2,2>", "launches": len(records),
+                         "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},
+            "outputs_finite": bool(finite),
+        }
+        if args.layers is not None or args.no_vae or R != 1024 or T != 50:
+            out["valid"] = False
+            out["note"] = "debug flags reduce the workload: not a benchmark number"
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, cfg)
+            except Exception as e:   # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,31 @@ int bagel_cfg_stage2_euler(float* x_t, const void* v_or_tmp, const float* partia
 /* torch.argmax(logits, -1) (bagel.py:984). */
 int bagel_argmax_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows, int32_t cols, bagel_stream_t stream);
 
+/* ---- VAE (fp32, NHWC) ------------------------------------------------------------------------------------- */
+/* Implicit-GEMM convolution / plain GEMM on the exact-fp32 MFMA.  mode 0: out[M,Cout] = in[M,Cin] w[Cout,Cin]^T
+ * (1x1 conv, attention products; M = B*Hout*Wout); 1: 3x3 stride 1 pad 1; 2: 3x3 stride 2 with the (0,1,0,1) pad of
+ * autoencoder.py:104-107; 3: nearest-2x upsample fused with the following 3x3 conv (autoencoder.py:116-118).
+ * w is [Cout, taps*Cin] (tap-major), +bias, +residual (ResnetBlock / AttnBlock skip adds, autoencoder.py:65,95).
+ * Replaces F.conv2d at autoencoder.py:76-78,102,114,139,170,221,248 and the SDPA matmuls at :60. */
+int bagel_conv_gemm_f32(const float* in, int64_t ld_in, const float* w, int64_t ld_w, const float* bias,
+                        const float* residual, float* out, int64_t ld_out, int32_t B, int32_t Hin, int32_t Win,
+                        int32_t Cin, int32_t Hout, int32_t Wout, int32_t Cout, int32_t mode, bagel_stream_t stream);
+
+/* GroupNorm(groups, eps, affine) (+swish) over NHWC fp32 (autoencoder.py:43,75,77,169,247; swish :34-35).
+ * partial_ws: B*groups*(64*2 + 2) floats. */
+int bagel_groupnorm_f32(const float* x, float* y, float* partial_ws, const float* gamma, const float* beta, int32_t B,
+                        int32_t HW, int32_t C, int32_t groups, float eps, int32_t swish, bagel_stream_t stream);
+
+/* x = softmax(scale * x) over rows, in place (single-head AttnBlock, autoencoder.py:60). */
+int bagel_softmax_rows_f32(float* x, int64_t ld, int32_t rows, int32_t cols, float scale, bagel_stream_t stream);
+
+/* z = scale * ((mean + exp(0.5 logvar) * noise) - shift)  (autoencoder.py:280-287,315-318); moments [n_pix, 2*zc]. */
+int bagel_vae_reparam_f32(const float* moments, const float* noise, float* z, int64_t n_pix, int32_t z_channels,
+                          float scale, float shift, bagel_stream_t stream);
+
+/* out = z / scale + shift (autoencoder.py:321). */
+int bagel_vae_unscale_f32(const float* z, float* out, int64_t n, float scale, float shift, bagel_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

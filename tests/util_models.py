@@ -25,3 +25,20 @@ def _weights(name):
 def oracle_weights(cfg):
     """(W, VW): bf16 Bagel weights and fp32 VAE weights, as the golden generator built them."""
     return _weights(cfg["name"])
+
+
+@functools.lru_cache(maxsize=2)
+def _product(name):
+    from oracle import configs
+    from bagel_amd.factory import build_bagel
+    cfg = {"tiny": configs.TINY, "tiny_d128": configs.TINY_D128}[name]
+    W, VW = _weights(name)
+    model, vae = build_bagel(cfg, device="cuda")
+    missing, unexpected = model.load_state_dict(W, strict=True), None
+    vae.load_state_dict(VW, strict=True)
+    return model, vae
+
+
+def product_model(cfg):
+    """(Bagel, AutoEncoder) on cuda:0 carrying exactly the oracle's synthetic weights."""
+    return _product(cfg["name"])
