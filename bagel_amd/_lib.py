@@ -61,7 +61,18 @@ def lib():
     return _lib
 
 
+_DEBUG_SYNC = bool(os.environ.get("BAGEL_DEBUG_SYNC"))
+
+
 def check(code, what=""):
     if code != 0:
         msg = lib().bagel_hip_last_error().decode()
         raise BagelHipError(f"{what} failed ({code}): {msg}")
+    if _DEBUG_SYNC:   # debugging aid: localise an asynchronous kernel fault to the launch that caused it
+        import sys
+        import torch
+        sys.stderr.write(f"[bagel_amd] {what} ...")
+        sys.stderr.flush()
+        torch.cuda.synchronize()
+        sys.stderr.write(" ok\n")
+        sys.stderr.flush()

@@ -28,7 +28,11 @@ class PositionEmbedding(nn.Module):
         super().__init__()
         self.max_num_patch_per_side = max_num_patch_per_side
         self.hidden_size = hidden_size
-        self.pos_embed = nn.Parameter(sincos_table_2d(hidden_size, max_num_patch_per_side), requires_grad=False)
+        table = sincos_table_2d(hidden_size, max_num_patch_per_side)
+        # torch.empty honours the ambient device / default dtype (factory.build_bagel allocates straight on the GPU in
+        # bf16); the fp32 table is rounded exactly like the reference's model.to(bf16).
+        self.pos_embed = nn.Parameter(torch.empty(table.shape), requires_grad=False)
+        self.pos_embed.data.copy_(table)
 
 
 class _Lin(nn.Module):

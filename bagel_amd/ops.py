@@ -16,7 +16,13 @@ RENORM_MODES = {"global": 0, "channel": 1, "text_channel": 2}
 
 
 def _ptr(t):
-    return None if t is None else t.data_ptr()
+    """Device address of ``t`` (None -> NULL).  Every pointer handed to the C ABI goes through here, so a host tensor
+    can never reach a kernel."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BagelHipError(f"expected a GPU tensor, got {t.device} {tuple(t.shape)} {t.dtype} (bagel_amd has no CPU path)")
+    return t.data_ptr()
 
 
 def _stream():
@@ -151,13 +157,14 @@ def timestep_sinusoid(t, freqs, out):
 
 def flow_add(seq, rows, temb, pos_table, pos_ids):
     _req(seq, BF16, "flow_add.seq"); _req(rows, torch.int32, "flow_add.rows"); _req(pos_ids, torch.int64, "flow_add.pos_ids")
+    _req(temb, BF16, "flow_add.temb"); _req(pos_table, BF16, "flow_add.pos_table")
     check(lib().bagel_flow_add_bf16(_ptr(seq), seq.stride(0), _ptr(rows), _ptr(temb), _ptr(pos_table), pos_table.stride(0),
                                     _ptr(pos_ids), rows.numel(), seq.shape[1], _stream()), "bagel_flow_add_bf16")
     return seq
 
 
 def add_table_rows(x, table, ids):
-    _req(x, BF16, "add_table_rows.x"); _req(ids, torch.int64, "add_table_rows.ids")
+    _req(x, BF16, "add_table_rows.x"); _req(ids, torch.int64, "add_table_rows.ids"); _req(table, BF16, "add_table_rows.table")
     check(lib().bagel_add_table_rows_bf16(_ptr(x), x.stride(0), _ptr(table), table.stride(0), _ptr(ids), x.shape[0],
                                           x.shape[1], _stream()), "bagel_add_table_rows_bf16")
     return x

@@ -122,7 +122,20 @@ def test_vit_text_context_understanding(golden, name):
     toks = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=8, do_sample=False, end_token_id=None,
                                **g["start_inputs"])
     assert toks.shape == g["tokens"].shape and toks.dtype == torch.int64
-    assert torch.equal(toks.cpu(), g["tokens"]), f"greedy tokens differ: {toks.cpu().tolist()} vs {g['tokens'].tolist()}"
+    # Greedy ids must equal the reference's up to the first step whose reference logits hold a NEAR TIE between the two
+    # candidates (random-init weights make those frequent): there, bf16 accumulation-order noise legitimately flips the
+    # argmax, the prefixes diverge and later steps are incomparable.  Near tie := the reference's own logit of our token
+    # is within 2^-6 * max|logit| (two bf16 ulps at the top of the range) of its maximum.
+    ours, ref, ref_logits = toks.cpu(), g["tokens"], g["logits"].float()
+    for s in range(1, ref.shape[0]):
+        if torch.equal(ours[s], ref[s]):
+            continue
+        row = ref_logits[s - 1]          # logits that chose token s, shape (B, V)
+        gap = row.max(-1).values - row.gather(-1, ours[s].view(-1, 1)).squeeze(-1)
+        tol = row.abs().max().item() * 2.0 ** -6
+        assert (gap <= tol).all(), (f"greedy tokens differ at step {s} without a near tie (gap {gap.tolist()} > {tol:.4g}): "
+                                    f"{ours.tolist()} vs {ref.tolist()}")
+        break
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
