@@ -8,16 +8,22 @@
 //   * V is consumed TRANSPOSED ([kv_head][d][key], written once by bagel_v_transpose): the PV product contracts
 //     over keys, so a [d][key] image lets both operands be fetched with conflict-free ds_read_b128.
 //
-// Kernel shape: one workgroup = 4 waves = 128 query rows of one (sample, head); each wave owns 32 rows.
+// Kernel shape: one workgroup = 8 waves (two per SIMD) = 256 query rows of one (sample, head); each wave owns 32 rows.
 //   S^T = K Q^T   with mfma_f32_32x32x16_bf16 (A = K tile from LDS, B = Q fragments held in registers), so every
 //                 lane holds 32 of the 64 scores of ONE query row: the row max / row sum need a single
 //                 cross-lane exchange (lane ^ 32).
-//   O^T = V^T P^T with the SAME instruction: P (bf16) is used straight from the score registers as the B
-//                 operand.  The MFMA row -> key assignment inside each 32-key block is permuted (quads 1<->2 of
-//                 every 16) when K fragments are read, which makes each lane's 8 k-slots 8 CONSECUTIVE keys, so
-//                 the V^T fragment is one ds_read_b128.
-//   K / V^T tiles (64 keys) stream HBM -> LDS by global_load_lds_dwordx4, double buffered, XOR-swizzled on the
-//   source side; counted vmcnt keeps the next tile in flight across the barrier.
+//   O^T = V^T P^T with the SAME instruction: P (bf16, v_cvt_pk_bf16_f32) is used straight from the score registers
+//                 as the B operand.  The MFMA row -> key assignment inside each 32-key block is permuted (quads
+//                 1<->2 of every 16) when K fragments are read, which makes each lane's 8 k-slots 8 CONSECUTIVE
+//                 keys, so the V^T fragment is one ds_read_b128.
+//   K / V^T tiles (64 keys) stream HBM -> LDS by global_load_lds_dwordx4 into a 3-deep ring, XOR-swizzled on the
+//   source side; ONE barrier per tile, counted vmcnt keeps two tiles in flight across it.
+//   Online softmax in base 2 with the scale folded into the exponent's fma; the running max is only raised (and O
+//   rescaled) when some row's tile max exceeds it by more than 2^8 ("deferred max": P <= 256, exact in fp32/bf16
+//   range; the final O/l normalisation makes the result independent of which max was used).
+//   Block order is XCD-aware: the (sample, kv-head) pairs are dealt round-robin to the 8 XCDs (blockIdx % 8), and all
+//   q-heads x q-tiles of one pair run back to back on that XCD, so its K/V (2.1 MB at 4098 keys) stays in the
+//   XCD's 4 MiB L2 while ~119 workgroups stream it.
 #include "common.h"
 
 struct AttnParams {
@@ -32,40 +38,66 @@ struct AttnParams {
     const int* vt_new_col;
     const int* vt_ctx_col;
     int nq, nkv, causal;
+    int batch, nqt;          // samples, 256-row query tiles per sample (from max_lq)
     float scale_log2;
 };
 
-__device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// 16 bytes per lane HBM -> LDS (destination = wave-uniform LDS byte address + lane*16).  Issued from inline asm on
+// purpose: hipcc cannot prove that the ring slot being filled is not the slot being read and would otherwise drain
+// the DMA (s_waitcnt vmcnt(0)) in front of the first ds_read of every tile; completion is tracked by this file's own
+// counted s_waitcnt vmcnt(N) + s_barrier (cdna_hip_programming.md 5.7).  M0 is saved/restored around the instruction.
+__device__ __forceinline__ void glds16a(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_uniform)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
 }
 
+#define ATTN_DEFER_LOG2 8.0f
+
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = D / 16;              // k-steps of the QK^T contraction
     constexpr int DB = D / 32;              // 32-row blocks of O^T
     constexpr int KROW = D * 2;             // bytes per K row in LDS
     constexpr int KT_BYTES = 64 * KROW;
     constexpr int VT_BYTES = D * 128;
     constexpr int STAGE = KT_BYTES + VT_BYTES;
-    constexpr int NLK = KT_BYTES / 1024 / 4;   // glds per wave for K   (4 @128, 2 @64)
-    constexpr int NLV = VT_BYTES / 1024 / 4;   // glds per wave for V^T
+    constexpr int NW = 8;
+    constexpr int NLK = KT_BYTES / 1024 / NW;   // glds per wave for K   (2 @128, 1 @64)
+    constexpr int NLV = VT_BYTES / 1024 / NW;   // glds per wave for V^T
+    constexpr int NL = NLK + NLV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
-    const int g = h / (p.nq / p.nkv);
+
+    // ---- XCD-aware work mapping ----
+    const int grp = p.nq / p.nkv;
+    const int nbpp = grp * p.nqt;                 // workgroups per (sample, kv-head) pair
+    const int npairs = p.batch * p.nkv;
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int pair = (kk / nbpp) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int w = kk % nbpp;
+    const int b = pair / p.nkv, g = pair % p.nkv;
+    const int h = g * grp + w % grp, qt = w / grp;
+
     const int q0 = p.cu_q[b];
     const int Lq = p.cu_q[b + 1] - q0;
-    if (qt * 128 >= Lq) return;
+    if (qt * 256 >= Lq) return;
     const int c0 = p.cu_ctx ? p.cu_ctx[b] : 0;
     const int C = p.cu_ctx ? p.cu_ctx[b + 1] - c0 : 0;
     const int vcol_new = p.vt_new_col[b];
     const int vcol_ctx = C > 0 ? p.vt_ctx_col[b] : 0;
 
     const int qi = lane & 31, hi = lane >> 5;
-    const int qrow = qt * 128 + wave * 32 + qi;            // row inside the sample (may exceed Lq-1: padding row)
+    const int wrow0 = qt * 256 + wave * 32;                // first row of this wave inside the sample
+    const int qrow = wrow0 + qi;                           // may exceed Lq-1: padding row
     const int qrow_c = qrow < Lq ? qrow : Lq - 1;
 
     // ---- Q fragments (B operand): Q[qrow][16*ks + 8*hi .. +8) ----
@@ -78,17 +110,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 
     // ---- tile schedule: ctx tiles then new tiles ----
     const int nt_ctx = (C + 63) >> 6;
-    const int qlast = min(Lq, qt * 128 + 128) - 1;
+    const int qlast = min(Lq, qt * 256 + 256) - 1;
     const int new_needed = p.causal ? (qlast + 1) : Lq;
     const int nt_new = (new_needed + 63) >> 6;
     const int T = nt_ctx + nt_new;
 
-    // ---- per-lane constants for the DMA issue ----
     // K tile: D=128: 256-B rows, instr j -> rows 4j + lane/16, chunk lane%16 ^ (row&15)
     //         D=64 : 128-B rows, instr j -> rows 8j + lane/8 , chunk lane%8  ^ ((row>>1)&7)
     // V^T tile: 128-B rows (64 keys), instr j -> d rows 8j + lane/8, chunk lane%8 ^ ((d>>1)&7)
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto issue = [&](int stage, int t) {
-        char* sb = smem + stage * STAGE;
+        const unsigned sb = smem_base + __builtin_amdgcn_readfirstlane(stage) * STAGE;
         const bool is_ctx = t < nt_ctx;
         const int ti = is_ctx ? t : t - nt_ctx;
         const int seglen = is_ctx ? C : Lq;
@@ -99,20 +131,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         const int vcol = (is_ctx ? vcol_ctx : vcol_new) + ti * 64;
 #pragma unroll
         for (int i = 0; i < NLK; ++i) {
-            const int j = wave + 4 * i;
+            const int j = wave + NW * i;
             int row, gch;
             if (D == 128) { row = 4 * j + (lane >> 4); gch = (lane & 15) ^ (row & 15); }
             else          { row = 8 * j + (lane >> 3); gch = (lane & 7) ^ ((row >> 1) & 7); }
             int key = ti * 64 + row;
             key = key < seglen ? key : seglen - 1;
-            glds16a(kbase + (long)key * ldk + (long)g * D + gch * 8, sb + j * 1024);
+            glds16a(kbase + (long)key * ldk + (long)g * D + gch * 8, sb + j * 1024u);
         }
 #pragma unroll
         for (int i = 0; i < NLV; ++i) {
-            const int j = wave + 4 * i;
+            const int j = wave + NW * i;
             const int d = 8 * j + (lane >> 3);
             const int gch = (lane & 7) ^ ((d >> 1) & 7);
-            glds16a(vbase + ((long)g * D + d) * ldvt + vcol + gch * 8, sb + KT_BYTES + j * 1024);
+            glds16a(vbase + ((long)g * D + d) * ldvt + vcol + gch * 8, sb + KT_BYTES + j * 1024u);
         }
     };
 
@@ -120,110 +152,117 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     // MFMA row i = lane&31 reads key pi(i): swap quads 1<->2 inside each 16
     const int quad = (qi >> 2) & 3;
     const int pkey = (qi & 16) | ((((quad & 1) << 1) | (quad >> 1)) << 2) | (qi & 3);
-    int koff[2];   // byte offset of this lane's K row for key block kb, swizzle folded in for chunk 0
     int kswz;      // XOR mask applied to the chunk index
     if (D == 128) { kswz = pkey & 15; }          // (32*kb + pkey) & 15 == pkey & 15
     else          { kswz = (pkey >> 1) & 7; }    // ((32*kb + pkey) >> 1) & 7
-    koff[0] = pkey * KROW;
-    koff[1] = (32 + pkey) * KROW;
+    const int koff0 = pkey * KROW;
     const int vswz = (qi >> 1) & 7;   // d = 32*db + qi  ->  ((d>>1)&7) == ((qi>>1)&7)
     const int voff = KT_BYTES + qi * 128;
+    // chunk byte offsets, loop invariant
+    int kch[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kch[ks] = koff0 + (((2 * ks + hi) ^ kswz) << 4);
+    int vch[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vch[j] = voff + (((2 * j + hi) ^ vswz) << 4);   // j = 2*kb + c
 
     f32x16_t o[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // m_run in log2 units (already multiplied by scale_log2)
 
     if (T > 0) issue(0, 0);
+    if (T > 1) issue(1, 1);
+    // Make hipcc retire ITS loads (the Q fragments) here: otherwise it places their counted vmcnt waits at the first
+    // use inside the tile loop, where they would also drain this file's in-flight DMA on every iteration.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+    int st = 0;
     for (int t = 0; t < T; ++t) {
-        const int st = t & 1;
-        if (t + 1 < T) {
-            issue(st ^ 1, t + 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLK + NLV) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every wave's DMA of tile t has landed, and every wave is done reading tile t-1 (ring slot (t+2)%3)
         asm volatile("s_barrier" ::: "memory");
+        if (t + 2 < T) issue(st >= 1 ? st - 1 : 2, t + 2);
         const char* sb = smem + st * STAGE;
+        st = st == 2 ? 0 : st + 1;
 
         // ---- S^T = K Q^T ----
         f32x16_t s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            bf16x8_t kf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8_t*)(sb + kb * 32 * KROW + kch[ks]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int ch = (2 * ks + hi) ^ kswz;
-                const bf16x8_t kf = *(const bf16x8_t*)(sb + koff[kb] + ch * 16);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-            }
+            for (int ks = 0; ks < KS; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kb], 0, 0, 0);
         }
 
-        // ---- scale, mask, online softmax ----
+        // ---- mask (tile tails, causal), row max ----
         const bool is_ctx = t < nt_ctx;
         const int ti = is_ctx ? t : t - nt_ctx;
         const int seglen = is_ctx ? C : Lq;
         const int kbase = ti * 64;
-        const bool need_mask = (kbase + 64 > seglen) || (p.causal && !is_ctx && (kbase + 63 > qt * 128 + wave * 32));
-        float mx = -INFINITY;
+        const bool need_mask = (kbase + 64 > seglen) || (p.causal && !is_ctx && (kbase + 63 > wrow0));
+        if (need_mask) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = s[kb][r] * p.scale_log2;
-                if (need_mask) {
+                for (int r = 0; r < 16; ++r) {
                     const int key = kbase + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
                     const bool ok = key < seglen && (!p.causal || is_ctx || key <= qrow);
-                    x = ok ? x : -INFINITY;
+                    s[kb][r] = ok ? s[kb][r] : -INFINITY;
                 }
-                s[kb][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        // m_new is finite for every real query row (its first tile always holds >= 1 visible key);
-        // padding rows are clamped copies of real rows.  Guard anyway so a fully masked tile cannot make NaN.
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_use);
-        m_run = m_new;
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;    // scale > 0: max commutes with it
+        // ---- deferred running max: raise it (and rescale O, l) only when some row outgrew it by > 2^8 ----
+        if (__any(mx > m_run + ATTN_DEFER_LOG2)) {
+            const float m_new = fmaxf(m_run, mx);
+            // a row with no visible key so far keeps m = -inf; use 0 in the exponent so nothing becomes NaN
+            const float alpha = __builtin_amdgcn_exp2f(m_run - (m_new == -INFINITY ? 0.f : m_new));
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        const float m_use = m_run == -INFINITY ? 0.f : m_run;
         float psum = 0.f;
-        bf16x8_t pf[2][2];
+        bf16x8_t pf[4];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                unsigned w[4];
+                unsigned wv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p0 = exp2f(s[kb][8 * c + 2 * e] - m_use);
-                    const float p1 = exp2f(s[kb][8 * c + 2 * e + 1] - m_use);
+                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * c + 2 * e], p.scale_log2, -m_use));
+                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * c + 2 * e + 1], p.scale_log2, -m_use));
                     psum += p0 + p1;
-                    w[e] = pack2bf(p0, p1);
+                    wv[e] = pack2bf(p0, p1);
                 }
-                u32x4_t wv = {w[0], w[1], w[2], w[3]};
-                pf[kb][c] = __builtin_bit_cast(bf16x8_t, wv);
+                u32x4_t v4 = {wv[0], wv[1], wv[2], wv[3]};
+                pf[2 * kb + c] = __builtin_bit_cast(bf16x8_t, v4);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int db = 0; db < DB; ++db) {
+            bf16x8_t vf[4];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int j = 0; j < 4; ++j) vf[j] = *(const bf16x8_t*)(sb + db * 4096 + vch[j]);
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int ch = (4 * kb + 2 * c + hi) ^ vswz;
-                    const bf16x8_t vf = *(const bf16x8_t*)(sb + voff + db * 4096 + ch * 16);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][c], o[db], 0, 0, 0);
-                }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int j = 0; j < 4; ++j) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], pf[j], o[db], 0, 0, 0);
+        }
     }
 
     // ---- epilogue: O[q][d] = O^T / l ; lane owns d = 32*db + 8*u + 4*hi + (0..3) ----
@@ -253,6 +292,7 @@ extern "C" int bagel_attn_varlen_bf16(const void* q, int64_t ldq, const void* k_
     BAGEL_REQUIRE(nq > 0 && nkv > 0 && nq % nkv == 0, "attn: bad head counts %d/%d", nq, nkv);
     BAGEL_REQUIRE(ldq % 8 == 0 && ldk_new % 8 == 0 && ldvt_new % 8 == 0 && ldo % 4 == 0 && ldk_ctx % 8 == 0 && ldvt_ctx % 8 == 0,
                   "attn: leading dims must keep 16-byte alignment");
+    BAGEL_REQUIRE(softmax_scale > 0.f, "attn: softmax_scale must be positive");
     if (batch <= 0 || max_lq <= 0) return BAGEL_OK;
     AttnParams p;
     p.q = (const bf16_t*)q; p.ldq = ldq;
@@ -263,15 +303,18 @@ extern "C" int bagel_attn_varlen_bf16(const void* q, int64_t ldq, const void* k_
     p.out = (bf16_t*)out; p.ldo = ldo;
     p.cu_q = cu_q; p.cu_ctx = cu_ctx; p.vt_new_col = vt_new_col; p.vt_ctx_col = vt_ctx_col;
     p.nq = nq; p.nkv = nkv; p.causal = causal;
+    p.batch = batch; p.nqt = ceil_div(max_lq, 256);
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    const dim3 grid(ceil_div(max_lq, 128), nq, batch), block(256);
+    const int nbpp = (nq / nkv) * p.nqt;
+    const int pairs_per_xcd = ceil_div((long)batch * nkv, 8);
+    const dim3 grid(8 * pairs_per_xcd * nbpp), block(512);
     if (head_dim == 128) {
-        constexpr int smem = 2 * (64 * 256 + 128 * 128);
+        constexpr int smem = 3 * (64 * 256 + 128 * 128);
         static bool set = false;
         if (!set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set = true; }
         hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, smem, stream, p);
     } else if (head_dim == 64) {
-        constexpr int smem = 2 * (64 * 128 + 64 * 128);
+        constexpr int smem = 3 * (64 * 128 + 64 * 128);
         hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, smem, stream, p);
     } else {
         return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn: head_dim %d not in {64,128} (pad the head)", head_dim);

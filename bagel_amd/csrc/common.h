@@ -25,14 +25,14 @@ int bagel_check_launch(const char* what);
 
 // ---- bf16 <-> f32 (round-to-nearest-even, identical to torch's CPU/GPU conversion) ----
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN) -- the same rounding torch uses.
+typedef __attribute__((ext_vector_type(2))) __bf16 hwbf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    hwbf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
 __device__ __forceinline__ float lo2f(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi2f(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
