@@ -241,6 +241,327 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_kernel(const GemmParams p
     }
 }
 
+
+// =========================================================================================================
+// "Ping-pong" 256x256x64 kernel (variant 3) for the large-M projections of the denoise forward.
+//
+// 8 waves = two GROUPS of four (group = wave/4 owns output rows [128*group, +128), wave%4 owns 64 columns).  The
+// hardware places wave w and wave w+4 of a workgroup on the same SIMD, so the two groups are run ONE SLOT OUT OF
+// PHASE: while a group-0 wave issues its 16 MFMAs of a quadrant (M slot) the group-1 wave on the same SIMD reads its
+// next fragments from LDS and issues DMA (L slot), and vice versa; every slot ends in one s_barrier.  The matrix pipe
+// of each SIMD therefore always has one wave in an M slot (cdna_hip_programming.md T3/T4/T5, built here on a
+// two-group stagger instead of the 8-phase template).
+//
+// A k-tile (64 deep) is four 16 KB LDS PIECES -- A0/A1 = the two 64-row halves of both groups' A rows, B0/B1 = the
+// two 32-column halves of all four waves' W rows -- consumed in the quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0);
+// the B0 fragments stay in registers for the 4th quadrant.  Two stages (128 KB LDS).  In the L slot of quadrant p of
+// tile t every wave issues its 2 DMA instructions of piece p of tile t+1, so every piece has 6-8 slots (~2000 cycles)
+// of flight; completion is enforced with a counted `s_waitcnt vmcnt(4)` (never 0 in steady state) in front of the
+// barrier that precedes the first read of that piece.  DMA goes through inline asm (see attention.hip: hipcc would
+// otherwise drain it in front of every ds_read).
+// =========================================================================================================
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_uniform)
+                 : "memory");
+}
+
+#define PP_BARRIER()                         \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int ABL>   // ABL != 0: timing-only ablations (wrong results): 1 = no DMA after the prologue, 2 = also no vmcnt waits
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int PIECE = 128 * 128;            // 128 rows x 64 bf16
+    constexpr int STAGE = 4 * PIECE;            // [A0 | B0 | B1 | A1]
+    constexpr int OFF_A0 = 0, OFF_B0 = PIECE, OFF_B1 = 2 * PIECE, OFF_A1 = 3 * PIECE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wj = wave & 3;
+    const bool g1 = grp != 0;
+
+    // ---- XCD-aware tile mapping (same as gemm_tn_kernel) ----
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    constexpr int GM = 4;
+    const int band = bid / (GM * p.tiles_n);
+    const int band_rows = min(GM, p.tiles_m - band * GM);
+    const int inb = bid - band * GM * p.tiles_n;
+    const int tm = band * GM + inb % band_rows;
+    const int tn = inb / band_rows;
+
+    const int gi = (p.ngroups > 1 && tm >= p.g[1].tile0) ? 1 : 0;
+    const bf16_t* __restrict__ Wg = p.g[gi].W;
+    const bf16_t* __restrict__ biasg = p.g[gi].bias;
+    const int* __restrict__ a_rows = p.g[gi].a_rows;
+    const int* __restrict__ c_rows = p.g[gi].c_rows;
+    const int Mg = p.g[gi].M;
+    const int m0 = (tm - p.g[gi].tile0) * BM;
+    const int n0 = tn * BN;
+
+    // ---- DMA sources: piece-local row lr = 8*j + lane/8 (j = wave + 8*i), LDS chunk lane%8, global chunk swizzled ----
+    const char* src[4][2];   // [piece][i]
+    unsigned dst[4][2];      // LDS byte offset inside a stage (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wave + 8 * i;
+        const int lr = j * 8 + (lane >> 3);
+        const int gch = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // A piece `half`: tile row = (lr>>6)*128 + half*64 + (lr&63)
+            int m = m0 + (lr >> 6) * 128 + half * 64 + (lr & 63);
+            m = m < Mg ? m : Mg - 1;
+            const long prow = a_rows ? (long)a_rows[m] : (long)m;
+            src[half ? 3 : 0][i] = (const char*)(p.A + prow * p.lda) + gch * 16;
+            // B piece `half`: tile col = (lr>>5)*64 + half*32 + (lr&31)
+            int n = n0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
+            n = n < p.N ? n : p.N - 1;
+            src[half ? 2 : 1][i] = (const char*)(Wg + (long)n * p.ldw) + gch * 16;
+        }
+        dst[0][i] = OFF_A0 + j * 1024; dst[1][i] = OFF_B0 + j * 1024; dst[2][i] = OFF_B1 + j * 1024; dst[3][i] = OFF_A1 + j * 1024;
+    }
+    // retire hipcc's own loads (a_rows gathers) before any hand-counted DMA is in flight
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(src[pc][i]));
+
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)smem);
+
+    // ---- fragment read offsets (mfma_f32_16x16x32_bf16: lane -> row lane&15, 8 k-elements at chunk lane/16 + 4*kh) ----
+    // (the 32x32x16 shape was measured 15-20 % slower in this structure: profiles/r01_gemm_experiments.md)
+    const int fr = lane & 15;
+    const int sw = fr >> 1;
+    const int ch0 = ((lane >> 4) ^ sw) << 4;          // kh = 0
+    const int ch1 = (((lane >> 4) + 4) ^ sw) << 4;    // kh = 1
+    const int a_row = (grp * 64 + fr) * 128;          // + i*2048 (16 rows)
+    const int b_row = (wj * 32 + fr) * 128;           // + jn*2048
+
+    f32x4_t acc[2][4][2][2];   // [ma][i][nb][jn]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K >> 6;
+
+    bool dma_on = true;
+    auto issue = [&](int piece, unsigned stage_base, long koff) {
+        if (ABL != 0 && !dma_on) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(src[piece][i] + koff, stage_base + dst[piece][i]);
+    };
+    bf16x8_t af[4][2], b0f[2][2], b1f[2][2];
+    auto read_a = [&](const char* sb, int off) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const bf16x8_t*)(sb + off + a_row + i * 2048 + ch0);
+            af[i][1] = *(const bf16x8_t*)(sb + off + a_row + i * 2048 + ch1);
+        }
+    };
+    auto read_b = [&](bf16x8_t (&bf)[2][2], const char* sb, int off) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf[j][0] = *(const bf16x8_t*)(sb + off + b_row + j * 2048 + ch0);
+            bf[j][1] = *(const bf16x8_t*)(sb + off + b_row + j * 2048 + ch1);
+        }
+    };
+    auto mma = [&](int ma, bf16x8_t (&bf0)[2][2], bf16x8_t (&bf1)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ma][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j][kh], af[i][kh], acc[ma][i][0][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ma][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j][kh], af[i][kh], acc[ma][i][1][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- schedule ---------------------------------------------------------------------------------------------------
+    // Two phases per k-tile, each an L slot (LDS reads + DMA issue) followed by an M slot of 32 MFMAs (~530 cycles):
+    //     L(t,0): reads A0,B0,B1(t)  issues A1(t+1)            M(t,0): A0 x (B0,B1)
+    //     L(t,1): reads A1(t)        issues A0,B0,B1(t+2)      M(t,1): A1 x (B0,B1)
+    // (16-MFMA slots -- four phases per tile -- measured ~1.40 PFLOP/s in the steady state; halving the number of
+    // barriers per tile amortises the ~120-cycle slot turn-around.)  The two LDS stages act as a prefetch ring: a
+    // piece's region is refilled one slot after BOTH groups have read it, so every piece has ~6 slots (~3.5k cycles)
+    // of flight.  Counted waits (vmcnt counts this wave's DMA instructions, 2 per piece, oldest first), placed in front
+    // of the barrier that precedes group 0's L slot (end of the M slot for group 0, end of the L slot for group 1):
+    //     before L(t,0): A0,B0,B1(t) landed; newer in flight: A1(t), A0,B0,B1(t+1)      -> vmcnt(8)
+    //     before L(t,1): A1(t) landed;       newer in flight: A0,B0,B1(t+1), A1(t+1)    -> vmcnt(8)
+    issue(0, smem_base, 0); issue(1, smem_base, 0); issue(2, smem_base, 0); issue(3, smem_base, 0);
+    if (nk > 1) {
+        issue(0, smem_base + STAGE, 128); issue(1, smem_base + STAGE, 128); issue(2, smem_base + STAGE, 128);
+        PP_VMCNT(8);
+    } else {
+        PP_VMCNT(2);
+    }
+    PP_BARRIER();
+    if (g1) PP_BARRIER();   // group 1 runs one slot behind
+    if (ABL != 0) { dma_on = false; PP_VMCNT(0); }
+
+    for (int t = 0; t < nk; ++t) {
+        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        const char* sb = smem + (t & 1) * STAGE;
+        const unsigned s_same = smem_base + (t & 1) * STAGE;          // tile t+2 reuses tile t's stage
+        const unsigned s_other = smem_base + ((t + 1) & 1) * STAGE;
+        // ---------------- phase 0: A0 x (B0, B1) ----------------
+        if (more1) issue(3, s_other, (long)(t + 1) * 128);            // A1(t+1): its region was last read in L(t-1,1)
+        read_a(sb, OFF_A0);
+        read_b(b0f, sb, OFF_B0);
+        read_b(b1f, sb, OFF_B1);
+        PP_LGKM0();
+        if (g1) { if (more1) PP_VMCNT(8); else PP_VMCNT(0); }         // A1(t) landed
+        PP_BARRIER();
+        mma(0, b0f, b1f);
+        if (!g1) { if (more1) PP_VMCNT(8); else PP_VMCNT(0); }
+        PP_BARRIER();
+        // ---------------- phase 1: A1 x (B0, B1) ----------------
+        if (more2) { issue(0, s_same, (long)(t + 2) * 128); issue(1, s_same, (long)(t + 2) * 128); issue(2, s_same, (long)(t + 2) * 128); }
+        read_a(sb, OFF_A1);
+        PP_LGKM0();
+        if (g1 && more1) { if (more2) PP_VMCNT(8); else PP_VMCNT(2); }   // A0,B0,B1(t+1) landed
+        PP_BARRIER();
+        mma(1, b0f, b1f);
+        if (!g1 && more1) { if (more2) PP_VMCNT(8); else PP_VMCNT(2); }
+        PP_BARRIER();
+    }
+    if (!g1) PP_BARRIER();
+
+    // ---- epilogue -------------------------------------------------------------------------------------------------
+    // 1) in registers (fragment layout: lane owns 4 consecutive columns of one row): bias, activation, SwiGLU pairing,
+    //    rounding to bf16 -- exactly the reference's cast points;
+    // 2) the bf16 tile goes through LDS (the k-loop stages are dead now) so that
+    // 3) every wave stores whole rows: 16 bytes per lane, 256/512 contiguous bytes per row, residual rows read the same
+    //    way -- 16 full-line store instructions per wave instead of 64 scattered 8-byte ones.
+    // LDS image: row-major [256][OWB] bf16, 8-byte chunk c8 of row r stored at chunk c8 ^ (r & 15) (conflict-free
+    // ds_write_b64 for the 16 rows of a fragment, conflict-free ds_read_b128 on the way out).
+    const bool swiglu = p.epi == EPI_SWIGLU16;
+    const int OWB = swiglu ? 128 : 256;            // output columns of the block tile
+    const int RS = OWB * 2;                        // row stride in bytes
+    PP_BARRIER();                                  // every wave is past its last fragment read
+    const int nsub = (lane >> 4) * 4;
+#pragma unroll
+    for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = grp * 128 + ma * 64 + i * 16 + fr;       // row inside the block tile
+            char* rowp = smem + r * RS;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                if (swiglu) {
+                    const int c = wj * 32 + nb * 16 + nsub;         // output column inside the block tile
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = bfround(acc[ma][i][nb][0][e]);
+                        const float u = bfround(acc[ma][i][nb][1][e]);
+                        o[e] = bfround(silu_f(g)) * u;
+                    }
+                    u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    *(u32x2_t*)(rowp + (((c >> 2) ^ (r & 15)) << 3)) = v;
+                } else {
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) {
+                        const int c = wj * 64 + nb * 32 + jn * 16 + nsub;
+                        const int n = n0 + c;
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[ma][i][nb][jn][e];
+                        if (biasg && n < p.N) {
+                            const u32x2_t bv = *(const u32x2_t*)(biasg + n);
+                            o[0] += lo2f(bv[0]); o[1] += hi2f(bv[0]); o[2] += lo2f(bv[1]); o[3] += hi2f(bv[1]);
+                        }
+                        if (p.epi == EPI_GELU_TANH) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bfround(o[e]));
+                        } else if (p.epi == EPI_SILU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = silu_f(bfround(o[e]));
+                        }
+                        u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                        *(u32x2_t*)(rowp + (((c >> 2) ^ (r & 15)) << 3)) = v;
+                    }
+                }
+            }
+        }
+    PP_LGKM0();
+    PP_BARRIER();
+    {
+        const int lpr = RS >> 4;                    // lanes per row (16-byte units): 32 or 16
+        const int rpi = 64 / lpr;                   // rows per wave-instruction: 2 or 4
+        const int q = lane % lpr;                   // 16-byte unit inside the row
+        const int nrow_it = 256 / (8 * rpi);        // iterations per wave: 16 or 8
+        const int ocol0 = swiglu ? (n0 >> 1) : n0;  // first output column of the block tile
+        const int ncols = swiglu ? (p.N >> 1) : p.N;
+        for (int it = 0; it < nrow_it; ++it) {
+            const int r = (it * 8 + wave) * rpi + lane / lpr;
+            const int m = m0 + r;
+            const int oc = ocol0 + q * 8;
+            if (m >= Mg || oc >= ncols) continue;
+            const int x = r & 15;
+            const int P = (q & ~7) | ((q & 7) ^ (x >> 1));
+            u32x4_t v = *(const u32x4_t*)(smem + r * RS + (P << 4));
+            if (x & 1) { v = (u32x4_t){v[2], v[3], v[0], v[1]}; }
+            const long prow = c_rows ? (long)c_rows[m] : (long)m;
+            if (p.R) {
+                const u32x4_t rv = *(const u32x4_t*)(p.R + prow * p.ldr + oc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pack2bf(lo2f(v[e]) + lo2f(rv[e]), hi2f(v[e]) + hi2f(rv[e]));
+            }
+            *(u32x4_t*)(p.C + prow * p.ldc + oc) = v;
+        }
+    }
+}
+
+template <int ABL>
+static int launch_gemm_pp(const GemmParams& p0, hipStream_t stream) {
+    GemmParams p = p0;
+    int t = 0;
+    for (int g = 0; g < p.ngroups; ++g) {
+        p.g[g].tile0 = t;
+        t += ceil_div(p.g[g].M, 256);
+    }
+    p.tiles_m = t;
+    p.tiles_n = ceil_div(p.N, 256);
+    if (t == 0) return BAGEL_OK;
+    constexpr int smem = 2 * 4 * 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_pp_kernel<ABL>, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, stream, p);
+    return bagel_check_launch("gemm_pp_kernel");
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
@@ -271,6 +592,8 @@ extern "C" int bagel_gemm_bf16(const void* A, int64_t lda,
     BAGEL_REQUIRE(K > 0 && (K % 8) == 0, "gemm: K=%d must be a positive multiple of 8 (pad the operand)", K);
     BAGEL_REQUIRE(N > 0 && (N % 8) == 0, "gemm: N=%d must be a multiple of 8", N);
     BAGEL_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (ldc % 4) == 0 && (ldr % 4) == 0, "gemm: leading dims must keep rows 16-byte aligned");
+    if (variant == 3 && ((ldc % 8) != 0 || (ldr % 8) != 0 || (((uintptr_t)C | (uintptr_t)R) & 15) != 0 || (epilogue == EPI_SWIGLU16 && (N % 16) != 0)))
+        variant = 1;   // the ping-pong kernel stores 16-byte row chunks
     BAGEL_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm: unknown epilogue %d", epilogue);
     BAGEL_REQUIRE(epilogue != EPI_SWIGLU16 || ((N % 32) == 0 && !bias0 && !R), "gemm: swiglu needs N%%32==0, no bias/residual");
     BAGEL_REQUIRE(M0 >= 0 && M1 >= 0 && (M1 == 0 || W1), "gemm: bad group sizes");
@@ -287,6 +610,10 @@ extern "C" int bagel_gemm_bf16(const void* A, int64_t lda,
         case 0: return launch_gemm<128, 128, 2, 2>(p, stream);
         case 1: return launch_gemm<256, 256, 2, 4>(p, stream);
         case 2: return launch_gemm<256, 128, 2, 2>(p, stream);
+        case 3:
+            if ((K & 63) != 0) return launch_gemm<256, 256, 2, 4>(p, stream);   // the ping-pong kernel has no K tail
+            return launch_gemm_pp<0>(p, stream);
+        case 13: return launch_gemm_pp<1>(p, stream);   // timing-only ablation (results are garbage): no DMA in the k-loop
         default: return bagel_set_error(BAGEL_ERR_ARG, "gemm: unknown variant %d", variant);
     }
 }

@@ -46,11 +46,12 @@ def default_gemm_variant(M, N, K):
     v = os.environ.get("BAGEL_GEMM_VARIANT")
     if v is not None:
         return int(v)
-    # measured on MI355X at the denoise shapes (M = 16392; profiles/r01_kernel_probe.json): the 256x256 / 8-wave tile
-    # wins on every projection (qkv 894 vs 754, gate_up 1050 vs 926, down 970 vs 681 TFLOP/s); small-M launches
-    # (prefill of a short prompt, decode, time embedder) keep the 128x128 tile so the grid still covers the chip.
+    # measured on MI355X at the denoise shapes (M = 16392; profiles/r01_kernel_probe*.json): the 256x256 two-group
+    # ping-pong kernel (variant 3) wins on every projection; small-M launches (prefill of a short prompt, decode, time
+    # embedder) keep the 128x128 tile so the grid still covers the chip.  Variant 3 needs K % 64 == 0 and falls back to
+    # the plain 256x256 kernel (variant 1) otherwise.
     if M >= 2048 and N >= 512:
-        return 1
+        return 3
     return 0
 
 

@@ -35,7 +35,8 @@ const char* bagel_hip_arch(void);
  * expert routing of qwen2_navit.py:526-548,593-594,812-820 without gather/scatter kernels.
  * Replaces F.linear at qwen2_navit.py:515-517,529-536,591-594; modeling_qwen2.py:200-201; bagel.py:803,832,978;
  * modeling_utils.py:107-110,120-124; siglip_navit.py:190,216-218,243,256-258.
- * variant: 0 = 128x128 tile/256 threads, 1 = 256x256/512, 2 = 256x128/256.  K % 8 == 0, N % 8 == 0. */
+ * variant: 0 = 128x128 tile/256 threads, 1 = 256x256/512, 2 = 256x128/256, 3 = 256x256 two-group ping-pong (K % 64 == 0,
+ * else falls back to 1).  K % 8 == 0, N % 8 == 0. */
 int bagel_gemm_bf16(const void* A, int64_t lda,
                     const void* W0, const void* bias0, const int32_t* a_rows0, const int32_t* c_rows0, int32_t M0,
                     const void* W1, const void* bias1, const int32_t* a_rows1, const int32_t* c_rows1, int32_t M1,

@@ -68,7 +68,7 @@ def ref_gemm(A, W, bias=None, epi=0, residual=None):
     return c
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(1, 128, 64), (7, 136, 128), (300, 520, 200), (1000, 256, 144), (513, 384, 3584), (130, 64, 512)])
 def test_gemm_plain_bias(M, N, K, variant):
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
@@ -89,7 +89,7 @@ def test_gemm_activation_and_residual(epi):
     close(X, ref_gemm(A, W, b, 0, R), ulps=2, what="gemm residual in place")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 def test_gemm_swiglu(variant):
     from bagel_amd.modeling.bagel.qwen2_navit import interleave_gate_up
     M, I, K = 333, 416, 256
@@ -101,7 +101,7 @@ def test_gemm_swiglu(variant):
     close(C, ref, ulps=2, what="gemm swiglu")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 def test_gemm_two_expert_groups(variant):
     """MoT routing: text rows -> W0, latent rows -> W1, rows interleaved like <start> latents <end> per sample."""
     H, N = 256, 392
@@ -122,6 +122,25 @@ def test_gemm_two_expert_groups(variant):
     ref[rows_t] = ref_gemm(A[rows_t], W0, b0, 0, R[rows_t])
     ref[rows_v] = ref_gemm(A[rows_v], W1, b1, 0, R[rows_v])
     close(C, ref, ulps=2, what="grouped gemm")
+
+
+def test_gemm_pingpong_race_screen():
+    """variant 3 (two-group ping-pong, hand-counted DMA waits) on a multi-tile problem: every repeat must be BIT-IDENTICAL
+    to the first (a missed vmcnt/barrier shows up as a sporadic mismatch) and within 1 bf16 ulp of the plain tile kernel
+    (the two use different MFMA shapes, hence a different summation association)."""
+    M, N, K = 1500, 1280, 2048
+    A, W, b = rnd(M, K, seed=11).to(DEV), rnd(N, K, seed=12, scale=K ** -0.5).to(DEV), rnd(N, seed=13, scale=0.1).to(DEV)
+    C0 = torch.empty((M, N), dtype=BF16, device=DEV)
+    ops().gemm(A, W, C0, bias0=b, variant=0)
+    first = None
+    for rep in range(6):
+        C3 = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+        ops().gemm(A, W, C3, bias0=b, variant=3)
+        if first is None:
+            first = C3
+            close(C3, C0.cpu(), ulps=1, what="ping-pong vs tile kernel")
+        else:
+            assert torch.equal(first.view(torch.int16), C3.view(torch.int16)), f"ping-pong GEMM is not deterministic (repeat {rep})"
 
 
 def test_gemm_gather_rows_dense_out():

@@ -46,7 +46,7 @@ def main():
         W0, W1 = rn(N, K, sc=K ** -0.5), rn(N, K, sc=K ** -0.5)
         A = x if K == H else rn(M, K)
         C = torch.empty((M, N // 2 if epi == 3 else N), dtype=BF16, device=DEV)
-        for variant in (0, 1, 2):
+        for variant in (1, 3):
             try:
                 ms = timeit(lambda: ops.gemm(A, W0, C, a_rows0=tr, c_rows0=tr, M0=len(text_rows), W1=W1, a_rows1=vr, c_rows1=vr,
                                              M1=len(vae_rows), epilogue=epi, variant=variant))
