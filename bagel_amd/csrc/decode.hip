@@ -1,0 +1,464 @@
+// Autoregressive text decode (Bagel.generate_text, bagel.py:930-1000; Qwen2 forward at Lq = 1): HBM-bound kernels.
+//
+// One decoded token streams every und-expert weight once (14.14 GB at 7B) plus the KV context; nothing here is
+// GEMM-shaped, so nothing goes to the MFMA.  The design rules are the HBM ones: 16-byte lanes, whole 1 KB wave
+// requests on contiguous weight rows, many loads in flight per lane, no re-reads, and all per-step state (token,
+// position, KV length, step counter) in device memory so a hipGraph of one step can be replayed without the host.
+//
+//   bagel_gemv_bf16              C[M<=4.., N] = A W^T (+bias)(act)(SwiGLU)(+R) with an optional fused Qwen2RMSNorm of
+//                                the A rows (modeling_qwen2.py:54-59, 200-201; qwen2_navit.py:515-517,591; bagel.py:978)
+//   bagel_kv_append_paged_bf16   this step's K/V rows -> page slot kv_len[b] (qwen2_navit.py:563-575 without the
+//                                whole-cache re-scatter)
+//   bagel_attn_decode_paged_bf16 Lq = 1 attention over a paged KV cache, split over the keys (flash-decoding), GQA
+//                                group shares every K/V byte (qwen2_navit.py:579-588)
+//   bagel_decode_advance         token bookkeeping of bagel.py:984-994 on the device
+#include "common.h"
+
+#define EPI_NONE 0
+#define EPI_GELU_TANH 1
+#define EPI_SILU 2
+#define EPI_SWIGLU16 3
+
+// =====================================================================================================================
+// Skinny GEMM.  A wave owns a PAIR of weight rows at a time (for SwiGLU16 the gate row and its up row, 16 apart, so
+// the product needs no second pass); every lane streams 16-byte chunks of both rows, U chunk-groups (= U KB per row)
+// in flight, and multiplies them with the activation rows staged once per workgroup in LDS (bf16, conflict-free
+// ds_read_b128).  fp32 accumulate, wave reduction, epilogue by lane 0 with the roundings of gemm.hip.
+// =====================================================================================================================
+struct GemvParams {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    const bf16_t* bias;
+    const bf16_t* R; long ldr;
+    bf16_t* C; long ldc;
+    const bf16_t* norm_w; float eps;
+    int M, N, K, epi;
+};
+
+template <int MR>
+__device__ __forceinline__ void gemv_fma(float (&a0)[MR][2], float (&a1)[MR][2], const u32x4_t wa, const u32x4_t wb,
+                                         const bf16_t* xs, int K, int chunk, bool ok) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        u32x4_t xv = *(const u32x4_t*)(xs + (long)m * K + (long)chunk * 8);
+        if (!ok) xv = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xl = lo2f(xv[e]), xh = hi2f(xv[e]);
+            a0[m][0] = fmaf(lo2f(wa[e]), xl, a0[m][0]);
+            a0[m][1] = fmaf(hi2f(wa[e]), xh, a0[m][1]);
+            a1[m][0] = fmaf(lo2f(wb[e]), xl, a1[m][0]);
+            a1[m][1] = fmaf(hi2f(wb[e]), xh, a1[m][1]);
+        }
+    }
+}
+
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
+    constexpr int U = 7;   // chunk groups in flight per row: K = 3584 -> exactly one batch, K = 18944 -> 5 batches + 2
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemv_smem[];
+    bf16_t* xs = (bf16_t*)gemv_smem;   // [MR][K]
+    __shared__ float red[MR][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, nch = K >> 3;
+    const int NP = p.N >> 1;
+    const bool swiglu = p.epi == EPI_SWIGLU16;
+
+    // ---- stage the activation rows (optionally RMS-normalised) --------------------------------------------------
+    if (p.norm_w) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const bf16_t* ar = p.A + (long)(m < p.M ? m : p.M - 1) * p.lda;
+            float ss = 0.f;
+            for (int c = tid; c < nch; c += 256) {
+                const u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = lo2f(v[e]), b = hi2f(v[e]);
+                    ss += a * a + b * b;
+                }
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red[m][wave] = ss;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const bf16_t* ar = p.A + (long)(m < p.M ? m : p.M - 1) * p.lda;
+        float inv = 1.f;
+        if (p.norm_w) inv = rsqrtf((red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K + p.eps);
+        for (int c = tid; c < nch; c += 256) {
+            u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
+            if (p.norm_w) {
+                const u32x4_t g = *(const u32x4_t*)(p.norm_w + (long)c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack2bf(bfround(lo2f(v[e]) * inv) * lo2f(g[e]), bfround(hi2f(v[e]) * inv) * hi2f(g[e]));
+            }
+            *(u32x4_t*)(xs + (long)m * K + (long)c * 8) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- weight-row pairs ---------------------------------------------------------------------------------------
+    const int nfull = nch >> 6, rem = nch & 63;
+    const int stride = gridDim.x * 4;
+    for (int pp = blockIdx.x * 4 + wave; pp < NP; pp += stride) {
+        const int r0 = swiglu ? ((pp >> 4) << 5) + (pp & 15) : 2 * pp;
+        const int r1 = swiglu ? r0 + 16 : r0 + 1;
+        const bf16_t* w0 = p.W + (long)r0 * p.ldw;
+        const bf16_t* w1 = p.W + (long)r1 * p.ldw;
+        float a0[MR][2], a1[MR][2];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) a0[m][0] = a0[m][1] = a1[m][0] = a1[m][1] = 0.f;
+        int g = 0;
+        for (; g + U <= nfull; g += U) {
+            u32x4_t wa[U], wb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long off = ((long)(g + u) * 64 + lane) * 8;
+                wa[u] = *(const u32x4_t*)(w0 + off);
+                wb[u] = *(const u32x4_t*)(w1 + off);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, (g + u) * 64 + lane, true);
+        }
+        if (g < nfull || rem) {
+            // tail: up to U-1 whole groups plus the ragged last one; out-of-range chunks read chunk 0 and multiply by 0
+            u32x4_t wa[U], wb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ch = (g + u) * 64 + lane;
+                const long off = (long)(ch < nch ? ch : 0) * 8;
+                wa[u] = *(const u32x4_t*)(w0 + off);
+                wb[u] = *(const u32x4_t*)(w1 + off);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ch = (g + u) * 64 + lane;
+                const bool ok = ch < nch;
+                gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, ok ? ch : 0, ok);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const float s0 = wave_sum(a0[m][0] + a0[m][1]);
+            const float s1 = wave_sum(a1[m][0] + a1[m][1]);
+            if (lane == 0 && m < p.M) {
+                if (swiglu) {
+                    const float gg = bfround(s0), uu = bfround(s1);
+                    p.C[(long)m * p.ldc + pp] = f2bf(bfround(silu_f(gg)) * uu);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int n = t ? r1 : r0;
+                        float o = t ? s1 : s0;
+                        if (p.bias) o += bf2f(p.bias[n]);
+                        if (p.epi == EPI_GELU_TANH) o = gelu_tanh_f(bfround(o));
+                        else if (p.epi == EPI_SILU) o = silu_f(bfround(o));
+                        if (p.R) o = bfround(o) + bf2f(p.R[(long)m * p.ldr + n]);
+                        p.C[(long)m * p.ldc + n] = f2bf(o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+#define GEMV_MAX_LDS (144 * 1024)
+
+template <int MR>
+static int launch_gemv(const GemvParams& p, hipStream_t stream) {
+    const size_t smem = (size_t)MR * p.K * sizeof(bf16_t);
+    static size_t attr_bytes = 0;   // largest dynamic-LDS size this instantiation has been enabled for
+    if (smem > 48 * 1024 && smem > attr_bytes) {
+        if (hipFuncSetAttribute((const void*)gemv_kernel<MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMV_MAX_LDS) != hipSuccess)
+            return bagel_set_error(BAGEL_ERR_LAUNCH, "gemv: cannot enable %zu bytes of LDS", smem);
+        attr_bytes = GEMV_MAX_LDS;
+    }
+    const int NP = p.N / 2;
+    // workgroups resident per CU: bounded by LDS (160 KB) and by 8 four-wave groups
+    int per_cu = (int)((160 * 1024) / (smem + 64));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int grid = ceil_div(NP, 4);
+    if (grid > 256 * per_cu) grid = 256 * per_cu;
+    hipLaunchKernelGGL((gemv_kernel<MR>), dim3(grid), dim3(256), smem, stream, p);
+    return bagel_check_launch("gemv_kernel");
+}
+
+extern "C" int bagel_gemv_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* R,
+                               int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N,
+                               int32_t K, int32_t epilogue, hipStream_t stream) {
+    BAGEL_REQUIRE(A && W && C, "gemv: null pointer");
+    BAGEL_REQUIRE(K > 0 && (K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0, "gemv: K/lda/ldw must be multiples of 8 (16-byte rows)");
+    BAGEL_REQUIRE(N > 0 && (N % 2) == 0, "gemv: N=%d must be even", N);
+    BAGEL_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemv: unknown epilogue %d", epilogue);
+    BAGEL_REQUIRE(epilogue != EPI_SWIGLU16 || ((N % 32) == 0 && !bias && !R), "gemv: swiglu needs N%%32==0, no bias/residual");
+    BAGEL_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)norm_w) & 15) == 0, "gemv: A/W/norm_w must be 16-byte aligned");
+    BAGEL_REQUIRE((size_t)K * sizeof(bf16_t) <= GEMV_MAX_LDS, "gemv: K=%d does not fit the LDS staging buffer", K);
+    if (M <= 0) return BAGEL_OK;
+    const int n_out = epilogue == EPI_SWIGLU16 ? N / 2 : N;
+    (void)n_out;
+    int m0 = 0;
+    while (m0 < M) {
+        int mr = (M - m0 >= 4) ? 4 : (M - m0 >= 2 ? 2 : 1);
+        while (mr > 1 && (size_t)mr * K * sizeof(bf16_t) > GEMV_MAX_LDS) mr >>= 1;
+        GemvParams p;
+        p.A = (const bf16_t*)A + (long)m0 * lda; p.lda = lda;
+        p.W = (const bf16_t*)W; p.ldw = ldw;
+        p.bias = (const bf16_t*)bias;
+        p.R = R ? (const bf16_t*)R + (long)m0 * ldr : nullptr; p.ldr = ldr;
+        p.C = (bf16_t*)C + (long)m0 * ldc; p.ldc = ldc;
+        p.norm_w = (const bf16_t*)norm_w; p.eps = eps;
+        p.M = mr; p.N = N; p.K = K; p.epi = epilogue;
+        int rc;
+        if (mr == 4) rc = launch_gemv<4>(p, stream);
+        else if (mr == 2) rc = launch_gemv<2>(p, stream);
+        else rc = launch_gemv<1>(p, stream);
+        if (rc != BAGEL_OK) return rc;
+        m0 += mr;
+    }
+    return BAGEL_OK;
+}
+
+// =====================================================================================================================
+// Paged KV cache.  Token j of sample b lives in row  block_table[b*bt_stride + j/PAGE] * PAGE + j%PAGE  of the layer's
+// K pool and V pool ([pages*PAGE, nkv*DP] bf16).  kv_len[b] is device memory: one captured step serves every length.
+// =====================================================================================================================
+#define BAGEL_KV_PAGE 64
+
+__global__ __launch_bounds__(256) void kv_append_paged_kernel(const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new,
+                                                              long ld_new, bf16_t* __restrict__ kpool, bf16_t* __restrict__ vpool,
+                                                              long ldp, const int* __restrict__ block_table, int bt_stride,
+                                                              const int* __restrict__ kv_len, int width) {
+    const int b = blockIdx.x, which = blockIdx.y;
+    const int j = kv_len[b];
+    const long row = (long)block_table[(long)b * bt_stride + j / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (j % BAGEL_KV_PAGE);
+    const bf16_t* src = (which ? v_new : k_new) + (long)b * ld_new;
+    bf16_t* dst = (which ? vpool : kpool) + row * ldp;
+    for (int c = threadIdx.x; c < (width >> 3); c += 256) *(u32x4_t*)(dst + c * 8) = *(const u32x4_t*)(src + c * 8);
+}
+
+extern "C" int bagel_kv_append_paged_bf16(const void* k_new, const void* v_new, int64_t ld_new, void* kpool, void* vpool,
+                                          int64_t ld_pool, const int32_t* block_table, int32_t bt_stride,
+                                          const int32_t* kv_len, int32_t batch, int32_t width, hipStream_t stream) {
+    BAGEL_REQUIRE(k_new && v_new && kpool && vpool && block_table && kv_len, "kv_append_paged: null pointer");
+    BAGEL_REQUIRE(width > 0 && (width % 8) == 0 && (ld_new % 8) == 0 && (ld_pool % 8) == 0, "kv_append_paged: width/ld must be multiples of 8");
+    BAGEL_REQUIRE((((uintptr_t)k_new | (uintptr_t)v_new | (uintptr_t)kpool | (uintptr_t)vpool) & 15) == 0, "kv_append_paged: 16-byte alignment");
+    if (batch <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(kv_append_paged_kernel, dim3(batch, 2), dim3(256), 0, stream, (const bf16_t*)k_new, (const bf16_t*)v_new,
+                       (long)ld_new, (bf16_t*)kpool, (bf16_t*)vpool, (long)ld_pool, block_table, bt_stride, kv_len, width);
+    return bagel_check_launch("kv_append_paged_kernel");
+}
+
+// Lq = 1 attention, split over the keys.  Workgroup (split, kv head, sample) covers keys [split*CH, +CH) for the G query
+// heads of one KV head, so each K/V byte is read once per GQA group.  DP/8 lanes own one key row (16 bytes each); the
+// 256/(DP/8) lane groups walk the chunk with a running (max, sum, acc) per head in base 2; groups are merged by wave
+// shuffles, waves through LDS.  Output: unnormalised fp32 partials + (max, sum) per (sample, head, split).
+#define DEC_CH 128
+
+template <int DP, int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kpool,
+                                                          const bf16_t* __restrict__ vpool, long ldp,
+                                                          const int* __restrict__ block_table, int bt_stride,
+                                                          const int* __restrict__ kv_len, int len_add, float* __restrict__ part_o,
+                                                          float* __restrict__ part_ml, int nq, int nsplit, float scale_log2e) {
+    constexpr int LPK = DP / 8;          // lanes per key row
+    constexpr int NG = 256 / LPK;        // key rows in flight per workgroup step
+    const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int L = kv_len[b] + len_add;
+    const int j0 = split * DEC_CH;
+    const int j1 = (L < j0 + DEC_CH) ? L : j0 + DEC_CH;
+    if (j0 >= j1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = tid % LPK, grp = tid / LPK;
+    __shared__ float sm_o[4][G][DP];
+    __shared__ float sm_m[4][G], sm_l[4][G];
+
+    float qf[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const u32x4_t v = *(const u32x4_t*)(q + (long)b * ldq + (long)(kvh * G + g) * DP + sub * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qf[g][2 * e] = lo2f(v[e]) * scale_log2e;
+            qf[g][2 * e + 1] = hi2f(v[e]) * scale_log2e;
+        }
+    }
+    float mx[G], ls[G], o[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        mx[g] = -1e30f;
+        ls[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+    }
+    const int* bt = block_table + (long)b * bt_stride;
+    for (int jj = j0; jj < j1; jj += NG) {
+        const int j = jj + grp;
+        const bool valid = j < j1;
+        const int jc = valid ? j : j1 - 1;
+        const long row = (long)bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
+        const u32x4_t kr = *(const u32x4_t*)(kpool + row * ldp + (long)kvh * DP + sub * 8);
+        const u32x4_t vr = *(const u32x4_t*)(vpool + row * ldp + (long)kvh * DP + sub * 8);
+        float kf[8], vf[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            kf[2 * e] = lo2f(kr[e]); kf[2 * e + 1] = hi2f(kr[e]);
+            vf[2 * e] = lo2f(vr[e]); vf[2 * e + 1] = hi2f(vr[e]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(qf[g][e], kf[e], s);
+#pragma unroll
+            for (int off = 1; off < LPK; off <<= 1) s += __shfl_xor(s, off, 64);
+            const float mn = valid ? fmaxf(mx[g], s) : mx[g];
+            const float corr = exp2f(mx[g] - mn);
+            const float pw = valid ? exp2f(s - mn) : 0.f;
+            ls[g] = ls[g] * corr + pw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[g][e] = fmaf(pw, vf[e], o[g][e] * corr);
+            mx[g] = mn;
+        }
+    }
+    // merge the lane groups of this wave (group id differs in the lane bits >= log2(LPK))
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float m2 = __shfl_xor(mx[g], off, 64);
+            const float l2 = __shfl_xor(ls[g], off, 64);
+            const float mn = fmaxf(mx[g], m2);
+            const float c1 = exp2f(mx[g] - mn), c2 = exp2f(m2 - mn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float o2 = __shfl_xor(o[g][e], off, 64);
+                o[g][e] = o[g][e] * c1 + o2 * c2;
+            }
+            ls[g] = ls[g] * c1 + l2 * c2;
+            mx[g] = mn;
+        }
+    }
+    if (lane < LPK) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm_o[wave][g][sub * 8 + e] = o[g][e];
+            if (sub == 0) { sm_m[wave][g] = mx[g]; sm_l[wave][g] = ls[g]; }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * DP; idx += 256) {
+        const int g = idx / DP, d = idx - g * DP;
+        const float m0 = sm_m[0][g], m1 = sm_m[1][g], m2 = sm_m[2][g], m3 = sm_m[3][g];
+        const float mn = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float c0 = exp2f(m0 - mn), c1 = exp2f(m1 - mn), c2 = exp2f(m2 - mn), c3 = exp2f(m3 - mn);
+        const float acc = sm_o[0][g][d] * c0 + sm_o[1][g][d] * c1 + sm_o[2][g][d] * c2 + sm_o[3][g][d] * c3;
+        const long slot = ((long)b * nq + kvh * G + g) * nsplit + split;
+        part_o[slot * DP + d] = acc;
+        if (d == 0) {
+            part_ml[slot * 2] = mn;
+            part_ml[slot * 2 + 1] = sm_l[0][g] * c0 + sm_l[1][g] * c1 + sm_l[2][g] * c2 + sm_l[3][g] * c3;
+        }
+    }
+}
+
+// out[b, h, :] = sum_s part_o[s] 2^(m_s - M) / sum_s l_s 2^(m_s - M)  over the splits that hold keys.
+template <int DP>
+__global__ void attn_decode_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                           const int* __restrict__ kv_len, int len_add, bf16_t* __restrict__ out, long ldo,
+                                           int nq, int nsplit) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const int L = kv_len[b] + len_add;
+    int ns = (L + DEC_CH - 1) / DEC_CH;
+    if (ns > nsplit) ns = nsplit;
+    const long base = ((long)b * nq + h) * nsplit;
+    float mn = -1e30f;
+    for (int s = 0; s < ns; ++s) mn = fmaxf(mn, part_ml[(base + s) * 2]);
+    float acc = 0.f, den = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        const float c = exp2f(part_ml[(base + s) * 2] - mn);
+        acc = fmaf(part_o[(base + s) * DP + d], c, acc);
+        den = fmaf(part_ml[(base + s) * 2 + 1], c, den);
+    }
+    out[(long)b * ldo + (long)h * DP + d] = f2bf(ns > 0 ? acc / den : 0.f);
+}
+
+template <int DP>
+static int launch_attn_decode(int G, dim3 grid, hipStream_t stream, const bf16_t* q, long ldq, const bf16_t* kpool, const bf16_t* vpool,
+                              long ldp, const int* bt, int bt_stride, const int* kv_len, int len_add, float* po, float* pml, int nq,
+                              int nsplit, float sl2e) {
+#define DEC_CASE(GG)                                                                                                          \
+    case GG:                                                                                                                  \
+        hipLaunchKernelGGL((attn_decode_kernel<DP, GG>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, \
+                           kv_len, len_add, po, pml, nq, nsplit, sl2e);                                                       \
+        break
+    switch (G) {
+        DEC_CASE(1); DEC_CASE(2); DEC_CASE(3); DEC_CASE(4); DEC_CASE(5); DEC_CASE(6); DEC_CASE(7); DEC_CASE(8);
+        default: return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_decode: GQA group %d > 8", G);
+    }
+#undef DEC_CASE
+    return bagel_check_launch("attn_decode_kernel");
+}
+
+extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
+                                            const int32_t* block_table, int32_t bt_stride, const int32_t* kv_len,
+                                            int32_t len_add, int32_t max_len, float* part_o, float* part_ml, void* out,
+                                            int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
+                                            float softmax_scale, hipStream_t stream) {
+    BAGEL_REQUIRE(q && kpool && vpool && block_table && kv_len && part_o && part_ml && out, "attn_decode: null pointer");
+    BAGEL_REQUIRE(head_dim == 64 || head_dim == 128, "attn_decode: head_dim %d not in {64,128} (pad the projection)", head_dim);
+    BAGEL_REQUIRE(nkv > 0 && nq % nkv == 0, "attn_decode: nq must be a multiple of nkv");
+    BAGEL_REQUIRE((ldq % 8) == 0 && (ld_pool % 8) == 0 && (ldo % 2) == 0, "attn_decode: leading dims");
+    BAGEL_REQUIRE((((uintptr_t)q | (uintptr_t)kpool | (uintptr_t)vpool) & 15) == 0, "attn_decode: 16-byte alignment");
+    if (batch <= 0 || max_len <= 0) return BAGEL_OK;
+    const int nsplit = ceil_div(max_len, DEC_CH);
+    const float sl2e = softmax_scale * 1.4426950408889634f;
+    const dim3 grid(nsplit, nkv, batch);
+    int rc;
+    if (head_dim == 128)
+        rc = launch_attn_decode<128>(nq / nkv, grid, stream, (const bf16_t*)q, (long)ldq, (const bf16_t*)kpool, (const bf16_t*)vpool,
+                                     (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
+    else
+        rc = launch_attn_decode<64>(nq / nkv, grid, stream, (const bf16_t*)q, (long)ldq, (const bf16_t*)kpool, (const bf16_t*)vpool,
+                                    (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
+    if (rc != BAGEL_OK) return rc;
+    if (head_dim == 128)
+        hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(nq, batch), dim3(128), 0, stream, part_o, part_ml, kv_len, len_add,
+                           (bf16_t*)out, (long)ldo, nq, nsplit);
+    else
+        hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(nq, batch), dim3(64), 0, stream, part_o, part_ml, kv_len, len_add,
+                           (bf16_t*)out, (long)ldo, nq, nsplit);
+    return bagel_check_launch("attn_decode_combine_kernel");
+}
+
+// Token bookkeeping of one decode step on the device (bagel.py:984-994): the chosen token becomes the next input,
+// positions and KV lengths advance, the token is logged at tokens_out[(step+1), b].
+__global__ void decode_advance_kernel(const long* __restrict__ next_tok, int* __restrict__ cur_tok32, long* __restrict__ tokens_out,
+                                      long* __restrict__ pos, int* __restrict__ kv_len, int* __restrict__ step, int batch,
+                                      int max_steps) {
+    const int b = threadIdx.x;
+    const int s = *step;
+    __syncthreads();
+    if (b < batch) {
+        const long t = next_tok[b];
+        cur_tok32[b] = (int)t;
+        if (s + 1 < max_steps) tokens_out[(long)(s + 1) * batch + b] = t;
+        pos[b] += 1;
+        kv_len[b] += 1;
+    }
+    if (b == 0) *step = s + 1;
+}
+
+extern "C" int bagel_decode_advance(const int64_t* next_tok, int32_t* cur_tok32, int64_t* tokens_out, int64_t* pos,
+                                    int32_t* kv_len, int32_t* step, int32_t batch, int32_t max_steps, hipStream_t stream) {
+    BAGEL_REQUIRE(next_tok && cur_tok32 && tokens_out && pos && kv_len && step, "decode_advance: null pointer");
+    BAGEL_REQUIRE(batch > 0 && batch <= 1024, "decode_advance: batch %d not in [1,1024]", batch);
+    hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(((batch + 63) / 64) * 64), 0, stream, (const long*)next_tok, cur_tok32,
+                       (long*)tokens_out, (long*)pos, kv_len, step, batch, max_steps);
+    return bagel_check_launch("decode_advance_kernel");
+}

@@ -266,31 +266,45 @@ extern "C" int bagel_cfg_stage2_euler(float* x_t, const void* v_or_tmp, const fl
 // ---------------------------------------------------------------------------------------------------------
 // argmax over bf16 logits rows (bagel.py:984); ties -> lowest index (torch.argmax).  One block per row.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ x, long ld, long* __restrict__ out, int cols) {
+__global__ __launch_bounds__(1024) void argmax_kernel(const bf16_t* __restrict__ x, long ld, long* __restrict__ out, int cols) {
     const bf16_t* r = x + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = threadIdx.x; c < cols; c += 256) {
+    // 16-byte lanes when the row allows it (the lm_head logits: 152064 columns = 19008 chunks, ~19 per thread)
+    const bool vec = ((((uintptr_t)r) & 15) == 0);
+    const int nvec = vec ? (cols >> 3) : 0;
+    for (int c = tid; c < nvec; c += 1024) {
+        const u32x4_t v = *(const u32x4_t*)(r + (long)c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = lo2f(v[e]), hi = hi2f(v[e]);
+            const int i0 = c * 8 + 2 * e;
+            if (lo > best) { best = lo; bi = i0; }          // within a thread the indices only grow: strict > keeps the lowest
+            if (hi > best) { best = hi; bi = i0 + 1; }
+        }
+    }
+    for (int c = nvec * 8 + tid; c < cols; c += 1024) {
         const float f = bf2f(r[c]);
         if (f > best || (f == best && c < bi)) { best = f; bi = c; }
     }
-    __shared__ float sv[256];
-    __shared__ int si[256];
-    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    sv[tid] = best; si[tid] = bi;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            const float f = sv[threadIdx.x + s]; const int j = si[threadIdx.x + s];
-            if (f > sv[threadIdx.x] || (f == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = f; si[threadIdx.x] = j; }
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float f = sv[tid + s]; const int j = si[tid + s];
+            if (f > sv[tid] || (f == sv[tid] && j < si[tid])) { sv[tid] = f; si[tid] = j; }
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = si[0];
+    if (tid == 0) out[blockIdx.x] = si[0] == 0x7fffffff ? 0 : si[0];   // a row of -inf: index 0, like torch
 }
 
 extern "C" int bagel_argmax_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows, int32_t cols, hipStream_t stream) {
     BAGEL_REQUIRE(logits && out && cols > 0, "argmax: bad arguments");
     if (rows <= 0) return BAGEL_OK;
-    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)logits, (long)ld, (long*)out, cols);
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, stream, (const bf16_t*)logits, (long)ld, (long*)out, cols);
     return bagel_check_launch("argmax_kernel");
 }

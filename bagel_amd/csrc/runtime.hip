@@ -24,3 +24,42 @@ int bagel_check_launch(const char* what) {
 extern "C" int bagel_hip_version(void) { return 100; }
 extern "C" const char* bagel_hip_last_error(void) { return g_err; }
 extern "C" const char* bagel_hip_arch(void) { return "gfx950"; }
+
+// ---- hipGraph capture of a launch sequence (the per-token decode step) ----------------------------------------------
+// The ops above only launch kernels on the caller's stream, so a step recorded once between begin/end replays with one
+// host call per token.  Capture is "relaxed": the host framework may touch its allocator on other threads meanwhile.
+extern "C" int bagel_graph_begin(hipStream_t stream) {
+    BAGEL_REQUIRE(stream != nullptr, "graph_begin: the legacy default stream cannot be captured; use a side stream");
+    hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) return bagel_set_error(BAGEL_ERR_LAUNCH, "graph_begin: %s", hipGetErrorString(e));
+    return BAGEL_OK;
+}
+
+extern "C" int bagel_graph_end(hipStream_t stream, void** exec_out) {
+    BAGEL_REQUIRE(exec_out != nullptr, "graph_end: null output");
+    *exec_out = nullptr;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(stream, &graph);
+    if (e != hipSuccess || graph == nullptr) {
+        (void)hipGetLastError();
+        return bagel_set_error(BAGEL_ERR_LAUNCH, "graph_end: capture failed: %s", hipGetErrorString(e));
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return bagel_set_error(BAGEL_ERR_LAUNCH, "graph_end: instantiate failed: %s", hipGetErrorString(e));
+    *exec_out = (void*)exec;
+    return BAGEL_OK;
+}
+
+extern "C" int bagel_graph_launch(void* exec, hipStream_t stream) {
+    BAGEL_REQUIRE(exec != nullptr, "graph_launch: null graph");
+    hipError_t e = hipGraphLaunch((hipGraphExec_t)exec, stream);
+    if (e != hipSuccess) return bagel_set_error(BAGEL_ERR_LAUNCH, "graph_launch: %s", hipGetErrorString(e));
+    return BAGEL_OK;
+}
+
+extern "C" int bagel_graph_destroy(void* exec) {
+    if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec);
+    return BAGEL_OK;
+}

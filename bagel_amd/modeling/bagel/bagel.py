@@ -481,39 +481,41 @@ class Bagel(nn.Module):
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def generate_text(self, past_key_values, packed_key_value_indexes, key_values_lens, packed_start_tokens,
-                      packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None):
-        """bagel.py:930-1000.  Returns the INPUT token of every step, shape (steps, B) int64 (first row = bos)."""
+                      packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None,
+                      use_graph=None):
+        """bagel.py:930-1000.  Returns the INPUT token of every step, shape (steps, B) int64 (first row = bos).
+
+        Execution: a ``DecodeSession`` (decode.py) -- paged KV cache adopted from ``past_key_values``, loop state on the
+        device, step 0 launched eagerly, the remaining steps replayed from one captured hipGraph (``use_graph=False``
+        or BAGEL_DECODE_GRAPH=0 keeps every step eager).  ``past_key_values`` receives the new K/V rows at the end, as
+        the reference's in-place cache update does."""
+        import os
+        from .decode import DecodeSession
         lm = self.language_model
-        dev = self.device
-        eng = lm.engine()
         kv_lens = [int(x) for x in key_values_lens.tolist()]
-        B = len(kv_lens)
-        pos = packed_query_position_ids.to(torch.long).clone()
-        curr = self._dev(packed_start_tokens, torch.long)
-        table = lm.model.embed_tokens.weight.data
-        head = lm.lm_head.weight.data
-        logits = torch.empty((B, head.shape[0]), dtype=BF16, device=dev)
-        x = torch.empty((B, self.hidden_size), dtype=BF16, device=dev)
-        generated = []
+        if packed_key_value_indexes is not None and int(packed_key_value_indexes.numel()) != sum(kv_lens):
+            raise ValueError("packed_key_value_indexes does not cover key_values_lens")
+        if max_length <= 0:
+            return torch.empty((0, len(kv_lens)), dtype=torch.long, device=self.device)
+        sess = DecodeSession(lm.engine(), lm.model.embed_tokens.weight.data, lm.lm_head.weight.data, past_key_values, kv_lens,
+                             packed_start_tokens, packed_query_position_ids, max_length)
+        self._last_decode_session = sess
+        if use_graph is None:
+            use_graph = os.environ.get("BAGEL_DECODE_GRAPH", "1") != "0"
+        sampler = None
+        if do_sample:
+            # sampling draws from torch's generator (an RNG stream cannot be matched across devices anyway, bagel.py:980-983)
+            sampler = lambda logits: torch.multinomial(torch.softmax(logits.float() / temperature, dim=-1), num_samples=1).squeeze(1)  # noqa: E731
         step = 0
         while step < max_length:
-            generated.append(curr)
-            ops.copy_rows(table, x, B, self.hidden_size, src_rows=curr.to(torch.int32))
-            plan = eng.plan([1] * B, pos, key_values_lens=kv_lens)
-            h = eng.forward(x, plan, "und", past_key_values, update=True, causal=True)
-            ops.gemm(h, head, logits, M0=B)
-            if do_sample:
-                # sampling draws from torch's generator; an RNG stream cannot be matched across devices anyway
-                probs = torch.softmax(logits.float() / temperature, dim=-1)
-                curr = torch.multinomial(probs, num_samples=1).squeeze(1)
-            else:
-                curr = ops.argmax(logits)
-            kv_lens = [k + 1 for k in kv_lens]
-            pos = pos + 1
+            if step == 1 and use_graph and max_length > 2:
+                sess.capture(include_advance=not do_sample)
+            sess.step(sampler)
             step += 1
-            if end_token_id is not None and int(curr[0]) == end_token_id:   # only support batch=1 (bagel.py:996)
+            if end_token_id is not None and sess.last_token(0) == end_token_id:   # only support batch=1 (bagel.py:996)
                 break
-        return torch.stack(generated, dim=0)
+        sess.write_back(past_key_values)
+        return sess.tokens_so_far()
 
     @torch.no_grad()
     def chat(self, tokenizer, new_token_ids, image_transform, images, prompt, max_length, do_sample=False, temperature=1.0):

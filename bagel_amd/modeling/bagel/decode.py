@@ -1,0 +1,222 @@
+"""Autoregressive text decode engine: paged KV cache + a per-token step whose whole state lives on the device.
+
+Mirrors the loop of ``Bagel.generate_text`` (bagel.py:930-1000) and the Lq = 1 path of
+``Qwen2Model.forward_inference`` (qwen2_navit.py:1018-1092, und mode), re-planned for MI355X:
+
+  * decode is HBM-bound (14.14 GB of und-expert weights per token at 7B), so every projection is the
+    skinny weight-streaming kernel (``bagel_gemv_bf16``) with the RMSNorm fused into its activation staging --
+    7 launches per layer instead of the reference's ~178 aten ops;
+  * the KV cache is paged (64-token pages, block table per sample); a step appends one row per sample in place
+    instead of re-allocating and re-scattering the whole cache per layer per token (qwen2_navit.py:563-575);
+  * token, position, KV length and step counter are device buffers advanced by ``bagel_decode_advance``, so one step
+    is captured ONCE into a hipGraph and replayed per token: the host issues one call per token and only reads a
+    token back when the caller asked for an end-token check (bagel.py:996).
+"""
+import torch
+
+from ... import ops
+
+BF16 = torch.bfloat16
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+class PagedKVCache:
+    """Per-layer K/V page pools + per-sample block tables.  ``order`` (optional permutation of the page ids) exists
+    so tests can prove that nothing assumes physically contiguous pages."""
+
+    PAGE = ops.KV_PAGE
+
+    def __init__(self, num_layers, batch, width, capacity_tokens, device, order=None):
+        self.num_layers, self.batch, self.width = num_layers, batch, width
+        self.pages_per_sample = max(1, _ceil_to(capacity_tokens, self.PAGE) // self.PAGE)
+        self.num_pages = batch * self.pages_per_sample
+        rows = self.num_pages * self.PAGE
+        self.k = torch.empty((num_layers, rows, width), dtype=BF16, device=device)
+        self.v = torch.empty((num_layers, rows, width), dtype=BF16, device=device)
+        ids = list(range(self.num_pages)) if order is None else [int(x) for x in order]
+        if sorted(ids) != list(range(self.num_pages)):
+            raise ValueError("order must be a permutation of the page ids")
+        self.block_table_host = [ids[b * self.pages_per_sample:(b + 1) * self.pages_per_sample] for b in range(batch)]
+        self.block_table = torch.tensor(self.block_table_host, dtype=torch.int32, device=device)
+        self.kv_len = torch.zeros((batch,), dtype=torch.int32, device=device)
+        self.capacity = self.pages_per_sample * self.PAGE
+
+    def physical_rows(self, b, start, stop):
+        """Pool rows of tokens [start, stop) of sample b."""
+        bt = self.block_table_host[b]
+        return [bt[j // self.PAGE] * self.PAGE + j % self.PAGE for j in range(start, stop)]
+
+    def adopt(self, cache, lens):
+        """Copy a NaiveCache (merged layout [ctx_0 | ctx_1 | ...], per-sample ``lens``) into the pages."""
+        if max(lens) > self.capacity:
+            raise ValueError("context longer than the page capacity")
+        dst = []
+        for b, n in enumerate(lens):
+            dst.extend(self.physical_rows(b, 0, n))
+        total = len(dst)
+        dev = self.k.device
+        dst_t = torch.tensor(dst, dtype=torch.int32, device=dev) if total else None
+        for li in range(self.num_layers):
+            if total:
+                ops.copy_rows(cache._k[li], self.k[li], total, self.width, dst_rows=dst_t)
+                ops.copy_rows(cache._v[li], self.v[li], total, self.width, dst_rows=dst_t)
+        self.kv_len.copy_(torch.tensor([int(n) for n in lens], dtype=torch.int32))
+
+    def gather(self, layer, ranges):
+        """Rows of ``ranges`` = [(b, start, stop), ...] of one layer -> contiguous (K, V) tensors."""
+        src = []
+        for b, s, e in ranges:
+            src.extend(self.physical_rows(b, s, e))
+        dev = self.k.device
+        k = torch.empty((len(src), self.width), dtype=BF16, device=dev)
+        v = torch.empty_like(k)
+        if src:
+            idx = torch.tensor(src, dtype=torch.int32, device=dev)
+            ops.copy_rows(self.k[layer], k, len(src), self.width, src_rows=idx)
+            ops.copy_rows(self.v[layer], v, len(src), self.width, src_rows=idx)
+        return k, v
+
+
+class DecodeSession:
+    """One ``generate_text`` call: device-resident loop state, the per-token launch sequence, and its hipGraph."""
+
+    def __init__(self, engine, embed_table, lm_head_weight, cache, kv_lens, start_tokens, position_ids, max_length,
+                 page_order=None):
+        self.eng = eng = engine
+        dev = eng.device
+        self.B = B = len(kv_lens)
+        self.max_length = int(max_length)
+        self.ctx_lens = [int(x) for x in kv_lens]
+        self.table, self.head = embed_table, lm_head_weight
+        nq, nkv, dp = eng.nq, eng.nkv, eng.dp
+        self.width = nkv * dp
+        L = len(eng.layers)
+        self.max_len = max(self.ctx_lens) + self.max_length   # longest key range a step can see
+        self.paged = PagedKVCache(L, B, self.width, self.max_len, dev, order=page_order)
+        has_ctx = cache is not None and not cache.is_empty(0) and sum(self.ctx_lens) > 0
+        if has_ctx:
+            if list(cache.lens(0)) != self.ctx_lens:
+                raise ValueError("key_values_lens does not match the KV cache contents")
+            self.paged.adopt(cache, self.ctx_lens)
+        elif sum(self.ctx_lens) != 0:
+            raise ValueError("key_values_lens is non-zero but the KV cache is empty")
+        e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
+        self.x = e(B, eng.H)
+        self.qkv = e(B, (nq + 2 * nkv) * dp)
+        self.att = e(B, nq * dp)
+        self.act = e(B, eng.I)
+        self.logits = e(B, lm_head_weight.shape[0])
+        self.cos = e(B, eng.hd // 2)
+        self.sin = e(B, eng.hd // 2)
+        self.part_o, self.part_ml = ops.attn_decode_workspace(B, nq, dp, self.max_len, dev)
+        self.pos = position_ids.to(device=dev, dtype=torch.long).clone().contiguous()
+        st = start_tokens.to(device=dev, dtype=torch.long).contiguous()
+        self.cur32 = st.to(torch.int32)
+        self.tokens = torch.zeros((self.max_length + 1, B), dtype=torch.long, device=dev)
+        self.tokens[0].copy_(st)
+        self.next_tok = torch.zeros((B,), dtype=torch.long, device=dev)
+        self.step_ctr = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.inv_freq = eng.model.rotary_emb.inv_freq(dev)
+        self.steps_done = 0
+        self.graph = None
+        self.graph_error = None
+
+    # ---- the launch sequence of one token (no host-dependent values: safe to capture) ---------------------------
+    def forward_launches(self):
+        """embed -> L x [norm+qkv, qk-norm/rope, KV append, attention, o_proj(+res), norm+gate/up (SwiGLU), down(+res)]
+        -> final norm + lm_head -> argmax."""
+        eng, B = self.eng, self.B
+        nq, nkv, dp, hd = eng.nq, eng.nkv, eng.dp, eng.hd
+        qw, kw_ = nq * dp, nkv * dp
+        x, qkv, att, act = self.x, self.qkv, self.att, self.act
+        k_v, v_v = qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
+        pg = self.paged
+        scale = hd ** -0.5
+        ops.rope_table_into(self.pos, self.inv_freq, self.cos, self.sin)
+        ops.copy_rows(self.table, x, B, eng.H, src_rows=self.cur32)
+        for li, P in enumerate(eng.layers):
+            ops.gemv(x, P.wqkv[0], qkv, bias=P.bqkv[0], norm_w=P.ln_in[0], eps=eng.eps)
+            ops.qknorm_rope(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
+                            None, None, None, nq, nkv, hd, dp, eng.eps, gen_mode=False, use_norm=eng.use_norm)
+            ops.kv_append_paged(k_v, v_v, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, kw_)
+            ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
+                                  self.part_ml, att, B, nq, nkv, dp, scale)
+            ops.gemv(att, P.wo[0], x, residual=x)
+            ops.gemv(x, P.wgu[0], act, epilogue=ops.EPI_SWIGLU16, norm_w=P.ln_post[0], eps=eng.eps)
+            ops.gemv(act, P.wd[0], x, residual=x)
+        ops.gemv(x, self.head, self.logits, norm_w=eng.model.norm.weight.data, eps=eng.eps)
+        ops.argmax_into(self.logits, self.next_tok)
+
+    def advance_launch(self):
+        ops.decode_advance(self.next_tok, self.cur32, self.tokens, self.pos, self.paged.kv_len, self.step_ctr, self.B,
+                           self.max_length + 1)
+
+    # ---- execution ---------------------------------------------------------------------------------------------
+    def capture(self, include_advance):
+        """Record one step into a hipGraph on a side stream.  Returns False (and keeps the eager path) if the runtime
+        refuses; the reason is kept in ``graph_error``."""
+        try:
+            side = torch.cuda.Stream(device=self.eng.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with ops.HipGraph.capture(side) as g:
+                self.forward_launches()
+                if include_advance:
+                    self.advance_launch()
+            self.graph, self._graph_has_advance = g, include_advance
+            return True
+        except ops.BagelHipError as err:
+            self.graph, self.graph_error = None, str(err)
+            return False
+
+    def step(self, sampled=None):
+        """Run one token.  ``sampled``: None -> greedy (argmax feeds the next step); else a callable
+        logits -> int64 token tensor (host-framework sampling, outside any graph)."""
+        if self.steps_done >= self.max_length:
+            raise ValueError("DecodeSession: max_length steps already taken")
+        if self.graph is not None:
+            cur = torch.cuda.current_stream()
+            self.graph.stream.wait_stream(cur)
+            self.graph.launch()
+            cur.wait_stream(self.graph.stream)
+            if not self._graph_has_advance:
+                if sampled is not None:
+                    self.next_tok.copy_(sampled(self.logits))
+                self.advance_launch()
+        else:
+            self.forward_launches()
+            if sampled is not None:
+                self.next_tok.copy_(sampled(self.logits))
+            self.advance_launch()
+        self.steps_done += 1
+
+    def tokens_so_far(self):
+        """(steps, B) int64: the INPUT token of every step taken (row 0 = the start tokens), bagel.py:942,999."""
+        return self.tokens[: self.steps_done].clone()
+
+    def last_token(self, b=0):
+        return int(self.tokens[self.steps_done, b])
+
+    def write_back(self, cache):
+        """Append the K/V rows of the decoded tokens to the caller's NaiveCache (the reference mutates it in place)."""
+        n = self.steps_done
+        if n == 0 or cache is None:
+            return
+        eng = self.eng
+        ranges = [(b, self.ctx_lens[b], self.ctx_lens[b] + n) for b in range(self.B)]
+        new_dst = ctx_dst = None
+        if self.B > 1:
+            nd, cd, base = [], [], 0
+            for b in range(self.B):
+                c = self.ctx_lens[b]
+                cd.extend(range(base, base + c))
+                nd.extend(range(base + c, base + c + n))
+                base += c + n
+            dev = eng.device
+            new_dst = torch.tensor(nd, dtype=torch.int32, device=dev)
+            ctx_dst = torch.tensor(cd, dtype=torch.int32, device=dev) if cd else None
+        for li in range(len(eng.layers)):
+            k, v = self.paged.gather(li, ranges)
+            cache.store(li, k, v, [n] * self.B, self.ctx_lens, eng.nkv, eng.hd, eng.dp, new_dst, ctx_dst)

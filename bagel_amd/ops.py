@@ -72,6 +72,10 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
             _req(r, torch.int32, "gemm.rows")
     if residual is not None:
         _req(residual, BF16, "gemm.residual")
+    if (variant is None and W1 is None and M1 == 0 and 0 < M0 <= GEMV_MAX_ROWS and a_rows0 is None and c_rows0 is None
+            and N % 2 == 0 and K * 2 <= GEMV_MAX_K_BYTES and A.data_ptr() % 16 == 0 and W0.data_ptr() % 16 == 0):
+        # a few rows: weight streaming is HBM-bound -> the skinny kernel (decode.hip), not an MFMA tile
+        return gemv(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if variant is None:
         variant = default_gemm_variant(M0 + M1, N, K)
     check(lib().bagel_gemm_bf16(_ptr(A), _ld(A), _ptr(W0), _ptr(bias0), _ptr(a_rows0), _ptr(c_rows0), M0,
@@ -79,6 +83,120 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
                                 _ptr(residual), _ld(residual) if residual is not None else 0, _ptr(C), _ld(C),
                                 N, K, epilogue, variant, _stream()), "bagel_gemm_bf16")
     return C
+
+
+GEMV_MAX_ROWS = 8
+GEMV_MAX_K_BYTES = 144 * 1024
+
+
+def gemv(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0):
+    """Skinny GEMM (M <= a few rows) with optional fused RMSNorm of the A rows; see bagel_gemv_bf16."""
+    _req(A, BF16, "gemv.A"); _req(W, BF16, "gemv.W"); _req(C, BF16, "gemv.C")
+    N, K = W.shape
+    if A.shape[-1] != K:
+        raise BagelHipError(f"gemv: A has K={A.shape[-1]}, W has K={K}")
+    if M is None:
+        M = A.shape[0]
+    if residual is not None:
+        _req(residual, BF16, "gemv.residual")
+    if norm_w is not None:
+        _req(norm_w, BF16, "gemv.norm_w")
+    check(lib().bagel_gemv_bf16(_ptr(A), _ld(A), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
+                                _ld(residual) if residual is not None else 0, _ptr(C), _ld(C), _ptr(norm_w), float(eps),
+                                M, N, K, epilogue, _stream()), "bagel_gemv_bf16")
+    return C
+
+
+KV_PAGE = 64          # tokens per KV page (BAGEL_KV_PAGE in decode.hip)
+DECODE_CHUNK = 128    # keys per attention split (DEC_CH in decode.hip)
+
+
+def kv_append_paged(k_new, v_new, kpool, vpool, block_table, kv_len, batch, width):
+    _req(k_new, BF16, "kv_append.k_new"); _req(v_new, BF16, "kv_append.v_new")
+    _req(kpool, BF16, "kv_append.kpool"); _req(vpool, BF16, "kv_append.vpool")
+    _req(block_table, torch.int32, "kv_append.block_table"); _req(kv_len, torch.int32, "kv_append.kv_len")
+    if k_new.stride(0) != v_new.stride(0) or kpool.stride(0) != vpool.stride(0):
+        raise BagelHipError("kv_append_paged: K and V must share row strides")
+    check(lib().bagel_kv_append_paged_bf16(_ptr(k_new), _ptr(v_new), k_new.stride(0), _ptr(kpool), _ptr(vpool), kpool.stride(0),
+                                           _ptr(block_table), block_table.stride(0), _ptr(kv_len), batch, width, _stream()),
+          "bagel_kv_append_paged_bf16")
+
+
+def attn_decode_workspace(batch, nq, head_dim, max_len, device):
+    ns = (max_len + DECODE_CHUNK - 1) // DECODE_CHUNK
+    return (torch.empty((batch * nq * ns * head_dim,), dtype=torch.float32, device=device),
+            torch.empty((batch * nq * ns * 2,), dtype=torch.float32, device=device))
+
+
+def attn_decode_paged(q, kpool, vpool, block_table, kv_len, len_add, max_len, part_o, part_ml, out, batch, nq, nkv, head_dim,
+                      softmax_scale):
+    """Lq = 1 attention over keys [0, kv_len[b] + len_add) of the paged cache; q:[B, >= nq*D] rows, out:[B, nq*D]."""
+    _req(q, BF16, "attn_decode.q"); _req(out, BF16, "attn_decode.out")
+    _req(kpool, BF16, "attn_decode.kpool"); _req(vpool, BF16, "attn_decode.vpool")
+    _req(block_table, torch.int32, "attn_decode.block_table"); _req(kv_len, torch.int32, "attn_decode.kv_len")
+    _req(part_o, torch.float32, "attn_decode.part_o"); _req(part_ml, torch.float32, "attn_decode.part_ml")
+    ns = (max_len + DECODE_CHUNK - 1) // DECODE_CHUNK
+    if part_o.numel() < batch * nq * ns * head_dim or part_ml.numel() < batch * nq * ns * 2:
+        raise BagelHipError("attn_decode_paged: workspace too small for max_len")
+    check(lib().bagel_attn_decode_paged_bf16(_ptr(q), q.stride(0), _ptr(kpool), _ptr(vpool), kpool.stride(0), _ptr(block_table),
+                                             block_table.stride(0), _ptr(kv_len), len_add, max_len, _ptr(part_o), _ptr(part_ml),
+                                             _ptr(out), out.stride(0), batch, nq, nkv, head_dim, float(softmax_scale), _stream()),
+          "bagel_attn_decode_paged_bf16")
+    return out
+
+
+def decode_advance(next_tok, cur_tok32, tokens_out, pos, kv_len, step, batch, max_steps):
+    _req(next_tok, torch.int64, "decode_advance.next_tok"); _req(cur_tok32, torch.int32, "decode_advance.cur_tok32")
+    _req(tokens_out, torch.int64, "decode_advance.tokens_out"); _req(pos, torch.int64, "decode_advance.pos")
+    _req(kv_len, torch.int32, "decode_advance.kv_len"); _req(step, torch.int32, "decode_advance.step")
+    check(lib().bagel_decode_advance(_ptr(next_tok), _ptr(cur_tok32), _ptr(tokens_out), _ptr(pos), _ptr(kv_len), _ptr(step),
+                                     batch, max_steps, _stream()), "bagel_decode_advance")
+
+
+class HipGraph:
+    """A captured launch sequence (hipGraph).  ``with HipGraph.capture(stream) as g: <launch ops>`` then ``g.launch()``."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self._exec = None
+
+    def __enter__(self):
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        try:
+            check(lib().bagel_graph_begin(self.stream.cuda_stream), "bagel_graph_begin")
+        except Exception:
+            self._ctx.__exit__(None, None, None)
+            raise
+        return self
+
+    def __exit__(self, et, ev, tb):
+        handle = ctypes.c_void_p(0)
+        try:
+            rc = lib().bagel_graph_end(self.stream.cuda_stream, ctypes.addressof(handle))
+        finally:
+            self._ctx.__exit__(None, None, None)
+        if et is None:
+            check(rc, "bagel_graph_end")
+            self._exec = handle.value
+        elif rc == 0 and handle.value:
+            lib().bagel_graph_destroy(handle.value)
+        return False
+
+    @classmethod
+    def capture(cls, stream):
+        return cls(stream)
+
+    def launch(self):
+        check(lib().bagel_graph_launch(self._exec, self.stream.cuda_stream), "bagel_graph_launch")
+
+    def __del__(self):
+        if getattr(self, "_exec", None):
+            try:
+                lib().bagel_graph_destroy(self._exec)
+            except Exception:
+                pass
+            self._exec = None
 
 
 def rmsnorm(x, w0, out, eps, w1=None, expert=None):
@@ -102,6 +220,18 @@ def rope_table(position_ids, inv_freq):
     rows, half = position_ids.numel(), inv_freq.numel()
     cos = torch.empty((rows, half), dtype=BF16, device=position_ids.device)
     sin = torch.empty_like(cos)
+    check(lib().bagel_rope_table(_ptr(position_ids), _ptr(inv_freq), _ptr(cos), _ptr(sin), rows, half, _stream()),
+          "bagel_rope_table")
+    return cos, sin
+
+
+def rope_table_into(position_ids, inv_freq, cos, sin):
+    """rope_table writing into caller-owned [rows, half] bf16 buffers (no allocation: graph-capturable)."""
+    _req(position_ids, torch.int64, "rope_table.position_ids"); _req(inv_freq, torch.float32, "rope_table.inv_freq")
+    _req(cos, BF16, "rope_table.cos"); _req(sin, BF16, "rope_table.sin")
+    rows, half = position_ids.numel(), inv_freq.numel()
+    if cos.numel() != rows * half or sin.numel() != rows * half or not cos.is_contiguous() or not sin.is_contiguous():
+        raise BagelHipError("rope_table_into: cos/sin must be contiguous [rows, half]")
     check(lib().bagel_rope_table(_ptr(position_ids), _ptr(inv_freq), _ptr(cos), _ptr(sin), rows, half, _stream()),
           "bagel_rope_table")
     return cos, sin
@@ -193,6 +323,13 @@ def cfg_stage2_euler(x_t, v_or_tmp, partials, nparts, renorm_min, dt, use_global
     check(lib().bagel_cfg_stage2_euler(_ptr(x_t), _ptr(v_or_tmp), _ptr(partials), nparts, float(renorm_min), float(dt),
                                        x_t.numel(), int(use_global_scale), _stream()), "bagel_cfg_stage2_euler")
     return x_t
+
+
+def argmax_into(logits, out):
+    _req(logits, BF16, "argmax.logits"); _req(out, torch.int64, "argmax.out")
+    check(lib().bagel_argmax_bf16(_ptr(logits), logits.stride(0), _ptr(out), logits.shape[0], logits.shape[1], _stream()),
+          "bagel_argmax_bf16")
+    return out
 
 
 def argmax(logits):

@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="debug only: skip the VAE decode (result flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=1)
+    ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
+    ap.add_argument("--only-understanding", action="store_true", help="debug only: skip the text->image leg (result flagged invalid)")
+    ap.add_argument("--und-new-tokens", type=int, default=256)
+    ap.add_argument("--und-image", type=int, default=980, help="side of the understanding image (980 -> 4900 ViT tokens)")
     return ap.parse_args()
 
 
@@ -124,6 +128,98 @@ def cpu_baseline(args, cfg):
                        f"x2 forwards x{steps} Euler steps (glue, prefill and VAE excluded)")
 
 
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md ("8 TB/s peak (spec); ~6.3 TB/s achievable")
+
+
+def understanding_leg(args, model, cfg, ids, dev, world, fence):
+    """BASELINE.json configs[1]: image understanding = SigLIP prefill (980^2 -> 4900 ViT tokens) + text prefill (32 ids) +
+    greedy KV-cached decode of N new tokens (eos disabled), batch 1 per GPU (bagel.py:996), replicas across ranks.
+    Decode is HBM-bound: algorithmic bytes/token = und-expert weights + lm_head + the KV context."""
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    L = model.config.llm_config.num_hidden_layers
+    llm = cfg["llm"]
+    g = torch.Generator().manual_seed(2)
+    image = torch.rand(3, args.und_image, args.und_image, generator=g) * 2 - 1
+    prompt_ids = torch.randint(0, 151643, (32,), generator=torch.Generator().manual_seed(1)).tolist()
+    tok = FixedTokenizer(prompt_ids)
+    ident = lambda t: t  # noqa: E731
+
+    def prefill():
+        cache = NaiveCache(L)
+        gi, lens, ropes = model.prepare_vit_images([0], [0], [image], ident, ids)
+        cache = model.forward_cache_update_vit(cache, **gi)
+        torch.cuda.synchronize()
+        t_vit = time.perf_counter()
+        gi, lens, ropes = model.prepare_prompts(lens, ropes, ["p"], tok, ids)
+        cache = model.forward_cache_update_text(cache, **gi)
+        torch.cuda.synchronize()
+        return cache, lens, ropes, t_vit
+
+    def decode(cache, lens, ropes, n):
+        st = model.prepare_start_tokens(lens, ropes, ids)
+        return model.generate_text(past_key_values=cache, max_length=n, do_sample=False, end_token_id=None, **st)
+
+    cache, lens, ropes, _ = prefill()          # warm-up: engines, workspaces, LDS attributes
+    decode(cache, lens, ropes, 8)
+    fence()
+    t0 = time.perf_counter()
+    cache, lens, ropes, t_vit = prefill()
+    t1 = time.perf_counter()
+    fence()
+    n = args.und_new_tokens
+    t2 = time.perf_counter()
+    toks = decode(cache, lens, ropes, n)
+    fence()
+    t3 = time.perf_counter()
+    sess = model._last_decode_session
+    dt = t3 - t2
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    H, I, nkv, V = llm["hidden_size"], llm["intermediate_size"], llm["num_key_value_heads"], llm["vocab_size"]
+    hd = H // llm["num_attention_heads"]
+    w_bytes = 2.0 * (L * (2 * H * H + 2 * H * nkv * hd + 3 * H * I) + V * H)
+    ctx = lens[0]
+    kv_bytes = 2.0 * nkv * hd * 2 * L * (ctx + n / 2.0)          # average context over the decoded span
+    bpt = w_bytes + kv_bytes
+    tps = n / dt
+    return {"metric": "understanding tokens/sec", "value": world * tps, "unit": "tokens/s", "per_gpu_tokens_per_s": tps,
+            "new_tokens": int(toks.shape[0]), "batch_per_gpu": 1, "context_tokens": int(ctx),
+            "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
+            "decode_ms_per_token": dt / n * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
+            "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer",
+            "roofline": {"bound": "hbm", "achieved": bpt * tps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bpt * tps / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "gemv_kernel<1> (decode step)",
+                         "algorithmic_bytes_per_token": bpt},
+            "workload": f"BAGEL-7B-MoT image understanding: {args.und_image}x{args.und_image} image -> {(args.und_image // 14) ** 2} ViT tokens (+2 markers) + 32+2 "
+                        f"prompt tokens prefill, greedy decode of {n} tokens, bf16, batch 1/GPU"}
+
+
+def understanding_subprocess(args, local):
+    """Run the configs[1] leg in a child process on the same GPU (a replica per rank): a fault or hang there can never
+    take the text->image number down with it."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding", "--no-cpu-baseline",
+           "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image)]
+    if args.layers is not None:
+        cmd += ["--layers", str(args.layers)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "understanding leg timed out after 900 s"}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line).get("understanding")
+            except ValueError:
+                break
+    return {"error": f"understanding leg exited {r.returncode}", "stderr_tail": r.stderr[-1500:]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -145,9 +241,10 @@ def main():
     from bagel_amd.parallel import broadcast_cache
 
     cfg = BAGEL_7B_MOT
-    model, vae = build_bagel(cfg, device=dev, num_layers=args.layers)
+    model, vae = build_bagel(cfg, device=dev, num_layers=args.layers, with_vae=not args.only_understanding)
     init_random_(model, seed=0)
-    init_random_(vae, seed=0)
+    if vae is not None:
+        init_random_(vae, seed=0)
     model.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device=dev).manual_seed(1))
     L = model.config.llm_config.num_hidden_layers
     B, R, T = args.batch, args.resolution, args.num_timesteps
@@ -193,6 +290,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.only_understanding:
+        # child mode (see understanding_subprocess): this process measures configs[1] only
+        try:
+            und = understanding_leg(args, model, cfg, ids, dev, world, fence)
+        except Exception as e:
+            import traceback
+            und = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
+        if rank == 0:
+            print(json.dumps({"metric": "understanding tokens/sec (debug: text->image leg skipped)", "valid": False,
+                              "understanding": und}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     for _ in range(args.warmup):
         one_step()
     records, orig_gemm, timed_gemm = gemm_profile_hook()
@@ -211,6 +322,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     finite = all(torch.isfinite(x).all().item() for x in latents)
+    und = None
+    if not args.no_understanding:
+        und = understanding_subprocess(args, local)
+        if world > 1:   # replicas: aggregate tokens/s = sum over ranks
+            v = und.get("per_gpu_tokens_per_s", 0.0) if isinstance(und, dict) else 0.0
+            tt = torch.tensor([v], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            if isinstance(und, dict) and "value" in und:
+                und["value"] = float(tt.item())
+                und["replicas"] = world
 
     if rank == 0:
         # the dominant kernel = the GEMM variant that carries the most FLOPs in the timed region
@@ -237,6 +358,7 @@ def main():
                          "traffic": None, "kernel": names.get(dom, str(dom)), "launches": len(records),
                          "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},
             "outputs_finite": bool(finite),
+            "understanding": und,
         }
         if args.layers is not None or args.no_vae or R != 1024 or T != 50:
             out["valid"] = False

@@ -110,6 +110,44 @@ int bagel_cfg_stage2_euler(float* x_t, const void* v_or_tmp, const float* partia
 /* torch.argmax(logits, -1) (bagel.py:984). */
 int bagel_argmax_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows, int32_t cols, bagel_stream_t stream);
 
+/* ---- autoregressive text decode (Bagel.generate_text, bagel.py:930-1000) ------------------------------------ */
+/* Skinny GEMM for M <= a few rows (HBM-bound weight streaming): C[M,N] = A[M,K] W[N,K]^T with the epilogues and
+ * roundings of bagel_gemm_bf16, plus an optional fused Qwen2RMSNorm of the A rows (norm_w != NULL:
+ * A <- w * bf16(A * rsqrt(mean(A^2) + eps)), modeling_qwen2.py:54-59) so a decode layer is 2 launches shorter.
+ * Replaces F.linear at Lq = 1: qwen2_navit.py:515-517,591; modeling_qwen2.py:200-201; lm_head bagel.py:978;
+ * TimestepEmbedder modeling_utils.py:107-110.  K % 8 == 0, N even; in-place residual (R == C) is allowed. */
+int bagel_gemv_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* R,
+                    int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N,
+                    int32_t K, int32_t epilogue, bagel_stream_t stream);
+
+/* Paged KV cache (64-token pages; token j of sample b at pool row block_table[b*bt_stride + j/64]*64 + j%64).
+ * Appends this step's K/V row of every sample at slot kv_len[b] (device memory) -- the in-place form of the
+ * per-layer cache rebuild at qwen2_navit.py:563-575. */
+int bagel_kv_append_paged_bf16(const void* k_new, const void* v_new, int64_t ld_new, void* kpool, void* vpool,
+                               int64_t ld_pool, const int32_t* block_table, int32_t bt_stride,
+                               const int32_t* kv_len, int32_t batch, int32_t width, bagel_stream_t stream);
+
+/* flash_attn_varlen_func at Lq = 1 (qwen2_navit.py:579-588) over the paged cache: keys [0, kv_len[b] + len_add) of
+ * sample b, split into 128-key chunks (grid sized for max_len), GQA heads share each K/V read; fp32 softmax.
+ * part_o: batch*nq*ceil(max_len/128)*head_dim floats, part_ml: batch*nq*ceil(max_len/128)*2 floats (workspace). */
+int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
+                                 const int32_t* block_table, int32_t bt_stride, const int32_t* kv_len,
+                                 int32_t len_add, int32_t max_len, float* part_o, float* part_ml, void* out,
+                                 int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
+                                 float softmax_scale, bagel_stream_t stream);
+
+/* Device-side bookkeeping of one decode step (bagel.py:984-994): cur_tok32 <- next_tok, tokens_out[step+1] <- next_tok,
+ * pos += 1, kv_len += 1, step += 1.  Keeps the host out of the token loop so one captured step can be replayed. */
+int bagel_decode_advance(const int64_t* next_tok, int32_t* cur_tok32, int64_t* tokens_out, int64_t* pos,
+                         int32_t* kv_len, int32_t* step, int32_t batch, int32_t max_steps, bagel_stream_t stream);
+
+/* hipGraph capture of a launch sequence on a (non-default) stream; replaces nothing in the reference (its decode loop
+ * is ~5k eager launches + host syncs per token). */
+int bagel_graph_begin(bagel_stream_t stream);
+int bagel_graph_end(bagel_stream_t stream, void** exec_out);
+int bagel_graph_launch(void* exec, bagel_stream_t stream);
+int bagel_graph_destroy(void* exec);
+
 /* ---- VAE (fp32, NHWC) ------------------------------------------------------------------------------------- */
 /* Implicit-GEMM convolution / plain GEMM on the exact-fp32 MFMA.  mode 0: out[M,Cout] = in[M,Cin] w[Cout,Cin]^T
  * (1x1 conv, attention products; M = B*Hout*Wout); 1: 3x3 stride 1 pad 1; 2: 3x3 stride 2 with the (0,1,0,1) pad of

@@ -1,0 +1,360 @@
+"""GPU parity of the autoregressive decode path (Bagel.generate_text, bagel.py:930-1000): the skinny weight-streaming
+GEMM, the paged KV cache + Lq=1 split attention, the device-side step bookkeeping, hipGraph replay, and the whole
+DecodeSession against the (already golden-pinned) packed prefill engine.
+
+Tolerances: as tests/test_ops_gpu.py (one bf16 op: max|d| <= 2^-7 max|ref|); token ids / bookkeeping / copies bit-exact.
+"""
+import copy
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_ops_gpu import close, ref_gemm, rnd
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+DEV = "cuda"
+
+
+def ops():
+    from bagel_amd import ops as o
+    return o
+
+
+def ref_rmsnorm(x, w, eps):
+    xf = x.float()
+    return w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(BF16)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# skinny GEMM
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1, 256, 3584), (1, 64, 18944), (2, 130, 256), (3, 96, 512), (4, 72, 1024), (8, 64, 264),
+                                   (5, 34, 8), (1, 512, 64), (2, 48, 18944), (4, 32, 7168)])
+def test_gemv_bias_residual(M, N, K):
+    A, W, b, R = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1), rnd(M, N, seed=4)
+    C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+    ops().gemv(A.to(DEV), W.to(DEV), C, bias=b.to(DEV))
+    close(C, ref_gemm(A, W, b), what=f"gemv {M}x{N}x{K}")
+    X = R.to(DEV).clone()
+    ops().gemv(A.to(DEV), W.to(DEV), X, bias=b.to(DEV), residual=X)        # in place, as the decode layer uses it
+    close(X, ref_gemm(A, W, b, 0, R), ulps=2, what=f"gemv residual {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("epi", [1, 2])
+def test_gemv_activations(epi):
+    M, N, K = 3, 136, 320
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+    C = torch.empty((M, N), dtype=BF16, device=DEV)
+    ops().gemv(A.to(DEV), W.to(DEV), C, bias=b.to(DEV), epilogue=epi)
+    close(C, ref_gemm(A, W, b, epi), ulps=2, what=f"gemv epi{epi}")
+
+
+@pytest.mark.parametrize("M,I,K", [(1, 416, 256), (2, 64, 3584), (4, 32, 512)])
+def test_gemv_swiglu_with_fused_rmsnorm(M, I, K):
+    from bagel_amd.modeling.bagel.qwen2_navit import interleave_gate_up
+    A, Wg, Wu = rnd(M, K, seed=1, scale=3.0), rnd(I, K, seed=2, scale=K ** -0.5), rnd(I, K, seed=3, scale=K ** -0.5)
+    w = (1.0 + 0.1 * rnd(K, seed=4).float()).to(BF16)
+    Wi = interleave_gate_up(Wg, Wu)
+    C = torch.empty((M, I), dtype=BF16, device=DEV)
+    ops().gemv(A.to(DEV), Wi.to(DEV), C, epilogue=3)
+    ref = F.silu((A.float() @ Wg.float().t()).to(BF16)) * (A.float() @ Wu.float().t()).to(BF16)
+    close(C, ref, ulps=2, what="gemv swiglu")
+    h = ref_rmsnorm(A, w, 1e-6)
+    ops().gemv(A.to(DEV), Wi.to(DEV), C, epilogue=3, norm_w=w.to(DEV), eps=1e-6)
+    ref = F.silu((h.float() @ Wg.float().t()).to(BF16)) * (h.float() @ Wu.float().t()).to(BF16)
+    close(C, ref, ulps=2, what="gemv rmsnorm+swiglu")
+
+
+def test_gemv_fused_rmsnorm_matches_two_kernel_path():
+    M, N, K = 2, 200, 3584
+    A, W, b = rnd(M, K, seed=1, scale=2.0), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+    w = (1.0 + 0.1 * rnd(K, seed=4).float()).to(BF16)
+    C = torch.empty((M, N), dtype=BF16, device=DEV)
+    ops().gemv(A.to(DEV), W.to(DEV), C, bias=b.to(DEV), norm_w=w.to(DEV), eps=1e-6)
+    close(C, ref_gemm(ref_rmsnorm(A, w, 1e-6), W, b), what="gemv fused rmsnorm")
+    h = torch.empty((M, K), dtype=BF16, device=DEV)
+    ops().rmsnorm(A.to(DEV), w.to(DEV), h, 1e-6)
+    C2 = torch.empty_like(C)
+    ops().gemm(h, W.to(DEV), C2, bias0=b.to(DEV), variant=0)     # the MFMA tile on the normalised rows
+    close(C, C2, what="gemv fused rmsnorm vs rmsnorm kernel + MFMA gemm")
+
+
+def test_gemm_routes_few_rows_to_gemv_and_strided_views():
+    """ops.gemm with M <= 8 and no index lists takes the skinny kernel; operands may be strided row views."""
+    K, N = 512, 96
+    buf = rnd(3, 3 * K, seed=1).to(DEV)
+    A = buf[:, K:2 * K]                                  # row stride 3K
+    W = rnd(N, K, seed=2, scale=K ** -0.5).to(DEV)
+    out = torch.zeros((3, 2 * N), dtype=BF16, device=DEV)
+    ops().gemm(A, W, out[:, N:])
+    close(out[:, N:], ref_gemm(A.cpu(), W.cpu()), what="gemm->gemv strided")
+    assert (out[:, :N] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# paged KV cache + Lq = 1 attention
+# ------------------------------------------------------------------------------------------------------------
+def ref_decode_attention(q, ks, vs, nq, nkv, D, scale):
+    """flash-attn definition at Lq=1: fp32 softmax(q k^T scale) v, GQA by head repeat; q:[B,nq*D]."""
+    outs = []
+    G = nq // nkv
+    for b in range(q.shape[0]):
+        qb = q[b].float().view(nq, D)
+        k = ks[b].float().view(-1, nkv, D).repeat_interleave(G, dim=1)      # [L, nq, D]
+        v = vs[b].float().view(-1, nkv, D).repeat_interleave(G, dim=1)
+        s = torch.einsum("hd,lhd->hl", qb, k) * scale
+        p = torch.softmax(s, dim=-1)
+        outs.append(torch.einsum("hl,lhd->hd", p, v).reshape(nq * D))
+    return torch.stack(outs).to(BF16)
+
+
+@pytest.mark.parametrize("lens,nq,nkv,D", [([700, 1, 129], 28, 4, 128), ([127, 128], 4, 2, 64), ([5], 8, 1, 128),
+                                            ([300, 64, 65, 1000], 6, 2, 64), ([4932], 28, 4, 128), ([33], 3, 3, 64)])
+def test_paged_append_and_decode_attention(lens, nq, nkv, D):
+    from bagel_amd.modeling.bagel.decode import PagedKVCache
+    o = ops()
+    B, width = len(lens), nkv * D
+    cap = max(lens) + 3
+    g = torch.Generator().manual_seed(7)
+    pages = B * ((cap + 63) // 64)
+    order = torch.randperm(pages, generator=g).tolist()                  # physically scattered pages
+    pg = PagedKVCache(1, B, width, cap, DEV, order=order)
+    ks = [rnd(n, width, seed=10 + b) for b, n in enumerate(lens)]
+    vs = [rnd(n, width, seed=20 + b) for b, n in enumerate(lens)]
+
+    class FakeCache:       # what PagedKVCache.adopt reads from a NaiveCache: merged rows per layer
+        _k = {0: torch.cat([k[:-1] for k in ks]).to(DEV)}
+        _v = {0: torch.cat([v[:-1] for v in vs]).to(DEV)}
+    if sum(n - 1 for n in lens) > 0:
+        pg.adopt(FakeCache, [n - 1 for n in lens])
+    else:
+        pg.kv_len.zero_()
+    # the last token of every sample arrives through the append kernel (slot kv_len[b])
+    new = torch.zeros((B, (nq + 2 * nkv) * D), dtype=BF16)
+    for b in range(B):
+        new[b, nq * D:nq * D + width] = ks[b][-1]
+        new[b, nq * D + width:] = vs[b][-1]
+    q = rnd(B, nq * D, seed=3)
+    new[:, :nq * D] = q
+    new = new.to(DEV)
+    o.kv_append_paged(new[:, nq * D:nq * D + width], new[:, nq * D + width:], pg.k[0], pg.v[0], pg.block_table, pg.kv_len, B, width)
+    for b, n in enumerate(lens):                                          # bit-exact placement
+        rows = torch.tensor(pg.physical_rows(b, 0, n), device=DEV)
+        assert torch.equal(pg.k[0][rows].cpu(), ks[b]) and torch.equal(pg.v[0][rows].cpu(), vs[b])
+    scale = D ** -0.5
+    ref = ref_decode_attention(q, ks, vs, nq, nkv, D, scale)
+    for max_len in (max(lens), max(lens) + 200):                          # grid larger than the live range is fine
+        po, pml = o.attn_decode_workspace(B, nq, D, max_len, DEV)
+        out = torch.full((B, nq * D), float("nan"), dtype=BF16, device=DEV)
+        o.attn_decode_paged(new, pg.k[0], pg.v[0], pg.block_table, pg.kv_len, 1, max_len, po, pml, out, B, nq, nkv, D, scale)
+        close(out, ref, what=f"decode attention lens={lens} max_len={max_len}")
+    # len_add = 0 sees only the adopted context
+    if min(lens) > 1:
+        ref0 = ref_decode_attention(q, [k[:-1] for k in ks], [v[:-1] for v in vs], nq, nkv, D, scale)
+        po, pml = o.attn_decode_workspace(B, nq, D, max(lens), DEV)
+        out = torch.empty((B, nq * D), dtype=BF16, device=DEV)
+        o.attn_decode_paged(new, pg.k[0], pg.v[0], pg.block_table, pg.kv_len, 0, max(lens), po, pml, out, B, nq, nkv, D, scale)
+        close(out, ref0, what="decode attention len_add=0")
+
+
+def test_decode_attention_sharp_softmax():
+    """One key dominates by a huge margin in a late split: the split merge must not lose it or overflow."""
+    from bagel_amd.modeling.bagel.decode import PagedKVCache
+    o = ops()
+    nq = nkv = 1
+    D, n = 128, 520
+    k, v = rnd(n, D, seed=1, scale=0.1), rnd(n, D, seed=2)
+    q = rnd(1, D, seed=3)
+    k[400] = (q[0].float() * 40).to(BF16)
+    pg = PagedKVCache(1, 1, D, n, DEV)
+
+    class FakeCache:
+        _k = {0: k.to(DEV)}
+        _v = {0: v.to(DEV)}
+    pg.adopt(FakeCache, [n])
+    po, pml = o.attn_decode_workspace(1, nq, D, n, DEV)
+    out = torch.empty((1, D), dtype=BF16, device=DEV)
+    o.attn_decode_paged(q.to(DEV), pg.k[0], pg.v[0], pg.block_table, pg.kv_len, 0, n, po, pml, out, 1, nq, nkv, D, 1.0)
+    close(out, ref_decode_attention(q, [k], [v], nq, nkv, D, 1.0), what="sharp softmax")
+
+
+def test_decode_advance_bookkeeping():
+    o = ops()
+    B, steps = 3, 5
+    nxt = torch.tensor([11, 22, 33], dtype=torch.long, device=DEV)
+    cur = torch.zeros(B, dtype=torch.int32, device=DEV)
+    toks = torch.zeros((steps, B), dtype=torch.long, device=DEV)
+    pos = torch.tensor([5, 6, 7], dtype=torch.long, device=DEV)
+    kvl = torch.tensor([50, 60, 70], dtype=torch.int32, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for s in range(steps):       # one call more than rows: the last write is dropped, the counters still advance
+        nxt.add_(1)
+        o.decode_advance(nxt, cur, toks, pos, kvl, step, B, steps)
+    assert step.item() == steps
+    assert pos.tolist() == [10, 11, 12] and kvl.tolist() == [55, 65, 75]
+    assert cur.tolist() == [16, 27, 38]
+    assert toks[0].tolist() == [0, 0, 0]
+    for s in range(1, steps):
+        assert toks[s].tolist() == [11 + s, 22 + s, 33 + s]
+
+
+def test_hip_graph_replay():
+    """A captured launch sequence replays with device-side state: out = W (x + step) via copy + gemv, step advanced by a kernel."""
+    o = ops()
+    K, N = 256, 64
+    W = rnd(N, K, seed=1, scale=K ** -0.5).to(DEV)
+    table = rnd(16, K, seed=2).to(DEV)
+    x = torch.zeros((1, K), dtype=BF16, device=DEV)
+    y = torch.zeros((1, N), dtype=BF16, device=DEV)
+    cur = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nxt = torch.zeros(1, dtype=torch.long, device=DEV)
+    toks = torch.zeros((8, 1), dtype=torch.long, device=DEV)
+    pos = torch.zeros(1, dtype=torch.long, device=DEV)
+    kvl = torch.zeros(1, dtype=torch.int32, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+
+    def launches():
+        o.copy_rows(table, x, 1, K, src_rows=cur)
+        o.gemv(x, W, y)
+        o.argmax_into(y, nxt)
+        o.decode_advance(nxt, cur, toks, pos, kvl, step, 1, 8)
+    def reset():
+        for t in (cur, nxt, toks, pos, kvl, step):
+            t.zero_()
+    reset()
+    for _ in range(6):                           # the recurrence, launched eagerly
+        launches()
+    torch.cuda.synchronize()
+    eager = toks.clone()
+    assert step.item() == 6 and len(set(eager[1:7, 0].tolist())) > 1, "degenerate recurrence: the test would prove nothing"
+    yy = ref_gemm(table[0:1].cpu(), W.cpu()).float()
+    assert yy[0, int(eager[1, 0])] >= yy.max() - 2.0 ** -6 * yy.abs().max(), "first token is not the (near-)argmax of W x"
+    reset()
+    launches()                                   # step 0 eager (warm-up), steps 1..5 from the graph
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with o.HipGraph.capture(side) as g:
+        launches()
+    torch.cuda.synchronize()
+    assert step.item() == 1, "capture must record, not execute"
+    for _ in range(5):
+        g.launch()
+    side.synchronize()
+    assert step.item() == 6 and pos.item() == 6 and kvl.item() == 6
+    assert torch.equal(toks, eager), "graph replay must reproduce the eager launches bit for bit"
+
+
+# ------------------------------------------------------------------------------------------------------------
+# DecodeSession / generate_text against the packed prefill engine (MFMA path, golden-pinned in test_model_gpu.py)
+# ------------------------------------------------------------------------------------------------------------
+def _context(model, cfg, prompts):
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    from oracle.configs import NEW_TOKEN_IDS_TINY, StubTokenizer
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    B = len(prompts)
+    gi, lens, ropes = model.prepare_prompts([0] * B, [0] * B, prompts, tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(NaiveCache(cfg["llm"]["num_hidden_layers"]), **gi)
+    return cache, lens, ropes, model.prepare_start_tokens(lens, ropes, NEW_TOKEN_IDS_TINY)
+
+
+def _prefill_engine_decode(model, cache, start, lens, tokens_in):
+    """Teacher-forced stepping through MoTEngine.forward at Lq=1 (varlen MFMA attention, contiguous cache):
+    returns the logits of every step."""
+    o = ops()
+    lm = model.language_model
+    eng = lm.engine()
+    B = len(lens)
+    table, head = lm.model.embed_tokens.weight.data, lm.lm_head.weight.data
+    pos = start["packed_query_position_ids"].clone()
+    kv = list(lens)
+    out = []
+    for s in range(tokens_in.shape[0]):
+        x = torch.empty((B, model.hidden_size), dtype=BF16, device=DEV)
+        o.copy_rows(table, x, B, model.hidden_size, src_rows=tokens_in[s].to(torch.int32))
+        plan = eng.plan([1] * B, pos, key_values_lens=kv)
+        h = eng.forward(x, plan, "und", cache, update=True, causal=True)
+        logits = torch.empty((B, head.shape[0]), dtype=BF16, device=DEV)
+        o.gemm(h, head, logits, M0=B, variant=0)
+        out.append(logits)
+        kv = [k + 1 for k in kv]
+        pos = pos + 1
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("prompts", [["a small red cube"], ["sky", "a much longer prompt about nothing in particular"]])
+def test_generate_text_graph_eager_and_prefill_engine(name, prompts):
+    from oracle.configs import TINY, TINY_D128
+    from tests.util_models import product_model
+    cfg = {"tiny": TINY, "tiny_d128": TINY_D128}[name]
+    model, _ = product_model(cfg)
+    cache, lens, ropes, start = _context(model, cfg, prompts)
+    n = 12
+    c_graph, c_eager, c_ref = copy.deepcopy(cache), copy.deepcopy(cache), copy.deepcopy(cache)
+    t_graph = model.generate_text(past_key_values=c_graph, max_length=n, end_token_id=None, use_graph=True, **start)
+    sess = model._last_decode_session
+    assert sess.graph is not None, f"hipGraph capture failed: {sess.graph_error}"
+    last_logits = sess.logits.clone()
+    t_eager = model.generate_text(past_key_values=c_eager, max_length=n, end_token_id=None, use_graph=False, **start)
+    assert t_graph.shape == (n, len(prompts)) and t_graph.dtype == torch.int64
+    assert torch.equal(t_graph, t_eager), "graph replay and eager stepping must be bit-identical"
+    assert torch.equal(t_graph[0].cpu(), start["packed_start_tokens"])
+    # the caller's cache received the new rows (reference: in-place update), identically on both paths
+    L = cfg["llm"]["num_hidden_layers"]
+    assert c_graph.seq_lens == cache.seq_lens + n * len(prompts)
+    for i in range(L):
+        assert torch.equal(c_graph.key_cache[i], c_eager.key_cache[i]) and torch.equal(c_graph.value_cache[i], c_eager.value_cache[i])
+    # teacher-forced comparison with the packed prefill engine on the same tokens
+    ref_logits = _prefill_engine_decode(model, c_ref, start, lens, t_graph)
+    close(last_logits, ref_logits[-1], ulps=4, rel_l2=2e-2, what="last-step logits vs prefill engine")
+    for i in range(L):
+        close(c_graph.key_cache[i], c_ref.key_cache[i], ulps=4, rel_l2=1e-2, what=f"K cache layer {i} after decode")
+        close(c_graph.value_cache[i], c_ref.value_cache[i], ulps=4, rel_l2=1e-2, what=f"V cache layer {i} after decode")
+    # greedy ids: equal to the prefill engine's argmax up to the first near tie (same rule as test_model_gpu.py)
+    for s in range(1, n):
+        ours, row = t_graph[s].cpu(), ref_logits[s - 1].float().cpu()
+        theirs = row.argmax(-1)
+        if torch.equal(ours, theirs):
+            continue
+        gap = row.max(-1).values - row.gather(-1, ours.view(-1, 1)).squeeze(-1)
+        assert (gap <= row.abs().max().item() * 2.0 ** -6).all(), f"step {s}: tokens differ without a near tie"
+
+
+def test_generate_text_end_token_and_scattered_pages():
+    from bagel_amd.modeling.bagel.decode import DecodeSession
+    from oracle.configs import TINY_D128 as cfg
+    from tests.util_models import product_model
+    model, _ = product_model(cfg)
+    cache, lens, ropes, start = _context(model, cfg, ["a small red cube"])
+    full = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=10, end_token_id=None, **start)
+    stop = int(full[4, 0])
+    first = next(s for s in range(1, 10) if int(full[s, 0]) == stop)      # the loop stops when this id is first produced
+    cut = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=10, end_token_id=stop, **start)
+    assert cut.shape[0] == first and torch.equal(cut, full[:first])
+    # physically scattered pages give the same tokens
+    lm = model.language_model
+    pages = (lens[0] + 10 + 63) // 64
+    order = list(reversed(range(pages)))
+    sess = DecodeSession(lm.engine(), lm.model.embed_tokens.weight.data, lm.lm_head.weight.data, copy.deepcopy(cache), lens,
+                         start["packed_start_tokens"], start["packed_query_position_ids"], 10, page_order=order)
+    for _ in range(10):
+        sess.step()
+    assert torch.equal(sess.tokens_so_far(), full)
+
+
+def test_generate_text_sampling_runs_and_is_seeded():
+    from oracle.configs import TINY as cfg
+    from tests.util_models import product_model
+    model, _ = product_model(cfg)
+    cache, lens, ropes, start = _context(model, cfg, ["sky"])
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        outs.append(model.generate_text(past_key_values=copy.deepcopy(cache), max_length=6, do_sample=True, temperature=0.7,
+                                        end_token_id=None, **start))
+    assert outs[0].shape == (6, 1) and torch.equal(outs[0], outs[1])
+    assert (outs[0] >= 0).all() and (outs[0] < cfg["llm"]["vocab_size"]).all()
