@@ -33,6 +33,7 @@ struct GemvParams {
     bf16_t* C; long ldc;
     const bf16_t* norm_w; float eps;
     int M, N, K, epi;
+    int ppw;   // weight-row pairs per wave
 };
 
 template <int MR>
@@ -53,6 +54,18 @@ __device__ __forceinline__ void gemv_fma(float (&a0)[MR][2], float (&a1)[MR][2],
     }
 }
 
+template <int U>
+__device__ __forceinline__ void gemv_load_batch(u32x4_t (&wa)[U], u32x4_t (&wb)[U], const bf16_t* w0, const bf16_t* w1, int g,
+                                                int lane, int nch) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int ch = (g + u) * 64 + lane;
+        const long off = (long)(ch < nch ? ch : 0) * 8;     // out-of-range chunks re-read chunk 0 and are multiplied by 0
+        wa[u] = *(const u32x4_t*)(w0 + off);
+        wb[u] = *(const u32x4_t*)(w1 + off);
+    }
+}
+
 template <int MR>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
     constexpr int U = 7;   // chunk groups in flight per row: K = 3584 -> exactly one batch, K = 18944 -> 5 batches + 2
@@ -63,6 +76,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
     const int K = p.K, nch = K >> 3;
     const int NP = p.N >> 1;
     const bool swiglu = p.epi == EPI_SWIGLU16;
+    const int ngr = (nch + 63) >> 6;
+    const int pbase = (blockIdx.x * 4 + wave) * p.ppw;
+    const int pend = (pbase + p.ppw < NP) ? pbase + p.ppw : NP;
+
+    // ---- the first weight batch of this wave goes out BEFORE the activation staging: its HBM latency overlaps the
+    //      norm/LDS work instead of following it (for N ~ H a wave's whole share is this one batch) ---------------------
+    u32x4_t wa[U], wb[U];
+    if (pbase < pend) {
+        const int r0 = swiglu ? ((pbase >> 4) << 5) + (pbase & 15) : 2 * pbase;
+        const int r1 = swiglu ? r0 + 16 : r0 + 1;
+        gemv_load_batch<U>(wa, wb, p.W + (long)r0 * p.ldw, p.W + (long)r1 * p.ldw, 0, lane, nch);
+    }
 
     // ---- stage the activation rows (optionally RMS-normalised) --------------------------------------------------
     if (p.norm_w) {
@@ -101,10 +126,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
     }
     __syncthreads();
 
-    // ---- weight-row pairs ---------------------------------------------------------------------------------------
-    const int nfull = nch >> 6, rem = nch & 63;
-    const int stride = gridDim.x * 4;
-    for (int pp = blockIdx.x * 4 + wave; pp < NP; pp += stride) {
+    // ---- weight-row pairs [pbase, pend) of this wave ----------------------------------------------------------------
+    for (int pp = pbase; pp < pend; ++pp) {
         const int r0 = swiglu ? ((pp >> 4) << 5) + (pp & 15) : 2 * pp;
         const int r1 = swiglu ? r0 + 16 : r0 + 1;
         const bf16_t* w0 = p.W + (long)r0 * p.ldw;
@@ -112,28 +135,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
         float a0[MR][2], a1[MR][2];
 #pragma unroll
         for (int m = 0; m < MR; ++m) a0[m][0] = a0[m][1] = a1[m][0] = a1[m][1] = 0.f;
-        int g = 0;
-        for (; g + U <= nfull; g += U) {
-            u32x4_t wa[U], wb[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const long off = ((long)(g + u) * 64 + lane) * 8;
-                wa[u] = *(const u32x4_t*)(w0 + off);
-                wb[u] = *(const u32x4_t*)(w1 + off);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, (g + u) * 64 + lane, true);
-        }
-        if (g < nfull || rem) {
-            // tail: up to U-1 whole groups plus the ragged last one; out-of-range chunks read chunk 0 and multiply by 0
-            u32x4_t wa[U], wb[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int ch = (g + u) * 64 + lane;
-                const long off = (long)(ch < nch ? ch : 0) * 8;
-                wa[u] = *(const u32x4_t*)(w0 + off);
-                wb[u] = *(const u32x4_t*)(w1 + off);
-            }
+        for (int g = 0; g < ngr; g += U) {
+            if (pp != pbase || g != 0) gemv_load_batch<U>(wa, wb, w0, w1, g, lane, nch);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ch = (g + u) * 64 + lane;
@@ -177,14 +180,16 @@ static int launch_gemv(const GemvParams& p, hipStream_t stream) {
             return bagel_set_error(BAGEL_ERR_LAUNCH, "gemv: cannot enable %zu bytes of LDS", smem);
         attr_bytes = GEMV_MAX_LDS;
     }
+    // Work split: one row pair per wave while that still gives <= 4096 workgroups (~2 full waves of resident groups on
+    // 256 CUs; the hardware dispatcher then balances the tail), more pairs per wave beyond that so the per-workgroup
+    // activation staging stays a small fraction of the L2 traffic.
     const int NP = p.N / 2;
-    // workgroups resident per CU: bounded by LDS (160 KB) and by 8 four-wave groups
-    int per_cu = (int)((160 * 1024) / (smem + 64));
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    int grid = ceil_div(NP, 4);
-    if (grid > 256 * per_cu) grid = 256 * per_cu;
-    hipLaunchKernelGGL((gemv_kernel<MR>), dim3(grid), dim3(256), smem, stream, p);
+    int ppw = NP / (4 * 4096);
+    if (ppw < 1) ppw = 1;
+    GemvParams q = p;
+    q.ppw = ppw;
+    const int grid = ceil_div(NP, 4 * ppw);
+    hipLaunchKernelGGL((gemv_kernel<MR>), dim3(grid), dim3(256), smem, stream, q);
     return bagel_check_launch("gemv_kernel");
 }
 
@@ -212,7 +217,7 @@ extern "C" int bagel_gemv_bf16(const void* A, int64_t lda, const void* W, int64_
         p.R = R ? (const bf16_t*)R + (long)m0 * ldr : nullptr; p.ldr = ldr;
         p.C = (bf16_t*)C + (long)m0 * ldc; p.ldc = ldc;
         p.norm_w = (const bf16_t*)norm_w; p.eps = eps;
-        p.M = mr; p.N = N; p.K = K; p.epi = epilogue;
+        p.M = mr; p.N = N; p.K = K; p.epi = epilogue; p.ppw = 1;
         int rc;
         if (mr == 4) rc = launch_gemv<4>(p, stream);
         else if (mr == 2) rc = launch_gemv<2>(p, stream);
@@ -253,6 +258,121 @@ extern "C" int bagel_kv_append_paged_bf16(const void* k_new, const void* v_new, 
     return bagel_check_launch("kv_append_paged_kernel");
 }
 
+// Decode-step epilogue of the fused QKV projection: q_norm/k_norm + RoPE (und cast points, identical arithmetic to
+// qknorm_rope_kernel<EPL> in norm.hip: bf16(w * bf16(x * rsqrt)), bf16 products and bf16 sum) with q rewritten in place
+// and the finished K row and the V row written straight into their page slot kv_len[b] -- one launch instead of
+// qknorm_rope + kv_append, and every head has its own 16 lanes so nothing is serialised (the packed-prefill kernel
+// walks the heads of a row in a loop, which is 12 us of pure latency at one row).
+//   qkv row: [nq*DP | nkv*DP | nkv*DP]; HD = 16*EPL true head dim, pad lanes [HD, DP) stay zero in the pages.
+template <int EPL>
+__global__ __launch_bounds__(256) void decode_qkv_post_kernel(bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ cosb,
+                                                              const bf16_t* __restrict__ sinb, const bf16_t* __restrict__ qw,
+                                                              const bf16_t* __restrict__ kw, bf16_t* __restrict__ kpool,
+                                                              bf16_t* __restrict__ vpool, long ldp,
+                                                              const int* __restrict__ block_table, int bt_stride,
+                                                              const int* __restrict__ kv_len, int nq, int nkv, int dp, float eps,
+                                                              int use_norm) {
+    constexpr int HD = 16 * EPL;
+    const int b = blockIdx.y;
+    const int sub = threadIdx.x & 15;
+    const int h = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int nheads = nq + 2 * nkv;
+    const bool act = h < nheads;
+    const int hh = act ? h : nheads - 1;
+    const bool is_q = hh < nq, is_v = hh >= nq + nkv;
+    const int e0 = sub * EPL;
+    const bool upper = sub >= 8;
+    const int j = kv_len[b];
+    const long prow = (long)block_table[(long)b * bt_stride + j / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (j % BAGEL_KV_PAGE);
+    bf16_t* src = qkv + (long)b * ld + (long)hh * dp + e0;
+    float cs[EPL], sn[EPL];
+    {
+        const int c0 = e0 & (HD / 2 - 1);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            cs[e] = bf2f(cosb[(long)b * (HD / 2) + c0 + e]);
+            sn[e] = bf2f(sinb[(long)b * (HD / 2) + c0 + e]);
+        }
+    }
+    float x[EPL], wf[EPL];
+    unsigned xr[EPL / 2];
+#pragma unroll
+    for (int e = 0; e < EPL / 2; ++e) xr[e] = *(const unsigned*)(src + 2 * e);
+    {
+        const bf16_t* wv = (is_q ? qw : kw) + e0;
+#pragma unroll
+        for (int e = 0; e < EPL / 2; ++e) {
+            const unsigned wr = use_norm ? *(const unsigned*)(wv + 2 * e) : 0u;
+            x[2 * e] = lo2f(xr[e]);
+            x[2 * e + 1] = hi2f(xr[e]);
+            wf[2 * e] = use_norm ? lo2f(wr) : 1.0f;
+            wf[2 * e + 1] = use_norm ? hi2f(wr) : 1.0f;
+        }
+    }
+    float nrm[EPL];
+    if (use_norm) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ss += x[e] * x[e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = rsqrtf(ss / (float)HD + eps);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) nrm[e] = bfround(wf[e] * bfround(x[e] * inv));
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) nrm[e] = x[e];
+    }
+    unsigned orr[EPL / 2];
+    {
+        float out[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float partner = __shfl_xor(nrm[e], 8, 64);
+            const float rot = upper ? partner : -partner;
+            out[e] = bfround(nrm[e] * cs[e]) + bfround(rot * sn[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EPL / 2; ++e) orr[e] = is_v ? xr[e] : pack2bf(out[2 * e], out[2 * e + 1]);
+    }
+    if (!act) return;
+    bf16_t* dst;
+    if (is_q) dst = src;
+    else if (!is_v) dst = kpool + prow * ldp + (long)(hh - nq) * dp + e0;
+    else dst = vpool + prow * ldp + (long)(hh - nq - nkv) * dp + e0;
+#pragma unroll
+    for (int e = 0; e < EPL / 2; ++e) *(unsigned*)(dst + 2 * e) = orr[e];
+    if (!is_q)
+        for (int off = HD; off < dp; off += HD)     // zero the pad lanes of the page row (the pools are uninitialised memory)
+#pragma unroll
+            for (int e = 0; e < EPL / 2; ++e) *(unsigned*)(dst + off + 2 * e) = 0u;
+}
+
+extern "C" int bagel_decode_qkv_post_bf16(void* qkv, int64_t ld, const void* cos_tab, const void* sin_tab, const void* q_w,
+                                          const void* k_w, void* kpool, void* vpool, int64_t ld_pool, const int32_t* block_table,
+                                          int32_t bt_stride, const int32_t* kv_len, int32_t batch, int32_t nq, int32_t nkv,
+                                          int32_t head_dim, int32_t head_dim_padded, float eps, int32_t use_norm,
+                                          hipStream_t stream) {
+    BAGEL_REQUIRE(qkv && cos_tab && sin_tab && kpool && vpool && block_table && kv_len, "decode_qkv_post: null pointer");
+    BAGEL_REQUIRE(!use_norm || (q_w && k_w), "decode_qkv_post: norm weights missing");
+    BAGEL_REQUIRE(head_dim_padded >= head_dim && head_dim_padded % head_dim == 0 && ld % 2 == 0 && ld_pool % 2 == 0,
+                  "decode_qkv_post: bad head_dim_padded/ld");
+    if (batch <= 0) return BAGEL_OK;
+    const dim3 grid(ceil_div(nq + 2 * nkv, 16), batch), block(256);
+#define QKP_LAUNCH(EPL)                                                                                                          \
+    hipLaunchKernelGGL(decode_qkv_post_kernel<EPL>, grid, block, 0, stream, (bf16_t*)qkv, (long)ld, (const bf16_t*)cos_tab,      \
+                       (const bf16_t*)sin_tab, (const bf16_t*)q_w, (const bf16_t*)k_w, (bf16_t*)kpool, (bf16_t*)vpool,           \
+                       (long)ld_pool, block_table, bt_stride, kv_len, nq, nkv, head_dim_padded, eps, use_norm)
+    switch (head_dim) {
+        case 128: QKP_LAUNCH(8); break;
+        case 64: QKP_LAUNCH(4); break;
+        case 32: QKP_LAUNCH(2); break;
+        default: return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "decode_qkv_post: head_dim %d not in {32,64,128}", head_dim);
+    }
+#undef QKP_LAUNCH
+    return bagel_check_launch("decode_qkv_post_kernel");
+}
+
 // Lq = 1 attention, split over the keys.  Workgroup (split, kv head, sample) covers keys [split*CH, +CH) for the G query
 // heads of one KV head, so each K/V byte is read once per GQA group.  DP/8 lanes own one key row (16 bytes each); the
 // 256/(DP/8) lane groups walk the chunk with a running (max, sum, acc) per head in base 2; groups are merged by wave
@@ -266,7 +386,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           const int* __restrict__ kv_len, int len_add, float* __restrict__ part_o,
                                                           float* __restrict__ part_ml, int nq, int nsplit, float scale_log2e) {
     constexpr int LPK = DP / 8;          // lanes per key row
-    constexpr int NG = 256 / LPK;        // key rows in flight per workgroup step
+    constexpr int NG = 256 / LPK;        // key rows per workgroup pass
+    constexpr int KU = DEC_CH / NG;      // keys of one lane group in the chunk: all of them are loaded before any is used
     const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int L = kv_len[b] + len_add;
     const int j0 = split * DEC_CH;
@@ -277,6 +398,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     __shared__ float sm_o[4][G][DP];
     __shared__ float sm_m[4][G], sm_l[4][G];
 
+    // one latency round: block-table entries -> K/V rows (16 bytes per lane each), then the query heads
+    const int* bt = block_table + (long)b * bt_stride;
+    int pg[KU];
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        const int j = j0 + grp + i * NG;
+        const int jc = j < j1 ? j : j1 - 1;
+        pg[i] = bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
+    }
+    u32x4_t kr[KU], vr[KU];
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        const long off = (long)pg[i] * ldp + (long)kvh * DP + sub * 8;
+        kr[i] = *(const u32x4_t*)(kpool + off);
+        vr[i] = *(const u32x4_t*)(vpool + off);
+    }
     float qf[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -295,19 +432,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
     }
-    const int* bt = block_table + (long)b * bt_stride;
-    for (int jj = j0; jj < j1; jj += NG) {
-        const int j = jj + grp;
-        const bool valid = j < j1;
-        const int jc = valid ? j : j1 - 1;
-        const long row = (long)bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
-        const u32x4_t kr = *(const u32x4_t*)(kpool + row * ldp + (long)kvh * DP + sub * 8);
-        const u32x4_t vr = *(const u32x4_t*)(vpool + row * ldp + (long)kvh * DP + sub * 8);
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        const bool valid = (j0 + grp + i * NG) < j1;
         float kf[8], vf[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            kf[2 * e] = lo2f(kr[e]); kf[2 * e + 1] = hi2f(kr[e]);
-            vf[2 * e] = lo2f(vr[e]); vf[2 * e + 1] = hi2f(vr[e]);
+            kf[2 * e] = lo2f(kr[i][e]); kf[2 * e + 1] = hi2f(kr[i][e]);
+            vf[2 * e] = lo2f(vr[i][e]); vf[2 * e + 1] = hi2f(vr[i][e]);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -367,25 +499,54 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
 }
 
-// out[b, h, :] = sum_s part_o[s] 2^(m_s - M) / sum_s l_s 2^(m_s - M)  over the splits that hold keys.
+// out[b, h, :] = sum_s part_o[s] 2^(m_s - M) / sum_s l_s 2^(m_s - M)  over the splits that hold keys.  One workgroup per
+// (head, sample): DP/4 lanes cover the head dim with float4 loads, 256/(DP/4) lane groups stride over the splits with a
+// running (max, sum, acc); the groups are merged through LDS.
 template <int DP>
-__global__ void attn_decode_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                           const int* __restrict__ kv_len, int len_add, bf16_t* __restrict__ out, long ldo,
-                                           int nq, int nsplit) {
-    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+__global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                  const int* __restrict__ kv_len, int len_add, bf16_t* __restrict__ out,
+                                                                  long ldo, int nq, int nsplit) {
+    constexpr int LPD = DP / 4;
+    constexpr int NSG = 256 / LPD;
+    const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int d4 = t % LPD, sg = t / LPD;
     const int L = kv_len[b] + len_add;
     int ns = (L + DEC_CH - 1) / DEC_CH;
     if (ns > nsplit) ns = nsplit;
     const long base = ((long)b * nq + h) * nsplit;
-    float mn = -1e30f;
-    for (int s = 0; s < ns; ++s) mn = fmaxf(mn, part_ml[(base + s) * 2]);
-    float acc = 0.f, den = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        const float c = exp2f(part_ml[(base + s) * 2] - mn);
-        acc = fmaf(part_o[(base + s) * DP + d], c, acc);
-        den = fmaf(part_ml[(base + s) * 2 + 1], c, den);
+    __shared__ float sm_m[NSG], sm_l[NSG];
+    __shared__ f32x4_t sm_o[NSG][LPD];
+    float m = -1e30f, l = 0.f;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = sg; s < ns; s += NSG) {
+        const float ms = part_ml[(base + s) * 2], lsv = part_ml[(base + s) * 2 + 1];
+        const f32x4_t ov = *(const f32x4_t*)(part_o + (base + s) * DP + d4 * 4);
+        const float mn = fmaxf(m, ms);
+        const float c1 = exp2f(m - mn), c2 = exp2f(ms - mn);
+        acc = acc * c1 + ov * c2;
+        l = l * c1 + lsv * c2;
+        m = mn;
     }
-    out[(long)b * ldo + (long)h * DP + d] = f2bf(ns > 0 ? acc / den : 0.f);
+    sm_o[sg][d4] = acc;
+    if (d4 == 0) { sm_m[sg] = m; sm_l[sg] = l; }
+    __syncthreads();
+    if (t < LPD) {
+        float mn = -1e30f;
+#pragma unroll
+        for (int g = 0; g < NSG; ++g) mn = fmaxf(mn, sm_m[g]);
+        f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+        float den = 0.f;
+#pragma unroll
+        for (int g = 0; g < NSG; ++g) {
+            const float c = exp2f(sm_m[g] - mn);
+            tot = tot + sm_o[g][t] * c;
+            den = fmaf(sm_l[g], c, den);
+        }
+        const float inv = den > 0.f ? 1.f / den : 0.f;
+        u32x2_t v = {pack2bf(tot[0] * inv, tot[1] * inv), pack2bf(tot[2] * inv, tot[3] * inv)};
+        *(u32x2_t*)(out + (long)b * ldo + (long)h * DP + t * 4) = v;
+    }
 }
 
 template <int DP>
@@ -413,7 +574,7 @@ extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const vo
     BAGEL_REQUIRE(q && kpool && vpool && block_table && kv_len && part_o && part_ml && out, "attn_decode: null pointer");
     BAGEL_REQUIRE(head_dim == 64 || head_dim == 128, "attn_decode: head_dim %d not in {64,128} (pad the projection)", head_dim);
     BAGEL_REQUIRE(nkv > 0 && nq % nkv == 0, "attn_decode: nq must be a multiple of nkv");
-    BAGEL_REQUIRE((ldq % 8) == 0 && (ld_pool % 8) == 0 && (ldo % 2) == 0, "attn_decode: leading dims");
+    BAGEL_REQUIRE((ldq % 8) == 0 && (ld_pool % 8) == 0 && (ldo % 4) == 0 && (((uintptr_t)out) & 7) == 0, "attn_decode: leading dims / out alignment");
     BAGEL_REQUIRE((((uintptr_t)q | (uintptr_t)kpool | (uintptr_t)vpool) & 15) == 0, "attn_decode: 16-byte alignment");
     if (batch <= 0 || max_len <= 0) return BAGEL_OK;
     const int nsplit = ceil_div(max_len, DEC_CH);
@@ -428,10 +589,10 @@ extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const vo
                                     (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
     if (rc != BAGEL_OK) return rc;
     if (head_dim == 128)
-        hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(nq, batch), dim3(128), 0, stream, part_o, part_ml, kv_len, len_add,
+        hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(nq, batch), dim3(256), 0, stream, part_o, part_ml, kv_len, len_add,
                            (bf16_t*)out, (long)ldo, nq, nsplit);
     else
-        hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(nq, batch), dim3(64), 0, stream, part_o, part_ml, kv_len, len_add,
+        hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(nq, batch), dim3(256), 0, stream, part_o, part_ml, kv_len, len_add,
                            (bf16_t*)out, (long)ldo, nq, nsplit);
     return bagel_check_launch("attn_decode_combine_kernel");
 }

@@ -126,22 +126,21 @@ class DecodeSession:
 
     # ---- the launch sequence of one token (no host-dependent values: safe to capture) ---------------------------
     def forward_launches(self):
-        """embed -> L x [norm+qkv, qk-norm/rope, KV append, attention, o_proj(+res), norm+gate/up (SwiGLU), down(+res)]
+        """embed -> L x [norm+qkv, qk-norm/rope + KV page append, attention (split + combine), o_proj(+res), norm+gate/up (SwiGLU),
+        down(+res)]
         -> final norm + lm_head -> argmax."""
         eng, B = self.eng, self.B
         nq, nkv, dp, hd = eng.nq, eng.nkv, eng.dp, eng.hd
         qw, kw_ = nq * dp, nkv * dp
         x, qkv, att, act = self.x, self.qkv, self.att, self.act
-        k_v, v_v = qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
         pg = self.paged
         scale = hd ** -0.5
         ops.rope_table_into(self.pos, self.inv_freq, self.cos, self.sin)
         ops.copy_rows(self.table, x, B, eng.H, src_rows=self.cur32)
         for li, P in enumerate(eng.layers):
             ops.gemv(x, P.wqkv[0], qkv, bias=P.bqkv[0], norm_w=P.ln_in[0], eps=eng.eps)
-            ops.qknorm_rope(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
-                            None, None, None, nq, nkv, hd, dp, eng.eps, gen_mode=False, use_norm=eng.use_norm)
-            ops.kv_append_paged(k_v, v_v, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, kw_)
+            ops.decode_qkv_post(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
+                                pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, nq, nkv, hd, dp, eng.eps, eng.use_norm)
             ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
                                   self.part_ml, att, B, nq, nkv, dp, scale)
             ops.gemv(att, P.wo[0], x, residual=x)

@@ -122,6 +122,20 @@ def kv_append_paged(k_new, v_new, kpool, vpool, block_table, kv_len, batch, widt
           "bagel_kv_append_paged_bf16")
 
 
+def decode_qkv_post(qkv, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len, batch, nq, nkv, head_dim, head_dim_padded, eps,
+                    use_norm):
+    """q/k norm + RoPE in place on q, finished K row and V row into page slot kv_len[b]; see bagel_decode_qkv_post_bf16."""
+    _req(qkv, BF16, "decode_qkv_post.qkv"); _req(kpool, BF16, "decode_qkv_post.kpool"); _req(vpool, BF16, "decode_qkv_post.vpool")
+    _req(block_table, torch.int32, "decode_qkv_post.block_table"); _req(kv_len, torch.int32, "decode_qkv_post.kv_len")
+    if kpool.stride(0) != vpool.stride(0):
+        raise BagelHipError("decode_qkv_post: K and V pools must share the row stride")
+    check(lib().bagel_decode_qkv_post_bf16(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(q_w), _ptr(k_w), _ptr(kpool),
+                                           _ptr(vpool), kpool.stride(0), _ptr(block_table), block_table.stride(0), _ptr(kv_len),
+                                           batch, nq, nkv, head_dim, head_dim_padded, float(eps), int(use_norm), _stream()),
+          "bagel_decode_qkv_post_bf16")
+    return qkv
+
+
 def attn_decode_workspace(batch, nq, head_dim, max_len, device):
     ns = (max_len + DECODE_CHUNK - 1) // DECODE_CHUNK
     return (torch.empty((batch * nq * ns * head_dim,), dtype=torch.float32, device=device),

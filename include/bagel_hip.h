@@ -127,6 +127,15 @@ int bagel_kv_append_paged_bf16(const void* k_new, const void* v_new, int64_t ld_
                                int64_t ld_pool, const int32_t* block_table, int32_t bt_stride,
                                const int32_t* kv_len, int32_t batch, int32_t width, bagel_stream_t stream);
 
+/* Decode-step epilogue of the fused QKV projection (qwen2_navit.py:518-557,563-575 at Lq = 1): q_norm/k_norm + RoPE
+ * with the und cast points of bagel_qknorm_rope_bf16, q rewritten in place, the finished K row and the V row stored
+ * into their page slot kv_len[b] (pad lanes zeroed).  One launch for qknorm_rope + kv_append. */
+int bagel_decode_qkv_post_bf16(void* qkv, int64_t ld, const void* cos_tab, const void* sin_tab, const void* q_w,
+                               const void* k_w, void* kpool, void* vpool, int64_t ld_pool, const int32_t* block_table,
+                               int32_t bt_stride, const int32_t* kv_len, int32_t batch, int32_t nq, int32_t nkv,
+                               int32_t head_dim, int32_t head_dim_padded, float eps, int32_t use_norm,
+                               bagel_stream_t stream);
+
 /* flash_attn_varlen_func at Lq = 1 (qwen2_navit.py:579-588) over the paged cache: keys [0, kv_len[b] + len_add) of
  * sample b, split into 128-key chunks (grid sized for max_len), GQA heads share each K/V read; fp32 softmax.
  * part_o: batch*nq*ceil(max_len/128)*head_dim floats, part_ml: batch*nq*ceil(max_len/128)*2 floats (workspace). */

@@ -235,16 +235,86 @@ def mot_layer(W, cfg, layer_idx, x, query_lens, cos_sin, q_idx, cache, kv_lens, 
     return res + h
 
 
+# ----------------------------------------------------------------------------------------------
+# TaylorSeer step skipping (modeling/cache_utils/taylorseer.py:11-153; hooks qwen2_navit.py:773-829,1034-1087)
+# ----------------------------------------------------------------------------------------------
+class TaylorState:
+    """``cache_init`` (taylorseer.py:120-153): the (cache_dic, current) pair of ONE forward stream (cond / cfg-text /
+    cfg-img each own one, bagel.py:680-684).  Constants are the reference's: fresh_threshold 3, max_order 6,
+    first_enhance 5, taylor_cache True, fresh_ratio 0."""
+
+    def __init__(self, num_steps):
+        self.fresh_threshold, self.max_order, self.first_enhance = 3, 6, 5
+        self.cache_counter = 0
+        self.cal_threshold = None
+        self.activated_steps = [0]
+        self.step = 0
+        self.num_steps = num_steps
+        self.type = None
+        self.factors = {}          # layer -> {order: bf16 tensor}
+
+
+def taylor_cal_type(st):
+    """``cal_type`` + ``force_scheduler`` (taylorseer.py:64-117) for taylor_cache=True, fresh_ratio=0."""
+    first_step = st.step < st.first_enhance
+    fresh_interval = st.fresh_threshold if first_step else st.cal_threshold
+    if first_step or st.cache_counter == fresh_interval - 1:
+        st.type = "full"
+        st.cache_counter = 0
+        st.activated_steps.append(st.step)
+        st.cal_threshold = int(round(st.fresh_threshold / 1.0))     # linear_step_weight = 0 -> step_factor = 1
+    else:
+        st.cache_counter += 1
+        st.type = "Taylor"
+    return st.type
+
+
+def taylor_derivative_approximation(st, layer, feature):
+    """``derivative_approximation`` (taylorseer.py:11-30): finite differences in the feature dtype (bf16)."""
+    dist = st.activated_steps[-1] - st.activated_steps[-2]
+    old = st.factors.get(layer, {})
+    new = {0: feature}
+    for i in range(st.max_order):
+        if old.get(i, None) is not None and st.step > st.first_enhance - 2:
+            new[i + 1] = (new[i] - old[i]) / dist
+        else:
+            break
+    st.factors[layer] = new
+
+
+def taylor_formula(st, layer):
+    """``taylor_formula`` (taylorseer.py:32-46): sum_i f_i x^i / i!, every product and sum rounded to bf16."""
+    x = st.step - st.activated_steps[-1]
+    out = 0
+    f = st.factors[layer]
+    for i in range(len(f)):
+        out += (1 / math.factorial(i)) * f[i] * (x ** i)
+    return out
+
+
 @_explicit_casts
 def llm_forward(W, cfg, x, query_lens, position_ids, q_idx, cache, kv_lens, kv_idx, update, causal,
-                mode="und", vae_idx=None, text_idx=None, num_layers=None):
-    """Qwen2Model.forward_inference, qwen2_navit.py:1018-1092."""
+                mode="und", vae_idx=None, text_idx=None, num_layers=None, taylor=None, taylor_last_layer_only=False):
+    """Qwen2Model.forward_inference, qwen2_navit.py:1018-1092.  ``taylor``: a TaylorState -> the TaylorSeer hooks of
+    :1034-1037,1057-1061,1086-1087 and of the layer (:773-829) are active.  On a 'Taylor' step every layer REPLACES the
+    sequence by its own extrapolation, so only the last layer's cache reaches the output; ``taylor_last_layer_only``
+    evaluates just that one (what the MI355X engine does) -- bit-identical, asserted in tests/test_oracle_golden.py."""
     hd = cfg["hidden_size"] // cfg["num_attention_heads"]
     cos_sin = rope_tables(position_ids, hd, cfg["rope_theta"], x.dtype)
     L = cfg["num_hidden_layers"] if num_layers is None else num_layers
+    typ = taylor_cal_type(taylor) if taylor is not None else "full"
     for i in range(L):
-        x = mot_layer(W, cfg, i, x, query_lens, cos_sin, q_idx, cache, kv_lens, kv_idx, update, causal,
-                      mode, vae_idx, text_idx)
+        if typ == "full":
+            if taylor is not None and taylor.step == 0:
+                taylor.factors[i] = {}                      # taylor_cache_init, taylorseer.py:48-56
+            x = mot_layer(W, cfg, i, x, query_lens, cos_sin, q_idx, cache, kv_lens, kv_idx, update, causal,
+                          mode, vae_idx, text_idx)
+            if taylor is not None and (not taylor_last_layer_only or i == L - 1):
+                taylor_derivative_approximation(taylor, i, x)
+        elif not taylor_last_layer_only or i == L - 1:
+            x = taylor_formula(taylor, i)
+    if taylor is not None:
+        taylor.step += 1
     eps = cfg["rms_norm_eps"]
     if mode == "und":
         x = rmsnorm(x, W["language_model.model.norm.weight"], eps)
@@ -344,9 +414,11 @@ def flow_schedule(num_timesteps, shift):
 
 @_explicit_casts
 def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, cfg_text_scale=1.0,
-                 cfg_img_scale=1.0, cfg_renorm_min=0.0, cfg_renorm_type="global"):
+                 cfg_img_scale=1.0, cfg_renorm_min=0.0, cfg_renorm_type="global", taylor=None,
+                 taylor_last_layer_only=False):
     """Bagel._forward_flow, bagel.py:757-907.  ``cfg_text``/``cfg_img`` = dict(cache, position_ids,
-    query_indexes, key_values_lens, key_value_indexes) or None."""
+    query_indexes, key_values_lens, key_value_indexes) or None.  ``taylor`` = (cond, cfg_text, cfg_img) TaylorStates
+    (bagel.py:816-818,836-838,855-857) or None."""
     H = cfg["llm"]["hidden_size"]
     te = embed_tokens(W, gi["packed_text_ids"])
     seq = te.new_zeros((int(sum(gi["packed_seqlens"])), H))
@@ -360,20 +432,21 @@ def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, 
     seq[gi["packed_vae_token_indexes"]] = h
     vae_idx, text_idx = gi["packed_vae_token_indexes"], gi["packed_text_indexes"]
 
-    def run(cache_, pos_ids, q_idx, kv_lens, kv_idx):
+    def run(cache_, pos_ids, q_idx, kv_lens, kv_idx, ts=None):
         out = llm_forward(W, cfg["llm"], seq, gi["packed_seqlens"], pos_ids, q_idx, cache_, kv_lens, kv_idx,
-                          False, False, "gen", vae_idx, text_idx)
+                          False, False, "gen", vae_idx, text_idx, taylor=ts, taylor_last_layer_only=taylor_last_layer_only)
         v = linear(out, W["llm2vae.weight"], W["llm2vae.bias"])
         return v[vae_idx]
 
+    ty = taylor if taylor is not None else (None, None, None)
     v_t = run(cache, gi["packed_position_ids"], gi["packed_indexes"], gi["key_values_lens"],
-              gi["packed_key_value_indexes"])
+              gi["packed_key_value_indexes"], ty[0])
     if cfg_text_scale > 1.0:
         c = cfg_text
-        v_ct = run(c["cache"], c["position_ids"], c["query_indexes"], c["key_values_lens"], c["key_value_indexes"])
+        v_ct = run(c["cache"], c["position_ids"], c["query_indexes"], c["key_values_lens"], c["key_value_indexes"], ty[1])
     if cfg_img_scale > 1.0:
         c = cfg_img
-        v_ci = run(c["cache"], c["position_ids"], c["query_indexes"], c["key_values_lens"], c["key_value_indexes"])
+        v_ci = run(c["cache"], c["position_ids"], c["query_indexes"], c["key_values_lens"], c["key_value_indexes"], ty[2])
 
     if cfg_text_scale > 1.0:
         if cfg_renorm_type == "text_channel":
@@ -400,8 +473,9 @@ def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, 
 @_explicit_casts
 def generate_image(W, cfg, gi, cache, cfg_text=None, cfg_img=None, num_timesteps=24, timestep_shift=1.0,
                    cfg_renorm_min=0.0, cfg_renorm_type="global", cfg_interval=(0, 1), cfg_text_scale=1.0,
-                   cfg_img_scale=1.0, max_steps=None):
-    """Bagel.generate_image, bagel.py:644-754."""
+                   cfg_img_scale=1.0, max_steps=None, enable_taylorseer=False, taylor_last_layer_only=False):
+    """Bagel.generate_image, bagel.py:644-754 (``enable_taylorseer``: :680-689)."""
+    taylor = tuple(TaylorState(num_timesteps) for _ in range(3)) if enable_taylorseer else None
     x_t = gi["packed_init_noises"]
     ts, dts = flow_schedule(num_timesteps, timestep_shift)
     for i, t in enumerate(ts):
@@ -413,7 +487,7 @@ def generate_image(W, cfg, gi, cache, cfg_text=None, cfg_img=None, num_timesteps
         else:
             s_t, s_i = 1.0, 1.0
         v_t = forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text, cfg_img, s_t, s_i, cfg_renorm_min,
-                           cfg_renorm_type)
+                           cfg_renorm_type, taylor, taylor_last_layer_only)
         x_t = x_t - v_t.to(x_t.device) * dts[i]
     return x_t.split((gi["packed_seqlens"] - 2).tolist())
 

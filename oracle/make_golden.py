@@ -160,6 +160,52 @@ def scenario_t2i(cfg, model, vae, W, VW):
     return out
 
 
+def scenario_taylorseer(cfg, model, vae, W, VW):
+    """text->image with enable_taylorseer=True (bagel.py:678-689): 14 timesteps = 13 forwards of the cond stream with the
+    schedule F F F F F T T F T T F T T; CFG only on part of the interval, so the cfg-text stream runs fewer forwards and
+    keeps its own step counter / Taylor cache."""
+    from modeling.bagel.qwen2_navit import NaiveCache
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    prompts = ["a tiny red cube", "sky"]
+    sizes = [(64, 64), (32, 64)]
+    ds = cfg["vae"]["downsample"] * cfg["bagel"]["latent_patch_size"]
+    pdim = cfg["bagel"]["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"]
+    out = {}
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        gi, newlens, newrope = model.prepare_prompts([0, 0], [0, 0], prompts, tok, NEW_TOKEN_IDS_TINY)
+        cache = model.forward_cache_update_text(NaiveCache(L), **gi)
+        ocache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi)
+        torch.manual_seed(46)
+        li = model.prepare_vae_latent(newlens, newrope, sizes, NEW_TOKEN_IDS_TINY)
+        ci = model.prepare_vae_latent_cfg([0, 0], [0, 0], sizes)
+        ocfg = dict(cache=O.OracleCache(L), position_ids=ci["cfg_packed_position_ids"],
+                    query_indexes=ci["cfg_packed_query_indexes"], key_values_lens=ci["cfg_key_values_lens"],
+                    key_value_indexes=ci["cfg_packed_key_value_indexes"])
+        runs = {}
+        for tag, kw in (("partial_cfg", dict(num_timesteps=14, timestep_shift=3.0, cfg_renorm_min=0.0, cfg_renorm_type="global",
+                                             cfg_interval=[0.4, 1.0], cfg_text_scale=4.0)),
+                        ("full_cfg", dict(num_timesteps=18, timestep_shift=2.0, cfg_renorm_min=0.2, cfg_renorm_type="channel",
+                                          cfg_interval=[0.0, 1.0], cfg_text_scale=3.0))):
+            lat = model.generate_image(
+                past_key_values=cache, cfg_text_past_key_values=NaiveCache(L),
+                cfg_text_packed_position_ids=ci["cfg_packed_position_ids"],
+                cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
+                cfg_text_key_values_lens=ci["cfg_key_values_lens"],
+                cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"], enable_taylorseer=True, **kw, **li)
+            model.language_model.model.enable_taylorseer = False
+            olat = O.generate_image(W, cfg, li, ocache, cfg_text=ocfg, enable_taylorseer=True, **kw)
+            same(list(lat), list(olat), f"taylorseer latents ({tag})")
+            olat2 = O.generate_image(W, cfg, li, ocache, cfg_text=ocfg, enable_taylorseer=True, taylor_last_layer_only=True, **kw)
+            same(list(lat), list(olat2), f"taylorseer latents, last-layer-only evaluation ({tag})")
+            plain = O.generate_image(W, cfg, li, ocache, cfg_text=ocfg, **kw)
+            dev = max(((a - b).norm() / b.norm()).item() for a, b in zip(lat, plain))
+            assert dev > 1e-4, "TaylorSeer run is indistinguishable from the plain sampler: the scenario proves nothing"
+            runs[tag] = dict(gen_kwargs=kw, latents=list(lat), rel_dev_from_plain_sampler=dev)
+    out.update(prompts=prompts, image_sizes=sizes, latent_inputs=li, cfg_inputs=ci, runs=runs)
+    return out
+
+
 def scenario_edit_und(cfg, model, vae, W, VW):
     """image(VAE+ViT) + text context -> (a) 3-forward edit sampling, (b) greedy text decode."""
     from modeling.bagel.qwen2_navit import NaiveCache
@@ -309,7 +355,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for cfg in (TINY, TINY_D128):
         model, vae, W, VW = build(cfg)
-        for name, fn in (("t2i", scenario_t2i), ("editund", scenario_edit_und), ("vae", scenario_vae),
+        for name, fn in (("t2i", scenario_t2i), ("editund", scenario_edit_und), ("taylorseer", scenario_taylorseer), ("vae", scenario_vae),
                          ("siglip", scenario_siglip)):
             if args.only and args.only != name:
                 continue

@@ -161,6 +161,48 @@ def test_paged_append_and_decode_attention(lens, nq, nkv, D):
         close(out, ref0, what="decode attention len_add=0")
 
 
+@pytest.mark.parametrize("hd,dp,nq,nkv,use_norm", [(128, 128, 28, 4, True), (32, 64, 4, 2, True), (64, 64, 3, 1, True), (128, 128, 5, 5, False)])
+def test_decode_qkv_post_equals_qknorm_rope_plus_append(hd, dp, nq, nkv, use_norm):
+    """The fused decode epilogue is bit-identical to the packed-prefill kernels it replaces (qknorm_rope, und cast points,
+    + kv_append), pad lanes of the page rows are zeroed, and physically scattered pages are honoured."""
+    from bagel_amd.modeling.bagel.decode import PagedKVCache
+    o = ops()
+    B = 3
+    width = nkv * dp
+    ld = (nq + 2 * nkv) * dp
+    qkv = torch.zeros((B, nq + 2 * nkv, dp), dtype=BF16)
+    qkv[:, :, :hd] = rnd(B, nq + 2 * nkv, hd, seed=1)
+    qkv = qkv.view(B, ld).to(DEV)
+    qw, kw = (1.0 + 0.1 * rnd(hd, seed=2).float()).to(BF16).to(DEV), (1.0 + 0.1 * rnd(hd, seed=3).float()).to(BF16).to(DEV)
+    pos = torch.tensor([5, 77, 4000], dtype=torch.long, device=DEV)
+    inv = (1.0 / (1e6 ** (torch.arange(0, hd, 2).float() / hd))).to(DEV)
+    cos, sin = o.rope_table(pos, inv)
+    lens = [3, 64, 130]
+    order = torch.randperm(B * 3, generator=torch.Generator().manual_seed(1)).tolist()
+    pg1 = PagedKVCache(1, B, width, 192, DEV, order=order)
+    pg2 = PagedKVCache(1, B, width, 192, DEV, order=order)
+    for pg in (pg1, pg2):
+        pg.k.fill_(float("nan")); pg.v.fill_(float("nan"))
+        pg.kv_len.copy_(torch.tensor(lens, dtype=torch.int32))
+    a = qkv.clone()
+    o.qknorm_rope(a, cos, sin, qw if use_norm else None, kw if use_norm else None, None, None, None, nq, nkv, hd, dp, 1e-6,
+                  gen_mode=False, use_norm=use_norm)
+    o.kv_append_paged(a[:, nq * dp:nq * dp + width], a[:, nq * dp + width:], pg1.k[0], pg1.v[0], pg1.block_table, pg1.kv_len, B, width)
+    b = qkv.clone()
+    o.decode_qkv_post(b, cos, sin, qw if use_norm else None, kw if use_norm else None, pg2.k[0], pg2.v[0], pg2.block_table,
+                      pg2.kv_len, B, nq, nkv, hd, dp, 1e-6, use_norm)
+    assert torch.equal(a[:, :nq * dp].view(torch.int16), b[:, :nq * dp].view(torch.int16)), "q rows differ"
+    assert torch.equal(b[:, nq * dp:], qkv[:, nq * dp:]), "k/v of the projection buffer must stay untouched"
+    for i, n in enumerate(lens):
+        r = pg1.physical_rows(i, n, n + 1)[0]
+        assert torch.equal(pg1.k[0][r].view(torch.int16), pg2.k[0][r].view(torch.int16)), "K page row differs"
+        assert torch.equal(pg1.v[0][r].view(torch.int16), pg2.v[0][r].view(torch.int16)), "V page row differs"
+        assert torch.isfinite(pg2.k[0][r].float()).all() and torch.isfinite(pg2.v[0][r].float()).all()
+    untouched = torch.ones(pg2.k.shape[1], dtype=torch.bool)
+    untouched[[pg2.physical_rows(i, n, n + 1)[0] for i, n in enumerate(lens)]] = False
+    assert torch.isnan(pg2.k[0][untouched.to(DEV)].float()).all(), "only the slot kv_len[b] may be written"
+
+
 def test_decode_attention_sharp_softmax():
     """One key dominates by a huge margin in a late split: the split merge must not lose it or overflow."""
     from bagel_amd.modeling.bagel.decode import PagedKVCache

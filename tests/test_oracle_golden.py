@@ -101,3 +101,35 @@ def test_siglip_matches_reference(golden, name):
     out = O.siglip_forward(W, cfg["vit"], g["tokens"], g["pos"], g["cu"], 35)
     assert torch.equal(out, g["out"])
     assert torch.equal(O.connector(W, out), g["connector_out"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_taylorseer_matches_reference(golden, name):
+    """enable_taylorseer=True (bagel.py:678-689; taylorseer.py): schedule, finite differences and the bf16 Taylor sum are
+    bit-exact, and evaluating only the LAST layer's extrapolation (what the MI355X engine does) is the same function."""
+    cfg = CFGS[name]
+    g = golden(f"{name}_taylorseer")
+    W, _ = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    gi, _, _ = P.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+    cache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi)
+    for tag, run in g["runs"].items():
+        for last_only in (False, True):
+            lat = O.generate_image(W, cfg, g["latent_inputs"], cache, cfg_text=_cfgd(O.OracleCache(L), g["cfg_inputs"]),
+                                   enable_taylorseer=True, taylor_last_layer_only=last_only, **run["gen_kwargs"])
+            for a, b in zip(lat, run["latents"]):
+                assert torch.equal(a, b), (tag, last_only)
+
+
+def test_taylorseer_schedule_known_answer():
+    """cal_type (taylorseer.py:83-117) with the reference constants: 5 full steps, then T T F repeating; the
+    finite-difference distance is the gap between the last two full steps."""
+    st = O.TaylorState(50)
+    kinds = []
+    for _ in range(49):
+        kinds.append("F" if O.taylor_cal_type(st) == "full" else "T")
+        st.step += 1
+    assert "".join(kinds) == "FFFFF" + "TTF" * 14 + "TT"
+    assert kinds.count("F") == 19
+    assert st.activated_steps[:8] == [0, 0, 1, 2, 3, 4, 7, 10]

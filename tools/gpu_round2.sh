@@ -30,5 +30,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES G
   head -40 gpurun_out/pmc_$tag.txt
   tail -3 gpurun_out/pmc_$tag.err
 done
-find gpurun_out -size +20M -delete
+rm -rf gpurun_out/prof_und gpurun_out/pmc_*/
+find gpurun_out -size +5M -delete
 du -sh gpurun_out
