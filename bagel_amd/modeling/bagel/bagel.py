@@ -15,6 +15,7 @@ from torch import nn
 from ... import ops
 from ...data.data_utils import (get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
 from .modeling_utils import MLPconnector, PositionEmbedding, TimestepEmbedder
+from ..cache_utils.taylorseer import TaylorSeerState
 from .qwen2_navit import NaiveCache, _Linear
 
 BF16 = torch.bfloat16
@@ -367,9 +368,10 @@ class Bagel(nn.Module):
                        cfg_img_scale=1.0, cfg_img_packed_query_indexes=None, cfg_img_packed_position_ids=None,
                        cfg_img_past_key_values=None, cfg_img_key_values_lens=None, cfg_img_packed_key_value_indexes=None,
                        cfg_type="parallel", enable_taylorseer=False):
-        if enable_taylorseer:
-            raise NotImplementedError("enable_taylorseer=True: TaylorSeer is out of scope for this build (SURVEY.md 8f)")
-        self.language_model.model.enable_taylorseer = False
+        # bagel.py:680-689: one TaylorSeer state per forward stream (cond, cfg-text, cfg-img)
+        self.language_model.model.enable_taylorseer = False     # the engine gets the state explicitly (see _velocity)
+        taylor = [TaylorSeerState(num_timesteps) for _ in range(3)] if enable_taylorseer else [None, None, None]
+        self._last_taylor_states = taylor
         if cfg_renorm_type not in ops.RENORM_MODES:
             raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
         st = self._flow_state(packed_text_ids, packed_text_indexes, packed_vae_position_ids, packed_vae_token_indexes,
@@ -396,7 +398,7 @@ class Bagel(nn.Module):
             self._flow_step(st, x_t, float(t), float(dts[i]), plan, past_key_values,
                             plan_t if s_t > 1.0 else None, cfg_text_past_key_values,
                             plan_i if (s_t > 1.0 and s_i > 1.0) else None, cfg_img_past_key_values,
-                            s_t, s_i, cfg_renorm_min, mode)
+                            s_t, s_i, cfg_renorm_min, mode, taylor)
         return x_t.split([int(n) - 2 for n in packed_seqlens.tolist()])
 
     def _flow_state(self, packed_text_ids, packed_text_indexes, packed_vae_position_ids, packed_vae_token_indexes,
@@ -413,24 +415,25 @@ class Bagel(nn.Module):
             tmp=torch.empty((nv, self.patch_latent_dim), dtype=BF16, device=dev),
             partials=torch.empty((2 * 256,), dtype=torch.float32, device=dev), embedded=False)
 
-    def _velocity(self, st, plan, cache, out):
+    def _velocity(self, st, plan, cache, out, taylor=None):
         """llm2vae(backbone(seq))[latent rows] -> out (bagel.py:820-833)."""
         h = self.language_model.engine().forward(st["seq"], plan, "gen" if self.use_moe else "und", cache, update=False,
-                                                 causal=False)
+                                                 causal=False, taylor=taylor)
         ops.gemm(h, self.llm2vae.weight.data, out, bias0=self.llm2vae.bias.data, a_rows0=st["vae_rows"], M0=out.shape[0])
         return out
 
-    def _flow_step(self, st, x_t, t, dt, plan, cache, plan_t, cache_t, plan_i, cache_i, s_t, s_i, renorm_min, mode):
+    def _flow_step(self, st, x_t, t, dt, plan, cache, plan_t, cache_t, plan_i, cache_i, s_t, s_i, renorm_min, mode,
+                   taylor=(None, None, None)):
         """One Euler step of bagel.py:698-746 (= _forward_flow + the update), all on the current stream."""
         seq = st["seq"]
         if not st["embedded"]:      # marker-token rows never change across steps
             self._embed_into(seq, st["text_ids"], st["text_rows"])
             st["embedded"] = True
         self._latent_tokens_into(seq, x_t, st["vae_rows"], st["vae_pos"], t)
-        v = self._velocity(st, plan, cache, st["v"][0])
+        v = self._velocity(st, plan, cache, st["v"][0], taylor[0])
         if plan_t is not None:
-            v_ct = self._velocity(st, plan_t, cache_t, st["v"][1])
-            v_ci = self._velocity(st, plan_i, cache_i, st["v"][2]) if plan_i is not None else None
+            v_ct = self._velocity(st, plan_t, cache_t, st["v"][1], taylor[1])
+            v_ci = self._velocity(st, plan_i, cache_i, st["v"][2], taylor[2]) if plan_i is not None else None
             nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
             ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
         else:

@@ -537,8 +537,11 @@ class MoTEngine:
         return ForwardPlan(self.device, query_lens, position_ids, inv_freq=self.model.rotary_emb.inv_freq(self.device), **kw)
 
     def forward(self, seq, plan: ForwardPlan, mode="und", cache: NaiveCache = None, update=True, causal=True,
-                num_layers=None):
-        """Qwen2Model.forward_inference (qwen2_navit.py:1018-1092).  ``seq`` is not modified."""
+                num_layers=None, taylor=None):
+        """Qwen2Model.forward_inference (qwen2_navit.py:1018-1092).  ``seq`` is not modified.
+        ``taylor``: a TaylorSeerState (cache_utils/taylorseer.py) -> the TaylorSeer hooks of :1034-1037,1057-1061,
+        1086-1087 are active: a 'full' step runs the layers and refreshes the feature cache, a 'Taylor' step replaces
+        the whole layer stack by the cached extrapolation."""
         if seq.shape != (plan.M, self.H):
             raise ValueError(f"packed sequence shape {tuple(seq.shape)} != ({plan.M}, {self.H})")
         gen = mode == "gen" and self.moe_mlp
@@ -547,7 +550,11 @@ class MoTEngine:
         gen_attn = gen and self.mot
         ws = self.workspace(plan.M, plan.vt_cols)
         x, h, qkv, att, act, vt = ws["x"], ws["h"], ws["qkv"], ws["attn"], ws["act"], ws["vt"]
-        x.copy_(seq)
+        skip_layers = taylor is not None and taylor.next_type() == "Taylor"
+        if skip_layers and update:
+            raise ValueError("a TaylorSeer-skipped forward cannot update the KV cache")
+        if not skip_layers:
+            x.copy_(seq)
         nq, nkv, dp, hd = self.nq, self.nkv, self.dp, self.hd
         qw, kw_ = nq * dp, nkv * dp
         q_v, k_v, v_v = qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
@@ -563,6 +570,9 @@ class MoTEngine:
             return dict(W0=w[0], bias0=None if b is None else b[0], M0=plan.M)
 
         nl = len(self.layers) if num_layers is None else num_layers
+        if skip_layers:
+            nl = 0
+            taylor.eval_into(x)
         for li in range(nl):
             P = self.layers[li]
             ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if gen_attn else None, expert=expert if gen_attn else None)
@@ -588,6 +598,10 @@ class MoTEngine:
             ops.rmsnorm(x, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if gen_attn else None, expert=expert if gen_attn else None)
             ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu, None, gen))
             ops.gemm(act, C=x, residual=x, **groups(P.wd, None, gen))
+        if taylor is not None:
+            if not skip_layers:
+                taylor.update(x)
+            taylor.advance()
         out = torch.empty_like(x)
         m = self.model
         if gen and self.mot or (gen and self.kind == "Qwen2MoEDecoderLayer"):
@@ -653,8 +667,9 @@ class Qwen2ForCausalLM(nn.Module):
                           past_key_values=None, key_values_lens=None, packed_key_value_indexes=None,
                           update_past_key_values=True, is_causal=True, mode="und", packed_vae_token_indexes=None,
                           packed_text_indexes=None, plan=None):
-        if getattr(self.model, "enable_taylorseer", False):
-            raise NotImplementedError("TaylorSeer step skipping is out of scope for this build (SURVEY.md section 8f)")
+        # TaylorSeer (qwen2_navit.py:1034-1037): the caller parks the stream's state on the model, like the reference's
+        # model.cache_dic / model.current (bagel.py:816-818)
+        taylor = getattr(self.model, "current", None) if getattr(self.model, "enable_taylorseer", False) else None
         eng = self.engine()
         if plan is None:
             gen = mode == "gen" and eng.moe_mlp
@@ -664,7 +679,7 @@ class Qwen2ForCausalLM(nn.Module):
         seq = packed_query_sequence
         if seq.device != eng.device or seq.dtype != BF16:
             seq = seq.to(device=eng.device, dtype=BF16)
-        out = eng.forward(seq, plan, mode, past_key_values, update_past_key_values, is_causal)
+        out = eng.forward(seq, plan, mode, past_key_values, update_past_key_values, is_causal, taylor=taylor)
         return BaseNavitOutputWithPast(packed_query_sequence=out, past_key_values=past_key_values)
 
     def forward(self, *args, **kwargs):

@@ -167,6 +167,35 @@ def decode_advance(next_tok, cur_tok32, tokens_out, pos, kv_len, step, batch, ma
                                      batch, max_steps, _stream()), "bagel_decode_advance")
 
 
+def _ptr_array(tensors, n):
+    arr = (ctypes.c_void_p * max(n, 1))()
+    for i in range(n):
+        _req(tensors[i], BF16, "taylor.factor")
+        if not tensors[i].is_contiguous():
+            raise BagelHipError("taylor: factor buffers must be contiguous")
+        arr[i] = _ptr(tensors[i])
+    return arr
+
+
+def taylor_update(feature, factors, n_diff, distance):
+    """TaylorSeer full step: factors[0] <- feature, factors[i+1] <- bf16(bf16(new_i - old_i) / distance), i < n_diff."""
+    _req(feature, BF16, "taylor_update.feature")
+    rows, cols = feature.shape
+    arr = _ptr_array(factors, n_diff + 1)
+    check(lib().bagel_taylor_update_bf16(_ptr(feature), feature.stride(0), ctypes.addressof(arr), n_diff, int(distance), rows, cols,
+                                         _stream()), "bagel_taylor_update_bf16")
+
+
+def taylor_eval(factors, n, x, out):
+    """TaylorSeer skipped step: out = sum_i bf16(bf16(factors[i] / i!) * x**i) with a bf16 running sum."""
+    _req(out, BF16, "taylor_eval.out")
+    rows, cols = out.shape
+    arr = _ptr_array(factors, n)
+    check(lib().bagel_taylor_eval_bf16(ctypes.addressof(arr), n, int(x), _ptr(out), out.stride(0), rows, cols, _stream()),
+          "bagel_taylor_eval_bf16")
+    return out
+
+
 class HipGraph:
     """A captured launch sequence (hipGraph).  ``with HipGraph.capture(stream) as g: <launch ops>`` then ``g.launch()``."""
 

@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="debug only: skip the VAE decode (result flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=1)
+    ap.add_argument("--no-taylorseer", action="store_true", help="skip the extra enable_taylorseer=True measurement")
     ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
     ap.add_argument("--only-understanding", action="store_true", help="debug only: skip the text->image leg (result flagged invalid)")
     ap.add_argument("--und-new-tokens", type=int, default=256)
@@ -197,6 +198,17 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
                         f"prompt tokens prefill, greedy decode of {n} tokens, bf16, batch 1/GPU"}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of ``kernel`` from the committed PMC pass (FETCH_SIZE x2 per the gfx950 correction of
+    MI355X_MICROARCH.md + WRITE_SIZE; separate rocprofv3 --pmc runs, profiles/r01_pmc_summary.json).  A profiler cannot
+    run inside the timed bench, so this is the per-launch figure of the same kernel on the same shapes; null if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
 def understanding_subprocess(args, local):
     """Run the configs[1] leg in a child process on the same GPU (a replica per rank): a fault or hang there can never
     take the text->image number down with it."""
@@ -260,7 +272,7 @@ def main():
     all_noise = torch.randn(world * B * n_img, pdim, generator=noise_gen)
     my_noise = all_noise[rank * B * n_img:(rank + 1) * B * n_img].to(dev)
 
-    def one_step():
+    def one_step(taylorseer=False):
         # conditioning context: computed once (rank 0) and broadcast; every sample shares the prompt (gen_images_mp.py:43)
         gi, newlens, newrope = model.prepare_prompts([0] * B, [0] * B, ["p"] * B, tok, ids)
         if rank == 0:
@@ -276,7 +288,8 @@ def main():
             past_key_values=cache, num_timesteps=T, cfg_text_scale=4.0, cfg_interval=[0, 1.0], cfg_renorm_min=0.0,
             cfg_renorm_type="global", timestep_shift=3.0, cfg_text_past_key_values=NaiveCache(L),
             cfg_text_packed_position_ids=ci["cfg_packed_position_ids"], cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
-            cfg_text_key_values_lens=ci["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"], **li)
+            cfg_text_key_values_lens=ci["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"],
+            enable_taylorseer=taylorseer, **li)
         imgs = []
         if not args.no_vae:
             for lat in latents:
@@ -322,6 +335,24 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     finite = all(torch.isfinite(x).all().item() for x in latents)
+    ts = None
+    if not args.no_taylorseer:
+        # the reference's own accelerator option (generate_image(enable_taylorseer=True), bagel.py:678-689): same workload,
+        # 19 instead of 49 full backbone forwards per stream.  It CHANGES the samples, so it is reported beside the headline
+        # number, never as it.
+        fence()
+        t1 = time.perf_counter()
+        lat_ts, _ = one_step(taylorseer=True)
+        fence()
+        dt_ts = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt_ts], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ts = float(tt.item())
+        st = model._last_taylor_states[0]
+        ts = {"value": world * B / dt_ts, "unit": "images/s", "ms_per_step": dt_ts * 1e3, "full_forwards_per_stream": st.full_steps,
+              "extrapolated_forwards_per_stream": st.taylor_steps, "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_ts),
+              "note": "enable_taylorseer=True (reference option, changes the samples): not the headline metric"}
     und = None
     if not args.no_understanding:
         und = understanding_subprocess(args, local)
@@ -355,10 +386,11 @@ def main():
                                    f"global renorm, timestep_shift 3, prompt {args.prompt_tokens}+2 tokens, {B} samples/GPU, VAE decode included",
                        "global_batch": world * B, "query_tokens_per_sample": n_img + 2, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                         "traffic": None, "kernel": names.get(dom, str(dom)), "launches": len(records),
+                         "traffic": pmc_traffic(names.get(dom, str(dom))), "kernel": names.get(dom, str(dom)), "launches": len(records),
                          "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},
             "outputs_finite": bool(finite),
             "understanding": und,
+            "taylorseer": ts,
         }
         if args.layers is not None or args.no_vae or R != 1024 or T != 50:
             out["valid"] = False

@@ -157,6 +157,15 @@ int bagel_graph_end(bagel_stream_t stream, void** exec_out);
 int bagel_graph_launch(void* exec, bagel_stream_t stream);
 int bagel_graph_destroy(void* exec);
 
+/* ---- TaylorSeer step skipping (modeling/cache_utils/taylorseer.py; generate_image(enable_taylorseer=True)) ---- */
+/* derivative_approximation (taylorseer.py:11-30) on the last decoder layer's output: factors[0] <- feature,
+ * factors[i+1] <- bf16(bf16(new_i - old_i) / distance) for i < n_diff, in place over n_diff+1 [rows, cols] buffers. */
+int bagel_taylor_update_bf16(const void* feature, int64_t ld_feature, void* const* factors, int32_t n_diff,
+                             int32_t distance, int64_t rows, int32_t cols, bagel_stream_t stream);
+/* taylor_formula (taylorseer.py:32-46): out = sum_{i<n} bf16(bf16(factors[i] / i!) * x^i), bf16 running sum. */
+int bagel_taylor_eval_bf16(void* const* factors, int32_t n, int32_t x, void* out, int64_t ld_out, int64_t rows,
+                           int32_t cols, bagel_stream_t stream);
+
 /* ---- VAE (fp32, NHWC) ------------------------------------------------------------------------------------- */
 /* Implicit-GEMM convolution / plain GEMM on the exact-fp32 MFMA.  mode 0: out[M,Cout] = in[M,Cin] w[Cout,Cin]^T
  * (1x1 conv, attention products; M = B*Hout*Wout); 1: 3x3 stride 1 pad 1; 2: 3x3 stride 2 with the (0,1,0,1) pad of

@@ -201,7 +201,7 @@ def scenario_taylorseer(cfg, model, vae, W, VW):
             plain = O.generate_image(W, cfg, li, ocache, cfg_text=ocfg, **kw)
             dev = max(((a - b).norm() / b.norm()).item() for a, b in zip(lat, plain))
             assert dev > 1e-4, "TaylorSeer run is indistinguishable from the plain sampler: the scenario proves nothing"
-            runs[tag] = dict(gen_kwargs=kw, latents=list(lat), rel_dev_from_plain_sampler=dev)
+            runs[tag] = dict(gen_kwargs=kw, latents=list(lat), latents_plain_sampler=list(plain), rel_dev_from_plain_sampler=dev)
     out.update(prompts=prompts, image_sizes=sizes, latent_inputs=li, cfg_inputs=ci, runs=runs)
     return out
 
