@@ -13,6 +13,7 @@
 //                                group shares every K/V byte (qwen2_navit.py:579-588)
 //   bagel_decode_advance         token bookkeeping of bagel.py:984-994 on the device
 #include "common.h"
+#include <stdlib.h>
 
 #define EPI_NONE 0
 #define EPI_GELU_TANH 1
@@ -66,41 +67,127 @@ __device__ __forceinline__ void gemv_load_batch(u32x4_t (&wa)[U], u32x4_t (&wb)[
     }
 }
 
-template <int MR>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
-    constexpr int U = 7;   // chunk groups in flight per row: K = 3584 -> exactly one batch, K = 18944 -> 5 batches + 2
+// whole batch in range: one base address per row, the U groups at constant strides (1 KB apart)
+template <int U>
+__device__ __forceinline__ void gemv_load_full(u32x4_t (&wa)[U], u32x4_t (&wb)[U], const bf16_t* w0, const bf16_t* w1, int g, int lane) {
+    const bf16_t* a = w0 + ((long)g * 64 + lane) * 8;
+    const bf16_t* b = w1 + ((long)g * 64 + lane) * 8;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        wa[u] = *(const u32x4_t*)(a + u * 512);
+        wb[u] = *(const u32x4_t*)(b + u * 512);
+    }
+}
+
+// One workgroup = 4 waves.  WPP = 1: every wave owns `ppw` consecutive row pairs and the whole K range.  WPP = 4 (long
+// rows, few of them: the down projection): the four waves split the K range of ONE pair and their partial sums meet in
+// LDS, so N/2 workgroups keep 4x more rows in flight than N/8 would.
+//
+// Issue order at the top is what the latency chain needs: (1) the activation chunks, the norm weights and the first
+// pair's bias/residual, (2) the wave's first weight batch, (3) the reduction / scaling / LDS staging, which waits only
+// for (1) (loads return in order: had the weights gone first, the staging would have waited for HBM), (4) the FMAs,
+// by which time the weights have landed.
+template <int MR, int WPP>
+__device__ __forceinline__ void gemv_body(const GemvParams& p) {
+    constexpr int U = 7;   // chunk groups in flight per row: K = 3584 -> exactly one batch, K = 18944 / 4 waves -> 7 + 3
     extern __shared__ __attribute__((aligned(16))) unsigned char gemv_smem[];
     bf16_t* xs = (bf16_t*)gemv_smem;   // [MR][K]
     __shared__ float red[MR][4];
+    __shared__ float part[4][2][MR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K, nch = K >> 3;
     const int NP = p.N >> 1;
     const bool swiglu = p.epi == EPI_SWIGLU16;
-    const int ngr = (nch + 63) >> 6;
-    const int pbase = (blockIdx.x * 4 + wave) * p.ppw;
-    const int pend = (pbase + p.ppw < NP) ? pbase + p.ppw : NP;
-
-    // ---- the first weight batch of this wave goes out BEFORE the activation staging: its HBM latency overlaps the
-    //      norm/LDS work instead of following it (for N ~ H a wave's whole share is this one batch) ---------------------
-    u32x4_t wa[U], wb[U];
-    if (pbase < pend) {
-        const int r0 = swiglu ? ((pbase >> 4) << 5) + (pbase & 15) : 2 * pbase;
-        const int r1 = swiglu ? r0 + 16 : r0 + 1;
-        gemv_load_batch<U>(wa, wb, p.W + (long)r0 * p.ldw, p.W + (long)r1 * p.ldw, 0, lane, nch);
+    const int ngr = (nch + 63) >> 6, nfull = nch >> 6;
+    // this wave's pairs and K range (in 64-chunk groups)
+    int pbase, pend, g_lo, g_hi;
+    if (WPP == 1) {
+        pbase = (blockIdx.x * 4 + wave) * p.ppw;
+        pend = (pbase + p.ppw < NP) ? pbase + p.ppw : NP;
+        g_lo = 0;
+        g_hi = ngr;
+    } else {
+        pbase = blockIdx.x;
+        pend = pbase + 1;                       // grid == NP
+        const int gq = (ngr + 3) >> 2;
+        g_lo = wave * gq;
+        g_hi = (g_lo + gq < ngr) ? g_lo + gq : ngr;
+        if (g_lo > g_hi) g_lo = g_hi;
     }
+    const int full_hi = g_hi < nfull ? g_hi : nfull;     // groups below this bound are complete for every lane
+    const int ch_hi = (g_hi * 64 < nch) ? g_hi * 64 : nch;
+    const bool fin = (WPP == 1) ? (lane == 0) : (tid == 0);   // the lane that runs the epilogue
 
-    // ---- stage the activation rows (optionally RMS-normalised) --------------------------------------------------
-    if (p.norm_w) {
+    // ---- (1) activation chunks (K <= 4096: kept in registers across the two norm passes), norm weights, epilogue operands
+    const bool small = nch <= 512;
+    u32x4_t xr[MR][2], gw[2];
+    if (small) {
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             const bf16_t* ar = p.A + (long)(m < p.M ? m : p.M - 1) * p.lda;
-            float ss = 0.f;
-            for (int c = tid; c < nch; c += 256) {
-                const u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = lo2f(v[e]), b = hi2f(v[e]);
-                    ss += a * a + b * b;
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + 256 * i;
+                xr[m][i] = c < nch ? *(const u32x4_t*)(ar + (long)c * 8) : u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+        if (p.norm_w) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + 256 * i;
+                gw[i] = c < nch ? *(const u32x4_t*)(p.norm_w + (long)c * 8) : u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+    }
+    float eb[2] = {0.f, 0.f}, er[MR][2];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) er[m][0] = er[m][1] = 0.f;
+    if (fin && pbase < pend && !swiglu) {
+        const int r0 = 2 * pbase;
+        if (p.bias) { eb[0] = bf2f(p.bias[r0]); eb[1] = bf2f(p.bias[r0 + 1]); }
+        if (p.R) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+                if (m < p.M) {
+                    const unsigned rv = *(const unsigned*)(p.R + (long)m * p.ldr + r0);     // r0 is even: one aligned dword
+                    er[m][0] = lo2f(rv);
+                    er[m][1] = hi2f(rv);
+                }
+        }
+    }
+
+    // ---- (2) first weight batch of this wave
+    u32x4_t wa[U], wb[U];
+    const bool pre_full = g_lo + U <= full_hi;
+    if (pbase < pend && g_lo < g_hi) {
+        const int r0 = swiglu ? ((pbase >> 4) << 5) + (pbase & 15) : 2 * pbase;
+        const int r1 = swiglu ? r0 + 16 : r0 + 1;
+        if (pre_full) gemv_load_full<U>(wa, wb, p.W + (long)r0 * p.ldw, p.W + (long)r1 * p.ldw, g_lo, lane);
+        else gemv_load_batch<U>(wa, wb, p.W + (long)r0 * p.ldw, p.W + (long)r1 * p.ldw, g_lo, lane, ch_hi);
+    }
+
+    // ---- (3) stage the activation rows in LDS (optionally RMS-normalised)
+    if (p.norm_w) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            float ss = 0.f;
+            if (small) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = lo2f(xr[m][i][e]), b = hi2f(xr[m][i][e]);
+                        ss += a * a + b * b;
+                    }
+            } else {
+                const bf16_t* ar = p.A + (long)(m < p.M ? m : p.M - 1) * p.lda;
+                for (int c = tid; c < nch; c += 256) {
+                    const u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = lo2f(v[e]), b = hi2f(v[e]);
+                        ss += a * a + b * b;
+                    }
                 }
             }
             ss = wave_sum(ss);
@@ -113,20 +200,36 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
         const bf16_t* ar = p.A + (long)(m < p.M ? m : p.M - 1) * p.lda;
         float inv = 1.f;
         if (p.norm_w) inv = rsqrtf((red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K + p.eps);
-        for (int c = tid; c < nch; c += 256) {
-            u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
-            if (p.norm_w) {
-                const u32x4_t g = *(const u32x4_t*)(p.norm_w + (long)c * 8);
+        if (small) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = pack2bf(bfround(lo2f(v[e]) * inv) * lo2f(g[e]), bfround(hi2f(v[e]) * inv) * hi2f(g[e]));
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + 256 * i;
+                if (c < nch) {
+                    u32x4_t v = xr[m][i];
+                    if (p.norm_w) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = pack2bf(bfround(lo2f(v[e]) * inv) * lo2f(gw[i][e]), bfround(hi2f(v[e]) * inv) * hi2f(gw[i][e]));
+                    }
+                    *(u32x4_t*)(xs + (long)m * K + (long)c * 8) = v;
+                }
             }
-            *(u32x4_t*)(xs + (long)m * K + (long)c * 8) = v;
+        } else {
+            for (int c = tid; c < nch; c += 256) {
+                u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
+                if (p.norm_w) {
+                    const u32x4_t g = *(const u32x4_t*)(p.norm_w + (long)c * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = pack2bf(bfround(lo2f(v[e]) * inv) * lo2f(g[e]), bfround(hi2f(v[e]) * inv) * hi2f(g[e]));
+                }
+                *(u32x4_t*)(xs + (long)m * K + (long)c * 8) = v;
+            }
         }
     }
     __syncthreads();
 
-    // ---- weight-row pairs [pbase, pend) of this wave ----------------------------------------------------------------
+    // ---- (4) weight-row pairs ----------------------------------------------------------------------------------------
     for (int pp = pbase; pp < pend; ++pp) {
         const int r0 = swiglu ? ((pp >> 4) << 5) + (pp & 15) : 2 * pp;
         const int r1 = swiglu ? r0 + 16 : r0 + 1;
@@ -135,62 +238,121 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
         float a0[MR][2], a1[MR][2];
 #pragma unroll
         for (int m = 0; m < MR; ++m) a0[m][0] = a0[m][1] = a1[m][0] = a1[m][1] = 0.f;
-        for (int g = 0; g < ngr; g += U) {
-            if (pp != pbase || g != 0) gemv_load_batch<U>(wa, wb, w0, w1, g, lane, nch);
+        int g = g_lo;
+        for (; g + U <= full_hi; g += U) {                     // whole batches: no predicates
+            if (pp != pbase || g != g_lo) gemv_load_full<U>(wa, wb, w0, w1, g, lane);
+#pragma unroll
+            for (int u = 0; u < U; ++u) gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, (g + u) * 64 + lane, true);
+        }
+        if (g < g_hi) {                                         // ragged tail batch (clamped loads, zeroed activations)
+            if (pp != pbase || g != g_lo) gemv_load_batch<U>(wa, wb, w0, w1, g, lane, ch_hi);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ch = (g + u) * 64 + lane;
-                const bool ok = ch < nch;
+                const bool ok = ch < ch_hi;
                 gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, ok ? ch : 0, ok);
             }
         }
+        float s0[MR], s1[MR];
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
-            const float s0 = wave_sum(a0[m][0] + a0[m][1]);
-            const float s1 = wave_sum(a1[m][0] + a1[m][1]);
-            if (lane == 0 && m < p.M) {
+            s0[m] = wave_sum(a0[m][0] + a0[m][1]);
+            s1[m] = wave_sum(a1[m][0] + a1[m][1]);
+        }
+        if (WPP > 1) {                                          // the four K quarters meet in LDS
+            if (lane == 0) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) { part[wave][0][m] = s0[m]; part[wave][1][m] = s1[m]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                s0[m] = (part[0][0][m] + part[1][0][m]) + (part[2][0][m] + part[3][0][m]);
+                s1[m] = (part[0][1][m] + part[1][1][m]) + (part[2][1][m] + part[3][1][m]);
+            }
+        }
+        if (fin) {
+            if (pp != pbase && !swiglu) {                       // later pairs of this wave: operands were not prefetched
+                if (p.bias) { eb[0] = bf2f(p.bias[r0]); eb[1] = bf2f(p.bias[r1]); }
+                if (p.R) {
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+                        if (m < p.M) {
+                            const unsigned rv = *(const unsigned*)(p.R + (long)m * p.ldr + r0);
+                            er[m][0] = lo2f(rv);
+                            er[m][1] = hi2f(rv);
+                        }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                if (m >= p.M) continue;
                 if (swiglu) {
-                    const float gg = bfround(s0), uu = bfround(s1);
+                    const float gg = bfround(s0[m]), uu = bfround(s1[m]);
                     p.C[(long)m * p.ldc + pp] = f2bf(bfround(silu_f(gg)) * uu);
                 } else {
+                    float o[2] = {s0[m], s1[m]};
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const int n = t ? r1 : r0;
-                        float o = t ? s1 : s0;
-                        if (p.bias) o += bf2f(p.bias[n]);
-                        if (p.epi == EPI_GELU_TANH) o = gelu_tanh_f(bfround(o));
-                        else if (p.epi == EPI_SILU) o = silu_f(bfround(o));
-                        if (p.R) o = bfround(o) + bf2f(p.R[(long)m * p.ldr + n]);
-                        p.C[(long)m * p.ldc + n] = f2bf(o);
+                        if (p.bias) o[t] += eb[t];
+                        if (p.epi == EPI_GELU_TANH) o[t] = gelu_tanh_f(bfround(o[t]));
+                        else if (p.epi == EPI_SILU) o[t] = silu_f(bfround(o[t]));
+                        if (p.R) o[t] = bfround(o[t]) + er[m][t];
                     }
+                    *(unsigned*)(p.C + (long)m * p.ldc + r0) = pack2bf(o[0], o[1]);      // rows r0, r0+1: one aligned dword
                 }
             }
         }
     }
 }
 
+template <int MR, int WPP>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) { gemv_body<MR, WPP>(p); }
+
 #define GEMV_MAX_LDS (144 * 1024)
 
-template <int MR>
+template <int MR, int WPP>
 static int launch_gemv(const GemvParams& p, hipStream_t stream) {
     const size_t smem = (size_t)MR * p.K * sizeof(bf16_t);
     static size_t attr_bytes = 0;   // largest dynamic-LDS size this instantiation has been enabled for
     if (smem > 48 * 1024 && smem > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)gemv_kernel<MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMV_MAX_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemv_kernel<MR, WPP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMV_MAX_LDS) != hipSuccess)
             return bagel_set_error(BAGEL_ERR_LAUNCH, "gemv: cannot enable %zu bytes of LDS", smem);
         attr_bytes = GEMV_MAX_LDS;
     }
-    // Work split: one row pair per wave while that still gives <= 4096 workgroups (~2 full waves of resident groups on
-    // 256 CUs; the hardware dispatcher then balances the tail), more pairs per wave beyond that so the per-workgroup
-    // activation staging stays a small fraction of the L2 traffic.
     const int NP = p.N / 2;
-    int ppw = NP / (4 * 4096);
-    if (ppw < 1) ppw = 1;
     GemvParams q = p;
-    q.ppw = ppw;
-    const int grid = ceil_div(NP, 4 * ppw);
-    hipLaunchKernelGGL((gemv_kernel<MR>), dim3(grid), dim3(256), smem, stream, q);
+    int grid;
+    if (WPP == 1) {
+        // one row pair per wave while that still gives <= ~4096 workgroups (the hardware dispatcher balances the tail),
+        // more pairs per wave beyond that so the per-workgroup activation staging stays a small share of the L2 traffic
+        static int wg_target = 0;
+        if (wg_target == 0) {
+            const char* e = getenv("BAGEL_GEMV_WGS");     // tuning knob; the default is what bench.py measures
+            wg_target = (e && atoi(e) > 0) ? atoi(e) : 4096;
+        }
+        int ppw = NP / (4 * wg_target);
+        if (ppw < 1) ppw = 1;
+        q.ppw = ppw;
+        grid = ceil_div(NP, 4 * ppw);
+    } else {
+        q.ppw = 1;
+        grid = NP;
+    }
+    hipLaunchKernelGGL((gemv_kernel<MR, WPP>), dim3(grid), dim3(256), smem, stream, q);
     return bagel_check_launch("gemv_kernel");
+}
+
+template <int MR>
+static int launch_gemv_any(const GemvParams& p, hipStream_t stream) {
+    // long rows and few of them (down projection: K = 18944, N = 3584): split K over the 4 waves of a workgroup
+    static int split_k = -1;
+    if (split_k < 0) {
+        const char* e = getenv("BAGEL_GEMV_SPLITK");
+        split_k = e ? atoi(e) : 1;
+    }
+    if (split_k && p.K >= 8192 && p.N / 2 <= 8192 && (p.N % 2) == 0) return launch_gemv<MR, 4>(p, stream);
+    return launch_gemv<MR, 1>(p, stream);
 }
 
 extern "C" int bagel_gemv_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* R,
@@ -203,6 +365,7 @@ extern "C" int bagel_gemv_bf16(const void* A, int64_t lda, const void* W, int64_
     BAGEL_REQUIRE(epilogue != EPI_SWIGLU16 || ((N % 32) == 0 && !bias && !R), "gemv: swiglu needs N%%32==0, no bias/residual");
     BAGEL_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)norm_w) & 15) == 0, "gemv: A/W/norm_w must be 16-byte aligned");
     BAGEL_REQUIRE((size_t)K * sizeof(bf16_t) <= GEMV_MAX_LDS, "gemv: K=%d does not fit the LDS staging buffer", K);
+    BAGEL_REQUIRE((ldc % 2) == 0 && (ldr % 2) == 0 && (((uintptr_t)C | (uintptr_t)R) & 3) == 0, "gemv: C/R rows must be 4-byte aligned");
     if (M <= 0) return BAGEL_OK;
     const int n_out = epilogue == EPI_SWIGLU16 ? N / 2 : N;
     (void)n_out;
@@ -219,9 +382,9 @@ extern "C" int bagel_gemv_bf16(const void* A, int64_t lda, const void* W, int64_
         p.norm_w = (const bf16_t*)norm_w; p.eps = eps;
         p.M = mr; p.N = N; p.K = K; p.epi = epilogue; p.ppw = 1;
         int rc;
-        if (mr == 4) rc = launch_gemv<4>(p, stream);
-        else if (mr == 2) rc = launch_gemv<2>(p, stream);
-        else rc = launch_gemv<1>(p, stream);
+        if (mr == 4) rc = launch_gemv_any<4>(p, stream);
+        else if (mr == 2) rc = launch_gemv_any<2>(p, stream);
+        else rc = launch_gemv_any<1>(p, stream);
         if (rc != BAGEL_OK) return rc;
         m0 += mr;
     }
@@ -379,7 +542,7 @@ extern "C" int bagel_decode_qkv_post_bf16(void* qkv, int64_t ld, const void* cos
 // shuffles, waves through LDS.  Output: unnormalised fp32 partials + (max, sum) per (sample, head, split).
 #define DEC_CH 128
 
-template <int DP, int G>
+template <int DP, int G, int CH>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kpool,
                                                           const bf16_t* __restrict__ vpool, long ldp,
                                                           const int* __restrict__ block_table, int bt_stride,
@@ -387,11 +550,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           float* __restrict__ part_ml, int nq, int nsplit, float scale_log2e) {
     constexpr int LPK = DP / 8;          // lanes per key row
     constexpr int NG = 256 / LPK;        // key rows per workgroup pass
-    constexpr int KU = DEC_CH / NG;      // keys of one lane group in the chunk: all of them are loaded before any is used
+    constexpr int KU = CH / NG;          // keys of one lane group in the chunk: all of them are loaded before any is used
     const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int L = kv_len[b] + len_add;
-    const int j0 = split * DEC_CH;
-    const int j1 = (L < j0 + DEC_CH) ? L : j0 + DEC_CH;
+    const int j0 = split * CH;
+    const int j1 = (L < j0 + CH) ? L : j0 + CH;
     if (j0 >= j1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = tid % LPK, grp = tid / LPK;
@@ -505,13 +668,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 template <int DP>
 __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                                   const int* __restrict__ kv_len, int len_add, bf16_t* __restrict__ out,
-                                                                  long ldo, int nq, int nsplit) {
+                                                                  long ldo, int nq, int nsplit, int ch) {
     constexpr int LPD = DP / 4;
     constexpr int NSG = 256 / LPD;
     const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const int d4 = t % LPD, sg = t / LPD;
     const int L = kv_len[b] + len_add;
-    int ns = (L + DEC_CH - 1) / DEC_CH;
+    int ns = (L + ch - 1) / ch;
     if (ns > nsplit) ns = nsplit;
     const long base = ((long)b * nq + h) * nsplit;
     __shared__ float sm_m[NSG], sm_l[NSG];
@@ -549,14 +712,14 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
     }
 }
 
-template <int DP>
+template <int DP, int CH>
 static int launch_attn_decode(int G, dim3 grid, hipStream_t stream, const bf16_t* q, long ldq, const bf16_t* kpool, const bf16_t* vpool,
                               long ldp, const int* bt, int bt_stride, const int* kv_len, int len_add, float* po, float* pml, int nq,
                               int nsplit, float sl2e) {
-#define DEC_CASE(GG)                                                                                                          \
-    case GG:                                                                                                                  \
-        hipLaunchKernelGGL((attn_decode_kernel<DP, GG>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, \
-                           kv_len, len_add, po, pml, nq, nsplit, sl2e);                                                       \
+#define DEC_CASE(GG)                                                                                                              \
+    case GG:                                                                                                                      \
+        hipLaunchKernelGGL((attn_decode_kernel<DP, GG, CH>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, \
+                           kv_len, len_add, po, pml, nq, nsplit, sl2e);                                                           \
         break
     switch (G) {
         DEC_CASE(1); DEC_CASE(2); DEC_CASE(3); DEC_CASE(4); DEC_CASE(5); DEC_CASE(6); DEC_CASE(7); DEC_CASE(8);
@@ -564,6 +727,16 @@ static int launch_attn_decode(int G, dim3 grid, hipStream_t stream, const bf16_t
     }
 #undef DEC_CASE
     return bagel_check_launch("attn_decode_kernel");
+}
+
+// keys per split: 128 (default) or 64 (BAGEL_DEC_CH=64: twice the workgroups, half the serial work per lane group)
+static int decode_chunk() {
+    static int ch = 0;
+    if (ch == 0) {
+        const char* e = getenv("BAGEL_DEC_CH");
+        ch = (e && atoi(e) == 64) ? 64 : DEC_CH;
+    }
+    return ch;
 }
 
 extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
@@ -577,23 +750,27 @@ extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const vo
     BAGEL_REQUIRE((ldq % 8) == 0 && (ld_pool % 8) == 0 && (ldo % 4) == 0 && (((uintptr_t)out) & 7) == 0, "attn_decode: leading dims / out alignment");
     BAGEL_REQUIRE((((uintptr_t)q | (uintptr_t)kpool | (uintptr_t)vpool) & 15) == 0, "attn_decode: 16-byte alignment");
     if (batch <= 0 || max_len <= 0) return BAGEL_OK;
-    const int nsplit = ceil_div(max_len, DEC_CH);
+    const int ch = decode_chunk();
+    const int nsplit = ceil_div(max_len, ch);
     const float sl2e = softmax_scale * 1.4426950408889634f;
     const dim3 grid(nsplit, nkv, batch);
+    const bf16_t *qq = (const bf16_t*)q, *kp = (const bf16_t*)kpool, *vp = (const bf16_t*)vpool;
     int rc;
-    if (head_dim == 128)
-        rc = launch_attn_decode<128>(nq / nkv, grid, stream, (const bf16_t*)q, (long)ldq, (const bf16_t*)kpool, (const bf16_t*)vpool,
-                                     (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
+    if (head_dim == 128 && ch == 128)
+        rc = launch_attn_decode<128, 128>(nq / nkv, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
+    else if (head_dim == 128)
+        rc = launch_attn_decode<128, 64>(nq / nkv, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
+    else if (ch == 128)
+        rc = launch_attn_decode<64, 128>(nq / nkv, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
     else
-        rc = launch_attn_decode<64>(nq / nkv, grid, stream, (const bf16_t*)q, (long)ldq, (const bf16_t*)kpool, (const bf16_t*)vpool,
-                                    (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
+        rc = launch_attn_decode<64, 64>(nq / nkv, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
     if (rc != BAGEL_OK) return rc;
     if (head_dim == 128)
         hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(nq, batch), dim3(256), 0, stream, part_o, part_ml, kv_len, len_add,
-                           (bf16_t*)out, (long)ldo, nq, nsplit);
+                           (bf16_t*)out, (long)ldo, nq, nsplit, ch);
     else
         hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(nq, batch), dim3(256), 0, stream, part_o, part_ml, kv_len, len_add,
-                           (bf16_t*)out, (long)ldo, nq, nsplit);
+                           (bf16_t*)out, (long)ldo, nq, nsplit, ch);
     return bagel_check_launch("attn_decode_combine_kernel");
 }
 

@@ -73,7 +73,9 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
     if residual is not None:
         _req(residual, BF16, "gemm.residual")
     if (variant is None and W1 is None and M1 == 0 and 0 < M0 <= GEMV_MAX_ROWS and a_rows0 is None and c_rows0 is None
-            and N % 2 == 0 and K * 2 <= GEMV_MAX_K_BYTES and A.data_ptr() % 16 == 0 and W0.data_ptr() % 16 == 0):
+            and N % 2 == 0 and K * 2 <= GEMV_MAX_K_BYTES and A.data_ptr() % 16 == 0 and W0.data_ptr() % 16 == 0
+            and C.data_ptr() % 4 == 0 and _ld(C) % 2 == 0
+            and (residual is None or (residual.data_ptr() % 4 == 0 and _ld(residual) % 2 == 0))):
         # a few rows: weight streaming is HBM-bound -> the skinny kernel (decode.hip), not an MFMA tile
         return gemv(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if variant is None:
@@ -108,7 +110,7 @@ def gemv(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w
 
 
 KV_PAGE = 64          # tokens per KV page (BAGEL_KV_PAGE in decode.hip)
-DECODE_CHUNK = 128    # keys per attention split (DEC_CH in decode.hip)
+DECODE_CHUNK = 64     # smallest keys-per-split the library may use (DEC_CH 128, or 64 with BAGEL_DEC_CH=64): sizes the workspace
 
 
 def kv_append_paged(k_new, v_new, kpool, vpool, block_table, kv_len, batch, width):

@@ -33,7 +33,8 @@ def ref_rmsnorm(x, w, eps):
 # skinny GEMM
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(1, 256, 3584), (1, 64, 18944), (2, 130, 256), (3, 96, 512), (4, 72, 1024), (8, 64, 264),
-                                   (5, 34, 8), (1, 512, 64), (2, 48, 18944), (4, 32, 7168)])
+                                   (5, 34, 8), (1, 512, 64), (2, 48, 18944), (4, 32, 7168), (1, 40, 8200), (3, 24, 18952),
+                                   (1, 3584, 18944), (1, 4608, 3584)])
 def test_gemv_bias_residual(M, N, K):
     A, W, b, R = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1), rnd(M, N, seed=4)
     C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
