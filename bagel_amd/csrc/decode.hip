@@ -55,6 +55,23 @@ __device__ __forceinline__ void gemv_fma(float (&a0)[MR][2], float (&a1)[MR][2],
     }
 }
 
+// same, activation chunk already in a register (split-K path: the lane that owns a weight chunk loads its own x chunk)
+template <int MR>
+__device__ __forceinline__ void gemv_fma_reg(float (&a0)[MR][2], float (&a1)[MR][2], const u32x4_t wa, const u32x4_t wb,
+                                             const u32x4_t (&xv)[MR]) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xl = lo2f(xv[m][e]), xh = hi2f(xv[m][e]);
+            a0[m][0] = fmaf(lo2f(wa[e]), xl, a0[m][0]);
+            a0[m][1] = fmaf(hi2f(wa[e]), xh, a0[m][1]);
+            a1[m][0] = fmaf(lo2f(wb[e]), xl, a1[m][0]);
+            a1[m][1] = fmaf(hi2f(wb[e]), xh, a1[m][1]);
+        }
+    }
+}
+
 template <int U>
 __device__ __forceinline__ void gemv_load_batch(u32x4_t (&wa)[U], u32x4_t (&wb)[U], const bf16_t* w0, const bf16_t* w1, int g,
                                                 int lane, int nch) {
@@ -166,7 +183,10 @@ __device__ __forceinline__ void gemv_body(const GemvParams& p) {
         else gemv_load_batch<U>(wa, wb, p.W + (long)r0 * p.ldw, p.W + (long)r1 * p.ldw, g_lo, lane, ch_hi);
     }
 
-    // ---- (3) stage the activation rows in LDS (optionally RMS-normalised)
+    // ---- (3) stage the activation rows in LDS (optionally RMS-normalised).  The split-K path has no staging at all:
+    //      a lane needs exactly the x chunks at its own weight-chunk positions and reads them from L2 next to the weights
+    //      (no norm there: the launcher only picks WPP = 4 for un-normalised inputs)
+    if (WPP == 1) {
     if (p.norm_w) {
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
@@ -228,6 +248,7 @@ __device__ __forceinline__ void gemv_body(const GemvParams& p) {
         }
     }
     __syncthreads();
+    }
 
     // ---- (4) weight-row pairs ----------------------------------------------------------------------------------------
     for (int pp = pbase; pp < pend; ++pp) {
@@ -241,16 +262,43 @@ __device__ __forceinline__ void gemv_body(const GemvParams& p) {
         int g = g_lo;
         for (; g + U <= full_hi; g += U) {                     // whole batches: no predicates
             if (pp != pbase || g != g_lo) gemv_load_full<U>(wa, wb, w0, w1, g, lane);
+            if (WPP == 1) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, (g + u) * 64 + lane, true);
+                for (int u = 0; u < U; ++u) gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, (g + u) * 64 + lane, true);
+            } else {
+                u32x4_t xv[U][MR];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+                        xv[u][m] = *(const u32x4_t*)(p.A + (long)(m < p.M ? m : p.M - 1) * p.lda + ((long)(g + u) * 64 + lane) * 8);
+#pragma unroll
+                for (int u = 0; u < U; ++u) gemv_fma_reg<MR>(a0, a1, wa[u], wb[u], xv[u]);
+            }
         }
         if (g < g_hi) {                                         // ragged tail batch (clamped loads, zeroed activations)
             if (pp != pbase || g != g_lo) gemv_load_batch<U>(wa, wb, w0, w1, g, lane, ch_hi);
+            if (WPP == 1) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int ch = (g + u) * 64 + lane;
-                const bool ok = ch < ch_hi;
-                gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, ok ? ch : 0, ok);
+                for (int u = 0; u < U; ++u) {
+                    const int ch = (g + u) * 64 + lane;
+                    const bool ok = ch < ch_hi;
+                    gemv_fma<MR>(a0, a1, wa[u], wb[u], xs, K, ok ? ch : 0, ok);
+                }
+            } else {
+                u32x4_t xv[U][MR];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ch = (g + u) * 64 + lane;
+                    const bool ok = ch < ch_hi;
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        xv[u][m] = *(const u32x4_t*)(p.A + (long)(m < p.M ? m : p.M - 1) * p.lda + (long)(ok ? ch : 0) * 8);
+                        if (!ok) xv[u][m] = u32x4_t{0u, 0u, 0u, 0u};
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) gemv_fma_reg<MR>(a0, a1, wa[u], wb[u], xv[u]);
             }
         }
         float s0[MR], s1[MR];
@@ -313,7 +361,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) { gemv_body<MR,
 
 template <int MR, int WPP>
 static int launch_gemv(const GemvParams& p, hipStream_t stream) {
-    const size_t smem = (size_t)MR * p.K * sizeof(bf16_t);
+    const size_t smem = WPP == 1 ? (size_t)MR * p.K * sizeof(bf16_t) : 0;     // the split-K path stages nothing
     static size_t attr_bytes = 0;   // largest dynamic-LDS size this instantiation has been enabled for
     if (smem > 48 * 1024 && smem > attr_bytes) {
         if (hipFuncSetAttribute((const void*)gemv_kernel<MR, WPP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMV_MAX_LDS) != hipSuccess)
@@ -351,7 +399,7 @@ static int launch_gemv_any(const GemvParams& p, hipStream_t stream) {
         const char* e = getenv("BAGEL_GEMV_SPLITK");
         split_k = e ? atoi(e) : 1;
     }
-    if (split_k && p.K >= 8192 && p.N / 2 <= 8192 && (p.N % 2) == 0) return launch_gemv<MR, 4>(p, stream);
+    if (split_k && !p.norm_w && p.K >= 8192 && p.N / 2 <= 8192 && (p.N % 2) == 0) return launch_gemv<MR, 4>(p, stream);
     return launch_gemv<MR, 1>(p, stream);
 }
 
@@ -587,37 +635,52 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             qf[g][2 * e + 1] = hi2f(v[e]) * scale_log2e;
         }
     }
+    // two passes over the KU keys held in registers: all scores first, then ONE max per head, so the accumulators are
+    // never rescaled (the online form costs 8 extra multiplies per key and head on a VALU-bound kernel)
+    float sc[KU][G];
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        float kf[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kf[2 * e] = lo2f(kr[i][e]); kf[2 * e + 1] = hi2f(kr[i][e]); }
+        const bool valid = (j0 + grp + i * NG) < j1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0 = fmaf(qf[g][2 * e], kf[2 * e], s0);
+                s1 = fmaf(qf[g][2 * e + 1], kf[2 * e + 1], s1);
+            }
+            float sv = s0 + s1;
+#pragma unroll
+            for (int off = 1; off < LPK; off <<= 1) sv += __shfl_xor(sv, off, 64);
+            sc[i][g] = valid ? sv : -1e30f;
+        }
+    }
     float mx[G], ls[G], o[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        mx[g] = -1e30f;
+        float m = sc[0][g];
+#pragma unroll
+        for (int i = 1; i < KU; ++i) m = fmaxf(m, sc[i][g]);
+        mx[g] = m;                          // -1e30 when this lane group holds no key of the chunk
         ls[g] = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < KU; ++i) {
-        const bool valid = (j0 + grp + i * NG) < j1;
-        float kf[8], vf[8];
+        float vf[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            kf[2 * e] = lo2f(kr[i][e]); kf[2 * e + 1] = hi2f(kr[i][e]);
-            vf[2 * e] = lo2f(vr[i][e]); vf[2 * e + 1] = hi2f(vr[i][e]);
-        }
+        for (int e = 0; e < 4; ++e) { vf[2 * e] = lo2f(vr[i][e]); vf[2 * e + 1] = hi2f(vr[i][e]); }
+        const bool valid = (j0 + grp + i * NG) < j1;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float s = 0.f;
+            const float pw = valid ? exp2f(sc[i][g] - mx[g]) : 0.f;
+            ls[g] += pw;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s = fmaf(qf[g][e], kf[e], s);
-#pragma unroll
-            for (int off = 1; off < LPK; off <<= 1) s += __shfl_xor(s, off, 64);
-            const float mn = valid ? fmaxf(mx[g], s) : mx[g];
-            const float corr = exp2f(mx[g] - mn);
-            const float pw = valid ? exp2f(s - mn) : 0.f;
-            ls[g] = ls[g] * corr + pw;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[g][e] = fmaf(pw, vf[e], o[g][e] * corr);
-            mx[g] = mn;
+            for (int e = 0; e < 8; ++e) o[g][e] = fmaf(pw, vf[e], o[g][e]);
         }
     }
     // merge the lane groups of this wave (group id differs in the lane bits >= log2(LPK))
