@@ -96,8 +96,14 @@ class InterleaveInferencer:
     def decode_image(self, latent, image_shape):
         from PIL import Image
         image = self.vae_model.decode(self.latent_to_chw(latent, image_shape))
-        image = (image * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255
-        return Image.fromarray(image.to(torch.uint8).cpu().numpy())   # truncating cast, as the reference
+        return Image.fromarray(self.image_to_u8(image).cpu().numpy())
+
+    @staticmethod
+    def image_to_u8(image):
+        """(1, 3, H, W) fp32 decoder output -> (H, W, 3) uint8 on the GPU: ((x * 0.5 + 0.5).clamp(0, 1) * 255) with the
+        reference's truncating cast (inferencer.py:182-183), one kernel."""
+        from . import ops
+        return ops.chw_f32_to_u8(image[0].float())
 
     @torch.no_grad()
     def gen_text(self, gen_context, max_length: int = 500, do_sample: bool = True, temperature: float = 1.0):

@@ -216,7 +216,7 @@ class Bagel(nn.Module):
         Hm = max(t.shape[1] for t in tensors)
         Wm = max(t.shape[2] for t in tensors)
         Cm = max(t.shape[0] for t in tensors)
-        padded = torch.zeros(size=(len(tensors), Cm, Hm, Wm))
+        padded = torch.zeros(size=(len(tensors), Cm, Hm, Wm), device=tensors[0].device)   # stays on the GPU when the transform does
         for i, t in enumerate(tensors):
             padded[i, :, : t.shape[1], : t.shape[2]] = t
         generation_input = {

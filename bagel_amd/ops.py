@@ -169,6 +169,52 @@ def decode_advance(next_tok, cur_tok32, tokens_out, pos, kv_len, step, batch, ma
                                      batch, max_steps, _stream()), "bagel_decode_advance")
 
 
+def resample_u8(src, dst, bounds, kk, vertical):
+    """One pass of the 8-bit bicubic resample.  src/dst: (H, W, C) uint8 on the GPU (rows may be strided);
+    bounds int32 [out, 2], kk int32 [out, ksize] on the GPU (host-computed fixed-point taps)."""
+    for t, n in ((src, "src"), (dst, "dst")):
+        _req(t, torch.uint8, "resample_u8." + n)
+        if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+            raise BagelHipError("resample_u8: expected (H, W, C) uint8 with packed pixels")
+    _req(bounds, torch.int32, "resample_u8.bounds"); _req(kk, torch.int32, "resample_u8.kk")
+    C = src.shape[2]
+    if vertical:
+        if dst.shape[1] != src.shape[1] or bounds.shape[0] != dst.shape[0]:
+            raise BagelHipError("resample_u8: vertical pass shape mismatch")
+        n_lines, out_len = src.shape[1] * C, dst.shape[0]
+    else:
+        if dst.shape[0] != src.shape[0] or bounds.shape[0] != dst.shape[1]:
+            raise BagelHipError("resample_u8: horizontal pass shape mismatch")
+        n_lines, out_len = src.shape[0], dst.shape[1]
+    check(lib().bagel_resample_u8(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), n_lines, out_len, C, _ptr(bounds), _ptr(kk),
+                                  kk.shape[1], int(vertical), _stream()), "bagel_resample_u8")
+    return dst
+
+
+def u8_to_chw_f32(src, mean, std):
+    """(H, W, C) uint8 -> (C, H, W) fp32 = ((x / 255) - mean) / std  (ToTensor + Normalize)."""
+    _req(src, torch.uint8, "u8_to_chw_f32.src")
+    H, W, C = src.shape
+    if src.stride(2) != 1 or src.stride(1) != C:
+        raise BagelHipError("u8_to_chw_f32: expected packed (H, W, C) pixels")
+    out = torch.empty((C, H, W), dtype=torch.float32, device=src.device)
+    m = (ctypes.c_float * C)(*[float(x) for x in mean])
+    s = (ctypes.c_float * C)(*[float(x) for x in std])
+    check(lib().bagel_u8_to_chw_f32(_ptr(src), src.stride(0), _ptr(out), H, W, C, ctypes.addressof(m), ctypes.addressof(s), _stream()),
+          "bagel_u8_to_chw_f32")
+    return out
+
+
+def chw_f32_to_u8(src):
+    """(C, H, W) fp32 in [-1, 1] -> (H, W, C) uint8 = trunc(clamp(x * 0.5 + 0.5, 0, 1) * 255)  (decode_image)."""
+    _req(src, torch.float32, "chw_f32_to_u8.src")
+    C, H, W = src.shape
+    out = torch.empty((H, W, C), dtype=torch.uint8, device=src.device)
+    check(lib().bagel_chw_f32_to_u8(_ptr(src), src.stride(0), src.stride(1), _ptr(out), out.stride(0), H, W, C, _stream()),
+          "bagel_chw_f32_to_u8")
+    return out
+
+
 def _ptr_array(tensors, n):
     arr = (ctypes.c_void_p * max(n, 1))()
     for i in range(n):

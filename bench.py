@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="debug only: skip the VAE decode (result flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=1)
+    ap.add_argument("--workload", choices=["t2i", "edit"], default="t2i",
+                    help="t2i = BASELINE configs[2]/[3] (the headline metric); edit = configs[4] image-edit (VAE enc + ViT + 3-forward CFG)")
     ap.add_argument("--no-taylorseer", action="store_true", help="skip the extra enable_taylorseer=True measurement")
     ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
     ap.add_argument("--only-understanding", action="store_true", help="debug only: skip the text->image leg (result flagged invalid)")
@@ -294,8 +296,54 @@ def main():
         if not args.no_vae:
             for lat in latents:
                 img = vae.decode(inf.latent_to_chw(lat, (R, R)))
-                imgs.append(((img * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8))
+                imgs.append(inf.image_to_u8(img))
         return latents, imgs
+
+    # ---- BASELINE configs[4]: image edit = VAE-encode + ViT-encode the source image into the context, prompt on top, then
+    #      the 3-forward sampler (cond + cfg-text + cfg-img, text_channel renorm; app.py:224-228), one request per GPU
+    if args.workload == "edit":
+        B = 1
+        gsrc = torch.Generator().manual_seed(3)
+        src_vae = (torch.rand(3, R, R, generator=gsrc) * 2 - 1).to(dev)        # vae_transform(image) stand-in
+        src_vit = (torch.rand(3, 980, 980, generator=gsrc) * 2 - 1).to(dev)    # vit_transform(image) stand-in
+        enc_noise = torch.randn(1, 16, R // 8, R // 8, generator=torch.Generator().manual_seed(43))
+        ident = lambda t: t  # noqa: E731
+        edit_noise = all_noise[rank * n_img:(rank + 1) * n_img].to(dev)
+
+        class _FixedNoiseVae:      # the reference draws randn_like inside encode; feed a seeded CPU draw
+            def encode(self, x):
+                return vae.encode(x, sample_noise=enc_noise)
+
+        def one_step(taylorseer=False):
+            ctx = dict(kv_lens=[0], ropes=[0], past_key_values=NaiveCache(L))
+            vi, l1, r1 = model.prepare_vae_images(ctx["kv_lens"], ctx["ropes"], [src_vae], ident, ids)
+            cache = model.forward_cache_update_vae(_FixedNoiseVae(), ctx["past_key_values"], **vi)
+            ti, l2, r2 = model.prepare_vit_images(l1, r1, [src_vit], ident, ids)
+            cache = model.forward_cache_update_vit(cache, **ti)
+            import copy
+            cfg_text_cache = copy.deepcopy(cache)
+            pi, l3, r3 = model.prepare_prompts(l2, r2, ["p"], tok, ids)
+            cache = model.forward_cache_update_text(cache, **pi)
+            pi2, l4, r4 = model.prepare_prompts([0], [0], ["p"], tok, ids)
+            cimg_cache = model.forward_cache_update_text(NaiveCache(L), **pi2)
+            li = model.prepare_vae_latent(l3, r3, [(R, R)], ids)
+            li["packed_init_noises"] = edit_noise
+            ct = model.prepare_vae_latent_cfg(l2, r2, [(R, R)])
+            cim = model.prepare_vae_latent_cfg(l4, r4, [(R, R)])
+            kw = {}
+            for tag, c, d in (("cfg_text", cfg_text_cache, ct), ("cfg_img", cimg_cache, cim)):
+                kw.update({f"{tag}_past_key_values": c, f"{tag}_packed_position_ids": d["cfg_packed_position_ids"],
+                           f"{tag}_packed_query_indexes": d["cfg_packed_query_indexes"], f"{tag}_key_values_lens": d["cfg_key_values_lens"],
+                           f"{tag}_packed_key_value_indexes": d["cfg_packed_key_value_indexes"]})
+            latents = model.generate_image(past_key_values=cache, num_timesteps=T, cfg_text_scale=4.0, cfg_img_scale=2.0,
+                                           cfg_interval=[0.0, 1.0], cfg_renorm_min=0.0, cfg_renorm_type="text_channel",
+                                           timestep_shift=3.0, enable_taylorseer=taylorseer, **kw, **li)
+            imgs = []
+            if not args.no_vae:
+                for lat in latents:
+                    imgs.append(inf.image_to_u8(vae.decode(inf.latent_to_chw(lat, (R, R)))))
+            one_step.context_tokens = l3[0]
+            return latents, imgs
 
     def fence():
         torch.cuda.synchronize()
@@ -382,7 +430,10 @@ def main():
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init BAGEL-7B-MoT weights, random prompt ids, seed-42 CPU noise)",
-            "config": {"workload": f"BAGEL-7B-MoT text->image {R}x{R}, {T} timesteps ({T - 1} Euler steps x [cond + CFG-text 4.0]), "
+            "config": {"workload": (f"BAGEL-7B-MoT image edit {R}x{R} (BASELINE configs[4]): VAE-encode + SigLIP(980^2) + {args.prompt_tokens}+2 prompt "
+                                    f"tokens -> {getattr(one_step, 'context_tokens', 0)}-token context, {T} timesteps ({T - 1} Euler steps x [cond + CFG-text 4.0 "
+                                    f"+ CFG-img 2.0]), text_channel renorm, 1 request/GPU, VAE decode included") if args.workload == "edit" else
+                                   f"BAGEL-7B-MoT text->image {R}x{R}, {T} timesteps ({T - 1} Euler steps x [cond + CFG-text 4.0]), "
                                    f"global renorm, timestep_shift 3, prompt {args.prompt_tokens}+2 tokens, {B} samples/GPU, VAE decode included",
                        "global_batch": world * B, "query_tokens_per_sample": n_img + 2, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
@@ -392,6 +443,8 @@ def main():
             "understanding": und,
             "taylorseer": ts,
         }
+        if args.workload == "edit":
+            out["metric"] = "images/sec (image edit 1024^2, 50-step, 3-forward CFG), 7B-MoT"
         if args.layers is not None or args.no_vae or R != 1024 or T != 50:
             out["valid"] = False
             out["note"] = "debug flags reduce the workload: not a benchmark number"

@@ -166,6 +166,22 @@ int bagel_taylor_update_bf16(const void* feature, int64_t ld_feature, void* cons
 int bagel_taylor_eval_bf16(void* const* factors, int32_t n, int32_t x, void* out, int64_t ld_out, int64_t rows,
                            int32_t cols, bagel_stream_t stream);
 
+/* ---- image pre/post-processing (data/transforms.py:15-115, inferencer.py:174-185) ---------------------------- */
+/* One separable pass of Pillow's 8-bit bicubic/antialias resample (what torchvision's resize of a PIL image runs for
+ * data/transforms.py:88).  bounds[o] = (first tap, tap count), kk[o][ksize] = 22-bit fixed-point weights, both computed
+ * by the host as Resample.c's precompute_coeffs/normalize_coeffs_8bpc do.  vertical = 0: n_lines rows, out_len output
+ * pixels x channels per row; vertical = 1: n_lines = bytes per row, out_len = output rows.  Strides in bytes. */
+int bagel_resample_u8(const void* in, int64_t in_stride, void* out, int64_t out_stride, int32_t n_lines,
+                      int32_t out_len, int32_t channels, const int32_t* bounds, const int32_t* kk, int32_t ksize,
+                      int32_t vertical, bagel_stream_t stream);
+/* ToTensor + Normalize (data/transforms.py:109-115): out[c][y][x] = ((in[y][x][c] / 255) - mean[c]) / std[c], fp32.
+ * mean/std are HOST arrays of C floats (passed by value to the kernel). */
+int bagel_u8_to_chw_f32(const void* in, int64_t in_stride, float* out, int32_t H, int32_t W, int32_t C,
+                        const float* mean, const float* stdv, bagel_stream_t stream);
+/* decode_image (inferencer.py:182-183): out[y][x][c] = uint8(trunc(clamp(in[c][y][x] * 0.5 + 0.5, 0, 1) * 255)). */
+int bagel_chw_f32_to_u8(const float* in, int64_t chan_stride, int64_t row_stride, void* out, int64_t out_stride,
+                        int32_t H, int32_t W, int32_t C, bagel_stream_t stream);
+
 /* ---- VAE (fp32, NHWC) ------------------------------------------------------------------------------------- */
 /* Implicit-GEMM convolution / plain GEMM on the exact-fp32 MFMA.  mode 0: out[M,Cout] = in[M,Cin] w[Cout,Cin]^T
  * (1x1 conv, attention products; M = B*Hout*Wout); 1: 3x3 stride 1 pad 1; 2: 3x3 stride 2 with the (0,1,0,1) pad of
