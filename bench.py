@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
     ap.add_argument("--only-understanding", action="store_true", help="debug only: skip the text->image leg (result flagged invalid)")
     ap.add_argument("--und-new-tokens", type=int, default=256)
+    ap.add_argument("--und-batch", type=int, default=1, help="requests decoded together per GPU (reference: 1, bagel.py:996)")
     ap.add_argument("--und-image", type=int, default=980, help="side of the understanding image (980 -> 4900 ViT tokens)")
     return ap.parse_args()
 
@@ -147,13 +148,15 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     tok = FixedTokenizer(prompt_ids)
     ident = lambda t: t  # noqa: E731
 
+    UB = args.und_batch
+
     def prefill():
         cache = NaiveCache(L)
-        gi, lens, ropes = model.prepare_vit_images([0], [0], [image], ident, ids)
+        gi, lens, ropes = model.prepare_vit_images([0] * UB, [0] * UB, [image] * UB, ident, ids)
         cache = model.forward_cache_update_vit(cache, **gi)
         torch.cuda.synchronize()
         t_vit = time.perf_counter()
-        gi, lens, ropes = model.prepare_prompts(lens, ropes, ["p"], tok, ids)
+        gi, lens, ropes = model.prepare_prompts(lens, ropes, ["p"] * UB, tok, ids)
         cache = model.forward_cache_update_text(cache, **gi)
         torch.cuda.synchronize()
         return cache, lens, ropes, t_vit
@@ -186,18 +189,18 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     w_bytes = 2.0 * (L * (2 * H * H + 2 * H * nkv * hd + 3 * H * I) + V * H)
     ctx = lens[0]
     kv_bytes = 2.0 * nkv * hd * 2 * L * (ctx + n / 2.0)          # average context over the decoded span
-    bpt = w_bytes + kv_bytes
-    tps = n / dt
+    bpt = w_bytes + UB * kv_bytes            # one weight pass serves the whole batch; every request reads its own KV
+    tps = UB * n / dt
     return {"metric": "understanding tokens/sec", "value": world * tps, "unit": "tokens/s", "per_gpu_tokens_per_s": tps,
-            "new_tokens": int(toks.shape[0]), "batch_per_gpu": 1, "context_tokens": int(ctx),
+            "new_tokens": int(toks.shape[0]), "batch_per_gpu": UB, "context_tokens": int(ctx),
             "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
-            "decode_ms_per_token": dt / n * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
+            "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
             "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer",
-            "roofline": {"bound": "hbm", "achieved": bpt * tps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bpt * tps / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "gemv_kernel<1> (decode step)",
-                         "algorithmic_bytes_per_token": bpt},
+            "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "gemv_kernel (decode step)",
+                         "algorithmic_bytes_per_step": bpt},
             "workload": f"BAGEL-7B-MoT image understanding: {args.und_image}x{args.und_image} image -> {(args.und_image // 14) ** 2} ViT tokens (+2 markers) + 32+2 "
-                        f"prompt tokens prefill, greedy decode of {n} tokens, bf16, batch 1/GPU"}
+                        f"prompt tokens prefill, greedy decode of {n} tokens, bf16, batch {UB}/GPU"}
 
 
 def pmc_traffic(kernel):
@@ -218,7 +221,7 @@ def understanding_subprocess(args, local):
     env = dict(os.environ)
     env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding", "--no-cpu-baseline",
-           "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image)]
+           "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image), "--und-batch", str(args.und_batch)]
     if args.layers is not None:
         cmd += ["--layers", str(args.layers)]
     try:
@@ -437,7 +440,7 @@ def main():
                                    f"global renorm, timestep_shift 3, prompt {args.prompt_tokens}+2 tokens, {B} samples/GPU, VAE decode included",
                        "global_batch": world * B, "query_tokens_per_sample": n_img + 2, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                         "traffic": pmc_traffic(names.get(dom, str(dom))), "kernel": names.get(dom, str(dom)), "launches": len(records),
+                         "traffic": pmc_traffic(names.get(dom, str(dom))) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None, "kernel": names.get(dom, str(dom)), "launches": len(records),
                          "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},
             "outputs_finite": bool(finite),
             "understanding": und,
