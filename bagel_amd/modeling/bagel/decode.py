@@ -105,6 +105,7 @@ class DecodeSession:
             raise ValueError("key_values_lens is non-zero but the KV cache is empty")
         e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
         self.x = e(B, eng.H)
+        self.h = e(B, eng.H)
         self.qkv = e(B, (nq + 2 * nkv) * dp)
         self.att = e(B, nq * dp)
         self.act = e(B, eng.I)
@@ -137,16 +138,26 @@ class DecodeSession:
         scale = hd ** -0.5
         ops.rope_table_into(self.pos, self.inv_freq, self.cos, self.sin)
         ops.copy_rows(self.table, x, B, eng.H, src_rows=self.cur32)
+        fused = B == 1      # one request: lane-FMA kernel with the RMSNorm fused in; a batch: RMSNorm kernel + skinny MFMA GEMM
+        h = self.h
+
+        def proj(inp, w, out, norm_w=None, **kw):
+            if fused:
+                return ops.gemv(inp, w, out, norm_w=norm_w, eps=eng.eps, **kw)
+            if norm_w is not None:
+                ops.rmsnorm(inp, norm_w, h, eng.eps)
+                inp = h
+            return ops.gemm(inp, w, out, bias0=kw.get("bias"), residual=kw.get("residual"), epilogue=kw.get("epilogue", ops.EPI_NONE), M0=B)
         for li, P in enumerate(eng.layers):
-            ops.gemv(x, P.wqkv[0], qkv, bias=P.bqkv[0], norm_w=P.ln_in[0], eps=eng.eps)
+            proj(x, P.wqkv[0], qkv, norm_w=P.ln_in[0], bias=P.bqkv[0])
             ops.decode_qkv_post(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
                                 pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, nq, nkv, hd, dp, eng.eps, eng.use_norm)
             ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
                                   self.part_ml, att, B, nq, nkv, dp, scale)
-            ops.gemv(att, P.wo[0], x, residual=x)
-            ops.gemv(x, P.wgu[0], act, epilogue=ops.EPI_SWIGLU16, norm_w=P.ln_post[0], eps=eng.eps)
-            ops.gemv(act, P.wd[0], x, residual=x)
-        ops.gemv(x, self.head, self.logits, norm_w=eng.model.norm.weight.data, eps=eng.eps)
+            proj(att, P.wo[0], x, residual=x)
+            proj(x, P.wgu[0], act, norm_w=P.ln_post[0], epilogue=ops.EPI_SWIGLU16)
+            proj(act, P.wd[0], x, residual=x)
+        proj(x, self.head, self.logits, norm_w=eng.model.norm.weight.data)
         ops.argmax_into(self.logits, self.next_tok)
 
     def advance_launch(self):

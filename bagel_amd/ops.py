@@ -72,11 +72,18 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
             _req(r, torch.int32, "gemm.rows")
     if residual is not None:
         _req(residual, BF16, "gemm.residual")
-    if (variant is None and W1 is None and M1 == 0 and 0 < M0 <= GEMV_MAX_ROWS and a_rows0 is None and c_rows0 is None
+    dense1 = variant is None and W1 is None and M1 == 0 and a_rows0 is None and c_rows0 is None
+    if (dense1 and 2 <= M0 <= SKINNY_MAX_ROWS and K % 32 == 0 and N % (32 if epilogue == EPI_SWIGLU16 else 16) == 0
+            and A.data_ptr() % 16 == 0 and W0.data_ptr() % 16 == 0 and C.data_ptr() % 8 == 0 and _ld(C) % 4 == 0
+            and (bias0 is None or bias0.data_ptr() % 8 == 0)
+            and (residual is None or (residual.data_ptr() % 8 == 0 and _ld(residual) % 4 == 0))):
+        # 2..64 rows: still a weight stream, but through the MFMA with no LDS tile (skinny.hip)
+        return gemm_skinny(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
+    if (dense1 and 0 < M0 <= GEMV_MAX_ROWS
             and N % 2 == 0 and K * 2 <= GEMV_MAX_K_BYTES and A.data_ptr() % 16 == 0 and W0.data_ptr() % 16 == 0
             and C.data_ptr() % 4 == 0 and _ld(C) % 2 == 0
             and (residual is None or (residual.data_ptr() % 4 == 0 and _ld(residual) % 2 == 0))):
-        # a few rows: weight streaming is HBM-bound -> the skinny kernel (decode.hip), not an MFMA tile
+        # one row (or a few that the MFMA path cannot take): lane-FMA weight streaming (decode.hip)
         return gemv(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if variant is None:
         variant = default_gemm_variant(M0 + M1, N, K)
@@ -89,6 +96,24 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
 
 GEMV_MAX_ROWS = 8
 GEMV_MAX_K_BYTES = 144 * 1024
+SKINNY_MAX_ROWS = 64
+
+
+def gemm_skinny(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None):
+    """C[M <= 64, N] = A W^T with the epilogues of ``gemm``; every wave streams 16 weight rows from HBM straight into the
+    MFMA (bagel_gemm_skinny_bf16)."""
+    _req(A, BF16, "gemm_skinny.A"); _req(W, BF16, "gemm_skinny.W"); _req(C, BF16, "gemm_skinny.C")
+    N, K = W.shape
+    if A.shape[-1] != K:
+        raise BagelHipError(f"gemm_skinny: A has K={A.shape[-1]}, W has K={K}")
+    if M is None:
+        M = A.shape[0]
+    if residual is not None:
+        _req(residual, BF16, "gemm_skinny.residual")
+    check(lib().bagel_gemm_skinny_bf16(_ptr(A), _ld(A), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
+                                       _ld(residual) if residual is not None else 0, _ptr(C), _ld(C), M, N, K, epilogue, _stream()),
+          "bagel_gemm_skinny_bf16")
+    return C
 
 
 def gemv(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0):

@@ -120,6 +120,14 @@ int bagel_gemv_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
                     int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N,
                     int32_t K, int32_t epilogue, bagel_stream_t stream);
 
+/* Skinny MFMA GEMM for 2..64 rows (batched decode steps, short-prompt prefill): same contract and roundings as
+ * bagel_gemm_bf16 on dense operands, but every wave streams its own 16 weight rows straight from HBM into the MFMA
+ * (no LDS tile), so the whole chip pulls on W even when N/128 would give a few dozen workgroups.
+ * K % 32 == 0, N % 16 == 0 (SwiGLU16: N % 32 == 0); in-place residual (R == C) allowed. */
+int bagel_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* R,
+                           int64_t ldr, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                           bagel_stream_t stream);
+
 /* Paged KV cache (64-token pages; token j of sample b at pool row block_table[b*bt_stride + j/64]*64 + j%64).
  * Appends this step's K/V row of every sample at slot kv_len[b] (device memory) -- the in-place form of the
  * per-layer cache rebuild at qwen2_navit.py:563-575. */

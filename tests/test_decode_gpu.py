@@ -84,6 +84,58 @@ def test_gemv_fused_rmsnorm_matches_two_kernel_path():
     close(C, C2, what="gemv fused rmsnorm vs rmsnorm kernel + MFMA gemm")
 
 
+@pytest.mark.parametrize("M,N,K", [(2, 64, 64), (5, 48, 3584), (16, 3584, 3584), (17, 208, 512), (34, 4608, 3584), (64, 96, 18944),
+                                   (33, 1040, 96), (8, 3584, 18944), (3, 16, 32)])
+def test_gemm_skinny_bias_residual(M, N, K):
+    A, W, b, R = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1), rnd(M, N, seed=4)
+    C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+    ops().gemm_skinny(A.to(DEV), W.to(DEV), C, bias=b.to(DEV))
+    close(C, ref_gemm(A, W, b), what=f"skinny {M}x{N}x{K}")
+    X = R.to(DEV).clone()
+    ops().gemm_skinny(A.to(DEV), W.to(DEV), X, bias=b.to(DEV), residual=X)
+    close(X, ref_gemm(A, W, b, 0, R), ulps=2, what=f"skinny residual {M}x{N}x{K}")
+    # the MFMA tile kernel on the same operands (different summation order only)
+    C2 = torch.empty_like(C)
+    ops().gemm(A.to(DEV), W.to(DEV), C2, bias0=b.to(DEV), variant=0)
+    close(C, C2, what=f"skinny vs 128x128 tile {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("epi", [1, 2])
+def test_gemm_skinny_activations(epi):
+    M, N, K = 20, 144, 320
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+    C = torch.empty((M, N), dtype=BF16, device=DEV)
+    ops().gemm_skinny(A.to(DEV), W.to(DEV), C, bias=b.to(DEV), epilogue=epi)
+    close(C, ref_gemm(A, W, b, epi), ulps=2, what=f"skinny epi{epi}")
+
+
+@pytest.mark.parametrize("M,I,K", [(2, 416, 256), (34, 18944, 3584), (50, 64, 512)])
+def test_gemm_skinny_swiglu(M, I, K):
+    from bagel_amd.modeling.bagel.qwen2_navit import interleave_gate_up
+    A, Wg, Wu = rnd(M, K, seed=1), rnd(I, K, seed=2, scale=K ** -0.5), rnd(I, K, seed=3, scale=K ** -0.5)
+    Wi = interleave_gate_up(Wg, Wu)
+    C = torch.full((M, I), float("nan"), dtype=BF16, device=DEV)
+    ops().gemm_skinny(A.to(DEV), Wi.to(DEV), C, epilogue=3)
+    ref = F.silu((A.float() @ Wg.float().t()).to(BF16)) * (A.float() @ Wu.float().t()).to(BF16)
+    close(C, ref, ulps=2, what="skinny swiglu")
+
+
+def test_gemm_routes_by_row_count():
+    """ops.gemm: 1 row -> lane-FMA gemv, 2..64 rows -> skinny MFMA, index lists / odd shapes -> tile kernels; all agree."""
+    K, N = 512, 96
+    W, b = rnd(N, K, seed=2, scale=K ** -0.5).to(DEV), rnd(N, seed=3, scale=0.1).to(DEV)
+    for M in (1, 2, 9, 64, 65):
+        A = rnd(M, K, seed=10 + M)
+        C = torch.empty((M, N), dtype=BF16, device=DEV)
+        ops().gemm(A.to(DEV), W, C, bias0=b)
+        close(C, ref_gemm(A, W.cpu(), b.cpu()), what=f"gemm routing M={M}")
+    A = rnd(5, 40, seed=1)                       # K % 32 != 0: not the skinny kernel, still correct
+    W2 = rnd(24, 40, seed=2, scale=0.2)
+    C = torch.empty((5, 24), dtype=BF16, device=DEV)
+    ops().gemm(A.to(DEV), W2.to(DEV), C)
+    close(C, ref_gemm(A, W2), what="gemm routing K=40")
+
+
 def test_gemm_routes_few_rows_to_gemv_and_strided_views():
     """ops.gemm with M <= 8 and no index lists takes the skinny kernel; operands may be strided row views."""
     K, N = 512, 96
