@@ -12,6 +12,7 @@
 // row, so the epilogue (same rounding points as gemm.hip) stores 8 bytes.  Few column blocks (N = 3584): the four waves
 // of a workgroup split K and meet in LDS.
 #include "common.h"
+#include <stdlib.h>
 
 #define EPI_NONE 0
 #define EPI_GELU_TANH 1
@@ -25,32 +26,34 @@ struct SkinnyParams {
     const bf16_t* R; long ldr;
     bf16_t* C; long ldc;
     int M, N, K, epi;
-    int split;      // 1: four column blocks per workgroup; 4: one column block, K split over the four waves
+    int split;      // K splits per column block (1, 2, 4 or 8 waves of the workgroup share one block)
 };
 
 template <int MT, bool SWIGLU>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyParams p) {
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
     constexpr int KU = 8;                       // 32-deep steps per batch (8 x 16 B per lane and operand in flight)
     constexpr int NACC = SWIGLU ? 2 : 1;
-    __shared__ f32x4_t part[3][NACC * MT][64];  // split-K partials of waves 1..3
+    extern __shared__ __attribute__((aligned(16))) unsigned char skinny_smem[];
+    f32x4_t (*part)[NACC * MT][64] = (f32x4_t (*)[NACC * MT][64])skinny_smem;     // [wave][acc][lane], only when split > 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int ncb = SWIGLU ? p.N / 32 : p.N / 16;
     const int nk = p.K >> 5;                    // 32-deep steps
-    int cb, k_lo, k_hi;
-    if (p.split == 4) {
-        cb = blockIdx.x;
-        const int per = (nk + 3) >> 2;
-        k_lo = wave * per;
+    // the workgroup's waves = (column blocks per workgroup) x (K splits): wave -> (block, split)
+    const int S = p.split;
+    const int nw = blockDim.x >> 6;
+    const int cb = blockIdx.x * (nw / S) + wave / S;
+    const int ks = wave % S;
+    const bool live = cb < ncb;
+    int k_lo = 0, k_hi = 0;
+    if (live) {
+        const int per = (nk + S - 1) / S;
+        k_lo = ks * per;
         k_hi = (k_lo + per < nk) ? k_lo + per : nk;
         if (k_lo > k_hi) k_lo = k_hi;
-    } else {
-        cb = blockIdx.x * 4 + wave;
-        k_lo = 0;
-        k_hi = nk;
-        if (cb >= ncb) return;                  // no barriers on this path
     }
-    const int wrow = SWIGLU ? cb * 32 : cb * 16;
+    const int cbc = live ? cb : ncb - 1;        // idle waves keep valid addresses (they run zero steps)
+    const int wrow = SWIGLU ? cbc * 32 : cbc * 16;
     const bf16_t* wg = p.W + (long)(wrow + r) * p.ldw + q * 8;           // gate (or the only) weight row of this lane
     const bf16_t* wu = wg + (long)16 * p.ldw;                           // SwiGLU: the matching up row
     const bf16_t* xa[MT];
@@ -88,20 +91,22 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyParams p) {
         }
     }
 
-    if (p.split == 4) {
-        if (wave > 0) {
+    if (S > 1) {                                // the K splits of a column block meet in LDS; split 0 finishes
+        if (ks > 0) {
 #pragma unroll
             for (int a = 0; a < NACC; ++a)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) part[wave - 1][a * MT + mt][lane] = acc[a][mt];
+                for (int mt = 0; mt < MT; ++mt) part[wave][a * MT + mt][lane] = acc[a][mt];
         }
         __syncthreads();
-        if (wave > 0) return;
+        if (ks > 0 || !live) return;
+        for (int o = 1; o < S; ++o)
 #pragma unroll
-        for (int a = 0; a < NACC; ++a)
+            for (int a = 0; a < NACC; ++a)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[a][mt] = (acc[a][mt] + part[0][a * MT + mt][lane]) + (part[1][a * MT + mt][lane] + part[2][a * MT + mt][lane]);
+                for (int mt = 0; mt < MT; ++mt) acc[a][mt] = acc[a][mt] + part[wave + o][a * MT + mt][lane];
+    } else if (!live) {
+        return;
     }
 
     // ---- epilogue: lane owns C[m = mt*16 + r][n .. n+3], n = cb*16 + 4*q (same rounding points as gemm.hip) ----
@@ -147,12 +152,23 @@ template <int MT>
 static int launch_skinny(const SkinnyParams& p, hipStream_t stream) {
     const bool sw = p.epi == EPI_SWIGLU16;
     const int ncb = sw ? p.N / 32 : p.N / 16;
+    const int nk = p.K / 32;
     SkinnyParams q = p;
-    // few column blocks (N = 3584 -> 224): split K over the four waves so ~900 waves stream; many: one block per wave
-    q.split = (ncb < 1024 && p.K >= 512) ? 4 : 1;
-    const int grid = q.split == 4 ? ncb : ceil_div(ncb, 4);
-    if (sw) hipLaunchKernelGGL((gemm_skinny_kernel<MT, true>), dim3(grid), dim3(256), 0, stream, q);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<MT, false>), dim3(grid), dim3(256), 0, stream, q);
+    // enough waves to keep ~8 KB x 3000 of weights in flight: split K over 2/4/8 waves when there are few column blocks
+    // (N = 3584 -> 224 blocks x 8; gate+up -> 1184 x 4; lm_head -> 9504 x 1), never below 4 steps per split
+    static int target = 0;
+    if (target == 0) {
+        const char* e = getenv("BAGEL_SKINNY_WAVES");
+        target = (e && atoi(e) > 0) ? atoi(e) : 3000;
+    }
+    int S = 1;
+    while (S < 8 && ncb * S < target && nk / (2 * S) >= 4) S *= 2;
+    q.split = S;
+    const int nw = S > 4 ? S : 4;                       // waves per workgroup
+    const int grid = ceil_div(ncb, nw / S);
+    const size_t smem = S > 1 ? (size_t)nw * (sw ? 2 : 1) * MT * 64 * sizeof(f32x4_t) : 0;
+    if (sw) hipLaunchKernelGGL((gemm_skinny_kernel<MT, true>), dim3(grid), dim3(64 * nw), smem, stream, q);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<MT, false>), dim3(grid), dim3(64 * nw), smem, stream, q);
     return bagel_check_launch("gemm_skinny_kernel");
 }
 
