@@ -493,6 +493,128 @@ def generate_image(W, cfg, gi, cache, cfg_text=None, cfg_img=None, num_timesteps
 
 
 # ----------------------------------------------------------------------------------------------
+# training forward (Bagel.forward bagel.py:101-229; forward_train chain qwen2_navit.py:406-497,713-755,970-1016)
+# ----------------------------------------------------------------------------------------------
+def attention_mask_per_sample(split_lens, attn_modes):
+    """prepare_attention_mask_per_sample (data/data_utils.py:72-103): additive fp32 mask of ONE sample, 0 = attend,
+    -inf = ignore.  causal split: lower triangle + everything before it; full/noise split: itself + everything before
+    it; a noise split is then hidden from every other split."""
+    n = sum(split_lens)
+    allow = torch.zeros((n, n), dtype=torch.bool)
+    c = 0
+    for s, mode in zip(split_lens, attn_modes):
+        assert mode in ("causal", "full", "noise")
+        allow[c:c + s, c:c + s] = torch.ones((s, s)).tril().bool() if mode == "causal" else True
+        allow[c:c + s, :c] = True
+        c += s
+    c = 0
+    for s, mode in zip(split_lens, attn_modes):
+        if mode == "noise":
+            allow[:, c:c + s] = False
+            allow[c:c + s, c:c + s] = True
+        c += s
+    return torch.zeros((n, n), dtype=torch.float).masked_fill_(~allow, float("-inf"))
+
+
+@_explicit_casts
+def mot_attention_train(W, pre, cfg, x, sample_lens, masks, cos_sin, und_idx, gen_idx):
+    """PackedAttentionMoT.forward_train with nested masks, qwen2_navit.py:406-497 (bf16 cast points for BOTH experts --
+    unlike forward_inference's gen mode there is no fp32 QK-norm here)."""
+    nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    hd = cfg["hidden_size"] // nh
+    eps = cfg["rms_norm_eps"]
+    a = pre + ".self_attn."
+    n = x.shape[0]
+    q, k, v = x.new_zeros((n, nh * hd)), x.new_zeros((n, nkv * hd)), x.new_zeros((n, nkv * hd))
+    xu, xg = x[und_idx], x[gen_idx]
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        t[und_idx] = linear(xu, W[a + f"{name}_proj.weight"], W[a + f"{name}_proj.bias"])
+        t[gen_idx] = linear(xg, W[a + f"{name}_proj_moe_gen.weight"], W[a + f"{name}_proj_moe_gen.bias"])
+    q, k, v = q.view(-1, nh, hd), k.view(-1, nkv, hd), v.view(-1, nkv, hd)
+    q_, k_ = q.new_zeros(q.shape), k.new_zeros(k.shape)
+    q_[und_idx] = rmsnorm(q[und_idx], W[a + "q_norm.weight"], eps)
+    q_[gen_idx] = rmsnorm(q[gen_idx], W[a + "q_norm_moe_gen.weight"], eps)
+    k_[und_idx] = rmsnorm(k[und_idx], W[a + "k_norm.weight"], eps)
+    k_[gen_idx] = rmsnorm(k[gen_idx], W[a + "k_norm_moe_gen.weight"], eps)
+    cos, sin = cos_sin
+    q_, k_ = apply_rope(q_, k_, cos, sin)
+    g = nh // nkv
+    k_ = k_[:, :, None, :].repeat(1, 1, g, 1).reshape(-1, nh, hd)
+    vv = v[:, :, None, :].repeat(1, 1, g, 1).reshape(-1, nh, hd)
+    outs = []
+    for qs, ks, vs, m in zip(q_.transpose(0, 1).split(sample_lens, dim=1), k_.transpose(0, 1).split(sample_lens, dim=1),
+                             vv.transpose(0, 1).split(sample_lens, dim=1), masks):
+        o = F.scaled_dot_product_attention(qs.to(BF16).unsqueeze(0), ks.to(BF16).unsqueeze(0), vs.to(BF16).unsqueeze(0),
+                                           m.to(BF16).unsqueeze(0))
+        outs.append(o.squeeze(0))
+    o = torch.cat(outs, dim=1).transpose(0, 1).reshape(-1, nh * hd)
+    o_ = o.new_zeros(o.shape)
+    o_[und_idx] = linear(o[und_idx], W[a + "o_proj.weight"])
+    o_[gen_idx] = linear(o[gen_idx], W[a + "o_proj_moe_gen.weight"])
+    return o_
+
+
+@_explicit_casts
+def llm_forward_train(W, cfg, x, sample_lens, masks, position_ids, und_idx, gen_idx):
+    """Qwen2Model.forward_train + Qwen2MoTDecoderLayer.forward_train, qwen2_navit.py:970-1016,713-755."""
+    hd = cfg["hidden_size"] // cfg["num_attention_heads"]
+    eps = cfg["rms_norm_eps"]
+    cos_sin = rope_tables(position_ids, hd, cfg["rope_theta"], x.dtype)
+    for i in range(cfg["num_hidden_layers"]):
+        pre = f"language_model.model.layers.{i}"
+        res = x
+        h = x.new_zeros(x.shape)
+        h[und_idx] = rmsnorm(x[und_idx], W[pre + ".input_layernorm.weight"], eps)
+        h[gen_idx] = rmsnorm(x[gen_idx], W[pre + ".input_layernorm_moe_gen.weight"], eps)
+        x = res + mot_attention_train(W, pre, cfg, h, sample_lens, masks, cos_sin, und_idx, gen_idx)
+        res = x
+        h = x.new_zeros(x.shape)
+        h[und_idx] = silu_mlp(rmsnorm(x[und_idx], W[pre + ".post_attention_layernorm.weight"], eps), W, pre + ".mlp")
+        h[gen_idx] = silu_mlp(rmsnorm(x[gen_idx], W[pre + ".post_attention_layernorm_moe_gen.weight"], eps), W, pre + ".mlp_moe_gen")
+        x = res + h
+    y = torch.zeros_like(x)
+    y[und_idx] = rmsnorm(x[und_idx], W["language_model.model.norm.weight"], eps)
+    y[gen_idx] = rmsnorm(x[gen_idx], W["language_model.model.norm_moe_gen.weight"], eps)
+    return y
+
+
+@_explicit_casts
+def bagel_forward_train(W, cfg, batch, noise, timestep_shift=1.0):
+    """Bagel.forward, bagel.py:101-229 (MoT, nested masks).  ``noise`` is the ``torch.randn_like(packed_latent_clean)``
+    draw of :184, passed in so that both sides use the same numbers.  Returns dict(mse fp32 [n_mse, 64], ce fp32 [n_ce])."""
+    H = cfg["llm"]["hidden_size"]
+    b = batch
+    te = embed_tokens(W, b["packed_text_ids"])
+    seq = te.new_zeros((b["sequence_length"], H))
+    seq[b["packed_text_indexes"]] = te
+    und_idx = b["packed_text_indexes"]
+    if b.get("packed_vit_tokens") is not None:
+        cu = F.pad(torch.cumsum(b["vit_token_seqlens"], dim=0), (1, 0)).to(torch.int32)
+        feats = siglip_forward(W, cfg["vit"], b["packed_vit_tokens"], b["packed_vit_position_ids"], cu,
+                               int(b["vit_token_seqlens"].max()))
+        emb = connector(W, feats) + W["vit_pos_embed.pos_embed"][b["packed_vit_position_ids"]]
+        seq[b["packed_vit_token_indexes"]] = emb
+        und_idx = torch.cat([b["packed_text_indexes"], b["packed_vit_token_indexes"]], dim=0)
+    p, C = cfg["bagel"]["latent_patch_size"], cfg["vae"]["z_channels"]
+    clean = torch.cat([patchify_latent(lat, h, w, p, C) for lat, (h, w) in zip(b["padded_latent"], b["patchified_vae_latent_shapes"])], 0)
+    t = torch.sigmoid(b["packed_timesteps"])
+    t = timestep_shift * t / (1 + (timestep_shift - 1) * t)
+    x_t = (1 - t[:, None]) * clean + t[:, None] * noise
+    lat = linear(x_t, W["vae2llm.weight"], W["vae2llm.bias"]) + timestep_embed(t, W) + W["latent_pos_embed.pos_embed"][b["packed_latent_position_ids"]]
+    seq[b["packed_vae_token_indexes"]] = lat
+    out = llm_forward_train(W, cfg["llm"], seq, b["sample_lens"], b["nested_attention_masks"], b["packed_position_ids"],
+                            und_idx, b["packed_vae_token_indexes"])
+    preds = linear(out[b["mse_loss_indexes"]], W["llm2vae.weight"], W["llm2vae.bias"])
+    target = noise - clean
+    mse = (preds - target[t > 0]) ** 2
+    ce = None
+    if b.get("ce_loss_indexes") is not None:
+        logits = linear(out[b["ce_loss_indexes"]], W["language_model.lm_head.weight"])
+        ce = F.cross_entropy(logits.float(), b["packed_label_ids"], reduction="none")
+    return dict(mse=mse, ce=ce)
+
+
+# ----------------------------------------------------------------------------------------------
 # autoregressive text decode (bagel.py:930-1000)
 # ----------------------------------------------------------------------------------------------
 @_explicit_casts

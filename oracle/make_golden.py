@@ -312,6 +312,127 @@ def scenario_edit_und(cfg, model, vae, W, VW):
     return out
 
 
+def scenario_train(cfg, model, vae, W, VW):
+    """Bagel.forward (training forward, bagel.py:101-229) on a hand-packed batch of two samples laid out exactly as
+    data/dataset_base.py:306-476 packs them: an understanding sample [text | ViT image | answer text with CE loss] and a
+    generation sample [prompt | clean VAE image (t = -inf, 'full') | noised VAE image ('noise', MSE loss)].  Nested
+    per-sample masks (the non-flex path; the SDPA backend pin of qwen2_navit.py:468 is a no-op context on CPU)."""
+    import contextlib
+    import modeling.bagel.qwen2_navit as qn
+    from data.data_utils import prepare_attention_mask_per_sample
+    ids = NEW_TOKEN_IDS_TINY
+    g = torch.Generator().manual_seed(21)
+    V = cfg["llm"]["vocab_size"]
+    ps = cfg["vit"]["patch_size"]
+    ds = cfg["vae"]["downsample"] * cfg["bagel"]["latent_patch_size"]
+    text_ids, text_idx, pos, vit_idx, vae_idx, ce_idx, labels, mse_idx, timesteps = [], [], [], [], [], [], [], [], []
+    vit_tokens, vit_pos, vit_lens, lat_pos, lat_shapes, latents = [], [], [], [], [], []
+    sample_lens, masks, all_splits, all_modes = [], [], [], []
+    curr = 0
+
+    def rand_ids(n):
+        return torch.randint(8, V, (n,), generator=g).tolist()
+
+    def text_split(tokens, rope, loss):
+        nonlocal curr
+        shifted = [ids["bos_token_id"]] + tokens
+        text_ids.extend(shifted)
+        text_idx.extend(range(curr, curr + len(shifted)))
+        if loss:
+            ce_idx.extend(range(curr, curr + len(shifted)))
+            labels.extend(tokens + [ids["eos_token_id"]])
+        curr += len(shifted)
+        text_ids.append(ids["eos_token_id"])
+        text_idx.append(curr)
+        curr += 1
+        n = len(shifted) + 1
+        pos.extend(range(rope, rope + n))
+        return n, rope + n
+
+    def vit_split(H, Wd, rope):
+        nonlocal curr
+        img = torch.rand(3, H, Wd, generator=g) * 2 - 1
+        text_ids.append(ids["start_of_image"]); text_idx.append(curr); curr += 1
+        toks = P.patchify(img, ps)
+        vit_idx.extend(range(curr, curr + toks.shape[0])); curr += toks.shape[0]
+        vit_tokens.append(toks); vit_lens.append(toks.shape[0])
+        vit_pos.append(P.position_ids_extrapolate(H, Wd, ps, cfg["bagel"]["vit_max_num_patch_per_side"]))
+        text_ids.append(ids["end_of_image"]); text_idx.append(curr); curr += 1
+        n = toks.shape[0] + 2
+        pos.extend([rope] * n)
+        return n, rope + 1
+
+    def vae_split(H, Wd, rope, loss):
+        nonlocal curr
+        h, w = H // ds, Wd // ds
+        text_ids.append(ids["start_of_image"]); text_idx.append(curr); curr += 1
+        n_img = h * w
+        vae_idx.extend(range(curr, curr + n_img))
+        if loss:
+            mse_idx.extend(range(curr, curr + n_img))
+            t = float(torch.randn(1, generator=g))
+        else:
+            t = float("-inf")
+        timesteps.extend([t] * n_img)
+        curr += n_img
+        lat_pos.append(P.position_ids_extrapolate(H, Wd, ds, cfg["bagel"]["max_latent_size"]))
+        lat_shapes.append((h, w))
+        latents.append(torch.randn(cfg["vae"]["z_channels"], H // cfg["vae"]["downsample"], Wd // cfg["vae"]["downsample"], generator=g))
+        text_ids.append(ids["end_of_image"]); text_idx.append(curr); curr += 1
+        pos.extend([rope] * (n_img + 2))
+        return n_img + 2, (rope if loss else rope + 1)
+
+    # sample A: understanding
+    splits, modes, rope = [], [], 0
+    n, rope = text_split(rand_ids(5), rope, False); splits.append(n); modes.append("causal")
+    n, rope = vit_split(42, 56, rope); splits.append(n); modes.append("full")
+    n, rope = text_split(rand_ids(7), rope, True); splits.append(n); modes.append("causal")
+    sample_lens.append(sum(splits)); masks.append(prepare_attention_mask_per_sample(splits, modes))
+    assert torch.equal(masks[-1], O.attention_mask_per_sample(splits, modes))
+    all_splits += splits; all_modes += modes
+    # sample B: generation (clean reference image + noised target), a second noised target of another size
+    splits, modes, rope = [], [], 0
+    n, rope = text_split(rand_ids(4), rope, False); splits.append(n); modes.append("causal")
+    n, rope = vae_split(64, 48, rope, False); splits.append(n); modes.append("full")
+    n, rope = vae_split(64, 48, rope, True); splits.append(n); modes.append("noise")
+    n, rope = text_split(rand_ids(3), rope, True); splits.append(n); modes.append("causal")
+    n, rope = vae_split(32, 64, rope, True); splits.append(n); modes.append("noise")
+    sample_lens.append(sum(splits)); masks.append(prepare_attention_mask_per_sample(splits, modes))
+    assert torch.equal(masks[-1], O.attention_mask_per_sample(splits, modes))
+    all_splits += splits; all_modes += modes
+
+    Hm = max(l.shape[1] for l in latents); Wm = max(l.shape[2] for l in latents)
+    padded = torch.zeros(len(latents), cfg["vae"]["z_channels"], Hm, Wm)
+    for i, l in enumerate(latents):
+        padded[i, :, :l.shape[1], :l.shape[2]] = l
+    batch = dict(
+        sequence_length=curr, packed_text_ids=torch.tensor(text_ids), packed_text_indexes=torch.tensor(text_idx),
+        sample_lens=sample_lens, packed_position_ids=torch.tensor(pos), nested_attention_masks=masks,
+        ce_loss_indexes=torch.tensor(ce_idx), packed_label_ids=torch.tensor(labels),
+        packed_vit_tokens=torch.cat(vit_tokens, 0), packed_vit_token_indexes=torch.tensor(vit_idx),
+        packed_vit_position_ids=torch.cat(vit_pos, 0), vit_token_seqlens=torch.tensor(vit_lens, dtype=torch.int),
+        padded_latent=padded, patchified_vae_latent_shapes=lat_shapes, packed_latent_position_ids=torch.cat(lat_pos, 0),
+        packed_vae_token_indexes=torch.tensor(vae_idx), packed_timesteps=torch.tensor(timesteps),
+        mse_loss_indexes=torch.tensor(mse_idx))
+    assert curr == sum(sample_lens) == len(pos)
+    qn.sdpa_kernel = lambda *a, **k: contextlib.nullcontext()
+    n_lat = len(vae_idx)
+    model.train()
+    try:
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            torch.manual_seed(47)
+            ref = model(**batch)
+    finally:
+        model.eval()
+    torch.manual_seed(47)
+    noise = torch.randn(n_lat, cfg["bagel"]["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"])
+    mine = O.bagel_forward_train(W, cfg, batch, noise, timestep_shift=cfg["bagel"]["timestep_shift"])
+    same(ref["mse"], mine["mse"], "train mse")
+    same(ref["ce"], mine["ce"], "train ce")
+    assert ref["mse"].shape[0] == len(mse_idx) and ref["ce"].shape[0] == len(ce_idx)
+    return dict(batch=batch, noise=noise, split_lens=all_splits, attn_modes=all_modes, mse=ref["mse"], ce=ref["ce"])
+
+
 def scenario_vae(cfg, model, vae, W, VW):
     g = torch.Generator().manual_seed(11)
     z = torch.randn(1, cfg["vae"]["z_channels"], 16, 24, generator=g)
@@ -355,7 +476,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for cfg in (TINY, TINY_D128):
         model, vae, W, VW = build(cfg)
-        for name, fn in (("t2i", scenario_t2i), ("editund", scenario_edit_und), ("taylorseer", scenario_taylorseer), ("vae", scenario_vae),
+        for name, fn in (("t2i", scenario_t2i), ("editund", scenario_edit_und), ("taylorseer", scenario_taylorseer), ("train", scenario_train), ("vae", scenario_vae),
                          ("siglip", scenario_siglip)):
             if args.only and args.only != name:
                 continue

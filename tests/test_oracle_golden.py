@@ -133,3 +133,20 @@ def test_taylorseer_schedule_known_answer():
     assert "".join(kinds) == "FFFFF" + "TTF" * 14 + "TT"
     assert kinds.count("F") == 19
     assert st.activated_steps[:8] == [0, 0, 1, 2, 3, 4, 7, 10]
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_training_forward_matches_reference(golden, name):
+    """Bagel.forward (bagel.py:101-229) with nested masks: per-token MSE and CE losses bit-exact; the mask rule restated."""
+    cfg = CFGS[name]
+    g = golden(f"{name}_train")
+    W, _ = oracle_weights(cfg)
+    out = O.bagel_forward_train(W, cfg, g["batch"], g["noise"], timestep_shift=cfg["bagel"]["timestep_shift"])
+    assert torch.equal(out["mse"], g["mse"]) and torch.equal(out["ce"], g["ce"])
+    # the masks in the fixture came from the reference's prepare_attention_mask_per_sample
+    i = 0
+    for n, m in zip(g["batch"]["sample_lens"], g["batch"]["nested_attention_masks"]):
+        lens, modes, tot = [], [], 0
+        while tot < n:
+            lens.append(g["split_lens"][i]); modes.append(g["attn_modes"][i]); tot += lens[-1]; i += 1
+        assert torch.equal(O.attention_mask_per_sample(lens, modes), m)
