@@ -35,6 +35,8 @@ struct AttnParams {
     bf16_t* out; long ldo;
     const int* cu_q;
     const int* cu_ctx;
+    const int* q_end;        // optional: explicit end rows (ranges need not tile the buffers; prefixes may overlap)
+    const int* ctx_end;
     const int* vt_new_col;
     const int* vt_ctx_col;
     int nq, nkv, causal;
@@ -88,10 +90,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     const int h = g * grp + w % grp, qt = w / grp;
 
     const int q0 = p.cu_q[b];
-    const int Lq = p.cu_q[b + 1] - q0;
+    const int Lq = (p.q_end ? p.q_end[b] : p.cu_q[b + 1]) - q0;
     if (qt * 256 >= Lq) return;
     const int c0 = p.cu_ctx ? p.cu_ctx[b] : 0;
-    const int C = p.cu_ctx ? p.cu_ctx[b + 1] - c0 : 0;
+    const int C = p.cu_ctx ? (p.ctx_end ? p.ctx_end[b] : p.cu_ctx[b + 1]) - c0 : 0;
     const int vcol_new = p.vt_new_col[b];
     const int vcol_ctx = C > 0 ? p.vt_ctx_col[b] : 0;
 
@@ -281,12 +283,42 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
+static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
+                       int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
+                       int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* cu_q, const int32_t* q_end, const int32_t* cu_ctx,
+                       const int32_t* ctx_end, const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t max_lq,
+                       int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale, hipStream_t stream);
+
 extern "C" int bagel_attn_varlen_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
                                       int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
                                       int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* cu_q, const int32_t* cu_ctx,
                                       const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t max_lq,
                                       int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale,
                                       hipStream_t stream) {
+    return attn_launch(q, ldq, k_new, ldk_new, vt_new, ldvt_new, k_ctx, ldk_ctx, vt_ctx, ldvt_ctx, out, ldo, cu_q, nullptr, cu_ctx,
+                       nullptr, vt_new_col, vt_ctx_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale, stream);
+}
+
+// Same kernel, explicit [start, end) row ranges per sequence: query/new-key rows q_start[b]..q_end[b] need not tile the
+// buffers and the context ranges ctx_start[b]..ctx_end[b] may overlap (prefixes of one stream) -- what the block mask of
+// the training forward decomposes into (data/data_utils.py:72-103; bagel.py:155-166).
+extern "C" int bagel_attn_varlen_ranges_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
+                                             int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
+                                             int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* q_start,
+                                             const int32_t* q_end, const int32_t* ctx_start, const int32_t* ctx_end,
+                                             const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch,
+                                             int32_t max_lq, int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal,
+                                             float softmax_scale, hipStream_t stream) {
+    BAGEL_REQUIRE(q_end && (!ctx_start || ctx_end), "attn_ranges: end arrays missing");
+    return attn_launch(q, ldq, k_new, ldk_new, vt_new, ldvt_new, k_ctx, ldk_ctx, vt_ctx, ldvt_ctx, out, ldo, q_start, q_end, ctx_start,
+                       ctx_end, vt_new_col, vt_ctx_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale, stream);
+}
+
+static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
+                       int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
+                       int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* cu_q, const int32_t* q_end, const int32_t* cu_ctx,
+                       const int32_t* ctx_end, const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t max_lq,
+                       int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale, hipStream_t stream) {
     BAGEL_REQUIRE(q && k_new && vt_new && out && cu_q && vt_new_col, "attn: null pointer");
     BAGEL_REQUIRE(!cu_ctx || (k_ctx && vt_ctx && vt_ctx_col), "attn: context segment incomplete");
     BAGEL_REQUIRE(nq > 0 && nkv > 0 && nq % nkv == 0, "attn: bad head counts %d/%d", nq, nkv);
@@ -301,7 +333,7 @@ extern "C" int bagel_attn_varlen_bf16(const void* q, int64_t ldq, const void* k_
     p.k_ctx = (const bf16_t*)k_ctx; p.ldk_ctx = ldk_ctx;
     p.vt_ctx = (const bf16_t*)vt_ctx; p.ldvt_ctx = ldvt_ctx;
     p.out = (bf16_t*)out; p.ldo = ldo;
-    p.cu_q = cu_q; p.cu_ctx = cu_ctx; p.vt_new_col = vt_new_col; p.vt_ctx_col = vt_ctx_col;
+    p.cu_q = cu_q; p.cu_ctx = cu_ctx; p.q_end = q_end; p.ctx_end = ctx_end; p.vt_new_col = vt_new_col; p.vt_ctx_col = vt_ctx_col;
     p.nq = nq; p.nkv = nkv; p.causal = causal;
     p.batch = batch; p.nqt = ceil_div(max_lq, 256);
     p.scale_log2 = softmax_scale * 1.4426950408889634f;

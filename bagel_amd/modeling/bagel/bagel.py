@@ -536,5 +536,92 @@ class Bagel(nn.Module):
         output = tokenizer.decode(toks[:, 0])
         return output.split("<|im_end|>")[0].split("<|im_start|>")[1]
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("the training forward (bagel.py:101-229) is outside this build's scope (SURVEY.md 8f)")
+    # ------------------------------------------------------------------------------------------------
+    # training forward (losses only; no autograd graph)
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _rows(index_or_mask):
+        t = torch.as_tensor(index_or_mask)
+        return torch.nonzero(t, as_tuple=False).flatten() if t.dtype == torch.bool else t.to(torch.long)
+
+    @torch.no_grad()
+    def forward(self, sequence_length, packed_text_ids, packed_text_indexes, sample_lens, packed_position_ids,
+                nested_attention_masks=None, split_lens=None, attn_modes=None, ce_loss_indexes=None, packed_label_ids=None,
+                packed_vit_tokens=None, packed_vit_token_indexes=None, packed_vit_position_ids=None, vit_token_seqlens=None,
+                padded_latent=None, patchified_vae_latent_shapes=None, packed_latent_position_ids=None,
+                packed_vae_token_indexes=None, packed_timesteps=None, mse_loss_indexes=None, noise=None):
+        """Bagel.forward (bagel.py:101-229): per-token losses ``dict(mse=[n_mse, 64] fp32, ce=[n_ce] fp32)`` of a packed
+        training batch -- the forward half of a training step (no autograd graph).
+
+        Same arguments as the reference plus ``noise`` (the ``randn_like`` draw of :184; drawn on the GPU when omitted).
+        The block mask comes as the per-sample additive masks of the non-flex path (decoded back into splits and checked)
+        or as flat ``split_lens`` + ``attn_modes``; it runs as per-split sequences of the varlen attention kernel."""
+        dev = self.device
+        H = self.hidden_size
+        total = int(sequence_length)
+        if total != int(sum(int(x) for x in sample_lens)):
+            raise NotImplementedError("sequence_length must equal sum(sample_lens) (the packer's pad split is part of the last sample)")
+        seq = torch.zeros((total, H), dtype=BF16, device=dev)
+        text_rows = self._rows(packed_text_indexes)
+        self._embed_into(seq, packed_text_ids, self._dev(text_rows, torch.int32))
+        und_rows = text_rows
+        if self.config.visual_und and packed_vit_tokens is not None:
+            lens = [int(x) for x in torch.as_tensor(vit_token_seqlens).tolist()]
+            cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+            feats = self.vit_model(packed_pixel_values=packed_vit_tokens, packed_flattened_position_ids=packed_vit_position_ids,
+                                   cu_seqlens=cu, max_seqlen=max(lens))
+            c = self.connector
+            n = feats.shape[0]
+            hmid = torch.empty((n, H), dtype=BF16, device=dev)
+            ops.gemm(feats, c.fc1.weight.data, hmid, bias0=c.fc1.bias.data, epilogue=ops.EPI_GELU_TANH)
+            emb = torch.empty_like(hmid)
+            ops.gemm(hmid, c.fc2.weight.data, emb, bias0=c.fc2.bias.data)
+            ops.add_table_rows(emb, self.vit_pos_embed.pos_embed.data, self._dev(packed_vit_position_ids, torch.long))
+            vit_rows = self._rows(packed_vit_token_indexes)
+            ops.copy_rows(emb, seq, n, H, dst_rows=self._dev(vit_rows, torch.int32))
+            und_rows = torch.cat([text_rows, vit_rows], dim=0)
+        gen_rows = None
+        if self.config.visual_gen and padded_latent is not None:
+            p, C = self.latent_patch_size, self.latent_channel
+            pieces = []
+            for latent, (h, w) in zip(padded_latent, patchified_vae_latent_shapes):
+                lat = latent[:, : h * p, : w * p].reshape(C, h, p, w, p)
+                pieces.append(lat.permute(1, 3, 2, 4, 0).reshape(h * w, p * p * C))      # "chpwq->hwpqc" (:180)
+            clean = torch.cat(pieces, dim=0).to(device=dev, dtype=torch.float32).contiguous()
+            if noise is None:
+                noise = torch.randn(clean.shape, dtype=torch.float32, device=dev)
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            # timestep warp on the host (a few floats; the same fp32 ops the reference runs): sigmoid, then the shift
+            t = torch.sigmoid(torch.as_tensor(packed_timesteps, dtype=torch.float32).cpu())
+            t = self.timestep_shift * t / (1 + (self.timestep_shift - 1) * t)
+            t_dev = t.to(dev).contiguous()
+            gen_rows = self._rows(packed_vae_token_indexes)
+            vae_rows = self._dev(gen_rows, torch.int32)
+            x16 = ops.flow_mix(clean, noise, t_dev)                                       # (1 - t) x0 + t eps, cast for vae2llm
+            ops.gemm(x16, self.vae2llm.weight.data, seq, bias0=self.vae2llm.bias.data, c_rows0=vae_rows, M0=x16.shape[0])
+            uniq, inv = torch.unique(t, return_inverse=True)
+            temb = torch.cat([self._timestep_embedding(float(u)) for u in uniq], dim=0)   # one time-MLP pass per distinct t
+            ops.flow_add_rows(seq, vae_rows, temb, inv.to(device=dev, dtype=torch.int32), self.latent_pos_embed.pos_embed.data,
+                              self._dev(packed_latent_position_ids, torch.long))
+        last = self.language_model.forward_train(
+            packed_sequence=seq, sample_lens=sample_lens, attention_mask=nested_attention_masks,
+            packed_position_ids=packed_position_ids, packed_und_token_indexes=und_rows, packed_gen_token_indexes=gen_rows,
+            split_lens=split_lens, attn_modes=attn_modes)
+        mse = None
+        if gen_rows is not None and mse_loss_indexes is not None:
+            mrows = self._rows(mse_loss_indexes)
+            preds = torch.empty((mrows.numel(), self.patch_latent_dim), dtype=BF16, device=dev)
+            ops.gemm(last, self.llm2vae.weight.data, preds, bias0=self.llm2vae.bias.data, a_rows0=self._dev(mrows, torch.int32),
+                     M0=mrows.numel())
+            src = torch.nonzero(t > 0, as_tuple=False).flatten()                         # has_mse (:215)
+            if src.numel() != mrows.numel():
+                raise ValueError("mse_loss_indexes must address exactly the latent tokens with timestep > 0")
+            mse = ops.mse_rows(preds, noise, clean, src.to(device=dev, dtype=torch.int32))
+        ce = None
+        if ce_loss_indexes is not None:
+            crows = self._rows(ce_loss_indexes)
+            head = self.language_model.lm_head.weight.data
+            logits = torch.empty((crows.numel(), head.shape[0]), dtype=BF16, device=dev)
+            ops.gemm(last, head, logits, a_rows0=self._dev(crows, torch.int32), M0=crows.numel())
+            ce = ops.cross_entropy(logits, self._dev(packed_label_ids, torch.long))
+        return dict(mse=mse, ce=ce)

@@ -437,6 +437,115 @@ class ForwardPlan:
 
 
 # ------------------------------------------------------------------------------------------------------------
+# training-forward plan: the causal / full / noise block mask as sequences of the varlen attention kernel
+# ------------------------------------------------------------------------------------------------------------
+def splits_from_mask(mask):
+    """Recover (split_lens, attn_modes) from one sample's additive mask built by prepare_attention_mask_per_sample
+    (data/data_utils.py:72-103).  Adjacent causal splits merge (same mask); the result is verified by rebuilding."""
+    allow = torch.isfinite(mask.detach().float().cpu()) if mask.dtype != torch.bool else mask.cpu()
+    n = allow.shape[0]
+    idx = torch.arange(n)
+    last = torch.where(allow, idx[None, :], torch.full((1, 1), -1)).max(dim=1).values.tolist()
+    lens, modes, r = [], [], 0
+    while r < n:
+        if last[r] > r:                                   # a full / noise block [r, last[r]]
+            e = last[r] + 1
+            hidden = e < n and not bool(allow[e, r])
+            lens.append(e - r); modes.append("noise" if hidden else "full")
+            r = e
+        else:
+            e = r
+            while e < n and last[e] == e and not (e + 1 < n and not bool(allow[e + 1, e])):
+                e += 1
+            if e == r:                                    # a single token hidden from what follows: 1-token noise split
+                lens.append(1); modes.append("noise"); r += 1
+            else:
+                lens.append(e - r); modes.append("causal"); r = e
+    rebuilt = torch.zeros((n, n), dtype=torch.bool)
+    c = 0
+    for L, m in zip(lens, modes):
+        rebuilt[c:c + L, :c] = True
+        rebuilt[c:c + L, c:c + L] = torch.ones((L, L)).tril().bool() if m == "causal" else True
+        c += L
+    c = 0
+    for L, m in zip(lens, modes):
+        if m == "noise":
+            rebuilt[:, c:c + L] = False
+            rebuilt[c:c + L, c:c + L] = True
+        c += L
+    if not torch.equal(rebuilt, allow):
+        raise NotImplementedError("attention mask is not a causal/full/noise split structure (data_utils.py:72-103)")
+    return lens, modes
+
+
+class TrainPlan:
+    """Host digest of (sample_lens, per-sample split structure, und/gen row lists, position ids) for forward_train.
+
+    Every split is one sequence of the attention kernel: its queries/new keys are its own rows, its context is the
+    PREFIX of its sample's non-noise ("clean") key stream -- causal splits run with the bottom-right causal flag, full
+    and noise splits without.  Two launches per layer cover any mask the reference's packer can produce."""
+
+    def __init__(self, device, sample_lens, sample_splits, position_ids, und_indexes, gen_indexes, inv_freq):
+        self.M = int(sum(sample_lens))
+        i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=device)  # noqa: E731
+        q_start, q_end, new_col, clean_rows, cu_clean, clean_col = [], [], [], [], [0], []
+        groups = {True: dict(qs=[], qe=[], cs=[], ce=[], ncol=[], ccol=[]), False: dict(qs=[], qe=[], cs=[], ce=[], ncol=[], ccol=[])}
+        row, col, ccol = 0, 0, 0
+        for n, (lens, modes) in zip(sample_lens, sample_splits):
+            if sum(lens) != n:
+                raise ValueError("split_lens do not add up to sample_lens")
+            clean_start, prefix = cu_clean[-1], 0
+            clean_col.append(ccol)
+            for L, mode in zip(lens, modes):
+                if mode not in ("causal", "full", "noise"):
+                    raise ValueError(f"unknown attn mode {mode}")
+                q_start.append(row); q_end.append(row + L); new_col.append(col)
+                g = groups[mode == "causal"]
+                g["qs"].append(row); g["qe"].append(row + L); g["cs"].append(clean_start); g["ce"].append(clean_start + prefix)
+                g["ncol"].append(col); g["ccol"].append(ccol)
+                if mode != "noise":
+                    clean_rows.extend(range(row, row + L))
+                    prefix += L
+                row += L
+                col += _ceil_to(max(L, 1), 64)
+            cu_clean.append(clean_start + prefix)
+            ccol += _ceil_to(max(prefix, 1), 64)
+        self.n_splits = len(q_start)
+        self.cu_splits = i32(q_start + [row])
+        self.new_col = i32(new_col)
+        self.vt_cols = col
+        self.max_split = max(e - s for s, e in zip(q_start, q_end)) if q_start else 0
+        self.n_clean = len(clean_rows)
+        self.clean_rows = i32(clean_rows) if clean_rows else None
+        self.n_samples = len(sample_lens)
+        self.cu_clean = i32(cu_clean)
+        self.clean_col = i32(clean_col)
+        self.vt_clean_cols = ccol
+        self.max_clean = max((b - a) for a, b in zip(cu_clean[:-1], cu_clean[1:])) if sample_lens else 0
+        self.groups = []
+        for causal in (True, False):
+            g = groups[causal]
+            if g["qs"]:
+                self.groups.append(dict(causal=causal, n=len(g["qs"]), max_lq=max(e - s for s, e in zip(g["qs"], g["qe"])),
+                                        qs=i32(g["qs"]), qe=i32(g["qe"]), cs=i32(g["cs"]), ce=i32(g["ce"]), ncol=i32(g["ncol"]),
+                                        ccol=i32(g["ccol"])))
+        pos = position_ids if torch.is_tensor(position_ids) else torch.tensor(position_ids, dtype=torch.long)
+        self.pos_ids = pos.to(device=device, dtype=torch.long).contiguous()
+        if self.pos_ids.numel() != self.M:
+            raise ValueError("position ids do not cover the packed sequence")
+        self.cos, self.sin = ops.rope_table(self.pos_ids, inv_freq)
+        u, g_ = _tolist(und_indexes), _tolist(gen_indexes)
+        if len(u) + len(g_) != self.M or len(set(u) | set(g_)) != self.M:
+            raise NotImplementedError("und and gen token indexes must partition the packed sequence")
+        self.text_idx, self.vae_idx = i32(u), (i32(g_) if g_ else None)
+        self.n_text, self.n_vae = len(u), len(g_)
+        ex = torch.zeros(self.M, dtype=torch.int32)
+        if g_:
+            ex[torch.tensor(g_, dtype=torch.long)] = 1
+        self.expert = ex.to(device)
+
+
+# ------------------------------------------------------------------------------------------------------------
 # engine: packed weights + workspaces + the layer loop
 # ------------------------------------------------------------------------------------------------------------
 def _pad_heads_rows(w, nheads, hd, dp):
@@ -611,6 +720,64 @@ class MoTEngine:
         return out
 
 
+def _engine_forward_train(self, seq, tp: "TrainPlan"):
+    """Qwen2Model.forward_train (qwen2_navit.py:970-1016) with Qwen2MoTDecoderLayer.forward_train (:713-755) and
+    PackedAttentionMoT.forward_train (:406-497): und rows (text + ViT) on the und expert, gen rows (VAE latents) on the gen
+    expert, bf16 cast points for BOTH experts' QK-norm (no fp32 path here, unlike forward_inference's gen mode), and the
+    block mask executed as per-split sequences (TrainPlan)."""
+    if not self.mot:
+        raise NotImplementedError("forward_train is built for Qwen2MoTDecoderLayer (BAGEL's layer_module)")
+    if seq.shape != (tp.M, self.H):
+        raise ValueError(f"packed sequence shape {tuple(seq.shape)} != ({tp.M}, {self.H})")
+    dev = self.device
+    nq, nkv, dp, hd = self.nq, self.nkv, self.dp, self.hd
+    qw, kw_ = nq * dp, nkv * dp
+    M = tp.M
+    e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
+    x, h, qkv, att, act = e(M, self.H), e(M, self.H), e(M, qw + 2 * kw_), e(M, qw), e(M, self.I)
+    vt = torch.zeros((kw_, _ceil_to(max(tp.vt_cols, 1), 256)), dtype=BF16, device=dev)
+    k_clean = torch.zeros((_ceil_to(tp.n_clean + 64, 64), kw_), dtype=BF16, device=dev)
+    v_clean = torch.zeros_like(k_clean)
+    vt_clean = torch.zeros((kw_, _ceil_to(max(tp.vt_clean_cols, 1), 256)), dtype=BF16, device=dev)
+    x.copy_(seq)
+    q_v, k_v, v_v = qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
+    two = tp.n_vae > 0
+    expert = tp.expert if two else None
+    scale = hd ** -0.5
+
+    def groups(w, b=None):
+        if two:
+            return dict(W0=w[0], bias0=None if b is None else b[0], a_rows0=tp.text_idx, c_rows0=tp.text_idx, M0=tp.n_text,
+                        W1=w[1], bias1=None if b is None else b[1], a_rows1=tp.vae_idx, c_rows1=tp.vae_idx, M1=tp.n_vae)
+        return dict(W0=w[0], bias0=None if b is None else b[0], M0=M)
+
+    for P in self.layers:
+        ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if two else None, expert=expert)
+        ops.gemm(h, C=qkv, **groups(P.wqkv, P.bqkv))
+        ops.qknorm_rope(qkv, tp.cos, tp.sin, P.qn[0] if self.use_norm else None, P.kn[0] if self.use_norm else None,
+                        P.qn[1] if (self.use_norm and two) else None, P.kn[1] if (self.use_norm and two) else None,
+                        expert, nq, nkv, hd, dp, self.eps, gen_mode=False, use_norm=self.use_norm)
+        ops.v_transpose(v_v, vt, tp.cu_splits, tp.new_col, tp.n_splits, tp.max_split, nkv, dp)
+        if tp.n_clean:
+            ops.copy_rows(k_v, k_clean, tp.n_clean, kw_, src_rows=tp.clean_rows)
+            ops.copy_rows(v_v, v_clean, tp.n_clean, kw_, src_rows=tp.clean_rows)
+            ops.v_transpose(v_clean, vt_clean, tp.cu_clean, tp.clean_col, tp.n_samples, tp.max_clean, nkv, dp)
+        for g in tp.groups:
+            ops.attn_varlen_ranges(q_v, k_v, vt, att, g["qs"], g["qe"], g["ncol"], g["n"], g["max_lq"], nq, nkv, dp, g["causal"], scale,
+                                   k_ctx=k_clean, vt_ctx=vt_clean, ctx_start=g["cs"], ctx_end=g["ce"], vt_ctx_col=g["ccol"])
+        ops.gemm(att, C=x, residual=x, **groups(P.wo))
+        ops.rmsnorm(x, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if two else None, expert=expert)
+        ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu))
+        ops.gemm(act, C=x, residual=x, **groups(P.wd))
+    out = torch.empty_like(x)
+    m = self.model
+    ops.rmsnorm(x, m.norm.weight.data, out, self.eps, w1=m.norm_moe_gen.weight.data if two else None, expert=expert)
+    return out
+
+
+MoTEngine.forward_train = _engine_forward_train
+
+
 class Qwen2ForCausalLM(nn.Module):
     """Same constructor, attribute names and ``forward_inference`` signature as qwen2_navit.py:1095-1188."""
 
@@ -682,7 +849,35 @@ class Qwen2ForCausalLM(nn.Module):
         out = eng.forward(seq, plan, mode, past_key_values, update_past_key_values, is_causal, taylor=taylor)
         return BaseNavitOutputWithPast(packed_query_sequence=out, past_key_values=past_key_values)
 
+    @torch.no_grad()
+    def forward_train(self, packed_sequence, sample_lens, attention_mask, packed_position_ids, packed_und_token_indexes=None,
+                      packed_gen_token_indexes=None, split_lens=None, attn_modes=None):
+        """qwen2_navit.py:1124-1143 (forward only: no autograd graph is built).  ``attention_mask``: the list of per-sample
+        additive masks of the non-flex path, or None with flat ``split_lens`` / ``attn_modes`` (the flex path's inputs)."""
+        eng = self.engine()
+        sample_lens = [int(x) for x in sample_lens]
+        if isinstance(attention_mask, (list, tuple)):
+            splits = [splits_from_mask(m) for m in attention_mask]
+        elif split_lens is not None and attn_modes is not None:
+            splits, i = [], 0
+            for n in sample_lens:
+                lens, modes, tot = [], [], 0
+                while tot < n:
+                    lens.append(int(split_lens[i])); modes.append(attn_modes[i]); tot += lens[-1]; i += 1
+                splits.append((lens, modes))
+        else:
+            raise NotImplementedError("pass nested_attention_masks, or split_lens + attn_modes (a flex BlockMask object cannot "
+                                      "be decoded: it hides the split structure it was built from)")
+        if packed_gen_token_indexes is None:
+            packed_gen_token_indexes = []
+        tp = TrainPlan(eng.device, sample_lens, splits, packed_position_ids, packed_und_token_indexes, packed_gen_token_indexes,
+                       self.model.rotary_emb.inv_freq(eng.device))
+        seq = packed_sequence
+        if seq.device != eng.device or seq.dtype != BF16:
+            seq = seq.to(device=eng.device, dtype=BF16)
+        return eng.forward_train(seq, tp)
+
     def forward(self, *args, **kwargs):
         if self.training:
-            raise NotImplementedError("training forward (forward_train) is outside this build's scope (SURVEY.md section 8f)")
+            return self.forward_train(*args, **kwargs)
         return self.forward_inference(*args, **kwargs)

@@ -240,6 +240,62 @@ def chw_f32_to_u8(src):
     return out
 
 
+def attn_varlen_ranges(q, k_new, vt_new, out, q_start, q_end, vt_new_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale,
+                       k_ctx=None, vt_ctx=None, ctx_start=None, ctx_end=None, vt_ctx_col=None):
+    """attn_varlen with explicit [start, end) row ranges per sequence (ranges may skip rows; context ranges may overlap)."""
+    for t, n in ((q, "q"), (k_new, "k_new"), (vt_new, "vt_new"), (out, "out")):
+        _req(t, BF16, "attn_ranges." + n)
+    for t in (q_start, q_end, vt_new_col, ctx_start, ctx_end, vt_ctx_col):
+        if t is not None:
+            _req(t, torch.int32, "attn_ranges.index")
+    check(lib().bagel_attn_varlen_ranges_bf16(
+        _ptr(q), q.stride(0), _ptr(k_new), k_new.stride(0), _ptr(vt_new), vt_new.stride(0),
+        _ptr(k_ctx), k_ctx.stride(0) if k_ctx is not None else 0, _ptr(vt_ctx), vt_ctx.stride(0) if vt_ctx is not None else 0,
+        _ptr(out), out.stride(0), _ptr(q_start), _ptr(q_end), _ptr(ctx_start), _ptr(ctx_end), _ptr(vt_new_col), _ptr(vt_ctx_col),
+        batch, max_lq, nq, nkv, head_dim, int(causal), float(softmax_scale), _stream()), "bagel_attn_varlen_ranges_bf16")
+    return out
+
+
+def flow_mix(clean, noise, t):
+    """bf16((1 - t[row]) * clean + t[row] * noise); clean/noise fp32 [n, cols], t fp32 [n]."""
+    _req(clean, torch.float32, "flow_mix.clean"); _req(noise, torch.float32, "flow_mix.noise"); _req(t, torch.float32, "flow_mix.t")
+    if not (clean.is_contiguous() and noise.is_contiguous() and t.is_contiguous()) or clean.shape != noise.shape or t.numel() != clean.shape[0]:
+        raise BagelHipError("flow_mix: contiguous [n, cols] inputs and t[n] expected")
+    out = torch.empty(clean.shape, dtype=BF16, device=clean.device)
+    check(lib().bagel_flow_mix_bf16(_ptr(clean), _ptr(noise), _ptr(t), _ptr(out), clean.shape[0], clean.shape[1], _stream()),
+          "bagel_flow_mix_bf16")
+    return out
+
+
+def flow_add_rows(seq, rows, temb, temb_ids, pos_table, pos_ids):
+    _req(seq, BF16, "flow_add_rows.seq"); _req(rows, torch.int32, "flow_add_rows.rows"); _req(pos_ids, torch.int64, "flow_add_rows.pos_ids")
+    _req(temb, BF16, "flow_add_rows.temb"); _req(temb_ids, torch.int32, "flow_add_rows.temb_ids"); _req(pos_table, BF16, "flow_add_rows.pos_table")
+    check(lib().bagel_flow_add_rows_bf16(_ptr(seq), seq.stride(0), _ptr(rows), _ptr(temb), temb.stride(0), _ptr(temb_ids), _ptr(pos_table),
+                                         pos_table.stride(0), _ptr(pos_ids), rows.numel(), seq.shape[1], _stream()),
+          "bagel_flow_add_rows_bf16")
+    return seq
+
+
+def mse_rows(pred, noise, clean, src_rows):
+    """(pred - (noise - clean)[src_rows])**2 -> fp32 [n, cols]."""
+    _req(pred, BF16, "mse_rows.pred"); _req(noise, torch.float32, "mse_rows.noise"); _req(clean, torch.float32, "mse_rows.clean")
+    _req(src_rows, torch.int32, "mse_rows.src_rows")
+    n, cols = src_rows.numel(), noise.shape[1]
+    out = torch.empty((n, cols), dtype=torch.float32, device=pred.device)
+    check(lib().bagel_mse_rows_f32(_ptr(pred), pred.stride(0), _ptr(noise), _ptr(clean), _ptr(src_rows), _ptr(out), n, cols, _stream()),
+          "bagel_mse_rows_f32")
+    return out
+
+
+def cross_entropy(logits, labels):
+    """Per-row -log softmax(logits)[label], fp32 math on bf16 logits."""
+    _req(logits, BF16, "cross_entropy.logits"); _req(labels, torch.int64, "cross_entropy.labels")
+    out = torch.empty((logits.shape[0],), dtype=torch.float32, device=logits.device)
+    check(lib().bagel_cross_entropy_bf16(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(out), logits.shape[0], logits.shape[1],
+                                         _stream()), "bagel_cross_entropy_bf16")
+    return out
+
+
 def _ptr_array(tensors, n):
     arr = (ctypes.c_void_p * max(n, 1))()
     for i in range(n):

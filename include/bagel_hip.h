@@ -74,6 +74,18 @@ int bagel_attn_varlen_bf16(const void* q, int64_t ldq, const void* k_new, int64_
                            int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale,
                            bagel_stream_t stream);
 
+/* bagel_attn_varlen_bf16 with explicit [start, end) row ranges per sequence: the ranges need not tile the buffers and
+ * the context ranges may overlap (prefixes of one key stream).  This is how the causal/full/noise block mask of the
+ * training forward (data/data_utils.py:72-103, bagel.py:155-166, SDPA/flex call qwen2_navit.py:452-487) runs on the
+ * same kernel: every split is a sequence whose context is the prefix of its sample's non-noise keys. */
+int bagel_attn_varlen_ranges_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
+                                  int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
+                                  int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* q_start,
+                                  const int32_t* q_end, const int32_t* ctx_start, const int32_t* ctx_end,
+                                  const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch,
+                                  int32_t max_lq, int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal,
+                                  float softmax_scale, bagel_stream_t stream);
+
 /* V[rows][nkv][D] -> V^T[nkv][D][cols] per sample (layout consumed by bagel_attn_varlen_bf16). */
 int bagel_v_transpose_bf16(const void* v, int64_t ld_src, void* vt, int64_t ld_dst, const int32_t* cu_rows,
                            const int32_t* col_start, int32_t batch, int32_t max_len, int32_t nkv, int32_t head_dim,
@@ -173,6 +185,22 @@ int bagel_taylor_update_bf16(const void* feature, int64_t ld_feature, void* cons
 /* taylor_formula (taylorseer.py:32-46): out = sum_{i<n} bf16(bf16(factors[i] / i!) * x^i), bf16 running sum. */
 int bagel_taylor_eval_bf16(void* const* factors, int32_t n, int32_t x, void* out, int64_t ld_out, int64_t rows,
                            int32_t cols, bagel_stream_t stream);
+
+/* ---- training forward glue (Bagel.forward, bagel.py:101-229) ---------------------------------------------------- */
+/* out = bf16((1 - t[row]) * clean + t[row] * noise)  -- the noised latent of bagel.py:187, cast as autocast does at :190. */
+int bagel_flow_mix_bf16(const float* clean, const float* noise, const float* t, void* out, int64_t n_rows,
+                        int32_t cols, bagel_stream_t stream);
+/* bagel_flow_add_bf16 with one timestep-embedding row per latent token group: seq[rows[i]] = bf16(bf16(seq[rows[i]] +
+ * temb[temb_ids[i]]) + pos_table[pos_ids[i]])  (bagel.py:188-191). */
+int bagel_flow_add_rows_bf16(void* seq, int64_t ld, const int32_t* rows, const void* temb, int64_t ld_temb,
+                             const int32_t* temb_ids, const void* pos_table, int64_t ld_pos, const int64_t* pos_ids,
+                             int32_t n, int32_t cols, bagel_stream_t stream);
+/* out[i][c] = (pred[i][c] - (noise[src_rows[i]][c] - clean[src_rows[i]][c]))^2, fp32  (bagel.py:214-217). */
+int bagel_mse_rows_f32(const void* pred, int64_t ld_pred, const float* noise, const float* clean,
+                       const int32_t* src_rows, float* out, int64_t n_rows, int32_t cols, bagel_stream_t stream);
+/* F.cross_entropy(logits.float(), labels, reduction="none") on bf16 logits (bagel.py:222). */
+int bagel_cross_entropy_bf16(const void* logits, int64_t ld, const int64_t* labels, float* out, int32_t rows,
+                             int32_t cols, bagel_stream_t stream);
 
 /* ---- image pre/post-processing (data/transforms.py:15-115, inferencer.py:174-185) ---------------------------- */
 /* One separable pass of Pillow's 8-bit bicubic/antialias resample (what torchvision's resize of a PIL image runs for

@@ -99,3 +99,24 @@ def test_flow_schedule_matches_reference_schedule():
     for T, s in ((5, 3.0), (50, 3.0), (24, 1.0)):
         a, b = Bagel.flow_schedule(T, s), flow_schedule(T, s)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_split_structure_is_recovered_from_the_reference_masks():
+    """qwen2_navit.splits_from_mask: the additive masks of prepare_attention_mask_per_sample (data_utils.py:72-103) decode
+    back to an equivalent (split_lens, attn_modes); anything else is refused."""
+    import pytest
+    import torch
+    from bagel_amd.modeling.bagel.qwen2_navit import splits_from_mask
+    from oracle import bagel_oracle as O
+    cases = [([6, 14, 9], ["causal", "full", "causal"]), ([5, 14, 14, 4, 10], ["causal", "full", "noise", "causal", "noise"]),
+             ([3], ["causal"]), ([4, 1, 2], ["full", "noise", "causal"]), ([2, 3, 3], ["causal", "causal", "full"]),
+             ([7, 7], ["noise", "noise"]), ([1, 1, 1], ["causal", "noise", "full"])]
+    for lens, modes in cases:
+        m = O.attention_mask_per_sample(lens, modes)
+        l2, m2 = splits_from_mask(m)
+        assert sum(l2) == sum(lens)
+        assert torch.equal(O.attention_mask_per_sample(l2, m2), m), (lens, modes, l2, m2)
+    bad = O.attention_mask_per_sample([4, 4], ["causal", "causal"])
+    bad[1, 3] = 0.0                                   # a key from the future inside a causal split
+    with pytest.raises(NotImplementedError):
+        splits_from_mask(bad)
