@@ -590,12 +590,62 @@ extern "C" int bagel_decode_qkv_post_bf16(void* qkv, int64_t ld, const void* cos
 // shuffles, waves through LDS.  Output: unnormalised fp32 partials + (max, sum) per (sample, head, split).
 #define DEC_CH 128
 
-template <int DP, int G, int CH>
+// Optional fusion of the QKV epilogue (decode_qkv_post_kernel) into the attention kernel: `q` then points at the RAW fused
+// projection row [nq*DP | nkv*DP | nkv*DP]; every lane group normalises/rotates the G query heads it needs itself (its DP/8
+// lanes hold exactly one head slice each, so the per-head reduction and the rotate-half partner are group-local), and the
+// lane group that owns key position kv_len[b] builds the new K row from the projection, uses it and stores K and V into the
+// page slot.  One launch fewer per layer; arithmetic identical to decode_qkv_post_kernel (bit-exact, tested).
+struct DecFuse {
+    const bf16_t* cosb; const bf16_t* sinb;     // [B, HD/2]
+    const bf16_t* qw; const bf16_t* kw;         // norm weights (HD) or nullptr
+    bf16_t* kpool; bf16_t* vpool;               // writable views of the pools
+    int nkv, hd, use_norm; float eps;
+};
+
+// one head slice (8 elements at lane position `sub` of a DP-padded head) through q_norm/k_norm + RoPE, und cast points
+template <int LPK>
+__device__ __forceinline__ void dec_post_head(const u32x4_t raw, const bf16_t* __restrict__ w, const float (&cs)[8], const float (&sn)[8],
+                                              int sub, int hd, float eps, int use_norm, float (&out)[8]) {
+    const bool real = sub * 8 < hd;
+    const int hl = hd >> 4;                      // lanes per rotate half (hd/2 elements / 8)
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[2 * e] = lo2f(raw[e]); x[2 * e + 1] = hi2f(raw[e]); }
+    float nrm[8];
+    if (use_norm) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+#pragma unroll
+        for (int o = LPK / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = rsqrtf(ss / (float)hd + eps);
+        u32x4_t wr = {0u, 0u, 0u, 0u};
+        if (real) wr = *(const u32x4_t*)(w + sub * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            nrm[2 * e] = bfround(lo2f(wr[e]) * bfround(x[2 * e] * inv));
+            nrm[2 * e + 1] = bfround(hi2f(wr[e]) * bfround(x[2 * e + 1] * inv));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) nrm[e] = x[e];
+    }
+    const bool upper = sub >= hl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float partner = __shfl_xor(nrm[e], hl, 64);
+        const float rot = upper ? partner : -partner;
+        const float v = bfround(nrm[e] * cs[e]) + bfround(rot * sn[e]);
+        out[e] = real ? bfround(v) : 0.f;
+    }
+}
+
+template <int DP, int G, int CH, bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kpool,
                                                           const bf16_t* __restrict__ vpool, long ldp,
                                                           const int* __restrict__ block_table, int bt_stride,
                                                           const int* __restrict__ kv_len, int len_add, float* __restrict__ part_o,
-                                                          float* __restrict__ part_ml, int nq, int nsplit, float scale_log2e) {
+                                                          float* __restrict__ part_ml, int nq, int nsplit, float scale_log2e, DecFuse fu) {
     constexpr int LPK = DP / 8;          // lanes per key row
     constexpr int NG = 256 / LPK;        // key rows per workgroup pass
     constexpr int KU = CH / NG;          // keys of one lane group in the chunk: all of them are loaded before any is used
@@ -626,13 +676,53 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         vr[i] = *(const u32x4_t*)(vpool + off);
     }
     float qf[G][8];
+    if (!FUSED) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const u32x4_t v = *(const u32x4_t*)(q + (long)b * ldq + (long)(kvh * G + g) * DP + sub * 8);
+        for (int g = 0; g < G; ++g) {
+            const u32x4_t v = *(const u32x4_t*)(q + (long)b * ldq + (long)(kvh * G + g) * DP + sub * 8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            qf[g][2 * e] = lo2f(v[e]) * scale_log2e;
-            qf[g][2 * e + 1] = hi2f(v[e]) * scale_log2e;
+            for (int e = 0; e < 4; ++e) {
+                qf[g][2 * e] = lo2f(v[e]) * scale_log2e;
+                qf[g][2 * e + 1] = hi2f(v[e]) * scale_log2e;
+            }
+        }
+    } else {
+        const int hd = fu.hd, half = hd >> 1;
+        const bool real = sub * 8 < hd;
+        float cs[8], sn[8];
+        {
+            const int c0 = (sub * 8) % half;     // element e of the head uses table column e mod HD/2
+            u32x4_t cv = {0u, 0u, 0u, 0u}, sv = {0u, 0u, 0u, 0u};
+            if (real) {
+                cv = *(const u32x4_t*)(fu.cosb + (long)b * half + c0);
+                sv = *(const u32x4_t*)(fu.sinb + (long)b * half + c0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[2 * e] = lo2f(cv[e]); cs[2 * e + 1] = hi2f(cv[e]); sn[2 * e] = lo2f(sv[e]); sn[2 * e + 1] = hi2f(sv[e]); }
+        }
+        const bf16_t* row = q + (long)b * ldq;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const u32x4_t raw = *(const u32x4_t*)(row + (long)(kvh * G + g) * DP + sub * 8);
+            float qv[8];
+            dec_post_head<LPK>(raw, fu.qw, cs, sn, sub, hd, fu.eps, fu.use_norm, qv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[g][e] = qv[e] * scale_log2e;
+        }
+        // the new key (position L-1 = kv_len[b]): built from the projection row by every group, used/stored by its owner
+        const u32x4_t kraw = *(const u32x4_t*)(row + (long)(nq + kvh) * DP + sub * 8);
+        const u32x4_t vnew = *(const u32x4_t*)(row + (long)(nq + fu.nkv + kvh) * DP + sub * 8);
+        float kv8[8];
+        dec_post_head<LPK>(kraw, fu.kw, cs, sn, sub, hd, fu.eps, fu.use_norm, kv8);
+        const u32x4_t knew = {pack2bf(kv8[0], kv8[1]), pack2bf(kv8[2], kv8[3]), pack2bf(kv8[4], kv8[5]), pack2bf(kv8[6], kv8[7])};
+        const int jn = L - 1;
+#pragma unroll
+        for (int i = 0; i < KU; ++i)
+            if (j0 + grp + i * NG == jn) { kr[i] = knew; vr[i] = vnew; }
+        if (jn >= j0 && jn < j1 && grp == (jn - j0) % NG) {
+            const long off = ((long)bt[jn / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jn % BAGEL_KV_PAGE)) * ldp + (long)kvh * DP + sub * 8;
+            *(u32x4_t*)(fu.kpool + off) = knew;
+            *(u32x4_t*)(fu.vpool + off) = vnew;
         }
     }
     // two passes over the KU keys held in registers: all scores first, then ONE max per head, so the accumulators are
@@ -671,10 +761,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
 #pragma unroll
     for (int i = 0; i < KU; ++i) {
-        float vf[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { vf[2 * e] = lo2f(vr[i][e]); vf[2 * e + 1] = hi2f(vr[i][e]); }
         const bool valid = (j0 + grp + i * NG) < j1;
+        float vf[8];       // a key past the range contributes exactly nothing, whatever its (clamped, possibly never-written) slot holds
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[2 * e] = valid ? lo2f(vr[i][e]) : 0.f; vf[2 * e + 1] = valid ? hi2f(vr[i][e]) : 0.f; }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float pw = valid ? exp2f(sc[i][g] - mx[g]) : 0.f;
@@ -775,14 +865,14 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
     }
 }
 
-template <int DP, int CH>
+template <int DP, int CH, bool FUSED>
 static int launch_attn_decode(int G, dim3 grid, hipStream_t stream, const bf16_t* q, long ldq, const bf16_t* kpool, const bf16_t* vpool,
                               long ldp, const int* bt, int bt_stride, const int* kv_len, int len_add, float* po, float* pml, int nq,
-                              int nsplit, float sl2e) {
-#define DEC_CASE(GG)                                                                                                              \
-    case GG:                                                                                                                      \
-        hipLaunchKernelGGL((attn_decode_kernel<DP, GG, CH>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, \
-                           kv_len, len_add, po, pml, nq, nsplit, sl2e);                                                           \
+                              int nsplit, float sl2e, DecFuse fu) {
+#define DEC_CASE(GG)                                                                                                                   \
+    case GG:                                                                                                                           \
+        hipLaunchKernelGGL((attn_decode_kernel<DP, GG, CH, FUSED>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, \
+                           kv_len, len_add, po, pml, nq, nsplit, sl2e, fu);                                                            \
         break
     switch (G) {
         DEC_CASE(1); DEC_CASE(2); DEC_CASE(3); DEC_CASE(4); DEC_CASE(5); DEC_CASE(6); DEC_CASE(7); DEC_CASE(8);
@@ -802,11 +892,10 @@ static int decode_chunk() {
     return ch;
 }
 
-extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
-                                            const int32_t* block_table, int32_t bt_stride, const int32_t* kv_len,
-                                            int32_t len_add, int32_t max_len, float* part_o, float* part_ml, void* out,
-                                            int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
-                                            float softmax_scale, hipStream_t stream) {
+static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
+                              const int32_t* block_table, int32_t bt_stride, const int32_t* kv_len, int32_t len_add, int32_t max_len,
+                              float* part_o, float* part_ml, void* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nkv,
+                              int32_t head_dim, float softmax_scale, const DecFuse* fuse, hipStream_t stream) {
     BAGEL_REQUIRE(q && kpool && vpool && block_table && kv_len && part_o && part_ml && out, "attn_decode: null pointer");
     BAGEL_REQUIRE(head_dim == 64 || head_dim == 128, "attn_decode: head_dim %d not in {64,128} (pad the projection)", head_dim);
     BAGEL_REQUIRE(nkv > 0 && nq % nkv == 0, "attn_decode: nq must be a multiple of nkv");
@@ -818,15 +907,20 @@ extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const vo
     const float sl2e = softmax_scale * 1.4426950408889634f;
     const dim3 grid(nsplit, nkv, batch);
     const bf16_t *qq = (const bf16_t*)q, *kp = (const bf16_t*)kpool, *vp = (const bf16_t*)vpool;
+    DecFuse fu = {};
+    if (fuse) fu = *fuse;
+    const int G = nq / nkv;
     int rc;
-    if (head_dim == 128 && ch == 128)
-        rc = launch_attn_decode<128, 128>(nq / nkv, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
-    else if (head_dim == 128)
-        rc = launch_attn_decode<128, 64>(nq / nkv, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
-    else if (ch == 128)
-        rc = launch_attn_decode<64, 128>(nq / nkv, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
-    else
-        rc = launch_attn_decode<64, 64>(nq / nkv, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, len_add, part_o, part_ml, nq, nsplit, sl2e);
+#define DEC_GO(DPV, CHV)                                                                                                           \
+    rc = fuse ? launch_attn_decode<DPV, CHV, true>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
+                                                   len_add, part_o, part_ml, nq, nsplit, sl2e, fu)                                  \
+              : launch_attn_decode<DPV, CHV, false>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
+                                                    len_add, part_o, part_ml, nq, nsplit, sl2e, fu)
+    if (head_dim == 128 && ch == 128) { DEC_GO(128, 128); }
+    else if (head_dim == 128) { DEC_GO(128, 64); }
+    else if (ch == 128) { DEC_GO(64, 128); }
+    else { DEC_GO(64, 64); }
+#undef DEC_GO
     if (rc != BAGEL_OK) return rc;
     if (head_dim == 128)
         hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(nq, batch), dim3(256), 0, stream, part_o, part_ml, kv_len, len_add,
@@ -835,6 +929,36 @@ extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const vo
         hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(nq, batch), dim3(256), 0, stream, part_o, part_ml, kv_len, len_add,
                            (bf16_t*)out, (long)ldo, nq, nsplit, ch);
     return bagel_check_launch("attn_decode_combine_kernel");
+}
+
+extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
+                                            const int32_t* block_table, int32_t bt_stride, const int32_t* kv_len,
+                                            int32_t len_add, int32_t max_len, float* part_o, float* part_ml, void* out,
+                                            int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
+                                            float softmax_scale, hipStream_t stream) {
+    return attn_decode_common(q, ldq, kpool, vpool, ld_pool, block_table, bt_stride, kv_len, len_add, max_len, part_o, part_ml, out, ldo,
+                              batch, nq, nkv, head_dim, softmax_scale, nullptr, stream);
+}
+
+// decode_qkv_post + attn_decode_paged in one launch (+ the combine): qkv = RAW fused projection rows; the new K/V row of every
+// sample goes to page slot kv_len[b] and takes part in the attention (keys [0, kv_len[b]]).
+extern "C" int bagel_attn_decode_fused_bf16(const void* qkv, int64_t ld, const void* cos_tab, const void* sin_tab, const void* q_w,
+                                            const void* k_w, void* kpool, void* vpool, int64_t ld_pool, const int32_t* block_table,
+                                            int32_t bt_stride, const int32_t* kv_len, int32_t max_len, float* part_o, float* part_ml,
+                                            void* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
+                                            int32_t head_dim_padded, float eps, int32_t use_norm, float softmax_scale,
+                                            hipStream_t stream) {
+    BAGEL_REQUIRE(cos_tab && sin_tab, "attn_decode_fused: null rope tables");
+    BAGEL_REQUIRE(!use_norm || (q_w && k_w), "attn_decode_fused: norm weights missing");
+    BAGEL_REQUIRE((head_dim == 32 || head_dim == 64 || head_dim == 128) && head_dim <= head_dim_padded, "attn_decode_fused: head_dim %d / padded %d",
+                  head_dim, head_dim_padded);
+    BAGEL_REQUIRE((((uintptr_t)cos_tab | (uintptr_t)sin_tab | (uintptr_t)q_w | (uintptr_t)k_w) & 15) == 0 && (head_dim / 2) % 8 == 0,
+                  "attn_decode_fused: rope tables / norm weights must be 16-byte aligned, head_dim/2 a multiple of 8");
+    DecFuse fu;
+    fu.cosb = (const bf16_t*)cos_tab; fu.sinb = (const bf16_t*)sin_tab; fu.qw = (const bf16_t*)q_w; fu.kw = (const bf16_t*)k_w;
+    fu.kpool = (bf16_t*)kpool; fu.vpool = (bf16_t*)vpool; fu.nkv = nkv; fu.hd = head_dim; fu.use_norm = use_norm; fu.eps = eps;
+    return attn_decode_common(qkv, ld, kpool, vpool, ld_pool, block_table, bt_stride, kv_len, 1, max_len, part_o, part_ml, out, ldo, batch,
+                              nq, nkv, head_dim_padded, softmax_scale, &fu, stream);
 }
 
 // Token bookkeeping of one decode step on the device (bagel.py:984-994): the chosen token becomes the next input,

@@ -121,6 +121,9 @@ class DecodeSession:
         self.next_tok = torch.zeros((B,), dtype=torch.long, device=dev)
         self.step_ctr = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.inv_freq = eng.model.rotary_emb.inv_freq(dev)
+        import os
+        # q/k norm + RoPE + page append inside the attention workgroups (one launch fewer per layer); needs head_dim/2 % 8 == 0
+        self.fused_attention = os.environ.get("BAGEL_DECODE_FUSED", "1") != "0" and (eng.hd // 2) % 8 == 0
         self.steps_done = 0
         self.graph = None
         self.graph_error = None
@@ -150,10 +153,15 @@ class DecodeSession:
             return ops.gemm(inp, w, out, bias0=kw.get("bias"), residual=kw.get("residual"), epilogue=kw.get("epilogue", ops.EPI_NONE), M0=B)
         for li, P in enumerate(eng.layers):
             proj(x, P.wqkv[0], qkv, norm_w=P.ln_in[0], bias=P.bqkv[0])
-            ops.decode_qkv_post(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
-                                pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, nq, nkv, hd, dp, eng.eps, eng.use_norm)
-            ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
-                                  self.part_ml, att, B, nq, nkv, dp, scale)
+            if self.fused_attention:
+                ops.attn_decode_fused(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
+                                      pg.k[li], pg.v[li], pg.block_table, pg.kv_len, self.max_len, self.part_o, self.part_ml, att, B,
+                                      nq, nkv, hd, dp, eng.eps, eng.use_norm, scale)
+            else:
+                ops.decode_qkv_post(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
+                                    pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, nq, nkv, hd, dp, eng.eps, eng.use_norm)
+                ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
+                                      self.part_ml, att, B, nq, nkv, dp, scale)
             proj(att, P.wo[0], x, residual=x)
             proj(x, P.wgu[0], act, norm_w=P.ln_post[0], epilogue=ops.EPI_SWIGLU16)
             proj(act, P.wd[0], x, residual=x)

@@ -646,7 +646,7 @@ class MoTEngine:
         return ForwardPlan(self.device, query_lens, position_ids, inv_freq=self.model.rotary_emb.inv_freq(self.device), **kw)
 
     def forward(self, seq, plan: ForwardPlan, mode="und", cache: NaiveCache = None, update=True, causal=True,
-                num_layers=None, taylor=None):
+                num_layers=None, taylor=None, final_norm=True):
         """Qwen2Model.forward_inference (qwen2_navit.py:1018-1092).  ``seq`` is not modified.
         ``taylor``: a TaylorSeerState (cache_utils/taylorseer.py) -> the TaylorSeer hooks of :1034-1037,1057-1061,
         1086-1087 are active: a 'full' step runs the layers and refreshes the feature cache, a 'Taylor' step replaces
@@ -711,6 +711,8 @@ class MoTEngine:
             if not skip_layers:
                 taylor.update(x)
             taylor.advance()
+        if not final_norm:
+            return x.clone()          # the raw residual stream after the last executed layer (full-size parity probes)
         out = torch.empty_like(x)
         m = self.model
         if gen and self.mot or (gen and self.kind == "Qwen2MoEDecoderLayer"):

@@ -186,6 +186,23 @@ def attn_decode_paged(q, kpool, vpool, block_table, kv_len, len_add, max_len, pa
     return out
 
 
+def attn_decode_fused(qkv, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len, max_len, part_o, part_ml, out, batch, nq, nkv,
+                      head_dim, head_dim_padded, eps, use_norm, softmax_scale):
+    """decode_qkv_post + attn_decode_paged in one launch (+ combine); qkv = raw fused projection rows."""
+    _req(qkv, BF16, "attn_decode_fused.qkv"); _req(out, BF16, "attn_decode_fused.out")
+    _req(kpool, BF16, "attn_decode_fused.kpool"); _req(vpool, BF16, "attn_decode_fused.vpool")
+    _req(block_table, torch.int32, "attn_decode_fused.block_table"); _req(kv_len, torch.int32, "attn_decode_fused.kv_len")
+    ns = (max_len + DECODE_CHUNK - 1) // DECODE_CHUNK
+    if part_o.numel() < batch * nq * ns * head_dim_padded or part_ml.numel() < batch * nq * ns * 2:
+        raise BagelHipError("attn_decode_fused: workspace too small for max_len")
+    check(lib().bagel_attn_decode_fused_bf16(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(q_w), _ptr(k_w), _ptr(kpool), _ptr(vpool),
+                                             kpool.stride(0), _ptr(block_table), block_table.stride(0), _ptr(kv_len), max_len,
+                                             _ptr(part_o), _ptr(part_ml), _ptr(out), out.stride(0), batch, nq, nkv, head_dim,
+                                             head_dim_padded, float(eps), int(use_norm), float(softmax_scale), _stream()),
+          "bagel_attn_decode_fused_bf16")
+    return out
+
+
 def decode_advance(next_tok, cur_tok32, tokens_out, pos, kv_len, step, batch, max_steps):
     _req(next_tok, torch.int64, "decode_advance.next_tok"); _req(cur_tok32, torch.int32, "decode_advance.cur_tok32")
     _req(tokens_out, torch.int64, "decode_advance.tokens_out"); _req(pos, torch.int64, "decode_advance.pos")

@@ -111,6 +111,7 @@ def cpu_baseline(args, cfg):
     n_img = (args.resolution // 16) ** 2
     Lq, C = n_img + 2, args.prompt_tokens + 2
     x = torch.randn(Lq, H, generator=g).to(torch.bfloat16)
+    x0 = x.clone()
     cache = O.OracleCache(nl)
     for li in range(nl):
         cache.key_cache[li] = torch.randn(C, nkv, hd, generator=g).to(torch.bfloat16)
@@ -126,7 +127,30 @@ def cpu_baseline(args, cfg):
     dt = (time.time() - t0) / nl
     steps = args.num_timesteps - 1
     sec_per_image = steps * 2 * llm["num_hidden_layers"] * dt
-    return dict(value=1.0 / sec_per_image, unit="images/s", cores=os.cpu_count(), kind="port",
+    # full-size parity: the same layer(s), same weights and inputs, through the HIP engine (checker use of the oracle)
+    parity = None
+    try:
+        from bagel_amd.factory import build_bagel
+        from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+        dev = torch.device("cuda", torch.cuda.current_device())
+        m1, _ = build_bagel(cfg, device=dev, num_layers=nl, with_vae=False)
+        m1.load_state_dict({k: v for k, v in W.items()}, strict=False)
+        eng = m1.language_model.engine()
+        c1 = NaiveCache(nl)
+        for li in range(nl):
+            c1.store(li, cache.key_cache[li].reshape(C, nkv * hd).to(dev), cache.value_cache[li].reshape(C, nkv * hd).to(dev), [C], [0],
+                     nkv, hd, eng.dp)
+        plan = eng.plan([Lq], torch.full((Lq,), C, dtype=torch.long), packed_query_indexes=q_idx, key_values_lens=[C],
+                        packed_key_value_indexes=kv_idx, text_indexes=text_idx, vae_indexes=vae_idx)
+        y = eng.forward(x0.to(dev), plan, "gen", c1, update=False, causal=False, num_layers=nl, final_norm=False)
+        torch.cuda.synchronize()
+        yc, xr = y.float().cpu(), x.float()
+        parity = {"what": f"residual stream after {nl} MoT layer(s), {Lq} tokens, 7B shapes: HIP engine vs oracle on identical weights/inputs",
+                  "rel_l2": float((yc - xr).norm() / xr.norm()), "max_abs": float((yc - xr).abs().max()), "ref_max_abs": float(xr.abs().max())}
+        del m1, eng, c1
+    except Exception as e:
+        parity = {"error": repr(e)}
+    return dict(value=1.0 / sec_per_image, unit="images/s", cores=os.cpu_count(), kind="port", parity_at_full_size=parity,
                 sample=f"oracle MoT decoder layer (gen mode, {Lq} query tokens on a {C}-token context, 7B shapes) x{nl}, "
                        f"{dt:.2f} s/layer-forward on {os.cpu_count()} threads; extrapolated x{llm['num_hidden_layers']} layers "
                        f"x2 forwards x{steps} Euler steps (glue, prefill and VAE excluded)")

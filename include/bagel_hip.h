@@ -165,6 +165,16 @@ int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const void* kpool, 
                                  int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
                                  float softmax_scale, bagel_stream_t stream);
 
+/* bagel_decode_qkv_post_bf16 + bagel_attn_decode_paged_bf16 in one launch (plus the combine): qkv = the RAW fused projection
+ * rows; q/k norm + RoPE happen inside the attention workgroups, the new K/V row goes to page slot kv_len[b] and is attended
+ * to (keys [0, kv_len[b]]).  Bit-identical to the two-kernel form. */
+int bagel_attn_decode_fused_bf16(const void* qkv, int64_t ld, const void* cos_tab, const void* sin_tab, const void* q_w,
+                                 const void* k_w, void* kpool, void* vpool, int64_t ld_pool, const int32_t* block_table,
+                                 int32_t bt_stride, const int32_t* kv_len, int32_t max_len, float* part_o, float* part_ml,
+                                 void* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
+                                 int32_t head_dim_padded, float eps, int32_t use_norm, float softmax_scale,
+                                 bagel_stream_t stream);
+
 /* Device-side bookkeeping of one decode step (bagel.py:984-994): cur_tok32 <- next_tok, tokens_out[step+1] <- next_tok,
  * pos += 1, kv_len += 1, step += 1.  Keeps the host out of the token loop so one captured step can be replayed. */
 int bagel_decode_advance(const int64_t* next_tok, int32_t* cur_tok32, int64_t* tokens_out, int64_t* pos,

@@ -256,6 +256,57 @@ def test_decode_qkv_post_equals_qknorm_rope_plus_append(hd, dp, nq, nkv, use_nor
     assert torch.isnan(pg2.k[0][untouched.to(DEV)].float()).all(), "only the slot kv_len[b] may be written"
 
 
+@pytest.mark.parametrize("hd,dp,nq,nkv,use_norm", [(128, 128, 28, 4, True), (32, 64, 4, 2, True), (64, 64, 3, 1, True), (128, 128, 8, 8, False)])
+def test_fused_decode_attention_equals_post_plus_attention(hd, dp, nq, nkv, use_norm):
+    """bagel_attn_decode_fused_bf16 == decode_qkv_post + attn_decode_paged, bit for bit: attention output and page rows,
+    with never-written (NaN) page slots around the live range."""
+    from bagel_amd.modeling.bagel.decode import PagedKVCache
+    o = ops()
+    lens = [3, 129, 500]
+    B, width = len(lens), nkv * dp
+    qkv = torch.zeros((B, nq + 2 * nkv, dp), dtype=BF16)
+    qkv[:, :, :hd] = rnd(B, nq + 2 * nkv, hd, seed=1)
+    qkv = qkv.view(B, -1).to(DEV)
+    qw, kw = (1.0 + 0.1 * rnd(hd, seed=2).float()).to(BF16).to(DEV), (1.0 + 0.1 * rnd(hd, seed=3).float()).to(BF16).to(DEV)
+    pos = torch.tensor([5, 77, 4000], dtype=torch.long, device=DEV)
+    inv = (1.0 / (1e6 ** (torch.arange(0, hd, 2).float() / hd))).to(DEV)
+    cos, sin = o.rope_table(pos, inv)
+    cap = max(lens) + 2
+    pages = B * ((cap + 63) // 64)
+    order = torch.randperm(pages, generator=torch.Generator().manual_seed(1)).tolist()
+    pgs = [PagedKVCache(1, B, width, cap, DEV, order=order) for _ in range(2)]
+    ctx_k = [torch.zeros(n, nkv, dp, dtype=BF16) for n in lens]
+    ctx_v = [torch.zeros(n, nkv, dp, dtype=BF16) for n in lens]
+    for b, n in enumerate(lens):
+        ctx_k[b][:, :, :hd] = rnd(n, nkv, hd, seed=10 + b)
+        ctx_v[b][:, :, :hd] = rnd(n, nkv, hd, seed=20 + b)
+
+    class Ctx:
+        _k = {0: torch.cat([k.view(-1, width) for k in ctx_k]).to(DEV)}
+        _v = {0: torch.cat([v.view(-1, width) for v in ctx_v]).to(DEV)}
+    for pg in pgs:
+        pg.k.fill_(float("nan")); pg.v.fill_(float("nan"))
+        pg.adopt(Ctx, lens)
+    scale = hd ** -0.5
+    max_len = max(lens) + 1
+    po, pml = o.attn_decode_workspace(B, nq, dp, max_len, DEV)
+    a, out_a = qkv.clone(), torch.full((B, nq * dp), float("nan"), dtype=BF16, device=DEV)
+    o.decode_qkv_post(a, cos, sin, qw if use_norm else None, kw if use_norm else None, pgs[0].k[0], pgs[0].v[0], pgs[0].block_table,
+                      pgs[0].kv_len, B, nq, nkv, hd, dp, 1e-6, use_norm)
+    o.attn_decode_paged(a, pgs[0].k[0], pgs[0].v[0], pgs[0].block_table, pgs[0].kv_len, 1, max_len, po, pml, out_a, B, nq, nkv, dp, scale)
+    b_, out_b = qkv.clone(), torch.full((B, nq * dp), float("nan"), dtype=BF16, device=DEV)
+    po2, pml2 = o.attn_decode_workspace(B, nq, dp, max_len, DEV)
+    o.attn_decode_fused(b_, cos, sin, qw if use_norm else None, kw if use_norm else None, pgs[1].k[0], pgs[1].v[0], pgs[1].block_table,
+                        pgs[1].kv_len, max_len, po2, pml2, out_b, B, nq, nkv, hd, dp, 1e-6, use_norm, scale)
+    assert torch.isfinite(out_b.float()).all()
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16)), "fused attention output differs"
+    assert torch.equal(b_, qkv), "the fused kernel must leave the projection buffer untouched"
+    for i, n in enumerate(lens):
+        r = pgs[0].physical_rows(i, n, n + 1)[0]
+        assert torch.equal(pgs[0].k[0][r].view(torch.int16), pgs[1].k[0][r].view(torch.int16)), "K page row differs"
+        assert torch.equal(pgs[0].v[0][r].view(torch.int16), pgs[1].v[0][r].view(torch.int16)), "V page row differs"
+
+
 def test_decode_attention_sharp_softmax():
     """One key dominates by a huge margin in a late split: the split merge must not lose it or overflow."""
     from bagel_amd.modeling.bagel.decode import PagedKVCache
