@@ -396,8 +396,6 @@ def main():
         one_step()
     records, orig_gemm, timed_gemm = gemm_profile_hook()
     ops.gemm = timed_gemm
-    import bagel_amd.modeling.bagel.qwen2_navit as qn
-    import bagel_amd.modeling.bagel.bagel as bg
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
