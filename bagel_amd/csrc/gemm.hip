@@ -17,6 +17,7 @@
 // XCD-aware tile order: blocks that land on the same XCD (blockIdx % 8) walk a 4-M-tile-wide band so the
 // A/W panels they share stay in that XCD's 4 MiB L2.
 #include "common.h"
+#include <stdlib.h>
 
 #define EPI_NONE 0
 #define EPI_GELU_TANH 1
@@ -39,6 +40,7 @@ struct GemmParams {
     long lda, ldw, ldr, ldc;
     int N, K;
     int tiles_m, tiles_n;
+    int gm;         // band height in M tiles of the XCD-local tile walk (ping-pong kernel)
     int epi;
     int ngroups;
     GemmGroup g[2];
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         const int xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    constexpr int GM = 4;
+    const int GM = p.gm;   // band height in M tiles (4 by default; BAGEL_GEMM_GM is a tuning knob)
     const int band = bid / (GM * p.tiles_n);
     const int band_rows = min(GM, p.tiles_m - band * GM);
     const int inb = bid - band * GM * p.tiles_n;
@@ -552,6 +554,12 @@ static int launch_gemm_pp(const GemmParams& p0, hipStream_t stream) {
     p.tiles_m = t;
     p.tiles_n = ceil_div(p.N, 256);
     if (t == 0) return BAGEL_OK;
+    static int gm = 0;
+    if (gm == 0) {
+        const char* e = getenv("BAGEL_GEMM_GM");
+        gm = (e && atoi(e) > 0) ? atoi(e) : 4;
+    }
+    p.gm = gm;
     constexpr int smem = 2 * 4 * 128 * 128;
     static bool attr_set = false;
     if (!attr_set) {
