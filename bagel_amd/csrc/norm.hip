@@ -254,3 +254,42 @@ extern "C" int bagel_qknorm_rope_bf16(void* qkv, int64_t ld, const void* cos_tab
 #undef QKR_LAUNCH
     return bagel_check_launch("qknorm_rope_kernel");
 }
+
+// SigLIP 2-D RoPE (siglip_navit.py:102-142,224-230): every head is split in halves, the first rotated by the token's
+// row position, the second by its column position; rotate_half pairs element j with j + hd/4 inside a half.  In place on
+// the q and k heads of the fused projection rows, bf16 products and bf16 sum like the eager reference ops.
+__global__ __launch_bounds__(256) void rope2d_kernel(bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ cos_h,
+                                                     const bf16_t* __restrict__ sin_h, const bf16_t* __restrict__ cos_w,
+                                                     const bf16_t* __restrict__ sin_w, const long* __restrict__ pos_ids, long n,
+                                                     int nheads, int hd, int dp) {
+    const int q4 = hd >> 2, h2 = hd >> 1;
+    const long total = n * nheads * 2 * q4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int j = (int)(t % q4);
+    const int half = (int)((t / q4) & 1);
+    const int head = (int)((t / (2 * q4)) % nheads);
+    const long row = t / ((long)2 * q4 * nheads);
+    const long pos = pos_ids[row];
+    const bf16_t* ct = (half ? cos_w : cos_h) + pos * h2;
+    const bf16_t* st = (half ? sin_w : sin_h) + pos * h2;
+    bf16_t* p = qkv + row * ld + (long)head * dp + half * h2;
+    const float x1 = bf2f(p[j]), x2 = bf2f(p[j + q4]);
+    const float o1 = bfround(x1 * bf2f(ct[j])) + bfround(-x2 * bf2f(st[j]));
+    const float o2 = bfround(x2 * bf2f(ct[j + q4])) + bfround(x1 * bf2f(st[j + q4]));
+    p[j] = f2bf(o1);
+    p[j + q4] = f2bf(o2);
+}
+
+extern "C" int bagel_rope2d_bf16(void* qkv, int64_t ld, const void* cos_h, const void* sin_h, const void* cos_w, const void* sin_w,
+                                 const int64_t* pos_ids, int64_t rows, int32_t nheads, int32_t head_dim, int32_t head_dim_padded,
+                                 hipStream_t stream) {
+    BAGEL_REQUIRE(qkv && cos_h && sin_h && cos_w && sin_w && pos_ids, "rope2d: null pointer");
+    BAGEL_REQUIRE(head_dim > 0 && head_dim % 4 == 0 && head_dim <= head_dim_padded, "rope2d: head_dim %d must be a multiple of 4", head_dim);
+    if (rows <= 0 || nheads <= 0) return BAGEL_OK;
+    const long total = rows * nheads * (head_dim / 2);
+    hipLaunchKernelGGL(rope2d_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, (bf16_t*)qkv, (long)ld, (const bf16_t*)cos_h,
+                       (const bf16_t*)sin_h, (const bf16_t*)cos_w, (const bf16_t*)sin_w, (const long*)pos_ids, (long)rows, nheads,
+                       head_dim, head_dim_padded);
+    return bagel_check_launch("rope2d_kernel");
+}

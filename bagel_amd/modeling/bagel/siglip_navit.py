@@ -1,7 +1,8 @@
 """Packed (NaViT) SigLIP vision encoder on MI355X -- API and state-dict keys of modeling/bagel/siglip_navit.py
 (SiglipVisionConfig :21-99, SiglipVisionEmbeddings.convert_conv2d_to_linear :167-181, SiglipVisionModel :374-402).
 
-Execution: patch Linear + learned position rows, then per layer LayerNorm -> fused QKV GEMM -> varlen attention
+Execution: patch Linear + learned position rows (or, with ``config.rope``, the 2-D RoPE of siglip_navit.py:102-142 applied to
+q/k after the projection), then per layer LayerNorm -> fused QKV GEMM -> varlen attention
 (non-causal, heads zero-padded 72 -> 128 inside the packed weights so the D=128 MFMA kernel applies; softmax scale
 stays 72^-1/2) -> out_proj with the residual in its epilogue -> LayerNorm -> fc1+GELU(tanh) epilogue -> fc2 +
 residual epilogue.  All bf16 with fp32 accumulation, rounding points as the reference under bf16 autocast.
@@ -96,11 +97,29 @@ class _Encoder(nn.Module):
         self.layers = nn.ModuleList([_EncoderLayer(config) for _ in range(config.num_hidden_layers)])
 
 
+class _Rope2D(nn.Module):
+    """RotaryEmbedding2D (siglip_navit.py:102-127): four persistent [max_h*max_w, dim] tables (state-dict entries)."""
+
+    def __init__(self, dim, max_h, max_w, base=10000):
+        super().__init__()
+        inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.int64).float().cpu() / dim))
+        gh = torch.arange(0, max_h).float()[:, None].repeat(1, max_w)
+        gw = torch.arange(0, max_w).float()[None, :].repeat(max_h, 1)
+        for name, g in (("h", gh), ("w", gw)):
+            fr = g[..., None] * inv[None, None, :]
+            e = torch.cat((fr, fr), dim=-1).flatten(0, 1)
+            self.register_buffer("cos_" + name, e.cos())
+            self.register_buffer("sin_" + name, e.sin())
+
+
 class SiglipVisionTransformer(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
         self.embeddings = _Embeddings(config)
+        if config.rope:
+            side = config.image_size // config.patch_size
+            self.rope = _Rope2D(config.hidden_size // config.num_attention_heads // 2, side, side)
         self.encoder = _Encoder(config)
         self.post_layernorm = _P(config.hidden_size)
 
@@ -133,9 +152,6 @@ class SiglipVisionModel(nn.Module):
             raise RuntimeError("call vision_model.embeddings.convert_conv2d_to_linear(vit_config) first (app.py:66)")
         if not pe.weight.is_cuda or pe.weight.dtype != BF16:
             raise ops.BagelHipError("bagel_amd runs bf16 weights on an MI355X: call model.to('cuda', torch.bfloat16) first")
-        if cfg.rope:
-            raise NotImplementedError("SigLIP 2-D RoPE (siglip_navit.py:102-142) is switched off for BAGEL (app.py:45); "
-                                      "not built in this round")
         D, nh = cfg.hidden_size, cfg.num_attention_heads
         hd = D // nh
         dp = padded_head_dim(hd)
@@ -153,7 +169,11 @@ class SiglipVisionModel(nn.Module):
                 wo=_pad_heads_cols(a.out_proj.weight.data, nh, hd, dp).contiguous(), bo=a.out_proj.bias.data,
                 ln1=(L.layer_norm1.weight.data, L.layer_norm1.bias.data), ln2=(L.layer_norm2.weight.data, L.layer_norm2.bias.data),
                 fc1=(L.mlp.fc1.weight.data, L.mlp.fc1.bias.data), fc2=(L.mlp.fc2.weight.data, L.mlp.fc2.bias.data)))
-        self._packed = dict(wpatch=w, bpatch=pe.bias.data, kin=kin, kpad=kpad, layers=layers, hd=hd, dp=dp, nh=nh)
+        rope = None
+        if cfg.rope:   # a bf16 model carries bf16-rounded tables (they are persistent buffers: model.to(bf16) casts them)
+            r = vm.rope
+            rope = tuple(getattr(r, n).to(device=w.device, dtype=BF16).contiguous() for n in ("cos_h", "sin_h", "cos_w", "sin_w"))
+        self._packed = dict(wpatch=w, bpatch=pe.bias.data, kin=kin, kpad=kpad, layers=layers, hd=hd, dp=dp, nh=nh, rope=rope)
         return self._packed
 
     @torch.no_grad()
@@ -179,12 +199,15 @@ class SiglipVisionModel(nn.Module):
         vt = torch.zeros((nh * dp, _ceil_to(c, 256)), dtype=BF16, device=dev)
         a16 = ops.f32_to_bf16(pix, cols_padded=P["kpad"])
         ops.gemm(a16, P["wpatch"], x, bias0=P["bpatch"])
-        ops.add_table_rows(x, self.vision_model.embeddings.position_embedding.weight.data, pos)
+        if P["rope"] is None:
+            ops.add_table_rows(x, self.vision_model.embeddings.position_embedding.weight.data, pos)
         qw = nh * dp
         scale = P["hd"] ** -0.5
         for L in P["layers"]:
             ops.layernorm(x, L["ln1"][0], L["ln1"][1], h, eps)
             ops.gemm(h, L["wqkv"], qkv, bias0=L["bqkv"])
+            if P["rope"] is not None:
+                ops.rope2d(qkv, P["rope"], pos, 2 * nh, P["hd"], dp)       # q heads then k heads
             ops.v_transpose(qkv[:, 2 * qw:], vt, cu, vcol, B, int(max_seqlen), nh, dp)
             ops.attn_varlen(qkv[:, :qw], qkv[:, qw:2 * qw], vt, att, cu, vcol, B, int(max_seqlen), nh, nh, dp, False, scale)
             ops.gemm(att, L["wo"], x, bias0=L["bo"], residual=x)

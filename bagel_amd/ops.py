@@ -434,6 +434,18 @@ def qknorm_rope(qkv, cos, sin, q_w0, k_w0, q_w1, k_w1, expert, nq, nkv, head_dim
     return qkv
 
 
+def rope2d(qkv, tables, pos_ids, nheads, head_dim, head_dim_padded):
+    """SigLIP 2-D RoPE in place on the first ``nheads`` heads (q then k) of every row; tables = (cos_h, sin_h, cos_w, sin_w)."""
+    _req(qkv, BF16, "rope2d.qkv"); _req(pos_ids, torch.int64, "rope2d.pos_ids")
+    for t in tables:
+        _req(t, BF16, "rope2d.table")
+        if not t.is_contiguous() or t.shape[1] != head_dim // 2:
+            raise BagelHipError("rope2d: tables must be contiguous [positions, head_dim/2]")
+    check(lib().bagel_rope2d_bf16(_ptr(qkv), qkv.stride(0), _ptr(tables[0]), _ptr(tables[1]), _ptr(tables[2]), _ptr(tables[3]),
+                                  _ptr(pos_ids), qkv.shape[0], nheads, head_dim, head_dim_padded, _stream()), "bagel_rope2d_bf16")
+    return qkv
+
+
 def attn_varlen(q, k_new, vt_new, out, cu_q, vt_new_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale,
                 k_ctx=None, vt_ctx=None, cu_ctx=None, vt_ctx_col=None):
     """q:[M, >=nq*D] rows with stride; k_new likewise; vt_new:[nkv*D, cols]; ctx triple optional."""

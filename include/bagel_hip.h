@@ -63,6 +63,13 @@ int bagel_qknorm_rope_bf16(void* qkv, int64_t ld, const void* cos_tab, const voi
                            int32_t rows, int32_t nq, int32_t nkv, int32_t head_dim, int32_t head_dim_padded,
                            float eps, int32_t gen_mode, int32_t use_norm, bagel_stream_t stream);
 
+/* SigLIP 2-D RoPE (siglip_navit.py:102-142,224-230; config.rope): in place on the first `nheads` heads of every row of the
+ * fused projection buffer (q heads then k heads): first half of a head rotated with (cos_h, sin_h)[pos], second half with
+ * (cos_w, sin_w)[pos]; tables [positions, head_dim/2] bf16. */
+int bagel_rope2d_bf16(void* qkv, int64_t ld, const void* cos_h, const void* sin_h, const void* cos_w, const void* sin_w,
+                      const int64_t* pos_ids, int64_t rows, int32_t nheads, int32_t head_dim, int32_t head_dim_padded,
+                      bagel_stream_t stream);
+
 /* flash_attn_varlen_func replacement (qwen2_navit.py:579-588 / 361-370, siglip_navit.py:232-241).
  * Keys/values of sample b = [context rows cu_ctx[b]:cu_ctx[b+1] of (k_ctx, vt_ctx)] ++ [new rows cu_q[b]:cu_q[b+1] of
  * (k_new, vt_new)]  -- the merged layout of qwen2_navit.py:563-570 without the copy.  V is passed transposed:

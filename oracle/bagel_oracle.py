@@ -209,9 +209,28 @@ def mot_attention(W, pre, cfg, layer_idx, x, query_lens, cos_sin, q_idx, cache, 
 @_explicit_casts
 def mot_layer(W, cfg, layer_idx, x, query_lens, cos_sin, q_idx, cache, kv_lens, kv_idx, update, causal,
               mode, vae_idx, text_idx):
-    """Qwen2MoTDecoderLayer.forward_inference, qwen2_navit.py:757-831 (TaylorSeer off)."""
+    """Qwen2MoTDecoderLayer.forward_inference, qwen2_navit.py:757-831 (TaylorSeer off); with ``cfg['layer_module']`` also
+    Qwen2DecoderLayer (:648-684, no modality routing at all) and Qwen2MoEDecoderLayer (:885-933, shared attention with the
+    und cast points, per-modality MLP only)."""
     pre = f"language_model.model.layers.{layer_idx}"
     eps = cfg["rms_norm_eps"]
+    kind = cfg.get("layer_module", "Qwen2MoTDecoderLayer")
+    if kind != "Qwen2MoTDecoderLayer":
+        res = x
+        h = rmsnorm(x, W[pre + ".input_layernorm.weight"], eps)
+        h = mot_attention(W, pre, cfg, layer_idx, h, query_lens, cos_sin, q_idx, cache, kv_lens, kv_idx, update, causal, "und",
+                          None, None)
+        x = res + h
+        res = x
+        h = rmsnorm(x, W[pre + ".post_attention_layernorm.weight"], eps)
+        if kind == "Qwen2MoEDecoderLayer" and mode == "gen":
+            o = torch.zeros_like(h).to(BF16)
+            o[text_idx] = silu_mlp(h[text_idx], W, pre + ".mlp")
+            o[vae_idx] = silu_mlp(h[vae_idx], W, pre + ".mlp_moe_gen")
+            h = o
+        else:
+            h = silu_mlp(h, W, pre + ".mlp")
+        return res + h
     res = x
     if mode == "und":
         h = rmsnorm(x, W[pre + ".input_layernorm.weight"], eps)
@@ -316,7 +335,7 @@ def llm_forward(W, cfg, x, query_lens, position_ids, q_idx, cache, kv_lens, kv_i
     if taylor is not None:
         taylor.step += 1
     eps = cfg["rms_norm_eps"]
-    if mode == "und":
+    if mode == "und" or "Mo" not in cfg.get("layer_module", "Qwen2MoTDecoderLayer"):     # use_moe, qwen2_navit.py:1074-1084
         x = rmsnorm(x, W["language_model.model.norm.weight"], eps)
     else:
         y = torch.zeros_like(x)
@@ -433,8 +452,9 @@ def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, 
     vae_idx, text_idx = gi["packed_vae_token_indexes"], gi["packed_text_indexes"]
 
     def run(cache_, pos_ids, q_idx, kv_lens, kv_idx, ts=None):
+        mode = "gen" if "Mo" in cfg["llm"].get("layer_module", "Qwen2MoTDecoderLayer") else "und"     # use_moe, bagel.py:808-815
         out = llm_forward(W, cfg["llm"], seq, gi["packed_seqlens"], pos_ids, q_idx, cache_, kv_lens, kv_idx,
-                          False, False, "gen", vae_idx, text_idx, taylor=ts, taylor_last_layer_only=taylor_last_layer_only)
+                          False, False, mode, vae_idx, text_idx, taylor=ts, taylor_last_layer_only=taylor_last_layer_only)
         v = linear(out, W["llm2vae.weight"], W["llm2vae.bias"])
         return v[vae_idx]
 
@@ -685,8 +705,8 @@ def siglip_forward(W, vcfg, pixels, pos_ids, cu_seqlens, max_seqlen):
     if not use_rope:
         x = x + F.embedding(pos_ids, W[pre + "embeddings.position_embedding.weight"])
     else:
-        ms = vcfg["image_size"] // vcfg["patch_size"]
-        ch, sh, cw, sw = [t[pos_ids] for t in rope2d_tables(hd // 2, ms, ms)]
+        # the RotaryEmbedding2D buffers are persistent state-dict entries: a bf16 model carries bf16-rounded tables
+        ch, sh, cw, sw = [W[pre + "rope." + n][pos_ids] for n in ("cos_h", "sin_h", "cos_w", "sin_w")]
     for i in range(vcfg["num_hidden_layers"]):
         lp = f"{pre}encoder.layers.{i}."
         res = x

@@ -38,6 +38,13 @@ TINY_D128 = dict(
     llm2vae_std=0.25,
 )
 
+# the SigLIP 2-D RoPE variant (siglip_navit.py:102-142,224-230; switched off for BAGEL-7B by app.py:45): same plumbing as TINY
+TINY_ROPE = dict(TINY, name="tiny_rope", vit=dict(TINY["vit"], rope=True))
+
+# the alternates of Decoder_layer_dict (qwen2_navit.py:936-940): dense layers, and shared attention + per-modality MLP
+TINY_DENSE = dict(TINY, name="tiny_dense", llm=dict(TINY["llm"], layer_module="Qwen2DecoderLayer"))
+TINY_MOE = dict(TINY, name="tiny_moe", llm=dict(TINY["llm"], layer_module="Qwen2MoEDecoderLayer"))
+
 # BAGEL-7B-MoT (public checkpoint config). Random-init in benchmarks.
 BAGEL_7B = dict(
     name="bagel_7b_mot",

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 from oracle import bagel_oracle as O          # noqa: E402
 from oracle import packers as P               # noqa: E402
 from oracle import ref_env                    # noqa: E402
-from oracle.configs import TINY, TINY_D128, NEW_TOKEN_IDS_TINY, StubTokenizer  # noqa: E402
+from oracle.configs import TINY, TINY_D128, TINY_DENSE, TINY_MOE, TINY_ROPE, NEW_TOKEN_IDS_TINY, StubTokenizer  # noqa: E402
 from oracle.weights import load_synth         # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -204,6 +204,35 @@ def scenario_taylorseer(cfg, model, vae, W, VW):
             runs[tag] = dict(gen_kwargs=kw, latents=list(lat), latents_plain_sampler=list(plain), rel_dev_from_plain_sampler=dev)
     out.update(prompts=prompts, image_sizes=sizes, latent_inputs=li, cfg_inputs=ci, runs=runs)
     return out
+
+
+def scenario_layer_kind(cfg, model, vae, W, VW):
+    """Decoder_layer_dict alternates (qwen2_navit.py:936-940): text prefill -> 4-timestep CFG sampling, compact fixture."""
+    from modeling.bagel.qwen2_navit import NaiveCache
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    prompts, sizes = ["a tiny red cube", "sky"], [(64, 64), (32, 64)]
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        gi, newlens, newrope = model.prepare_prompts([0, 0], [0, 0], prompts, tok, NEW_TOKEN_IDS_TINY)
+        cache = model.forward_cache_update_text(NaiveCache(L), **gi)
+        ocache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi)
+        same(cache_to_lists(cache, L), cache_to_lists(ocache, L), "text prefill cache")
+        torch.manual_seed(48)
+        li = model.prepare_vae_latent(newlens, newrope, sizes, NEW_TOKEN_IDS_TINY)
+        ci = model.prepare_vae_latent_cfg([0, 0], [0, 0], sizes)
+        kw = dict(num_timesteps=5, timestep_shift=3.0, cfg_renorm_min=0.0, cfg_renorm_type="global", cfg_interval=[0.0, 1.0],
+                  cfg_text_scale=4.0)
+        lat = model.generate_image(
+            past_key_values=cache, cfg_text_past_key_values=NaiveCache(L),
+            cfg_text_packed_position_ids=ci["cfg_packed_position_ids"], cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=ci["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"],
+            **kw, **li)
+        ocfg = dict(cache=O.OracleCache(L), position_ids=ci["cfg_packed_position_ids"], query_indexes=ci["cfg_packed_query_indexes"],
+                    key_values_lens=ci["cfg_key_values_lens"], key_value_indexes=ci["cfg_packed_key_value_indexes"])
+        olat = O.generate_image(W, cfg, li, ocache, cfg_text=ocfg, **kw)
+        same(list(lat), list(olat), "generate_image latents")
+    kc, vc = cache_to_lists(cache, L)
+    return dict(prompts=prompts, latent_inputs=li, cfg_inputs=ci, gen_kwargs=kw, latents=list(lat), key_cache=kc, value_cache=vc)
 
 
 def scenario_edit_und(cfg, model, vae, W, VW):
@@ -474,7 +503,19 @@ def main():
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    for cfg in (TINY, TINY_D128):
+    for cfg in (TINY_DENSE, TINY_MOE):
+        if args.only not in (None, "kinds"):
+            continue
+        model, vae, W, VW = build(cfg)
+        data = scenario_layer_kind(cfg, model, vae, W, VW)
+        path = os.path.join(GOLD, f"{cfg['name']}_t2i.pt")
+        torch.save(data, path)
+        print(f"[golden] {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  oracle == reference bit-exact")
+    for cfg in (TINY, TINY_D128, TINY_ROPE):
+        if args.only == "kinds":
+            continue
+        if cfg is TINY_ROPE and args.only not in (None, "siglip"):
+            continue
         model, vae, W, VW = build(cfg)
         for name, fn in (("t2i", scenario_t2i), ("editund", scenario_edit_und), ("taylorseer", scenario_taylorseer), ("train", scenario_train), ("vae", scenario_vae),
                          ("siglip", scenario_siglip)):
@@ -482,6 +523,8 @@ def main():
                 continue
             if name == "vae" and cfg is not TINY:
                 continue   # VAE config is shared
+            if cfg is TINY_ROPE and name != "siglip":
+                continue   # only the ViT differs
             data = fn(cfg, model, vae, W, VW)
             path = os.path.join(GOLD, f"{cfg['name']}_{name}.pt")
             torch.save(data, path)

@@ -16,9 +16,14 @@ def bagel_shapes(cfg):
     s = {}
     lm = "language_model."
     s[lm + "model.embed_tokens.weight"] = (V, H)
+    kind = llm.get("layer_module", "Qwen2MoTDecoderLayer")
+    # Decoder_layer_dict (qwen2_navit.py:936-940): MoT duplicates attention + norms + MLP per modality (:381-398,687-705),
+    # MoE only the MLP (:834-846), the dense layer nothing (:603-615)
+    attn_sufs = ("", "_moe_gen") if kind == "Qwen2MoTDecoderLayer" else ("",)
+    mlp_sufs = ("", "_moe_gen") if kind in ("Qwen2MoTDecoderLayer", "Qwen2MoEDecoderLayer") else ("",)
     for i in range(llm["num_hidden_layers"]):
         p = f"{lm}model.layers.{i}."
-        for suf in ("", "_moe_gen"):
+        for suf in attn_sufs:
             s[p + f"self_attn.q_proj{suf}.weight"] = (nh * hd, H)
             s[p + f"self_attn.q_proj{suf}.bias"] = (nh * hd,)
             s[p + f"self_attn.k_proj{suf}.weight"] = (nkv * hd, H)
@@ -28,13 +33,15 @@ def bagel_shapes(cfg):
             s[p + f"self_attn.o_proj{suf}.weight"] = (H, nh * hd)
             s[p + f"self_attn.q_norm{suf}.weight"] = (hd,)
             s[p + f"self_attn.k_norm{suf}.weight"] = (hd,)
+            s[p + f"input_layernorm{suf}.weight"] = (H,)
+            s[p + f"post_attention_layernorm{suf}.weight"] = (H,)
+        for suf in mlp_sufs:
             s[p + f"mlp{suf}.gate_proj.weight"] = (I, H)
             s[p + f"mlp{suf}.up_proj.weight"] = (I, H)
             s[p + f"mlp{suf}.down_proj.weight"] = (H, I)
-            s[p + f"input_layernorm{suf}.weight"] = (H,)
-            s[p + f"post_attention_layernorm{suf}.weight"] = (H,)
     s[lm + "model.norm.weight"] = (H,)
-    s[lm + "model.norm_moe_gen.weight"] = (H,)
+    if "Mo" in kind:                      # Qwen2Model.use_moe (:948,957-958)
+        s[lm + "model.norm_moe_gen.weight"] = (H,)
     s[lm + "lm_head.weight"] = (V, H)
     # Bagel glue
     pdim = bg["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"]
@@ -58,6 +65,10 @@ def bagel_shapes(cfg):
     s[vp + "embeddings.patch_embedding.bias"] = (D,)
     if not vit.get("rope", False):
         s[vp + "embeddings.position_embedding.weight"] = ((vit["image_size"] // vit["patch_size"]) ** 2, D)
+    else:   # RotaryEmbedding2D buffers (siglip_navit.py:102-127,337-340): persistent, hence state-dict entries
+        side = vit["image_size"] // vit["patch_size"]
+        for n in ("cos_h", "sin_h", "cos_w", "sin_w"):
+            s[vp + "rope." + n] = (side * side, D // vit["num_attention_heads"] // 2)
     for i in range(vit["num_hidden_layers"]):
         p = f"{vp}encoder.layers.{i}."
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):

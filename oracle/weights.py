@@ -45,7 +45,7 @@ def synth_state_dict(shapes: dict, seed: int = 0, dtype=torch.float32) -> dict:
     """shapes: {state-dict key: shape}. Keys ending in 'pos_embed' are skipped (frozen tables)."""
     out = {}
     for name in sorted(shapes):
-        if name.endswith("pos_embed"):
+        if name.endswith("pos_embed") or ".rope." in name:      # frozen tables (sin-cos position tables, SigLIP 2-D RoPE)
             continue
         out[name] = synth_tensor(name, shapes[name], seed, dtype)
     return out

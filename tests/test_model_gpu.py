@@ -9,11 +9,11 @@ import copy
 import pytest
 import torch
 
-from oracle.configs import TINY, TINY_D128, NEW_TOKEN_IDS_TINY, StubTokenizer
+from oracle.configs import TINY, TINY_D128, TINY_DENSE, TINY_MOE, TINY_ROPE, NEW_TOKEN_IDS_TINY, StubTokenizer
 from tests.util_models import product_model
 
 pytestmark = pytest.mark.gpu
-CFGS = {"tiny": TINY, "tiny_d128": TINY_D128}
+CFGS = {"tiny": TINY, "tiny_d128": TINY_D128, "tiny_rope": TINY_ROPE, "tiny_dense": TINY_DENSE, "tiny_moe": TINY_MOE}
 
 
 def rel_l2(a, b):
@@ -138,7 +138,7 @@ def test_vit_text_context_understanding(golden, name):
         break
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_rope"])      # tiny_rope: SigLIP 2-D RoPE (siglip_navit.py:102-142)
 def test_siglip_encoder(golden, name):
     cfg = CFGS[name]
     g = golden(f"{name}_siglip")
@@ -165,3 +165,24 @@ def test_vae_matches_reference(golden):
     u8 = ((img * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8).cpu()
     diff = (u8.int() - g["image_u8"].int()).abs()
     assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 0.01
+
+
+@pytest.mark.parametrize("name", ["tiny_dense", "tiny_moe"])
+def test_dense_and_moe_layer_kinds(golden, name):
+    """Qwen2DecoderLayer / Qwen2MoEDecoderLayer run as degenerate routings of the MoT plan (no routing at all /
+    shared attention with the und cast points + per-modality MLP and final norm) -- vs the reference's goldens."""
+    cfg = CFGS[name]
+    g = golden(f"{name}_t2i")
+    model, _ = product_model(cfg)
+    assert model.use_moe == (name == "tiny_moe")
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    gi, _, _ = model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+    for i in range(L):
+        check(cache.key_cache[i], g["key_cache"][i], 1e-2, f"K cache layer {i}")
+        check(cache.value_cache[i], g["value_cache"][i], 1e-2, f"V cache layer {i}")
+    lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **g["gen_kwargs"],
+                               **g["latent_inputs"])
+    for a, b in zip(lat, g["latents"]):
+        check(a, b, 2e-2, "latents")

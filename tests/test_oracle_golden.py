@@ -7,10 +7,10 @@ import torch
 
 from oracle import bagel_oracle as O
 from oracle import packers as P
-from oracle.configs import TINY, TINY_D128, NEW_TOKEN_IDS_TINY, StubTokenizer
+from oracle.configs import TINY, TINY_D128, TINY_DENSE, TINY_MOE, TINY_ROPE, NEW_TOKEN_IDS_TINY, StubTokenizer
 from tests.util_models import oracle_weights
 
-CFGS = {"tiny": TINY, "tiny_d128": TINY_D128}
+CFGS = {"tiny": TINY, "tiny_d128": TINY_D128, "tiny_rope": TINY_ROPE, "tiny_dense": TINY_DENSE, "tiny_moe": TINY_MOE}
 
 
 def _cache(keys, vals):
@@ -93,7 +93,7 @@ def test_vae_matches_reference(golden):
                        g["image_u8"])
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_rope"])      # tiny_rope: the 2-D RoPE variant (config.rope=True)
 def test_siglip_matches_reference(golden, name):
     cfg = CFGS[name]
     g = golden(f"{name}_siglip")
@@ -150,3 +150,20 @@ def test_training_forward_matches_reference(golden, name):
         while tot < n:
             lens.append(g["split_lens"][i]); modes.append(g["attn_modes"][i]); tot += lens[-1]; i += 1
         assert torch.equal(O.attention_mask_per_sample(lens, modes), m)
+
+
+@pytest.mark.parametrize("name", ["tiny_dense", "tiny_moe"])
+def test_dense_and_moe_layer_kinds_match_reference(golden, name):
+    """Decoder_layer_dict alternates (qwen2_navit.py:936-940): Qwen2DecoderLayer and Qwen2MoEDecoderLayer, bit-exact."""
+    cfg = CFGS[name]
+    g = golden(f"{name}_t2i")
+    W, _ = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    gi, _, _ = P.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+    cache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi)
+    for i in range(L):
+        assert torch.equal(cache.key_cache[i], g["key_cache"][i]) and torch.equal(cache.value_cache[i], g["value_cache"][i])
+    lat = O.generate_image(W, cfg, g["latent_inputs"], cache, cfg_text=_cfgd(O.OracleCache(L), g["cfg_inputs"]), **g["gen_kwargs"])
+    for a, b in zip(lat, g["latents"]):
+        assert torch.equal(a, b)

@@ -3,14 +3,14 @@ import pytest
 import torch
 
 from oracle import ref_env
-from oracle.configs import TINY, TINY_D128
+from oracle.configs import TINY, TINY_D128, TINY_DENSE, TINY_MOE, TINY_ROPE
 from oracle.shapes import bagel_shapes, vae_shapes
 from tests.util_models import oracle_weights
 
 pytestmark = pytest.mark.skipif(not ref_env.reference_available(), reason="/root/reference not present")
 
 
-@pytest.mark.parametrize("cfg", [TINY, TINY_D128], ids=lambda c: c["name"])
+@pytest.mark.parametrize("cfg", [TINY, TINY_D128, TINY_ROPE, TINY_DENSE, TINY_MOE], ids=lambda c: c["name"])
 def test_shapes_and_weights_equal_reference(cfg):
     from oracle import make_golden as G
     model, vae, W, VW = G.build(cfg)
