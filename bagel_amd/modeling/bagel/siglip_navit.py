@@ -102,9 +102,10 @@ class _Rope2D(nn.Module):
 
     def __init__(self, dim, max_h, max_w, base=10000):
         super().__init__()
-        inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.int64).float().cpu() / dim))
-        gh = torch.arange(0, max_h).float()[:, None].repeat(1, max_w)
-        gw = torch.arange(0, max_w).float()[None, :].repeat(max_h, 1)
+        # built on the host in fp32 whatever the ambient default device/dtype is (the factory constructs under a device context)
+        inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.int64, device="cpu").float() / dim))
+        gh = torch.arange(0, max_h, device="cpu").float()[:, None].repeat(1, max_w)
+        gw = torch.arange(0, max_w, device="cpu").float()[None, :].repeat(max_h, 1)
         for name, g in (("h", gh), ("w", gw)):
             fr = g[..., None] * inv[None, None, :]
             e = torch.cat((fr, fr), dim=-1).flatten(0, 1)
