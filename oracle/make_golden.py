@@ -462,6 +462,40 @@ def scenario_train(cfg, model, vae, W, VW):
     return dict(batch=batch, noise=noise, split_lens=all_splits, attn_modes=all_modes, mse=ref["mse"], ce=ref["ce"])
 
 
+def scenario_inferencer(cfg, model, vae, W, VW):
+    """The reference's InterleaveInferencer end to end (inferencer.py:22-313) on the tiny model: text -> image, image + text ->
+    edited image, image + text -> text.  PIL in, PIL / str out; transforms = the reference's ImageTransform (torchvision entry
+    points replaced by the stand-ins of make_golden_image.py); tokenizer = the deterministic stub.  No oracle restatement of
+    the inferencer exists: the fixture pins the PRODUCT's mirror (bagel_amd/inferencer.py) directly to these outputs."""
+    import numpy as np
+    from PIL import Image
+    from oracle.make_golden_image import _install_standins
+    _install_standins()
+    from data.transforms import ImageTransform
+    from inferencer import InterleaveInferencer
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    inf = InterleaveInferencer(model, _Fp32Vae(vae), tok, ImageTransform(64, 32, 16), ImageTransform(56, 28, 14), NEW_TOKEN_IDS_TINY)
+    rng = np.random.default_rng(9)
+    src = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    out = {"source_image": torch.from_numpy(src)}
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        torch.manual_seed(50)
+        kw = dict(num_timesteps=5, cfg_text_scale=4.0, cfg_img_scale=1.0, cfg_interval=[0.4, 1.0], timestep_shift=3.0,
+                  cfg_renorm_type="global", image_shapes=(64, 48))
+        r = inf(text="a tiny red cube", **kw)
+        out["t2i"] = dict(kwargs=kw, text="a tiny red cube", seed=50, image=torch.from_numpy(np.array(r["image"])))
+        torch.manual_seed(51)
+        kw2 = dict(num_timesteps=4, cfg_text_scale=4.0, cfg_img_scale=2.0, cfg_interval=[0.0, 1.0], timestep_shift=3.0,
+                   cfg_renorm_type="text_channel")
+        r = inf(image=Image.fromarray(src, "RGB"), text="make it blue", **kw2)
+        out["edit"] = dict(kwargs=kw2, text="make it blue", seed=51, image=torch.from_numpy(np.array(r["image"])))
+        kw3 = dict(understanding_output=True, do_sample=False, max_think_token_n=6)
+        r = inf(image=Image.fromarray(src, "RGB"), text="what is it", **kw3)
+        out["understanding"] = dict(kwargs=kw3, text="what is it", answer=r["text"])
+    assert out["t2i"]["image"].shape == (64, 48, 3) and out["edit"]["image"].dtype == torch.uint8 and isinstance(out["understanding"]["answer"], str)
+    return out
+
+
 def scenario_vae(cfg, model, vae, W, VW):
     g = torch.Generator().manual_seed(11)
     z = torch.randn(1, cfg["vae"]["z_channels"], 16, 24, generator=g)
@@ -517,7 +551,7 @@ def main():
         if cfg is TINY_ROPE and args.only not in (None, "siglip"):
             continue
         model, vae, W, VW = build(cfg)
-        for name, fn in (("t2i", scenario_t2i), ("editund", scenario_edit_und), ("taylorseer", scenario_taylorseer), ("train", scenario_train), ("vae", scenario_vae),
+        for name, fn in (("t2i", scenario_t2i), ("editund", scenario_edit_und), ("taylorseer", scenario_taylorseer), ("train", scenario_train), ("inferencer", scenario_inferencer), ("vae", scenario_vae),
                          ("siglip", scenario_siglip)):
             if args.only and args.only != name:
                 continue
@@ -528,7 +562,8 @@ def main():
             data = fn(cfg, model, vae, W, VW)
             path = os.path.join(GOLD, f"{cfg['name']}_{name}.pt")
             torch.save(data, path)
-            print(f"[golden] {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  oracle == reference bit-exact")
+            how = "reference outputs (pins the product's inferencer mirror directly)" if name == "inferencer" else "oracle == reference bit-exact"
+            print(f"[golden] {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  {how}")
 
 
 if __name__ == "__main__":
