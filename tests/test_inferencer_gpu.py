@@ -4,7 +4,8 @@ text -> image, image + text -> edited image, image + text -> text.  PIL in, PIL 
 draw their noise from the host generator in the reference's order).
 
 Tolerance for the uint8 images: the latents carry the bf16 accumulation-order noise of tests/test_model_gpu.py (rel-L2 <= 2-3e-2)
-through the fp32 VAE; mean |diff| <= 2 grey levels and 99 % of the pixels within 12 levels (measured: ~0.5 / ~4)."""
+through the fp32 VAE: text -> image mean |diff| <= 1.5 grey levels, 99 % of the pixels within 8 (measured 0.5 / 2); the edit
+path (VAE encode + ViT + 3 forwards per step, latents <= 3e-2) mean <= 3, p99 <= 14 (measured 1.6 / 7)."""
 import re
 
 import numpy as np
@@ -24,14 +25,14 @@ def _inferencer(cfg):
     return InterleaveInferencer(model, vae, tok, ImageTransform(64, 32, 16), ImageTransform(56, 28, 14), NEW_TOKEN_IDS_TINY)
 
 
-def _compare(img, ref, what):
+def _compare(img, ref, what, mean_tol, p99_tol):
     a = np.asarray(img).astype(np.int32)
     b = ref.numpy().astype(np.int32)
     assert a.shape == b.shape, (what, a.shape, b.shape)
     d = np.abs(a - b)
     mean, p99 = float(d.mean()), float(np.percentile(d, 99))
     print(f"{what}: mean |diff| {mean:.3f}, p99 {p99:.1f}, max {int(d.max())}")
-    assert mean <= 2.0 and p99 <= 12, f"{what}: image differs from the reference's (mean {mean:.2f}, p99 {p99:.1f})"
+    assert mean <= mean_tol and p99 <= p99_tol, f"{what}: image differs from the reference's (mean {mean:.2f}, p99 {p99:.1f})"
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
@@ -45,12 +46,12 @@ def test_interleave_inferencer_matches_reference(golden, name):
     torch.manual_seed(g["t2i"]["seed"])
     r = inf(text=g["t2i"]["text"], **g["t2i"]["kwargs"])
     assert isinstance(r["image"], Image.Image) and r["text"] is None
-    _compare(r["image"], g["t2i"]["image"], "text -> image")
+    _compare(r["image"], g["t2i"]["image"], "text -> image", 1.5, 8)
     torch.manual_seed(g["edit"]["seed"])
     r = inf(image=src, text=g["edit"]["text"], **g["edit"]["kwargs"])
-    _compare(r["image"], g["edit"]["image"], "image + text -> image")
+    _compare(r["image"], g["edit"]["image"], "image + text -> image", 3.0, 14)
     r = inf(image=src, text=g["understanding"]["text"], **g["understanding"]["kwargs"])
-    ours, ref = re.findall(r"\\[(\\d+)\\]", r["text"]), re.findall(r"\\[(\\d+)\\]", g["understanding"]["answer"])
+    ours, ref = re.findall(r"\[(\d+)\]", r["text"]), re.findall(r"\[(\d+)\]", g["understanding"]["answer"])
     assert r["image"] is None and len(ours) == len(ref) and ours[0] == ref[0], (r["text"], g["understanding"]["answer"])
     # greedy ids may part ways at a near tie (random-init logits; the tie rule itself is tested in test_model_gpu.py): whatever
     # follows the first difference is incomparable, everything before it must be equal
