@@ -17,8 +17,9 @@ __version__ = "0.1.0"
 
 
 def install_as_reference():
-    """Make ``modeling``, ``modeling.bagel``, ``modeling.bagel.qwen2_navit``, ``modeling.autoencoder``, ``inferencer``
-    and ``data.data_utils`` import THIS implementation (for unmodified reference entry scripts)."""
+    """Make ``modeling`` (``.bagel[.*]``, ``.autoencoder``, ``.cache_utils.taylorseer``, ``.qwen2``), ``inferencer`` and ``data``
+    (``.data_utils``, ``.transforms``) import THIS implementation: every import of the reference's inference entry scripts
+    (app.py:10-19, eval/gen/gen_images_mp.py:11-19, inferencer.py:10-11) then resolves here."""
     names = {
         "modeling": "bagel_amd.modeling",
         "modeling.bagel": "bagel_amd.modeling.bagel",
@@ -27,9 +28,13 @@ def install_as_reference():
         "modeling.bagel.siglip_navit": "bagel_amd.modeling.bagel.siglip_navit",
         "modeling.bagel.modeling_utils": "bagel_amd.modeling.bagel.modeling_utils",
         "modeling.autoencoder": "bagel_amd.modeling.autoencoder",
+        "modeling.cache_utils": "bagel_amd.modeling.cache_utils",
+        "modeling.cache_utils.taylorseer": "bagel_amd.modeling.cache_utils.taylorseer",
+        "modeling.qwen2": "bagel_amd.modeling.qwen2",
         "inferencer": "bagel_amd.inferencer",
         "data": "bagel_amd.data",
         "data.data_utils": "bagel_amd.data.data_utils",
+        "data.transforms": "bagel_amd.data.transforms",
     }
     for alias, real in names.items():
         try:

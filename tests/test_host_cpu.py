@@ -120,3 +120,27 @@ def test_split_structure_is_recovered_from_the_reference_masks():
     bad[1, 3] = 0.0                                   # a key from the future inside a causal split
     with pytest.raises(NotImplementedError):
         splits_from_mask(bad)
+
+
+def test_install_as_reference_resolves_the_entry_script_imports():
+    """The import lines of app.py:10-19 / eval/gen/gen_images_mp.py:11-19 / inferencer.py:10-11, verbatim, after
+    bagel_amd.install_as_reference() -- in a fresh interpreter so the aliases cannot leak into this one."""
+    import subprocess
+    import sys
+    code = (
+        "import bagel_amd; bagel_amd.install_as_reference()\n"
+        "from data.data_utils import add_special_tokens, pil_img2rgb\n"
+        "from data.transforms import ImageTransform\n"
+        "from inferencer import InterleaveInferencer\n"
+        "from modeling.autoencoder import load_ae\n"
+        "from modeling.bagel.qwen2_navit import NaiveCache\n"
+        "from modeling.bagel import (BagelConfig, Bagel, Qwen2Config, Qwen2ForCausalLM, SiglipVisionConfig, SiglipVisionModel)\n"
+        "from modeling.qwen2 import Qwen2Tokenizer\n"
+        "from modeling.cache_utils.taylorseer import cache_init\n"
+        "import bagel_amd.inferencer as I\n"
+        "assert InterleaveInferencer is I.InterleaveInferencer and NaiveCache(3).num_layers == 3\n"
+        "assert Qwen2Tokenizer.__name__ == 'Qwen2Tokenizer'\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
