@@ -58,3 +58,52 @@ def test_interleave_inferencer_matches_reference(golden, name):
     first = next((i for i, (a, b) in enumerate(zip(ours, ref)) if a != b), len(ref))
     assert ours[:first] == ref[:first]
     print(f"understanding: {first}/{len(ref)} leading tokens equal to the reference's")
+
+
+def test_reference_construction_recipe_through_the_aliases(golden):
+    """The construction recipe of app.py:39-66,137-145 written against the REFERENCE's module names (``from modeling.bagel import
+    ...``), run in a fresh interpreter after ``bagel_amd.install_as_reference()``: modules built on the CPU in fp32, Conv2d patch
+    embedding converted to Linear, ``load_state_dict(strict=False)``, ``.to('cuda', bfloat16).eval()``, InterleaveInferencer call.
+    The produced image must match the reference inferencer's golden like the factory-built model's does."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tempfile.mkdtemp(), "img.pt")
+    code = f"""
+import sys, torch, numpy as np
+sys.path.insert(0, {root!r})
+import bagel_amd; bagel_amd.install_as_reference()
+from data.transforms import ImageTransform
+from inferencer import InterleaveInferencer
+from modeling.autoencoder import AutoEncoder, AutoEncoderParams
+from modeling.bagel import BagelConfig, Bagel, Qwen2Config, Qwen2ForCausalLM, SiglipVisionConfig, SiglipVisionModel
+from oracle.configs import TINY as cfg, NEW_TOKEN_IDS_TINY, StubTokenizer
+from tests.util_models import oracle_weights
+W, VW = oracle_weights(cfg)
+llm_config = Qwen2Config(**cfg["llm"])
+vit_config = SiglipVisionConfig(**cfg["vit"])
+vae_config = AutoEncoderParams(**cfg["vae"])
+vae_model = AutoEncoder(vae_config)
+vae_model.load_state_dict(VW, strict=True)
+config = BagelConfig(visual_gen=True, visual_und=True, llm_config=llm_config, vit_config=vit_config, vae_config=vae_config, **cfg["bagel"])
+language_model = Qwen2ForCausalLM(llm_config)
+vit_model = SiglipVisionModel(vit_config)
+model = Bagel(language_model, vit_model, config)
+model.vit_model.vision_model.embeddings.convert_conv2d_to_linear(vit_config)
+missing, unexpected = model.load_state_dict(W, strict=False)
+assert not unexpected, unexpected
+model = model.to("cuda", torch.bfloat16).eval()
+vae_model = vae_model.to("cuda").eval()
+inf = InterleaveInferencer(model, vae_model, StubTokenizer(cfg["llm"]["vocab_size"]), ImageTransform(64, 32, 16), ImageTransform(56, 28, 14), NEW_TOKEN_IDS_TINY)
+g = torch.load({os.path.join(root, 'tests', 'golden', 'tiny_inferencer.pt')!r}, weights_only=False)
+torch.manual_seed(g["t2i"]["seed"])
+r = inf(text=g["t2i"]["text"], **g["t2i"]["kwargs"])
+torch.save(torch.from_numpy(np.array(r["image"])), {out!r})
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+    img = torch.load(out)
+    _compare(img.numpy(), golden("tiny_inferencer")["t2i"]["image"], "reference recipe, text -> image", 1.5, 8)
