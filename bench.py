@@ -159,6 +159,51 @@ def cpu_baseline(args, cfg):
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md ("8 TB/s peak (spec); ~6.3 TB/s achievable")
 
 
+def cpu_decode_baseline(cfg, ctx):
+    """The oracle's MoT decoder layer in und mode at Lq = 1 on a ``ctx``-token KV context (7B shapes, one layer, a few steps) on the
+    host cores, extrapolated to tokens/s as 1 / (layers * t_layer + t_lm_head)."""
+    from oracle import bagel_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    llm = cfg["llm"]
+    H, I, nh, nkv, V = llm["hidden_size"], llm["intermediate_size"], llm["num_attention_heads"], llm["num_key_value_heads"], llm["vocab_size"]
+    hd = H // nh
+    g = torch.Generator().manual_seed(0)
+    p = "language_model.model.layers.0."
+    W = {}
+    for n, shp in (("q_proj", (nh * hd, H)), ("k_proj", (nkv * hd, H)), ("v_proj", (nkv * hd, H)), ("o_proj", (H, nh * hd))):
+        W[p + f"self_attn.{n}.weight"] = (torch.randn(shp, generator=g) * shp[1] ** -0.5).to(torch.bfloat16)
+        if n != "o_proj":
+            W[p + f"self_attn.{n}.bias"] = (torch.randn(shp[0], generator=g) * 0.02).to(torch.bfloat16)
+    for n in ("q_norm", "k_norm"):
+        W[p + f"self_attn.{n}.weight"] = torch.ones(hd, dtype=torch.bfloat16)
+    for n, shp in (("gate_proj", (I, H)), ("up_proj", (I, H)), ("down_proj", (H, I))):
+        W[p + f"mlp.{n}.weight"] = (torch.randn(shp, generator=g) * shp[1] ** -0.5).to(torch.bfloat16)
+    for n in ("input_layernorm", "post_attention_layernorm"):
+        W[p + f"{n}.weight"] = torch.ones(H, dtype=torch.bfloat16)
+    head = (torch.randn((V, H), generator=g) * H ** -0.5).to(torch.bfloat16)
+    cache = O.OracleCache(1)
+    cache.key_cache[0] = torch.randn(ctx, nkv, hd, generator=g).to(torch.bfloat16)
+    cache.value_cache[0] = torch.randn(ctx, nkv, hd, generator=g).to(torch.bfloat16)
+    x = torch.randn(1, H, generator=g).to(torch.bfloat16)
+    cos_sin = O.rope_tables(torch.tensor([ctx]), hd, llm["rope_theta"], torch.bfloat16)
+    ql, kl = torch.tensor([1], dtype=torch.int), torch.tensor([ctx], dtype=torch.int)
+    q_idx, kv_idx = torch.tensor([ctx]), torch.arange(ctx)
+    steps = 4
+    O.mot_layer(W, llm, 0, x, ql, cos_sin, q_idx, cache, kl, kv_idx, False, True, "und", None, None)      # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        O.mot_layer(W, llm, 0, x, ql, cos_sin, q_idx, cache, kl, kv_idx, False, True, "und", None, None)
+    t_layer = (time.time() - t0) / steps
+    t0 = time.time()
+    for _ in range(steps):
+        O.linear(x, head)
+    t_head = (time.time() - t0) / steps
+    sec = llm["num_hidden_layers"] * t_layer + t_head
+    return dict(value=1.0 / sec, unit="tokens/s", cores=os.cpu_count(), kind="port",
+                sample=f"oracle MoT layer (und mode, Lq = 1 on a {ctx}-token context, 7B shapes) x{steps}: {t_layer * 1e3:.1f} ms/layer, lm_head "
+                       f"{t_head * 1e3:.1f} ms; extrapolated x{llm['num_hidden_layers']} layers + lm_head")
+
+
 def understanding_leg(args, model, cfg, ids, dev, world, fence):
     """BASELINE.json configs[1]: image understanding = SigLIP prefill (980^2 -> 4900 ViT tokens) + text prefill (32 ids) +
     greedy KV-cached decode of N new tokens (eos disabled), batch 1 per GPU (bagel.py:996), replicas across ranks.
@@ -210,6 +255,12 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
         dt = float(tt.item())
     H, I, nkv, V = llm["hidden_size"], llm["intermediate_size"], llm["num_key_value_heads"], llm["vocab_size"]
     hd = H // llm["num_attention_heads"]
+    cpu = None
+    if not args.no_cpu_baseline and int(os.environ.get("RANK", 0)) == 0:
+        try:
+            cpu = cpu_decode_baseline(cfg, lens[0])
+        except Exception as e:
+            cpu = {"error": repr(e)}
     w_bytes = 2.0 * (L * (2 * H * H + 2 * H * nkv * hd + 3 * H * I) + V * H)
     ctx = lens[0]
     kv_bytes = 2.0 * nkv * hd * 2 * L * (ctx + n / 2.0)          # average context over the decoded span
@@ -219,7 +270,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "new_tokens": int(toks.shape[0]), "batch_per_gpu": UB, "context_tokens": int(ctx),
             "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
             "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
-            "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer",
+            "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer", "cpu_baseline": cpu,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "gemv_kernel (decode step)",
                          "algorithmic_bytes_per_step": bpt},
@@ -244,7 +295,7 @@ def understanding_subprocess(args, local):
     import subprocess
     env = dict(os.environ)
     env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1")
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding", "--no-cpu-baseline",
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding"] + (["--no-cpu-baseline"] if args.no_cpu_baseline or int(os.environ.get("RANK", 0)) != 0 else []) + [
            "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image), "--und-batch", str(args.und_batch)]
     if args.layers is not None:
         cmd += ["--layers", str(args.layers)]
