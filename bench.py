@@ -272,7 +272,8 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
             "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer", "cpu_baseline": cpu,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "gemv_kernel (decode step)",
+                         "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_decode_traffic() if (UB == 1 and args.und_image == 980) else None,
+                         "kernel": "gemv_kernel (decode step)",
                          "algorithmic_bytes_per_step": bpt},
             "workload": f"BAGEL-7B-MoT image understanding: {args.und_image}x{args.und_image} image -> {(args.und_image // 14) ** 2} ViT tokens (+2 markers) + 32+2 "
                         f"prompt tokens prefill, greedy decode of {n} tokens, bf16, batch {UB}/GPU"}
@@ -285,6 +286,15 @@ def pmc_traffic(kernel):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
             return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
+def pmc_decode_traffic():
+    """HBM-side bytes of one decode step (all its kernels) from the committed PMC passes; see pmc_traffic."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            return json.load(f)["decode_step"]["traffic_bytes_per_step_corrected"]
     except Exception:
         return None
 
