@@ -31,26 +31,53 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths):
+    """Content hash of the inputs of one object (source + shared headers + flags): robust against the mtime churn of a
+    repository snapshot copied to another box, unlike a timestamp comparison."""
+    import hashlib
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def _manifest_path():
+    return os.path.join(OBJ, "manifest.json")
+
+
+def _load_manifest():
+    import json
+    try:
+        with open(_manifest_path()) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def build(force=False, keep_temps=False, verbose=True):
-    hipcc = _hipcc()
+    import json
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "bagel_hip.h")]
+    manifest = _load_manifest()
+    digests = {s: _digest([os.path.join(CSRC, s)] + [h for h in headers if h.startswith(CSRC)]) for s in sources()}
+    todo = [s for s in sources() if force or manifest.get(s) != digests[s] or not os.path.exists(os.path.join(OBJ, s[:-4] + ".o"))]
+    if not todo and os.path.exists(LIB) and manifest.get("__lib__") == sorted(digests.values()):
+        return LIB                                     # everything up to date (by content)
+    try:
+        hipcc = _hipcc()
+    except RuntimeError:
+        if os.path.exists(LIB) and not todo:
+            return LIB
+        raise
     jobs = []
-    for s in sources():
+    for s in todo:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s[:-4] + ".o")
-        if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
-            if keep_temps:
-                cmd.append("-save-temps=obj")
-            jobs.append((s, cmd))
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if keep_temps:
+            cmd.append("-save-temps=obj")
+        jobs.append((s, cmd))
     def run(job):
         name, cmd = job
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
@@ -64,13 +91,16 @@ def build(force=False, keep_temps=False, verbose=True):
                 if verbose:
                     print(f"[bagel_amd.build] compiled {name}")
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
-    if force or jobs or _stale(LIB, objs):
-        r = subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs, capture_output=True, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(r.stdout + r.stderr)
-            raise RuntimeError("link of libbagel_hip.so failed")
-        if verbose:
-            print(f"[bagel_amd.build] linked {LIB}")
+    r = subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("link of libbagel_hip.so failed")
+    if verbose:
+        print(f"[bagel_amd.build] linked {LIB}")
+    manifest = dict(digests)
+    manifest["__lib__"] = sorted(digests.values())
+    with open(_manifest_path(), "w") as f:
+        json.dump(manifest, f, indent=1)
     return LIB
 
 
