@@ -163,7 +163,10 @@ def cpu_decode_baseline(cfg, ctx):
     """The oracle's MoT decoder layer in und mode at Lq = 1 on a ``ctx``-token KV context (7B shapes, one layer, a few steps) on the
     host cores, extrapolated to tokens/s as 1 / (layers * t_layer + t_lm_head)."""
     from oracle import bagel_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    # one-row matrix-vector products are memory-bound and thread-sync bound: 256 threads ran them 80x SLOWER than 8 on the GPU
+    # box (2.6 s vs 31 ms per layer), so the baseline uses a moderate team and reports that count as `cores`
+    threads = min(os.cpu_count(), 32)
+    torch.set_num_threads(threads)
     llm = cfg["llm"]
     H, I, nh, nkv, V = llm["hidden_size"], llm["intermediate_size"], llm["num_attention_heads"], llm["num_key_value_heads"], llm["vocab_size"]
     hd = H // nh
@@ -199,7 +202,7 @@ def cpu_decode_baseline(cfg, ctx):
         O.linear(x, head)
     t_head = (time.time() - t0) / steps
     sec = llm["num_hidden_layers"] * t_layer + t_head
-    return dict(value=1.0 / sec, unit="tokens/s", cores=os.cpu_count(), kind="port",
+    return dict(value=1.0 / sec, unit="tokens/s", cores=threads, kind="port",
                 sample=f"oracle MoT layer (und mode, Lq = 1 on a {ctx}-token context, 7B shapes) x{steps}: {t_layer * 1e3:.1f} ms/layer, lm_head "
                        f"{t_head * 1e3:.1f} ms; extrapolated x{llm['num_hidden_layers']} layers + lm_head")
 
