@@ -144,3 +144,13 @@ def test_install_as_reference_resolves_the_entry_script_imports():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_position_id_variants_product_equals_oracle():
+    """get_flattened_position_ids_extrapolate / _interpolate (data/data_utils.py:53-69; BagelConfig.interpolate_pos): integers, bit-exact."""
+    from bagel_amd.data import data_utils as D
+    for (h, w, p, side) in ((64, 64, 16, 64), (1024, 1024, 16, 64), (980, 980, 14, 70), (42, 56, 14, 10), (48, 80, 16, 32), (16, 16, 16, 4),
+                            (224, 448, 14, 70)):
+        assert torch.equal(D.get_flattened_position_ids_extrapolate(h, w, p, side), P.position_ids_extrapolate(h, w, p, side))
+        assert torch.equal(D.get_flattened_position_ids_interpolate(h, w, p, side), P.position_ids_interpolate(h, w, p, side))
+    assert D.get_flattened_position_ids_extrapolate(32, 48, 16, 8).tolist() == [0, 1, 2, 8, 9, 10]
