@@ -415,8 +415,6 @@ extern "C" int bagel_gemv_bf16(const void* A, int64_t lda, const void* W, int64_
     BAGEL_REQUIRE((size_t)K * sizeof(bf16_t) <= GEMV_MAX_LDS, "gemv: K=%d does not fit the LDS staging buffer", K);
     BAGEL_REQUIRE((ldc % 2) == 0 && (ldr % 2) == 0 && (((uintptr_t)C | (uintptr_t)R) & 3) == 0, "gemv: C/R rows must be 4-byte aligned");
     if (M <= 0) return BAGEL_OK;
-    const int n_out = epilogue == EPI_SWIGLU16 ? N / 2 : N;
-    (void)n_out;
     int m0 = 0;
     while (m0 < M) {
         int mr = (M - m0 >= 4) ? 4 : (M - m0 >= 2 ? 2 : 1);

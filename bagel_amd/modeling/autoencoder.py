@@ -1,7 +1,7 @@
 """FLUX-style KL autoencoder (API of the reference's modeling/autoencoder.py: AutoEncoderParams :20-31, AutoEncoder
 :290-322, load_ae :339-360).  Parameter names/shapes equal the reference state dict (``ae.safetensors`` loads
 unchanged); the arithmetic runs in the HIP kernels of bagel_amd/csrc/vae.hip (fp32, as the reference's VAE)."""
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List
 
 import torch

@@ -137,7 +137,6 @@ class DecodeSession:
         -> final norm + lm_head -> argmax."""
         eng, B = self.eng, self.B
         nq, nkv, dp, hd = eng.nq, eng.nkv, eng.dp, eng.hd
-        qw, kw_ = nq * dp, nkv * dp
         x, qkv, att, act = self.x, self.qkv, self.att, self.act
         pg = self.paged
         scale = hd ** -0.5

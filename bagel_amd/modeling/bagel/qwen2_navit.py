@@ -14,9 +14,7 @@ What is different is HOW a forward runs (MoTEngine below):
   * every host-side scalar the reference syncs for (sum(query_lens), max(...).item(), :563,585-586) is computed
     once per ForwardPlan on the host; the 28-layer loop launches kernels only.
 """
-import copy
 import json
-import math
 
 import torch
 from torch import nn
