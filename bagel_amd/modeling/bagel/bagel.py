@@ -485,13 +485,15 @@ class Bagel(nn.Module):
     @torch.no_grad()
     def generate_text(self, past_key_values, packed_key_value_indexes, key_values_lens, packed_start_tokens,
                       packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None,
-                      use_graph=None):
+                      use_graph=None, weight_quant=None):
         """bagel.py:930-1000.  Returns the INPUT token of every step, shape (steps, B) int64 (first row = bos).
 
         Execution: a ``DecodeSession`` (decode.py) -- paged KV cache adopted from ``past_key_values``, loop state on the
         device, step 0 launched eagerly, the remaining steps replayed from one captured hipGraph (``use_graph=False``
         or BAGEL_DECODE_GRAPH=0 keeps every step eager).  ``past_key_values`` receives the new K/V rows at the end, as
-        the reference's in-place cache update does."""
+        the reference's in-place cache update does.  ``weight_quant="int8"`` (or ``model.decode_weight_quant``) streams row-wise
+        INT8 copies of the layer weights instead of bf16 -- an option that changes results, like the reference's quantised
+        load modes; default off."""
         import os
         from .decode import DecodeSession
         lm = self.language_model
@@ -500,8 +502,10 @@ class Bagel(nn.Module):
             raise ValueError("packed_key_value_indexes does not cover key_values_lens")
         if max_length <= 0:
             return torch.empty((0, len(kv_lens)), dtype=torch.long, device=self.device)
+        if weight_quant is None:
+            weight_quant = getattr(self, "decode_weight_quant", None)    # model-level switch, like the reference's load-time modes (app.py:114-131)
         sess = DecodeSession(lm.engine(), lm.model.embed_tokens.weight.data, lm.lm_head.weight.data, past_key_values, kv_lens,
-                             packed_start_tokens, packed_query_position_ids, max_length)
+                             packed_start_tokens, packed_query_position_ids, max_length, weight_quant=weight_quant)
         self._last_decode_session = sess
         if use_graph is None:
             use_graph = os.environ.get("BAGEL_DECODE_GRAPH", "1") != "0"

@@ -84,7 +84,7 @@ class DecodeSession:
     """One ``generate_text`` call: device-resident loop state, the per-token launch sequence, and its hipGraph."""
 
     def __init__(self, engine, embed_table, lm_head_weight, cache, kv_lens, start_tokens, position_ids, max_length,
-                 page_order=None):
+                 page_order=None, weight_quant=None):
         self.eng = eng = engine
         dev = eng.device
         self.B = B = len(kv_lens)
@@ -126,9 +126,26 @@ class DecodeSession:
         # bit-identical).  Measured SLOWER on MI355X (3.69 vs 3.61 ms/token at 7B: every workgroup redoes the 7 query heads and
         # gains a dependent load round), so the two-kernel form stays the default; needs head_dim/2 % 8 == 0.
         self.fused_attention = os.environ.get("BAGEL_DECODE_FUSED", "0") == "1" and (eng.hd // 2) % 8 == 0
+        # weight-only INT8 for the four projections of every layer (option; lm_head stays bf16 like the reference's quantised
+        # modes keep it): the engine caches the quantised copies next to the bf16 ones
+        if weight_quant not in (None, "int8"):
+            raise NotImplementedError(f"weight_quant={weight_quant!r}: only 'int8' (row-wise absmax, W8A16) is built")
+        self.weight_quant = weight_quant
+        self.w8 = self._quantised_weights() if weight_quant else None
+        if self.w8 is not None and (eng.H % 16 or eng.I % 16 or (nq * dp) % 16):
+            raise NotImplementedError("int8 weights need row lengths that are multiples of 16")
         self.steps_done = 0
         self.graph = None
         self.graph_error = None
+
+    def _quantised_weights(self):
+        eng = self.eng
+        cache = getattr(eng, "_w8_cache", None)
+        if cache is None:
+            cache = [dict(wqkv=ops.quantize_rows_i8(P.wqkv[0]), wo=ops.quantize_rows_i8(P.wo[0]), wgu=ops.quantize_rows_i8(P.wgu[0]),
+                          wd=ops.quantize_rows_i8(P.wd[0])) for P in eng.layers]
+            eng._w8_cache = cache
+        return cache
 
     # ---- the launch sequence of one token (no host-dependent values: safe to capture) ---------------------------
     def forward_launches(self):
@@ -146,6 +163,8 @@ class DecodeSession:
         h = self.h
 
         def proj(inp, w, out, norm_w=None, **kw):
+            if isinstance(w, tuple):        # (u8 weights, fp32 row scales)
+                return ops.gemv_w8(inp, w[0], w[1], out, norm_w=norm_w, eps=eng.eps, M=B, **kw)
             if fused:
                 return ops.gemv(inp, w, out, norm_w=norm_w, eps=eng.eps, **kw)
             if norm_w is not None:
@@ -153,7 +172,8 @@ class DecodeSession:
                 inp = h
             return ops.gemm(inp, w, out, bias0=kw.get("bias"), residual=kw.get("residual"), epilogue=kw.get("epilogue", ops.EPI_NONE), M0=B)
         for li, P in enumerate(eng.layers):
-            proj(x, P.wqkv[0], qkv, norm_w=P.ln_in[0], bias=P.bqkv[0])
+            Q = self.w8[li] if self.w8 is not None else None
+            proj(x, Q["wqkv"] if Q else P.wqkv[0], qkv, norm_w=P.ln_in[0], bias=P.bqkv[0])
             if self.fused_attention:
                 ops.attn_decode_fused(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
                                       pg.k[li], pg.v[li], pg.block_table, pg.kv_len, self.max_len, self.part_o, self.part_ml, att, B,
@@ -163,9 +183,9 @@ class DecodeSession:
                                     pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, nq, nkv, hd, dp, eng.eps, eng.use_norm)
                 ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
                                       self.part_ml, att, B, nq, nkv, dp, scale)
-            proj(att, P.wo[0], x, residual=x)
-            proj(x, P.wgu[0], act, norm_w=P.ln_post[0], epilogue=ops.EPI_SWIGLU16)
-            proj(act, P.wd[0], x, residual=x)
+            proj(att, Q["wo"] if Q else P.wo[0], x, residual=x)
+            proj(x, Q["wgu"] if Q else P.wgu[0], act, norm_w=P.ln_post[0], epilogue=ops.EPI_SWIGLU16)
+            proj(act, Q["wd"] if Q else P.wd[0], x, residual=x)
         proj(x, self.head, self.logits, norm_w=eng.model.norm.weight.data)
         ops.argmax_into(self.logits, self.next_tok)
 

@@ -134,6 +134,32 @@ def gemv(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w
     return C
 
 
+def quantize_rows_i8(W):
+    """bf16 [N, K] -> (u8 [N, K] = round(W / s) + 128, fp32 s [N] = rowwise absmax / 127); see bagel_quantize_rows_i8."""
+    _req(W, BF16, "quantize_rows_i8.W")
+    N, K = W.shape
+    q = torch.empty((N, K), dtype=torch.uint8, device=W.device)
+    s = torch.empty((N,), dtype=torch.float32, device=W.device)
+    check(lib().bagel_quantize_rows_i8(_ptr(W), W.stride(0), _ptr(q), q.stride(0), _ptr(s), N, K, _stream()), "bagel_quantize_rows_i8")
+    return q, s
+
+
+def gemv_w8(A, Wq, scale, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0):
+    """``gemv`` on row-wise INT8 weights (u8 + fp32 scales), activations bf16; see bagel_gemv_w8_bf16."""
+    _req(A, BF16, "gemv_w8.A"); _req(Wq, torch.uint8, "gemv_w8.Wq"); _req(scale, torch.float32, "gemv_w8.scale"); _req(C, BF16, "gemv_w8.C")
+    N, K = Wq.shape
+    if A.shape[-1] != K or scale.numel() != N:
+        raise BagelHipError("gemv_w8: shape mismatch")
+    if M is None:
+        M = A.shape[0]
+    if residual is not None:
+        _req(residual, BF16, "gemv_w8.residual")
+    check(lib().bagel_gemv_w8_bf16(_ptr(A), _ld(A), _ptr(Wq), Wq.stride(0), _ptr(scale), _ptr(bias), _ptr(residual),
+                                   _ld(residual) if residual is not None else 0, _ptr(C), _ld(C), _ptr(norm_w), float(eps), M, N, K,
+                                   epilogue, _stream()), "bagel_gemv_w8_bf16")
+    return C
+
+
 KV_PAGE = 64          # tokens per KV page (BAGEL_KV_PAGE in decode.hip)
 DECODE_CHUNK = 64     # smallest keys-per-split the library may use (DEC_CH 128, or 64 with BAGEL_DEC_CH=64): sizes the workspace
 

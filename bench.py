@@ -251,6 +251,25 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     t3 = time.perf_counter()
     sess = model._last_decode_session
     dt = t3 - t2
+    # option: row-wise INT8 layer weights (the analogue of the reference's quantised load modes; changes results) -- reported
+    # beside the bf16 number, never as it
+    w8 = None
+    if UB == 1:
+        try:
+            cache8, lens8, ropes8, _ = prefill()
+            st8 = model.prepare_start_tokens(lens8, ropes8, ids)
+            model.generate_text(past_key_values=cache8, max_length=8, do_sample=False, end_token_id=None, weight_quant="int8", **st8)
+            cache8, lens8, ropes8, _ = prefill()
+            st8 = model.prepare_start_tokens(lens8, ropes8, ids)
+            fence()
+            t4 = time.perf_counter()
+            model.generate_text(past_key_values=cache8, max_length=n, do_sample=False, end_token_id=None, weight_quant="int8", **st8)
+            fence()
+            dt8 = time.perf_counter() - t4
+            w8 = {"value": n / dt8, "unit": "tokens/s", "decode_ms_per_token": dt8 / n * 1e3, "weights": "row-wise absmax INT8 (W8A16), lm_head bf16",
+                  "note": "weight_quant='int8' option (changes results): not the headline metric"}
+        except Exception as e:
+            w8 = {"error": repr(e)}
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -274,6 +293,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
             "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
             "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer", "cpu_baseline": cpu,
+            "int8_weights": w8,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_decode_traffic() if (UB == 1 and args.und_image == 980) else None,
                          "kernel": "gemv_kernel (decode step)",

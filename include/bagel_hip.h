@@ -147,6 +147,17 @@ int bagel_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ld
                            int64_t ldr, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                            bagel_stream_t stream);
 
+/* Weight-only INT8 for the decode path (MI355X analogue of the reference's quantised inference modes, app.py:114-131,
+ * bitsandbytes NF4 / LLM.int8).  An OPTION that changes results; the bf16 path is the default.
+ * quantize: q[n,k] = round(W[n,k] / scale[n]) + 128 (u8), scale[n] = max_k |W[n,k]| / 127 (row-wise absmax). */
+int bagel_quantize_rows_i8(const void* w, int64_t ldw, void* q, int64_t ldq, float* scale, int32_t rows, int32_t cols,
+                           bagel_stream_t stream);
+/* bagel_gemv_bf16 on u8 weights: y_n = scale[n] * (sum_k q[n,k] x_k - 128 sum_k x_k), fp32 accumulate, activations bf16,
+ * same epilogues / fused RMSNorm / roundings.  K % 16 == 0, ldw in bytes % 16 == 0. */
+int bagel_gemv_w8_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldw, const float* scale, const void* bias,
+                       const void* R, int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M,
+                       int32_t N, int32_t K, int32_t epilogue, bagel_stream_t stream);
+
 /* Paged KV cache (64-token pages; token j of sample b at pool row block_table[b*bt_stride + j/64]*64 + j%64).
  * Appends this step's K/V row of every sample at slot kv_len[b] (device memory) -- the in-place form of the
  * per-layer cache rebuild at qwen2_navit.py:563-575. */

@@ -523,3 +523,82 @@ def test_generate_text_short_runs_and_empty_context(max_length):
     t = model.generate_text(past_key_values=empty, max_length=4, end_token_id=None, **st)
     assert t.shape == (4, 1) and empty.seq_lens == 4, "the decoded rows must land in the (previously empty) cache"
     assert model.generate_text(past_key_values=NaiveCache(L), max_length=0, end_token_id=None, **st).shape == (0, 1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# weight-only INT8 decode option (MI355X analogue of the reference's quantised load modes, app.py:114-131)
+# ------------------------------------------------------------------------------------------------------------
+def test_quantize_rows_i8_exact():
+    W = rnd(37, 272, seed=1, scale=0.05)
+    W[5] = 0                                                        # an all-zero row must not divide by zero
+    q, s = ops().quantize_rows_i8(W.to(DEV))
+    amax = W.float().abs().amax(dim=1)
+    s_ref = torch.where(amax > 0, amax / 127.0, torch.ones_like(amax))
+    q_ref = (torch.round(W.float() / s_ref[:, None]).clamp(-127, 127) + 128).to(torch.uint8)
+    assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu(), q_ref)
+    deq = (q.cpu().float() - 128) * s.cpu()[:, None]
+    assert (deq - W.float()).abs().max() <= 0.5 * s_ref.max() + 1e-9
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 3584), (1, 64, 18944), (2, 130, 256), (3, 96, 512), (4, 72, 1040), (1, 4608, 3584), (5, 34, 16)])
+def test_gemv_w8_matches_dequantised_reference(M, N, K):
+    """y = s_n (sum u8 x - 128 sum x) equals the fp32 product with the DEQUANTISED weights to fp32 rounding (then one bf16 rounding)."""
+    o = ops()
+    A, W, b, R = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1), rnd(M, N, seed=4)
+    q, s = o.quantize_rows_i8(W.to(DEV))
+    Wd = ((q.cpu().float() - 128) * s.cpu()[:, None])
+    ref = (A.float() @ Wd.t() + b.float()).to(BF16)
+    C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+    o.gemv_w8(A.to(DEV), q, s, C, bias=b.to(DEV))
+    close(C, ref, what=f"gemv_w8 {M}x{N}x{K}")
+    X = R.to(DEV).clone()
+    o.gemv_w8(A.to(DEV), q, s, X, bias=b.to(DEV), residual=X)
+    close(X, R + ref, ulps=2, what="gemv_w8 residual")
+    # and it is a faithful approximation of the bf16 product: row-wise absmax INT8 keeps ~0.5 % relative error
+    full = (A.float() @ W.float().t() + b.float())
+    err = ((C.float().cpu() - full).norm() / full.norm()).item()
+    assert err < 2e-2, f"int8 weights: rel_l2 {err:.3g} vs the bf16-weight product"
+
+
+def test_gemv_w8_swiglu_and_fused_norm():
+    from bagel_amd.modeling.bagel.qwen2_navit import interleave_gate_up
+    o = ops()
+    M, I, K = 2, 96, 512
+    A, Wg, Wu = rnd(M, K, seed=1, scale=2.0), rnd(I, K, seed=2, scale=K ** -0.5), rnd(I, K, seed=3, scale=K ** -0.5)
+    w = (1.0 + 0.1 * rnd(K, seed=4).float()).to(BF16)
+    Wi = interleave_gate_up(Wg, Wu)
+    q, s = o.quantize_rows_i8(Wi.to(DEV))
+    Wd = ((q.cpu().float() - 128) * s.cpu()[:, None]).view(I // 16, 2, 16, K)
+    Wgd, Wud = Wd[:, 0].reshape(I, K), Wd[:, 1].reshape(I, K)
+    h = ref_rmsnorm(A, w, 1e-6)
+    ref = F.silu((h.float() @ Wgd.t()).to(BF16)) * (h.float() @ Wud.t()).to(BF16)
+    C = torch.empty((M, I), dtype=BF16, device=DEV)
+    o.gemv_w8(A.to(DEV), q, s, C, epilogue=3, norm_w=w.to(DEV), eps=1e-6)
+    close(C, ref, ulps=2, what="gemv_w8 rmsnorm+swiglu")
+
+
+def test_generate_text_int8_weights_option():
+    """weight_quant='int8': same loop, graph replay == eager, logits within the quantisation noise of the bf16 path."""
+    from oracle.configs import TINY_D128 as cfg
+    from tests.util_models import product_model
+    model, _ = product_model(cfg)
+    cache, lens, ropes, start = _context(model, cfg, ["a small red cube"])
+    n = 8
+    ref = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, **start)
+    ref_logits = model._last_decode_session.logits.float().clone()
+    a = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, weight_quant="int8", use_graph=True, **start)
+    sess = model._last_decode_session
+    assert sess.weight_quant == "int8" and sess.graph is not None
+    q_logits = sess.logits.float().clone()
+    b = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, weight_quant="int8", use_graph=False, **start)
+    assert torch.equal(a, b) and a.shape == ref.shape
+    if torch.equal(a, ref):          # same token history -> the last-step logits are comparable
+        err = ((q_logits - ref_logits).norm() / ref_logits.norm()).item()
+        assert err < 5e-2, f"int8-weight logits differ from bf16-weight logits by rel_l2 {err:.3g}"
+    assert torch.equal(a[0], ref[0])
+    model.decode_weight_quant = "int8"                                     # the model-level switch (load-time mode in the reference)
+    try:
+        c = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, **start)
+    finally:
+        model.decode_weight_quant = None
+    assert torch.equal(c, a)
