@@ -107,3 +107,19 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
     img = torch.load(out)
     _compare(img.numpy(), golden("tiny_inferencer")["t2i"]["image"], "reference recipe, text -> image", 1.5, 8)
+
+
+def test_chat_entry_point_matches_inferencer_understanding(golden):
+    """Bagel.chat (bagel.py:1004-1074, the eval/vlm entry): ViT prefill per image -> text prefill -> greedy decode; the same
+    request through InterleaveInferencer(understanding_output=True) must give the same answer (and both match the reference's)."""
+    from PIL import Image
+    from oracle.configs import TINY, NEW_TOKEN_IDS_TINY, StubTokenizer
+    g = golden("tiny_inferencer")
+    inf = _inferencer(TINY)
+    src = Image.fromarray(g["source_image"].numpy(), "RGB")
+    want = inf(image=src, text=g["understanding"]["text"], **g["understanding"]["kwargs"])["text"]
+    tok = StubTokenizer(TINY["llm"]["vocab_size"])
+    # chat feeds the resized image through the ViT transform itself (bagel.py:1022-1035)
+    got = inf.model.chat(tok, NEW_TOKEN_IDS_TINY, inf.vit_transform, [inf.vae_transform.resize_transform(src)], g["understanding"]["text"],
+                         max_length=g["understanding"]["kwargs"]["max_think_token_n"])
+    assert got == want == g["understanding"]["answer"], (got, want, g["understanding"]["answer"])
