@@ -492,7 +492,13 @@ def scenario_inferencer(cfg, model, vae, W, VW):
         kw3 = dict(understanding_output=True, do_sample=False, max_think_token_n=6)
         r = inf(image=Image.fromarray(src, "RGB"), text="what is it", **kw3)
         out["understanding"] = dict(kwargs=kw3, text="what is it", answer=r["text"])
+        torch.manual_seed(52)
+        kw4 = dict(think=True, max_think_token_n=5, do_sample=False, num_timesteps=4, cfg_text_scale=4.0, cfg_img_scale=1.0,
+                   cfg_interval=[0.4, 1.0], timestep_shift=3.0, cfg_renorm_type="global", image_shapes=(32, 48))
+        r = inf(text="a tiny red cube", **kw4)          # planning text first (inferencer.py:259-266), then the image conditioned on it
+        out["think"] = dict(kwargs=kw4, text="a tiny red cube", seed=52, thought=r["text"], image=torch.from_numpy(np.array(r["image"])))
     assert out["t2i"]["image"].shape == (64, 48, 3) and out["edit"]["image"].dtype == torch.uint8 and isinstance(out["understanding"]["answer"], str)
+    assert isinstance(out["think"]["thought"], str) and out["think"]["image"].shape == (32, 48, 3)
     return out
 
 

@@ -123,3 +123,22 @@ def test_chat_entry_point_matches_inferencer_understanding(golden):
     got = inf.model.chat(tok, NEW_TOKEN_IDS_TINY, inf.vit_transform, [inf.vae_transform.resize_transform(src)], g["understanding"]["text"],
                          max_length=g["understanding"]["kwargs"]["max_think_token_n"])
     assert got == want == g["understanding"]["answer"], (got, want, g["understanding"]["answer"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_think_then_generate_flow(golden, name):
+    """think=True (inferencer.py:236-266): system prompt -> greedy planning text -> the text is fed back as context -> image.  The
+    planning text must match the reference's up to a greedy near-tie; when it matches entirely the image is comparable too."""
+    from oracle.configs import TINY, TINY_D128
+    cfg = {"tiny": TINY, "tiny_d128": TINY_D128}[name]
+    g = golden(f"{name}_inferencer")["think"]
+    inf = _inferencer(cfg)
+    torch.manual_seed(g["seed"])
+    r = inf(text=g["text"], **g["kwargs"])
+    ours, ref = re.findall(r"\[(\d+)\]", r["text"]), re.findall(r"\[(\d+)\]", g["thought"])
+    assert len(ours) == len(ref) and ours[0] == ref[0], (r["text"], g["thought"])
+    assert r["image"].size == (g["image"].shape[1], g["image"].shape[0])
+    if ours == ref:
+        _compare(r["image"], g["image"], "think -> image", 1.5, 8)
+    else:
+        print(f"planning text diverged at a near tie ({r['text']} vs {g['thought']}): image not comparable")
