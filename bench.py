@@ -328,7 +328,7 @@ def understanding_subprocess(args, local):
     import subprocess
     env = dict(os.environ)
     env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1")
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding"] + (["--no-cpu-baseline"] if args.no_cpu_baseline or int(os.environ.get("RANK", 0)) != 0 else []) + [
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding"] + (["--no-cpu-baseline"] if args.no_cpu_baseline or int(os.environ.get("WORLD_SIZE", 1)) != 1 else []) + [
            "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image), "--und-batch", str(args.und_batch)]
     if args.layers is not None:
         cmd += ["--layers", str(args.layers)]
@@ -557,7 +557,9 @@ def main():
         if args.layers is not None or args.no_vae or R != 1024 or T != 50:
             out["valid"] = False
             out["note"] = "debug flags reduce the workload: not a benchmark number"
-        if not args.no_cpu_baseline:
+        if world > 1:
+            out["cpu_baseline"] = None      # timed on rank 0 at N=1 only: the host cores are shared by N ranks here
+        elif not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, cfg)
             except Exception as e:   # the baseline is reported, never required for the GPU number
