@@ -570,6 +570,420 @@ static int launch_gemm_pp(const GemmParams& p0, hipStream_t stream) {
     return bagel_check_launch("gemm_pp_kernel");
 }
 
+// =========================================================================================================
+// Persistent form of the ping-pong kernel (variant 4).
+//
+// One workgroup per CU (the LDS allows no second one) walks the tile list with stride gridDim.x, so the per-tile costs
+// that a fresh workgroup pays in the open -- dispatch, the HBM latency of the first k-tile, the store tail -- run
+// underneath neighbouring work instead:
+//   * when the k-loop of tile X ends, the DMA of k-tile 0 of tile X+1 is issued into LDS stage 0 BEFORE the epilogue of
+//     tile X starts; the epilogue stages the bf16 tile through stage 1 only (two 128-row passes for a plain epilogue,
+//     one pass for SwiGLU whose tile is half as wide), then k-tile 1 goes into stage 1 and the k-loop restarts with
+//     exactly the in-flight DMA sequence its counted waits expect;
+//   * hipcc does not see the asm DMA, so ANY wait it inserts for a load of its own drains the DMA pipe as well.  The
+//     MoT row lists (A gather rows, C scatter rows) therefore never pass through a hipcc-counted load: the 256 + 256
+//     indices of tile X+2 are fetched at the end of tile X by a 4-byte LDS-DMA (one instruction per wave) into a
+//     three-deep table ring behind the two k-tile stages and read back with ds_read.  What is left for hipcc are the
+//     residual rows (issued before k-tile 0, so waiting for them costs their own latency only) and the bias;
+//   * the epilogue's stores are never waited for individually: the restart wait `vmcnt(6)` (only the six newest DMA
+//     instructions may be in flight) covers k-tile 0 and every store, whatever order loads and stores retire in.
+// Tile order: work item w keeps its XCD (gridDim.x is a multiple of 8), same band walk as variant 3.
+// =========================================================================================================
+__device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_uniform)
+                 : "memory");
+}
+
+// MODE fixes the epilogue at compile time (0 SwiGLU pairing, 1 residual add, 2 bias, 3 plain) so that no load of hipcc's sits
+// behind a run-time branch: after such a join its wait counting turns conservative and drains the DMA pipe.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
+    constexpr bool SWIGLU = MODE == 0, HAS_R = MODE == 1, HAS_BIAS = MODE == 2;
+    constexpr int BM = 256, BN = 256;
+    constexpr int PIECE = 128 * 128;
+    constexpr int STAGE = 4 * PIECE;
+    constexpr int OFF_A0 = 0, OFF_B0 = PIECE, OFF_B1 = 2 * PIECE, OFF_A1 = 3 * PIECE;
+    constexpr int TBL = 2 * STAGE;                 // row tables: [3 buffers][A rows | C rows][256] int
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wj = wave & 3;
+    const bool g1 = grp != 0;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int nk = p.K >> 6;
+    const int stride = gridDim.x;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)smem);
+
+    auto tile_of = [&](int w, int& tm, int& tn) {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = w & 7, loc = w >> 3;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int GM = p.gm;
+        const int band = bid / (GM * p.tiles_n);
+        const int band_rows = min(GM, p.tiles_m - band * GM);
+        const int inb = bid - band * GM * p.tiles_n;
+        tm = band * GM + inb % band_rows;
+        tn = inb / band_rows;
+    };
+    auto group_of = [&](int tm) { return (p.ngroups > 1 && tm >= p.g[1].tile0) ? 1 : 0; };
+    // Row tables of tile row tm into ring slot `buf`: waves 0-3 fetch the 256 physical A rows, waves 4-7 the 256 physical
+    // C/R rows (logical rows past the group's end are clamped; their results are never stored).
+    auto fetch_tables = [&](int tm, int buf) {
+        const int gi = group_of(tm);
+        const int Mg = p.g[gi].M;
+        const int m0 = (tm - p.g[gi].tile0) * BM;
+        const int* __restrict__ lst = g1 ? p.g[gi].c_rows : p.g[gi].a_rows;
+        int m = m0 + wj * 64 + lane;
+        m = m < Mg ? m : Mg - 1;
+        const unsigned off = TBL + buf * 2048 + grp * 1024 + wj * 256;
+        if (lst) glds4_asm(lst + m, smem_base + off);
+        else *(int*)(smem + off + lane * 4) = m;
+    };
+    const char* src[4][2];   // [piece][i]
+    // DMA sources of tile (tm, tn): piece-local row lr = 8*j + lane/8 (j = wave + 8*i), LDS chunk lane%8, global chunk
+    // swizzled; A rows come from the table in ring slot `buf`.  `ln` is an opaque copy of the lane id (keeps hipcc from
+    // hoisting this arithmetic out of the tile loop and spilling it across the k-loop).
+    auto make_src = [&](int tm, int tn, int buf, int ln) {
+        const bf16_t* __restrict__ Wg = p.g[group_of(tm)].W;
+        const int n0 = tn * BN;
+        const int* atab = (const int*)(smem + TBL + buf * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (wave + 8 * i) * 8 + (ln >> 3);
+            const int gch16 = ((ln & 7) ^ ((lr >> 1) & 7)) * 16;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int row = atab[(lr >> 6) * 128 + half * 64 + (lr & 63)];
+                src[half ? 3 : 0][i] = (const char*)(p.A + (long)row * p.lda) + gch16;
+                int n = n0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
+                n = n < p.N ? n : p.N - 1;
+                src[half ? 2 : 1][i] = (const char*)(Wg + (long)n * p.ldw) + gch16;
+            }
+        }
+    };
+    auto pin_src = [&]() {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(src[pc][i]));
+    };
+    auto issue = [&](int piece, unsigned stage_base, long koff) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wave + 8 * i;
+            const unsigned d = (piece == 0 ? OFF_A0 : piece == 1 ? OFF_B0 : piece == 2 ? OFF_B1 : OFF_A1) + j * 1024;
+            glds16_asm(src[piece][i] + koff, stage_base + d);
+        }
+    };
+
+    const int fr = lane & 15;
+    const int sw = fr >> 1;
+    const int ch0 = ((lane >> 4) ^ sw) << 4;
+    const int ch1 = (((lane >> 4) + 4) ^ sw) << 4;
+    const int a_row = (grp * 64 + fr) * 128;
+    const int b_row = (wj * 32 + fr) * 128;
+
+    f32x4_t acc[2][4][2][2];   // [ma][i][nb][jn]
+    bf16x8_t af[4][2], b0f[2][2], b1f[2][2];
+    auto read_a = [&](const char* sb, int off) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const bf16x8_t*)(sb + off + a_row + i * 2048 + ch0);
+            af[i][1] = *(const bf16x8_t*)(sb + off + a_row + i * 2048 + ch1);
+        }
+    };
+    auto read_b = [&](bf16x8_t (&bf)[2][2], const char* sb, int off) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf[j][0] = *(const bf16x8_t*)(sb + off + b_row + j * 2048 + ch0);
+            bf[j][1] = *(const bf16x8_t*)(sb + off + b_row + j * 2048 + ch1);
+        }
+    };
+    auto mma = [&](int ma, bf16x8_t (&bf0)[2][2], bf16x8_t (&bf1)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ma][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j][kh], af[i][kh], acc[ma][i][0][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ma][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j][kh], af[i][kh], acc[ma][i][1][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- first tile: row tables of tiles 0 and 1, then the standard two-k-tile prologue ----
+    int w = blockIdx.x, tm, tn;
+    tile_of(w, tm, tn);
+    int wn = w + stride, tmn = 0, tnn = 0;
+    fetch_tables(tm, 0);
+    if (wn < nblk) { tile_of(wn, tmn, tnn); fetch_tables(tmn, 1); }
+    PP_VMCNT(0);
+    PP_LGKM0();
+    PP_BARRIER();
+    make_src(tm, tn, 0, lane);
+    pin_src();
+    issue(0, smem_base, 0); issue(1, smem_base, 0); issue(2, smem_base, 0); issue(3, smem_base, 0);
+    issue(0, smem_base + STAGE, 128); issue(1, smem_base + STAGE, 128); issue(2, smem_base + STAGE, 128);
+    PP_VMCNT(8);
+    PP_BARRIER();
+    if (g1) PP_BARRIER();   // group 1 runs one slot behind
+
+    char* const stg = smem + STAGE;                // the epilogue stages through LDS stage 1 only
+    int slot = 0;                                  // ring slot of the current tile's tables (tile counter mod 3)
+    for (;;) {
+        const int gi = group_of(tm);
+        const bf16_t* __restrict__ biasg = p.g[gi].bias;
+        const int Mg = p.g[gi].M;
+        const int m0 = (tm - p.g[gi].tile0) * BM;
+        const int n0 = tn * BN;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        // ---- k-loop: identical to variant 3 (see the schedule comment there) ----
+        for (int t = 0; t < nk; ++t) {
+            const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+            const char* sb = smem + (t & 1) * STAGE;
+            const unsigned s_same = smem_base + (t & 1) * STAGE;
+            const unsigned s_other = smem_base + ((t + 1) & 1) * STAGE;
+            if (more1) issue(3, s_other, (long)(t + 1) * 128);
+            read_a(sb, OFF_A0);
+            read_b(b0f, sb, OFF_B0);
+            read_b(b1f, sb, OFF_B1);
+            PP_LGKM0();
+            if (g1) { if (more1) PP_VMCNT(8); else PP_VMCNT(0); }
+            PP_BARRIER();
+            mma(0, b0f, b1f);
+            if (!g1) { if (more1) PP_VMCNT(8); else PP_VMCNT(0); }
+            PP_BARRIER();
+            if (more2) { issue(0, s_same, (long)(t + 2) * 128); issue(1, s_same, (long)(t + 2) * 128); issue(2, s_same, (long)(t + 2) * 128); }
+            read_a(sb, OFF_A1);
+            PP_LGKM0();
+            if (g1 && more1) { if (more2) PP_VMCNT(8); else PP_VMCNT(2); }
+            PP_BARRIER();
+            mma(1, b0f, b1f);
+            if (!g1 && more1) { if (more2) PP_VMCNT(8); else PP_VMCNT(2); }
+            PP_BARRIER();
+        }
+        if (!g1) PP_BARRIER();
+        PP_BARRIER();                              // every wave is past its last fragment read: both stages are free
+
+        // ---- between two k-loops.  Opaque copies of the lane / wave ids keep hipcc from hoisting this block's address
+        //      arithmetic out of the tile loop (it spilled ~200 VGPRs across the k-loop doing so) ----
+        int elane = lane, ewave = wave;
+        asm volatile("" : "+v"(elane));
+        asm volatile("" : "+s"(ewave));
+        const int efr = elane & 15, ensub = (elane >> 4) * 4, egrp = ewave >> 2, ewj = ewave & 3;
+        const int* ctab = (const int*)(smem + TBL + slot * 2048 + 1024);
+        const bool has_next = wn < nblk;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        const int w2 = wn + stride;
+        int tm2 = 0, tn2 = 0;
+
+        // next tile: tables of the tile after it, then k-tile 0 into stage 0
+        auto start_next = [&]() {
+            if (has_next) {
+                if (w2 < nblk) { tile_of(w2, tm2, tn2); fetch_tables(tm2, slot2); }
+                make_src(tmn, tnn, slot1, elane);
+                pin_src();
+                issue(0, smem_base, 0); issue(1, smem_base, 0); issue(2, smem_base, 0); issue(3, smem_base, 0);
+            }
+        };
+
+        // ---- epilogue of the current tile, staged through LDS stage 1 (64 KB); only the stores are predicated ----
+        if constexpr (SWIGLU) {
+            // LDS image: [256 rows][128 bf16], 8-byte chunk c8 of row r stored at c8 ^ (r & 15)
+            const int qs = elane & 15;
+            const int oc = (n0 >> 1) + qs * 8;
+            const bool col_ok = oc < (p.N >> 1);
+            int crow[8];                           // physical C rows of this lane's 8 store rows
+            const int rb = ewave * 4 + (elane >> 4);          // store row of iteration `it` = it*32 + rb, rb < 32
+#pragma unroll
+            for (int it = 0; it < 8; ++it) crow[it] = ctab[it * 32 + rb];
+            start_next();
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = egrp * 128 + ma * 64 + i * 16 + efr;
+                    char* rowp = stg + r * 256;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const int c = ewj * 32 + nb * 16 + ensub;
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g = bfround(acc[ma][i][nb][0][e]);
+                            const float u = bfround(acc[ma][i][nb][1][e]);
+                            o[e] = bfround(silu_f(g)) * u;
+                        }
+                        u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                        *(u32x2_t*)(rowp + (((c >> 2) ^ efr) << 3)) = v;
+                    }
+                }
+            PP_LGKM0();
+            PP_BARRIER();
+            {
+                const int x = rb & 15;             // = row & 15 for every iteration
+                const int P = (qs & ~7) | ((qs & 7) ^ (x >> 1));
+                const char* rd = stg + rb * 256 + (P << 4);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    u32x4_t v = *(const u32x4_t*)(rd + it * 8192);
+                    if (x & 1) { v = (u32x4_t){v[2], v[3], v[0], v[1]}; }
+                    if (col_ok && m0 + it * 32 + rb < Mg) *(u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc) = v;
+                }
+            }
+            PP_LGKM0();
+        } else {
+            // hipcc's own loads go out FIRST: bias (retired here), residual rows of pass 0 (waited for in the store-out, by
+            // which time k-tile 0 -- issued right behind them -- costs nothing extra)
+            const int qs = elane & 31;
+            const int oc = n0 + qs * 8;
+            const bool col_ok = oc < p.N;
+            const int occ = col_ok ? oc : 0;
+            u32x2_t bv[2][2];
+            if constexpr (HAS_BIAS) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) {
+                        const int n = n0 + ewj * 64 + nb * 32 + jn * 16 + ensub;
+                        bv[nb][jn] = *(const u32x2_t*)(biasg + min(n, p.N - 4));
+                    }
+            }
+            // staging row of iteration `it` = it*16 + rbase (rbase < 16) -> tile row (it>>2)*128 + ma*64 + (it&3)*16 + rbase
+            const int rbase = ewave * 2 + (elane >> 5);
+            int crow[8];                           // physical C rows of this lane's 8 store rows of the pass
+#pragma unroll
+            for (int it = 0; it < 8; ++it) crow[it] = ctab[rbase + (it >> 2) * 128 + (it & 3) * 16];
+            if constexpr (HAS_BIAS) {              // retired here, before the next tile's DMA is in flight
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+v"(bv[nb][jn]));
+            }
+            u32x4_t rv[8];
+            if constexpr (HAS_R) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) rv[it] = *(const u32x4_t*)(p.R + (long)crow[it] * p.ldr + occ);
+            }
+            start_next();
+            // two passes of 128 rows (pass ma = rows [64*ma, 64*ma+64) of both groups); LDS image [128][256 bf16]
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma) {
+                if (ma == 1) {
+                    PP_BARRIER();                  // pass 0's reads of the staging area have retired
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) crow[it] = ctab[rbase + (it >> 2) * 128 + 64 + (it & 3) * 16];
+                    if constexpr (HAS_R) {         // residual rows of pass 1: in flight underneath the fragment phase
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) rv[it] = *(const u32x4_t*)(p.R + (long)crow[it] * p.ldr + occ);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = egrp * 64 + i * 16 + efr;
+                    char* rowp = stg + rr * 512;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn) {
+                            const int c = ewj * 64 + nb * 32 + jn * 16 + ensub;
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = acc[ma][i][nb][jn][e];
+                            if constexpr (HAS_BIAS) {
+                                o[0] += lo2f(bv[nb][jn][0]); o[1] += hi2f(bv[nb][jn][0]);
+                                o[2] += lo2f(bv[nb][jn][1]); o[3] += hi2f(bv[nb][jn][1]);
+                            }
+                            u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                            *(u32x2_t*)(rowp + (((c >> 2) ^ efr) << 3)) = v;
+                        }
+                }
+                PP_LGKM0();
+                PP_BARRIER();
+                const int P = (qs & ~7) | ((qs & 7) ^ (rbase >> 1));   // rbase = staging row & 15 for every iteration
+                const char* rd = stg + rbase * 512 + (P << 4);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int r = (it >> 2) * 128 + ma * 64 + (it & 3) * 16 + rbase;
+                    u32x4_t v = *(const u32x4_t*)(rd + it * 8192);
+                    if (rbase & 1) { v = (u32x4_t){v[2], v[3], v[0], v[1]}; }
+                    if constexpr (HAS_R) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = pack2bf(lo2f(v[e]) + lo2f(rv[it][e]), hi2f(v[e]) + hi2f(rv[it][e]));
+                    }
+                    if (col_ok && m0 + r < Mg) *(u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc) = v;
+                }
+                PP_LGKM0();
+            }
+        }
+        if (!has_next) break;
+        // ---- restart: k-tile 1 of the next tile into stage 1 once the staging area is drained ----
+        PP_BARRIER();
+        make_src(tmn, tnn, slot1, elane);
+        pin_src();
+        issue(0, smem_base + STAGE, 128); issue(1, smem_base + STAGE, 128); issue(2, smem_base + STAGE, 128);
+        PP_VMCNT(6);                               // k-tile 0 (issued before the epilogue), the tables and every store have retired
+        PP_BARRIER();
+        if (g1) PP_BARRIER();
+        w = wn; tm = tmn; tn = tnn;
+        wn = w2; tmn = tm2; tnn = tn2;
+        slot = slot1;
+    }
+}
+
+template <int MODE>
+static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream) {
+    GemmParams p = p0;
+    int t = 0;
+    for (int g = 0; g < p.ngroups; ++g) {
+        p.g[g].tile0 = t;
+        t += ceil_div(p.g[g].M, 256);
+    }
+    p.tiles_m = t;
+    p.tiles_n = ceil_div(p.N, 256);
+    if (t == 0) return BAGEL_OK;
+    static int gm = 0, wgs = 0;
+    if (gm == 0) {
+        const char* e = getenv("BAGEL_GEMM_GM");
+        gm = (e && atoi(e) > 0) ? atoi(e) : 4;
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* w = getenv("BAGEL_GEMM_PERSIST_WGS");
+        wgs = (w && atoi(w) > 0) ? atoi(w) : cus;
+        wgs = wgs < 8 ? 8 : (wgs & ~7);            // a multiple of 8 keeps every work item of a workgroup on its XCD
+    }
+    p.gm = gm;
+    constexpr int smem = 2 * 4 * 128 * 128 + 3 * 2048;   // two k-tile stages + the three-deep row-table ring
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_pq_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    const int nblk = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(gemm_pq_kernel<MODE>, dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
+    return bagel_check_launch("gemm_pq_kernel");
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
@@ -600,7 +1014,7 @@ extern "C" int bagel_gemm_bf16(const void* A, int64_t lda,
     BAGEL_REQUIRE(K > 0 && (K % 8) == 0, "gemm: K=%d must be a positive multiple of 8 (pad the operand)", K);
     BAGEL_REQUIRE(N > 0 && (N % 8) == 0, "gemm: N=%d must be a multiple of 8", N);
     BAGEL_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (ldc % 4) == 0 && (ldr % 4) == 0, "gemm: leading dims must keep rows 16-byte aligned");
-    if (variant == 3 && ((ldc % 8) != 0 || (ldr % 8) != 0 || (((uintptr_t)C | (uintptr_t)R) & 15) != 0 || (epilogue == EPI_SWIGLU16 && (N % 16) != 0)))
+    if ((variant == 3 || variant == 4) && ((ldc % 8) != 0 || (ldr % 8) != 0 || (((uintptr_t)C | (uintptr_t)R) & 15) != 0 || (epilogue == EPI_SWIGLU16 && (N % 16) != 0)))
         variant = 1;   // the ping-pong kernel stores 16-byte row chunks
     BAGEL_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm: unknown epilogue %d", epilogue);
     BAGEL_REQUIRE(epilogue != EPI_SWIGLU16 || ((N % 32) == 0 && !bias0 && !R), "gemm: swiglu needs N%%32==0, no bias/residual");
@@ -621,6 +1035,16 @@ extern "C" int bagel_gemm_bf16(const void* A, int64_t lda,
         case 3:
             if ((K & 63) != 0) return launch_gemm<256, 256, 2, 4>(p, stream);   // the ping-pong kernel has no K tail
             return launch_gemm_pp<0>(p, stream);
+        case 4: {   // persistent ping-pong; epilogue combinations it does not instantiate go to variant 3
+            if ((K & 63) != 0) return launch_gemm<256, 256, 2, 4>(p, stream);
+            const bool has_bias = p.g[0].bias != nullptr || p.g[1].bias != nullptr;
+            const bool all_bias = p.g[0].bias != nullptr && p.g[1].bias != nullptr;
+            if (K < 128 || epilogue == EPI_GELU_TANH || epilogue == EPI_SILU || (has_bias && (R || !all_bias))) return launch_gemm_pp<0>(p, stream);
+            if (epilogue == EPI_SWIGLU16) return launch_gemm_pq<0>(p, stream);
+            if (R) return launch_gemm_pq<1>(p, stream);
+            if (has_bias) return launch_gemm_pq<2>(p, stream);
+            return launch_gemm_pq<3>(p, stream);
+        }
         case 13: return launch_gemm_pp<1>(p, stream);   // timing-only ablation (results are garbage): no DMA in the k-loop
         default: return bagel_set_error(BAGEL_ERR_ARG, "gemm: unknown variant %d", variant);
     }

@@ -46,12 +46,14 @@ def default_gemm_variant(M, N, K):
     v = os.environ.get("BAGEL_GEMM_VARIANT")
     if v is not None:
         return int(v)
-    # measured on MI355X at the denoise shapes (M = 16392; profiles/r01_kernel_probe*.json): the 256x256 two-group
-    # ping-pong kernel (variant 3) wins on every projection; small-M launches (prefill of a short prompt, decode, time
-    # embedder) keep the 128x128 tile so the grid still covers the chip.  Variant 3 needs K % 64 == 0 and falls back to
-    # the plain 256x256 kernel (variant 1) otherwise.
+    # measured on MI355X at the denoise shapes (M = 16392; profiles/r01_kernel_probe*.json, r01_gemm_persistent.log): the
+    # 256x256 two-group ping-pong kernel wins on every projection, and its persistent form (variant 4: one workgroup per CU
+    # walks the tile list, next tile's first DMA under the current epilogue) is bit-identical to the one-tile-per-workgroup
+    # form (variant 3) and 3.5 % faster over the four GEMMs of a layer; the library falls back to variant 3 for the epilogue
+    # combinations variant 4 does not instantiate and to the plain 256x256 kernel (variant 1) when K % 64 != 0.  Small-M
+    # launches (prefill of a short prompt, decode, time embedder) keep the 128x128 tile so the grid still covers the chip.
     if M >= 2048 and N >= 512:
-        return 3
+        return 4
     return 0
 
 

@@ -524,7 +524,7 @@ def main():
     if rank == 0:
         # the dominant kernel = the GEMM variant that carries the most FLOPs in the timed region
         names = {0: "gemm_tn_kernel<128,128,2,2>", 1: "gemm_tn_kernel<256,256,2,4>", 2: "gemm_tn_kernel<256,128,2,2>",
-                 3: "gemm_pp_kernel<0>"}
+                 3: "gemm_pp_kernel<0>", 4: "gemm_pq_kernel<*>"}
         by_v = {}
         for r in records:
             by_v[r[3]] = by_v.get(r[3], 0.0) + r[0]

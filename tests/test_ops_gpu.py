@@ -68,7 +68,7 @@ def ref_gemm(A, W, bias=None, epi=0, residual=None):
     return c
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(1, 128, 64), (7, 136, 128), (300, 520, 200), (1000, 256, 144), (513, 384, 3584), (130, 64, 512)])
 def test_gemm_plain_bias(M, N, K, variant):
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
@@ -89,7 +89,7 @@ def test_gemm_activation_and_residual(epi):
     close(X, ref_gemm(A, W, b, 0, R), ulps=2, what="gemm residual in place")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4])
 def test_gemm_swiglu(variant):
     from bagel_amd.modeling.bagel.qwen2_navit import interleave_gate_up
     M, I, K = 333, 416, 256
@@ -101,7 +101,7 @@ def test_gemm_swiglu(variant):
     close(C, ref, ulps=2, what="gemm swiglu")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4])
 def test_gemm_two_expert_groups(variant):
     """MoT routing: text rows -> W0, latent rows -> W1, rows interleaved like <start> latents <end> per sample."""
     H, N = 256, 392
@@ -141,6 +141,25 @@ def test_gemm_pingpong_race_screen():
             close(C3, C0.cpu(), ulps=1, what="ping-pong vs tile kernel")
         else:
             assert torch.equal(first.view(torch.int16), C3.view(torch.int16)), f"ping-pong GEMM is not deterministic (repeat {rep})"
+
+
+@pytest.mark.parametrize("wgs", ["8", "24", ""])
+def test_gemm_persistent_identical_to_pingpong(wgs):
+    """variant 4 (persistent ping-pong: tile loop inside the kernel, next tile's DMA under the current epilogue, MoT row lists
+    through an LDS table ring) must reproduce variant 3 BIT FOR BIT on every epilogue mode, with and without row lists, over
+    repeats -- with 8 / 24 workgroups (every workgroup walks several tiles even on these small problems) and with the default
+    one-per-CU grid.  Own process: the grid size is read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if wgs:
+        env["BAGEL_GEMM_PERSIST_WGS"] = wgs
+    else:
+        env.pop("BAGEL_GEMM_PERSIST_WGS", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_persist_check.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL IDENTICAL" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_gemm_gather_rows_dense_out():
