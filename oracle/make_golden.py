@@ -565,6 +565,8 @@ def main():
                 continue   # VAE config is shared
             if cfg is TINY_ROPE and name != "siglip":
                 continue   # only the ViT differs
+            if name == "inferencer":
+                model, vae, W, VW = build(cfg)   # enable_taylorseer leaves per-layer cache state on the reference modules
             data = fn(cfg, model, vae, W, VW)
             path = os.path.join(GOLD, f"{cfg['name']}_{name}.pt")
             torch.save(data, path)
