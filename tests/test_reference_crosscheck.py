@@ -60,3 +60,54 @@ def test_oracle_bit_exact_vs_live_reference_variants(cfg):
     model, vae, W, VW = G.build(cfg)
     fn = G.scenario_siglip if cfg is TINY_ROPE else G.scenario_layer_kind
     assert fn(cfg, model, vae, W, VW)
+
+
+def _same_out(a, b, what):
+    """Packer outputs: dict of tensors / lists, bit-exact incl. dtype and shape."""
+    assert set(a) == set(b), (what, set(a) ^ set(b))
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert torch.is_tensor(b[k]) and a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (what, k)
+        else:
+            assert a[k] == b[k], (what, k)
+
+
+def test_product_packers_equal_live_reference_on_random_inputs():
+    """Randomised differential test of every host packer on the path (bagel.py:232-266,299-360,417-489,
+    552-641,909-927) -- the PRODUCT's Bagel.prepare_* against the unmodified reference's on 40 random request shapes
+    (ragged batches, empty prompts, non-zero running kv lens / rope offsets, non-square images): integer tensors, lists and
+    the seeded init noise must be bit-identical."""
+    import random
+    from oracle import make_golden as G
+    from oracle.configs import NEW_TOKEN_IDS_TINY as ids, StubTokenizer
+    from bagel_amd.factory import build_bagel
+    ref, _, _, _ = G.build(TINY)
+    mine, _ = build_bagel(TINY, device="cpu")
+    tok = StubTokenizer(TINY["llm"]["vocab_size"])
+    ident = lambda t: t  # noqa: E731
+    rng = random.Random(1234)
+    words = ["a", "red", "cube", "", "on the table", "sky", "x y z w", "hello world again"]
+    for case in range(40):
+        B = rng.randint(1, 4)
+        kv = [rng.randint(0, 40) for _ in range(B)]
+        rope = [rng.randint(0, 30) for _ in range(B)]
+        prompts = [" ".join(rng.choice(words) for _ in range(rng.randint(0, 3))) for _ in range(B)]
+        a, b = mine.prepare_prompts(list(kv), list(rope), prompts, tok, ids), ref.prepare_prompts(list(kv), list(rope), prompts, tok, ids)
+        _same_out(a[0], b[0], f"prepare_prompts #{case}"); assert a[1:] == b[1:]
+        sizes = [(16 * rng.randint(1, 6), 16 * rng.randint(1, 6)) for _ in range(B)]
+        torch.manual_seed(case); a = mine.prepare_vae_latent(list(kv), list(rope), sizes, ids)
+        torch.manual_seed(case); b = ref.prepare_vae_latent(list(kv), list(rope), sizes, ids)
+        _same_out(a, b, f"prepare_vae_latent #{case}")
+        _same_out(mine.prepare_vae_latent_cfg(list(kv), list(rope), sizes), ref.prepare_vae_latent_cfg(list(kv), list(rope), sizes),
+                  f"prepare_vae_latent_cfg #{case}")
+        _same_out(mine.prepare_start_tokens(list(kv), list(rope), ids), ref.prepare_start_tokens(list(kv), list(rope), ids),
+                  f"prepare_start_tokens #{case}")
+        g = torch.Generator().manual_seed(case)
+        imgs = [torch.randn(3, 16 * rng.randint(1, 4), 16 * rng.randint(1, 4), generator=g) for _ in range(B)]
+        ts = rng.choice([0, 0.5])
+        a = mine.prepare_vae_images(list(kv), list(rope), imgs, ident, ids, timestep=ts)
+        b = ref.prepare_vae_images(list(kv), list(rope), imgs, ident, ids, timestep=ts)
+        _same_out(a[0], b[0], f"prepare_vae_images #{case}"); assert a[1:] == b[1:]
+        imgs = [torch.randn(3, 14 * rng.randint(1, 5), 14 * rng.randint(1, 5), generator=g) for _ in range(B)]
+        a, b = mine.prepare_vit_images(list(kv), list(rope), imgs, ident, ids), ref.prepare_vit_images(list(kv), list(rope), imgs, ident, ids)
+        _same_out(a[0], b[0], f"prepare_vit_images #{case}"); assert a[1:] == b[1:]
