@@ -25,6 +25,7 @@
 //   q-heads x q-tiles of one pair run back to back on that XCD, so its K/V (2.1 MB at 4098 keys) stays in the
 //   XCD's 4 MiB L2 while ~119 workgroups stream it.
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnParams {
     const bf16_t* q; long ldq;
@@ -61,7 +62,13 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 
 #define ATTN_DEFER_LOG2 8.0f
 
-template <int D>
+// SCHED = 0: hipcc's own instruction order.  SCHED = 1 (BAGEL_ATTN_SCHED=1): the same arithmetic in the same order -- results
+// are bit-identical -- with the LDS fragment reads software-pipelined by hand (sched_group_barrier): hipcc's schedule reads one
+// K / V^T fragment, waits for it, issues its MFMA, reads the next ... (a full LDS round trip in front of every MFMA: 32 per
+// tile); SCHED = 1 keeps 8 fragment reads in flight under the MFMAs and fetches the first half of the V^T tile before the
+// softmax so it lands under the exp/convert VALU work.  Waves 4-7 (the second-dispatched half, the arbitration loser on
+// every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.
+template <int D, int SCHED>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = D / 16;              // k-steps of the QK^T contraction
     constexpr int DB = D / 32;              // 32-row blocks of O^T
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
     int st = 0;
+    if (SCHED == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
         else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -193,15 +201,50 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 
         // ---- S^T = K Q^T ----
         f32x16_t s[2];
+        bf16x8_t vpre[2][4];   // SCHED = 1: V^T fragments of O^T blocks 0 and 1, fetched ahead of the softmax
+        if (SCHED == 0) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            bf16x8_t kf[KS];
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8_t kf[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8_t*)(sb + kb * 32 * KROW + kch[ks]);
+                for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8_t*)(sb + kb * 32 * KROW + kch[ks]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kb], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kb], 0, 0, 0);
+            }
+        } else {
+            // order pinned below: KS reads | KS x (MFMA, read) | KS x (MFMA, V read) -- every MFMA has KS reads in flight behind it
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8_t kf0[KS], kf1[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf0[ks] = *(const bf16x8_t*)(sb + kch[ks]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf1[ks] = *(const bf16x8_t*)(sb + 32 * KROW + kch[ks]);
+#pragma unroll
+            for (int db = 0; db < 2 && db < DB; ++db)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vpre[db][j] = *(const bf16x8_t*)(sb + db * 4096 + vch[j]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s[0], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s[1], 0, 0, 0);
+            constexpr int NVPRE = (DB < 2 ? DB : 2) * 4;
+            __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);                 // kf0 reads
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // QK MFMA (block 0)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // one kf1 read
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // QK MFMA (block 1)
+                if (ks < NVPRE) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one V^T read
+            }
+            if (NVPRE > KS) __builtin_amdgcn_sched_group_barrier(0x100, NVPRE - KS, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- mask (tile tails, causal), row max ----
@@ -257,13 +300,42 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         l_run += psum;
 
         // ---- O^T += V^T P^T ----
+        if (SCHED == 0) {
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            bf16x8_t vf[4];
+            for (int db = 0; db < DB; ++db) {
+                bf16x8_t vf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vf[j] = *(const bf16x8_t*)(sb + db * 4096 + vch[j]);
+                for (int j = 0; j < 4; ++j) vf[j] = *(const bf16x8_t*)(sb + db * 4096 + vch[j]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], pf[j], o[db], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], pf[j], o[db], 0, 0, 0);
+            }
+        } else {
+            // blocks 0/1 from the prefetched fragments while the fragments of blocks 2/3 are read; then blocks 2/3
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8_t vlate[2][4];
+            if (DB > 2) {
+#pragma unroll
+                for (int db = 2; db < DB; ++db)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vlate[db - 2][j] = *(const bf16x8_t*)(sb + db * 4096 + vch[j]);
+            }
+#pragma unroll
+            for (int db = 0; db < 2 && db < DB; ++db)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vpre[db][j], pf[j], o[db], 0, 0, 0);
+            if (DB > 2) {
+#pragma unroll
+                for (int db = 2; db < DB; ++db)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlate[db - 2][j], pf[j], o[db], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // PV MFMA (blocks 0/1)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one V^T read (blocks 2/3)
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -340,14 +412,21 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     const int nbpp = (nq / nkv) * p.nqt;
     const int pairs_per_xcd = ceil_div((long)batch * nkv, 8);
     const dim3 grid(8 * pairs_per_xcd * nbpp), block(512);
+    static const int sched = [] { const char* e = getenv("BAGEL_ATTN_SCHED"); return e ? atoi(e) : 0; }();   // read-once tuning knob
     if (head_dim == 128) {
         constexpr int smem = 3 * (64 * 256 + 128 * 128);
         static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set = true; }
-        hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, smem, stream, p);
+        if (!set) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            set = true;
+        }
+        if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<128, 1>), grid, block, smem, stream, p);
+        else            hipLaunchKernelGGL((attn_fwd_kernel<128, 0>), grid, block, smem, stream, p);
     } else if (head_dim == 64) {
         constexpr int smem = 3 * (64 * 128 + 64 * 128);
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, smem, stream, p);
+        if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<64, 1>), grid, block, smem, stream, p);
+        else            hipLaunchKernelGGL((attn_fwd_kernel<64, 0>), grid, block, smem, stream, p);
     } else {
         return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn: head_dim %d not in {64,128} (pad the head)", head_dim);
     }

@@ -56,12 +56,47 @@ def main():
         ref = torch.softmax(q @ k.t() * D ** -0.5, -1) @ v
         got = out[b * Lq:(b + 1) * Lq, h * D:(h + 1) * D].float()
         worst = max(worst, ((got - ref).abs().max() / ref.abs().max()).item())
+    dump = os.environ.get("BAGEL_ATTN_PROBE_DUMP")
+    if dump:
+        full = out.cpu().clone()
+        run(True)
+        torch.cuda.synchronize()
+        torch.save({"full": full, "causal": out.cpu().clone()}, dump)
     ms = timeit(run)
     fl = 4.0 * B * Lq * (Lq + C_ctx) * nq * D
-    print(f"attn_denoise: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  max_rel_err {worst:.3e}", flush=True)
+    tag = f"[BAGEL_ATTN_SCHED={os.environ.get('BAGEL_ATTN_SCHED', '0')}] "
+    print(f"{tag}attn_denoise: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  max_rel_err {worst:.3e}", flush=True)
     ms_c = timeit(lambda: run(True))
-    print(f"attn_causal : {ms_c:.3f} ms  {fl / 2 / ms_c / 1e9:.1f} TFLOP/s (half the work)", flush=True)
+    print(f"{tag}attn_causal : {ms_c:.3f} ms  {fl / 2 / ms_c / 1e9:.1f} TFLOP/s (half the work)", flush=True)
+
+
+def compare():
+    """python tools/attn_probe.py --compare: the kernel's schedule variants (BAGEL_ATTN_SCHED, read once per process) in child
+    processes on the same seeded inputs -- outputs must be BIT-IDENTICAL (the variants only reorder instructions) -- and timed."""
+    import subprocess
+    import tempfile
+    outs = {}
+    for v in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
+            path = f.name
+        env = dict(os.environ, BAGEL_ATTN_SCHED=v, BAGEL_ATTN_PROBE_DUMP=path)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
+        sys.stdout.write(r.stdout)
+        if r.returncode != 0:
+            sys.stdout.write(r.stderr[-2000:])
+            raise SystemExit(f"variant {v} failed")
+        outs[v] = torch.load(path)
+        os.unlink(path)
+    for k in ("full", "causal"):
+        same = torch.equal(outs["0"][k], outs["1"][k])
+        print(f"BAGEL_ATTN_SCHED 0 vs 1, {k}: {'bit-identical' if same else 'DIFFERENT'}", flush=True)
+        if not same:
+            d = (outs["0"][k].float() - outs["1"][k].float()).abs().max().item()
+            raise SystemExit(f"schedule variants differ ({k}): max|d| = {d}")
 
 
 if __name__ == "__main__":
-    main()
+    if "--compare" in sys.argv:
+        compare()
+    else:
+        main()
