@@ -67,7 +67,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // K / V^T fragment, waits for it, issues its MFMA, reads the next ... (a full LDS round trip in front of every MFMA: 32 per
 // tile); SCHED = 1 keeps 8 fragment reads in flight under the MFMAs and fetches the first half of the V^T tile before the
 // softmax so it lands under the exp/convert VALU work.  Waves 4-7 (the second-dispatched half, the arbitration loser on
-// every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.
+// every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.  Waves with no live query row
+// skip the arithmetic (1 904 workgroups at the denoise shape, 112 of them with 2 live rows of 256).
 template <int D, int SCHED>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = D / 16;              // k-steps of the QK^T contraction
@@ -198,6 +199,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         if (t + 2 < T) issue(st >= 1 ? st - 1 : 2, t + 2);
         const char* sb = smem + st * STAGE;
         st = st == 2 ? 0 : st + 1;
+        // SCHED = 1: a wave whose 32 query rows all lie past the end of the sample (the last 256-row tile of a 4098-row sample
+        // has 2 live rows: 7 of its 8 waves) keeps feeding the DMA ring and the barrier but skips the arithmetic -- it stores nothing.
+        if (SCHED == 1 && wrow0 >= Lq) continue;
 
         // ---- S^T = K Q^T ----
         f32x16_t s[2];
