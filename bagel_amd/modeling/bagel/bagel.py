@@ -8,6 +8,8 @@ Host/device split: every ``prepare_*`` packer runs on the host and returns the r
 T-1 step Euler loop only launches kernels (the reference re-derives lengths and syncs the host several times per
 layer per step).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -16,7 +18,7 @@ from ... import ops
 from ...data.data_utils import (get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
 from .modeling_utils import MLPconnector, PositionEmbedding, TimestepEmbedder
 from ..cache_utils.taylorseer import TaylorSeerState
-from .qwen2_navit import NaiveCache, _Linear
+from .qwen2_navit import NaiveCache, _Linear, concat_plans
 
 BF16 = torch.bfloat16
 
@@ -110,6 +112,10 @@ class Bagel(nn.Module):
             nn.init.constant_(self.llm2vae.weight, 0)
             nn.init.constant_(self.llm2vae.bias, 0)
         self._k64 = {}
+        # opt-in execution options of generate_image (results agree with the default path within bf16 accumulation-order noise
+        # on the 2 marker rows per sample; see _stream_batch / MoTEngine.forward): off unless asked for
+        self.cfg_batched = os.environ.get("BAGEL_CFG_BATCH", "0") == "1"
+        self.und_side_path = os.environ.get("BAGEL_UND_SIDE", "1") == "1"
 
     # ------------------------------------------------------------------------------------------------
     # helpers
@@ -391,6 +397,10 @@ class Bagel(nn.Module):
         x_t = packed_init_noises.to(device=self.device, dtype=torch.float32).contiguous().clone()
         timesteps, dts = self.flow_schedule(num_timesteps, timestep_shift)
         mode = ops.RENORM_MODES[cfg_renorm_type]
+        multi = None
+        if self.cfg_batched and plan_t is not None and not enable_taylorseer:
+            multi = self._stream_batch(st, [plan, plan_t] + ([plan_i] if plan_i is not None else []),
+                                       [past_key_values, cfg_text_past_key_values] + ([cfg_img_past_key_values] if plan_i is not None else []))
         for i, t in enumerate(timesteps):
             use_cfg = bool(t > cfg_interval[0] and t <= cfg_interval[1])   # fp32 tensor vs python float, as bagel.py:701
             s_t = cfg_text_scale if use_cfg else 1.0
@@ -398,8 +408,23 @@ class Bagel(nn.Module):
             self._flow_step(st, x_t, float(t), float(dts[i]), plan, past_key_values,
                             plan_t if s_t > 1.0 else None, cfg_text_past_key_values,
                             plan_i if (s_t > 1.0 and s_i > 1.0) else None, cfg_img_past_key_values,
-                            s_t, s_i, cfg_renorm_min, mode, taylor)
+                            s_t, s_i, cfg_renorm_min, mode, taylor, multi)
         return x_t.split([int(n) - 2 for n in packed_seqlens.tolist()])
+
+    def _stream_batch(self, st, plans, caches):
+        """Opt-in (``model.cfg_batched`` / BAGEL_CFG_BATCH=1): the conditional and the CFG forwards of a denoise step share the
+        query sequence and differ only in position ids and context (bagel.py:820-870), so they run as ONE forward over
+        [stream 0's samples | stream 1's | ...] -- row-wise operators and per-sample attention make every row's arithmetic the
+        same as in separate forwards.  What it buys is tile quantisation: 4 x 4096 latent rows per stream are 64 row tiles of
+        256, i.e. 3.5 / 4.5 / 37 rounds of the 256 persistent GEMM workgroups per projection (paid as 4 / 5 / 38); two streams
+        are exactly 7 / 9 / 74 once the 2-per-sample marker rows take the dense side path (ForwardPlan.und_side)."""
+        S, M = len(plans), plans[0].M
+        pm = concat_plans(plans)
+        pm.und_side = self.und_side_path
+        cm = NaiveCache.concat(caches, [p.B for p in plans])
+        return dict(plan=pm, cache=cm, S=S, M=M,
+                    seq=torch.empty((S * M, self.hidden_size), dtype=BF16, device=self.device),
+                    vae_rows=[(st["vae_rows"] + s * M).contiguous() for s in range(S)])
 
     def _flow_state(self, packed_text_ids, packed_text_indexes, packed_vae_position_ids, packed_vae_token_indexes,
                     packed_seqlens):
@@ -423,13 +448,27 @@ class Bagel(nn.Module):
         return out
 
     def _flow_step(self, st, x_t, t, dt, plan, cache, plan_t, cache_t, plan_i, cache_i, s_t, s_i, renorm_min, mode,
-                   taylor=(None, None, None)):
+                   taylor=(None, None, None), multi=None):
         """One Euler step of bagel.py:698-746 (= _forward_flow + the update), all on the current stream."""
         seq = st["seq"]
         if not st["embedded"]:      # marker-token rows never change across steps
             self._embed_into(seq, st["text_ids"], st["text_rows"])
             st["embedded"] = True
         self._latent_tokens_into(seq, x_t, st["vae_rows"], st["vae_pos"], t)
+        if multi is not None and plan_t is not None and multi["S"] == 2 + (plan_i is not None):
+            # every stream of this step in one forward (see _stream_batch)
+            S, M = multi["S"], multi["M"]
+            for s in range(S):
+                multi["seq"][s * M:(s + 1) * M].copy_(seq)
+            h = self.language_model.engine().forward(multi["seq"], multi["plan"], "gen" if self.use_moe else "und", multi["cache"],
+                                                     update=False, causal=False)
+            for s in range(S):
+                ops.gemm(h, self.llm2vae.weight.data, st["v"][s], bias0=self.llm2vae.bias.data, a_rows0=multi["vae_rows"][s],
+                         M0=st["v"][s].shape[0])
+            v, v_ct, v_ci = st["v"][0], st["v"][1], (st["v"][2] if plan_i is not None else None)
+            nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
+            ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
+            return
         v = self._velocity(st, plan, cache, st["v"][0], taylor[0])
         if plan_t is not None:
             v_ct = self._velocity(st, plan_t, cache_t, st["v"][1], taylor[1])

@@ -177,6 +177,35 @@ class NaiveCache:
                 c._lens[i] = list(self._lens[i])
         return c
 
+    @staticmethod
+    def concat(caches, batch_sizes):
+        """The contexts of several forward streams as ONE cache whose samples are [stream 0's | stream 1's | ...]; a stream
+        without context (``None`` or an empty cache, e.g. the CFG-text stream of text->image) contributes ``batch_sizes[s]``
+        zero-length samples.  Rows are copied (the result is read-only context for a batched denoise forward)."""
+        L = next(c for c in caches if c is not None).num_layers
+        out = NaiveCache(L)
+        live = [c for c in caches if c is not None and not c.is_empty(0)]
+        if not live:
+            return out
+        out._nkv, out._hd, out._dp = live[0]._nkv, live[0]._hd, live[0]._dp
+        for i in range(L):
+            ks, vs, lens = [], [], []
+            for c, B in zip(caches, batch_sizes):
+                if c is None or c.is_empty(i):
+                    lens += [0] * B
+                    continue
+                if len(c._lens[i]) != B or (c._nkv, c._dp) != (out._nkv, out._dp):
+                    raise ValueError("NaiveCache.concat: stream caches disagree on the batch size or the head layout")
+                n = int(sum(c._lens[i]))
+                ks.append(c._k[i][:n])
+                vs.append(c._v[i][:n])
+                lens += [int(x) for x in c._lens[i]]
+            out._k[i] = torch.cat(ks).contiguous()
+            out._v[i] = torch.cat(vs).contiguous()
+            out._lens[i] = lens
+        out._total = int(sum(out._lens[0]))
+        return out
+
     # -- engine side
     def is_empty(self, layer):
         return self._k[layer] is None
@@ -379,7 +408,7 @@ class ForwardPlan:
     """Host-side digest of (query_lens, key_values_lens, packed_*_indexes, position ids, MoT index lists)."""
 
     def __init__(self, device, query_lens, position_ids, packed_query_indexes=None, key_values_lens=None,
-                 packed_key_value_indexes=None, text_indexes=None, vae_indexes=None, inv_freq=None):
+                 packed_key_value_indexes=None, text_indexes=None, vae_indexes=None, inv_freq=None, cos_sin=None):
         q = _tolist(query_lens)
         B = len(q)
         c = _tolist(key_values_lens) if key_values_lens is not None else [0] * B
@@ -420,7 +449,8 @@ class ForwardPlan:
         self.pos_ids = pos.to(device=device, dtype=torch.long).contiguous()
         if self.pos_ids.numel() != self.M:
             raise ValueError("position ids do not cover the packed query sequence")
-        self.cos, self.sin = ops.rope_table(self.pos_ids, inv_freq)
+        self.cos, self.sin = cos_sin if cos_sin is not None else ops.rope_table(self.pos_ids, inv_freq)
+        self.und_side = False      # see MoTEngine.forward: marker rows through the dense side path
         # MoT routing
         self.text_idx = self.vae_idx = self.expert = None
         if text_indexes is not None and vae_indexes is not None:
@@ -432,6 +462,27 @@ class ForwardPlan:
             ex[torch.tensor(v, dtype=torch.long)] = 1
             self.expert = ex.to(device)
             self.n_text, self.n_vae = len(t), len(v)
+
+
+def concat_plans(plans):
+    """ONE plan for several forward streams over the same packed batch: the conditional and the CFG forwards of a denoise
+    step (bagel.py:820-870: same query sequence, different position ids / context) become the samples [stream 0 | stream 1 | ...]
+    of one forward.  Row r of stream s is row s*M + r; every per-sample quantity is simply concatenated (attention never crosses
+    samples, every other op is row-wise), and the RoPE tables are the streams' own tables stacked."""
+    p0 = plans[0]
+    dev = p0.cu_q.device
+    q, c, t, v, off = [], [], [], [], 0
+    routed = all(x.text_idx is not None for x in plans)
+    for x in plans:
+        q += x.q_lens
+        c += x.ctx_lens
+        if routed:
+            t += [off + i for i in _tolist(x.text_idx)]
+            v += [off + i for i in _tolist(x.vae_idx)]
+        off += x.M
+    return ForwardPlan(dev, q, torch.cat([x.pos_ids for x in plans]), key_values_lens=c,
+                       text_indexes=t if routed else None, vae_indexes=v if routed else None,
+                       cos_sin=(torch.cat([x.cos for x in plans]).contiguous(), torch.cat([x.sin for x in plans]).contiguous()))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -593,13 +644,13 @@ class MoTEngine:
         if self.H % 64 or self.I % 64 or (self.nq * self.dp) % 64:
             raise NotImplementedError("hidden/intermediate sizes must be multiples of 64 for the GEMM K loop")
         p0 = model.embed_tokens.weight
-        if not p0.is_cuda or p0.dtype != BF16:
-            raise ops.BagelHipError("bagel_amd runs bf16 weights on an MI355X: call model.to('cuda', torch.bfloat16) first")
+        ops.require_gpu_bf16(p0, "MoTEngine")
         self.device = p0.device
         self.model = model
         self.lm_head = lm_head
         self.layers = [self._pack_layer(l) for l in model.layers]
         self._ws = {}
+        self._ws_side = {}
 
     def _pack_layer(self, L):
         nq, nkv, hd, dp = self.nq, self.nkv, self.hd, self.dp
@@ -680,10 +731,35 @@ class MoTEngine:
         if skip_layers:
             nl = 0
             taylor.eval_into(x)
+        # Marker-row side path (plan.und_side, MoT gen mode).  The und group of a denoise forward is 2 rows per sample; as a row
+        # group of the tile GEMM it costs a whole 256-row tile row in every projection.  With the gen rows alone the tile count of
+        # a stream-batched forward (concat_plans) is an exact multiple of the 256 persistent workgroups (2 x 4 x 4096 rows = 128
+        # row tiles), so the marker rows travel beside it as a small dense matrix [n_text, H]: their projections are weight-streaming
+        # skinny GEMMs, their q/k/v rows are scattered into the fused projection buffer before the attention and their attention
+        # rows gathered after it.  Same operators, same rounding points; only the GEMM kernel that serves those rows differs.
+        side = bool(gen_attn and plan.und_side and nl > 0 and 2 <= plan.n_text <= ops.SKINNY_MAX_ROWS)
+        if side:
+            nt = plan.n_text
+            sw = self._ws_side.get(nt)
+            if sw is None:
+                e = lambda *s: torch.empty(s, dtype=BF16, device=self.device)  # noqa: E731
+                sw = self._ws_side[nt] = dict(x=e(nt, self.H), h=e(nt, self.H), qkv=e(nt, (nq + 2 * nkv) * dp), attn=e(nt, nq * dp),
+                                              act=e(nt, self.I))
+            xu, hu, qu, au, actu = sw["x"], sw["h"], sw["qkv"], sw["attn"], sw["act"]
+            ops.copy_rows(x, xu, nt, self.H, src_rows=plan.text_idx)
+
+            def gen_only(w, b=None):
+                return dict(W0=w[1], bias0=None if b is None else b[1], a_rows0=plan.vae_idx, c_rows0=plan.vae_idx, M0=plan.n_vae)
         for li in range(nl):
             P = self.layers[li]
             ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if gen_attn else None, expert=expert if gen_attn else None)
-            ops.gemm(h, C=qkv, **groups(P.wqkv, P.bqkv, gen_attn))
+            if side:
+                ops.rmsnorm(xu, P.ln_in[0], hu, self.eps)
+                ops.gemm(hu, P.wqkv[0], qu, bias0=P.bqkv[0])
+                ops.copy_rows(qu, qkv, nt, qu.shape[1], dst_rows=plan.text_idx)
+                ops.gemm(h, C=qkv, **gen_only(P.wqkv, P.bqkv))
+            else:
+                ops.gemm(h, C=qkv, **groups(P.wqkv, P.bqkv, gen_attn))
             ops.qknorm_rope(qkv, plan.cos, plan.sin, P.qn[0] if self.use_norm else None, P.kn[0] if self.use_norm else None,
                             P.qn[1] if (self.use_norm and gen_attn) else None, P.kn[1] if (self.use_norm and gen_attn) else None,
                             expert if gen_attn else None, nq, nkv, hd, dp, self.eps, gen_mode=(mode == "gen" and self.mot),
@@ -701,10 +777,23 @@ class MoTEngine:
                 if cache is None:
                     raise ValueError("update_past_key_values=True needs a NaiveCache")
                 cache.store(li, k_v, v_v, plan.q_lens, plan.ctx_lens, nkv, hd, dp, plan.new_dst, plan.ctx_dst)
+            if side:
+                ops.copy_rows(att, au, nt, au.shape[1], src_rows=plan.text_idx)
+                ops.gemm(au, P.wo[0], xu, residual=xu)
+                ops.gemm(att, C=x, residual=x, **gen_only(P.wo))
+                ops.rmsnorm(xu, P.ln_post[0], hu, self.eps)
+                ops.rmsnorm(x, P.ln_post[0], h, self.eps, w1=P.ln_post[1], expert=expert)
+                ops.gemm(hu, P.wgu[0], actu, epilogue=ops.EPI_SWIGLU16)
+                ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **gen_only(P.wgu))
+                ops.gemm(actu, P.wd[0], xu, residual=xu)
+                ops.gemm(act, C=x, residual=x, **gen_only(P.wd))
+                continue
             ops.gemm(att, C=x, residual=x, **groups(P.wo, None, gen_attn))
             ops.rmsnorm(x, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if gen_attn else None, expert=expert if gen_attn else None)
             ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu, None, gen))
             ops.gemm(act, C=x, residual=x, **groups(P.wd, None, gen))
+        if side:
+            ops.copy_rows(xu, x, nt, self.H, dst_rows=plan.text_idx)
         if taylor is not None:
             if not skip_layers:
                 taylor.update(x)

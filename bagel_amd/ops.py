@@ -29,6 +29,13 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def require_gpu_bf16(t, what):
+    """The engines run bf16 weights resident on an MI355X; anything else is refused before a kernel could see it."""
+    if not t.is_cuda or t.dtype != BF16:
+        raise BagelHipError(f"{what}: bagel_amd runs bf16 weights on an MI355X (got {t.device}, {t.dtype}): "
+                            "call model.to('cuda', torch.bfloat16) first")
+
+
 def _req(t, dtype, name):
     if not t.is_cuda:
         raise BagelHipError(f"{name}: expected a GPU tensor (bagel_amd has no CPU path)")

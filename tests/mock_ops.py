@@ -1,0 +1,240 @@
+"""TEST INFRASTRUCTURE ONLY -- a torch-CPU stand-in for the operators of ``bagel_amd.ops`` that the prefill and the
+image-generation path launch, so that the HOST logic above the C ABI (ForwardPlan, NaiveCache, MoT routing lists, the
+denoise loop, stream-batched CFG, the marker-row side path) can be exercised by ``pytest -m "not gpu"`` in a container
+without a GPU.
+
+It is NOT a fallback of the product: nothing under ``bagel_amd/`` imports it, the product still raises
+(``bagel_amd._lib`` / ``ops._ptr``) when it is handed a host tensor, and no parity or performance claim rests on it --
+the kernels themselves are checked on the MI355X by the ``-m gpu`` tests.  A test installs it explicitly with
+``mock_ops.install(monkeypatch)``.
+
+Every function follows the data-layout contract of the entry point it stands in for (include/bagel_hip.h): the fused
+[q | k | v] projection rows with padded head slots, V^T images with per-sample column offsets, row gather / scatter
+lists, the SwiGLU16 gate/up row interleave.  Products are accumulated in fp64 and rounded once to fp32, so a row's
+result does not depend on which rows it is batched with: two host-side schedules of the same arithmetic must agree
+bit for bit, which is what the stream-batching tests assert."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BF16 = torch.bfloat16
+
+
+def _bf(x):
+    return x.to(BF16)
+
+
+def _rows(idx, n, M):
+    return idx.long()[:n] if idx is not None else torch.arange(M)
+
+
+def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, bias1=None, a_rows1=None, c_rows1=None,
+         M1=0, residual=None, epilogue=0, variant=None):
+    N, K = W0.shape
+    if M0 is None:
+        M0 = a_rows0.numel() if a_rows0 is not None else A.shape[0]
+    for W, b, ar, cr, M in ((W0, bias0, a_rows0, c_rows0, M0), (W1, bias1, a_rows1, c_rows1, M1)):
+        if W is None or M == 0:
+            continue
+        ai, ci = _rows(ar, M, M), _rows(cr, M, M)
+        acc = (A[ai, :K].double() @ W.double().t()).float()
+        if b is not None:
+            acc = acc + b.float()
+        y = _bf(acc)
+        if epilogue == 1:
+            y = _bf(F.gelu(y.float(), approximate="tanh"))
+        elif epilogue == 2:
+            y = _bf(F.silu(y.float()))
+        elif epilogue == 3:      # rows [16 gate | 16 up] ... -> N/2 columns
+            y = y.view(M, N // 32, 2, 16)
+            g, u = y[:, :, 0], y[:, :, 1]
+            y = _bf(_bf(F.silu(g.float())).float() * u.float()).reshape(M, N // 2)
+        if residual is not None:
+            y = _bf(y.float() + residual[ci, :y.shape[1]].float())
+        C[ci, :y.shape[1]] = y
+    return C
+
+
+def gemv(A, W, C, *, bias=None, residual=None, epilogue=0, M=None, norm_w=None, eps=0.0):
+    if norm_w is not None:
+        A = rmsnorm(A, norm_w, torch.empty_like(A), eps)
+    return gemm(A, W, C, bias0=bias, residual=residual, epilogue=epilogue, M0=M if M is not None else A.shape[0])
+
+
+def gemm_skinny(A, W, C, *, bias=None, residual=None, epilogue=0, M=None):
+    return gemm(A, W, C, bias0=bias, residual=residual, epilogue=epilogue, M0=M if M is not None else A.shape[0])
+
+
+def rmsnorm(x, w0, out, eps, w1=None, expert=None):
+    h = x.float()
+    h = _bf(h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + eps))
+    w = w0.float().expand(x.shape[0], -1)
+    if expert is not None and w1 is not None:
+        w = torch.where(expert.bool()[:, None], w1.float()[None], w0.float()[None])
+    out.copy_(_bf(w * h.float()))
+    return out
+
+
+def layernorm(x, w, b, out, eps):
+    out.copy_(_bf(F.layer_norm(x.float(), (x.shape[1],), w.float(), b.float(), eps)))
+    return out
+
+
+def rope_table(position_ids, inv_freq):
+    ang = position_ids.float()[:, None] * inv_freq.float()[None, :]
+    return _bf(torch.cos(ang)), _bf(torch.sin(ang))
+
+
+def qknorm_rope(qkv, cos, sin, q_w0, k_w0, q_w1, k_w1, expert, nq, nkv, head_dim, head_dim_padded, eps, gen_mode, use_norm):
+    M, hd, dp = qkv.shape[0], head_dim, head_dim_padded
+    heads = qkv[:, :(nq + nkv) * dp].view(M, nq + nkv, dp)
+    x = heads[:, :, :hd].float()
+    ex = expert.bool() if expert is not None else torch.zeros(M, dtype=torch.bool)
+    if use_norm:
+        wq = torch.where(ex[:, None], q_w1.float()[None], q_w0.float()[None]) if q_w1 is not None else q_w0.float().expand(M, -1)
+        wk = torch.where(ex[:, None], k_w1.float()[None], k_w0.float()[None]) if k_w1 is not None else k_w0.float().expand(M, -1)
+        w = torch.cat([wq[:, None, :].expand(M, nq, hd), wk[:, None, :].expand(M, nkv, hd)], 1)
+        inv = torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
+        x = w * (x * inv) if gen_mode else _bf(w * _bf(x * inv).float()).float()
+    c = torch.cat([cos, cos], -1).float()[:, None, :]
+    s = torch.cat([sin, sin], -1).float()[:, None, :]
+    rot = torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
+    out = x * c + rot * s if gen_mode else _bf(x * c).float() + _bf(rot * s).float()
+    heads[:, :, :hd] = _bf(out)
+    return qkv
+
+
+def v_transpose(v, vt, cu_rows, col_start, batch, max_len, nkv, head_dim):
+    cu, col = cu_rows.tolist(), col_start.tolist()
+    for b in range(batch):
+        L = cu[b + 1] - cu[b]
+        if L <= 0:
+            continue
+        pad = (L + 63) // 64 * 64
+        vt[:nkv * head_dim, col[b]:col[b] + pad] = 0
+        vt[:nkv * head_dim, col[b]:col[b] + L] = v[cu[b]:cu[b + 1], :nkv * head_dim].t()
+    return vt
+
+
+def attn_varlen(q, k_new, vt_new, out, cu_q, vt_new_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale,
+                k_ctx=None, vt_ctx=None, cu_ctx=None, vt_ctx_col=None):
+    D, grp = head_dim, nq // nkv
+    cq, ncol = cu_q.tolist(), vt_new_col.tolist()
+    cc = cu_ctx.tolist() if cu_ctx is not None else None
+    ccol = vt_ctx_col.tolist() if vt_ctx_col is not None else None
+    for b in range(batch):
+        q0, Lq = cq[b], cq[b + 1] - cq[b]
+        C = cc[b + 1] - cc[b] if cc is not None else 0
+        if Lq <= 0:
+            continue
+        for h in range(nq):
+            g = h // grp
+            ks = [k_new[q0:q0 + Lq, g * D:(g + 1) * D]]
+            vs = [vt_new[g * D:(g + 1) * D, ncol[b]:ncol[b] + Lq].t()]
+            if C > 0:
+                ks.insert(0, k_ctx[cc[b]:cc[b] + C, g * D:(g + 1) * D])
+                vs.insert(0, vt_ctx[g * D:(g + 1) * D, ccol[b]:ccol[b] + C].t())
+            k, v = torch.cat(ks).double(), torch.cat(vs).double()
+            s = (q[q0:q0 + Lq, h * D:(h + 1) * D].double() @ k.t()).float() * softmax_scale
+            if causal:      # bottom-right aligned
+                Lk = C + Lq
+                mask = torch.ones(Lq, Lk).tril(diagonal=Lk - Lq).bool()
+                s = s.masked_fill(~mask, float("-inf"))
+            p = torch.softmax(s, -1)
+            out[q0:q0 + Lq, h * D:(h + 1) * D] = _bf((p.double() @ v).float())
+    return out
+
+
+def copy_rows(src, dst, n, cols, src_rows=None, dst_rows=None):
+    si = src_rows.long()[:n] if src_rows is not None else torch.arange(n)
+    di = dst_rows.long()[:n] if dst_rows is not None else torch.arange(n)
+    dst[di, :cols] = src[si, :cols]
+    return dst
+
+
+def f32_to_bf16(src, dst=None, cols_padded=None):
+    rows, cols = src.shape
+    cp = cols if cols_padded is None else cols_padded
+    if dst is None:
+        dst = torch.empty((rows, cp), dtype=BF16)
+    dst[:, :cols] = _bf(src)
+    dst[:, cols:cp] = 0
+    return dst
+
+
+def timestep_sinusoid(t, freqs, out):
+    half = freqs.numel()
+    a = torch.tensor(float(t), dtype=torch.float32) * freqs.float()
+    out.view(-1)[:half] = _bf(torch.cos(a))
+    out.view(-1)[half:2 * half] = _bf(torch.sin(a))
+
+
+def flow_add(seq, rows, temb, pos_table, pos_ids):
+    r = rows.long()
+    seq[r] = _bf(_bf(seq[r].float() + temb.float().view(1, -1)).float() + pos_table[pos_ids.long()].float())
+    return seq
+
+
+def add_table_rows(x, table, ids):
+    x.copy_(_bf(x.float() + table[ids.long()].float()))
+    return x
+
+
+def _r(x):
+    return x.to(BF16).float()
+
+
+def _mix(base, x, s):
+    return _r(base + _r(s * _r(x - base)))
+
+
+def _scale(ss0, ss1, mn):
+    n0, n1 = _r(torch.sqrt(ss0)), _r(torch.sqrt(ss1))
+    return torch.clamp(_r(n0 / _r(n1 + 1e-8)), min=float(_r(torch.tensor(mn))), max=1.0)
+
+
+def cfg_stage1(v, v_ct, v_ci, tmp, partials, text_scale, img_scale, renorm_min, mode):
+    a = v.float()
+    vt_ = _mix(v_ct.float(), a, text_scale)
+    t = vt_ if (mode == 2 or v_ci is None) else _mix(v_ci.float(), vt_, img_scale)
+    if mode == 0:
+        tmp.copy_(_bf(t))
+        partials[0], partials[1] = a.pow(2).sum(), t.pow(2).sum()
+        return 1
+    sc = _scale(a.pow(2).sum(-1, keepdim=True), t.pow(2).sum(-1, keepdim=True), renorm_min)
+    o = _r(t * sc)
+    if mode == 2 and v_ci is not None:
+        o = _mix(v_ci.float(), o, img_scale)
+    tmp.copy_(_bf(o))
+    return 1
+
+
+def cfg_stage2_euler(x_t, v_or_tmp, partials, nparts, renorm_min, dt, use_global_scale):
+    vt = v_or_tmp.float()
+    if use_global_scale:
+        vt = _r(vt * _scale(partials[0], partials[1], renorm_min))
+    x_t.sub_(_r(vt * dt).view(x_t.shape))
+    return x_t
+
+
+def argmax(logits):
+    return torch.argmax(logits.float(), -1)
+
+
+def require_gpu_bf16(t, what=""):
+    return None
+
+
+_NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
+          "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
+          "argmax", "require_gpu_bf16"]
+
+
+def install(monkeypatch):
+    """Replace the launch wrappers of bagel_amd.ops by the CPU stand-ins for the duration of one test."""
+    from bagel_amd import ops
+    g = globals()
+    for n in _NAMES:
+        monkeypatch.setattr(ops, n, g[n])
+    assert math.isfinite(1.0)

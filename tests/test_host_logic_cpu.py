@@ -1,0 +1,147 @@
+"""CPU: the HOST logic of the product above the C ABI -- ForwardPlan, NaiveCache, the MoT row lists, the prefill, the
+denoise loop with CFG, the opt-in stream-batched CFG forward and the marker-row side path -- run with the launch wrappers of
+``bagel_amd.ops`` replaced by the torch stand-ins of tests/mock_ops.py (test infrastructure; the kernels themselves are
+checked on the GPU by the ``-m gpu`` tests) and compared against the REFERENCE's golden vectors.
+
+What this pins without a GPU: every index tensor, buffer layout and call order the engines hand to the C ABI."""
+import copy
+
+import pytest
+import torch
+
+from oracle.configs import TINY, TINY_D128, TINY_DENSE, TINY_MOE, NEW_TOKEN_IDS_TINY, StubTokenizer
+from tests import mock_ops
+from tests.util_models import oracle_weights
+
+CFGS = {"tiny": TINY, "tiny_d128": TINY_D128, "tiny_dense": TINY_DENSE, "tiny_moe": TINY_MOE}
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30)).item()
+
+
+def cpu_model(cfg):
+    from bagel_amd.factory import build_bagel
+    W, _ = oracle_weights(cfg)
+    model, _ = build_bagel(cfg, device="cpu", with_vae=False)
+    model.load_state_dict(W, strict=True)
+    return model.to(torch.bfloat16).eval()
+
+
+def new_cache(cfg):
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    return NaiveCache(cfg["llm"]["num_hidden_layers"])
+
+
+def cfg_kwargs(tag, cache, d):
+    return {f"{tag}_past_key_values": cache, f"{tag}_packed_position_ids": d["cfg_packed_position_ids"],
+            f"{tag}_packed_query_indexes": d["cfg_packed_query_indexes"], f"{tag}_key_values_lens": d["cfg_key_values_lens"],
+            f"{tag}_packed_key_value_indexes": d["cfg_packed_key_value_indexes"]}
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_dense", "tiny_moe"])
+def test_text_to_image_host_path_matches_reference(golden, monkeypatch, name):
+    """prepare_prompts -> forward_cache_update_text -> generate_image (cond + CFG-text, global / channel renorm) through the
+    product's engines with stand-in operators vs the reference's KV cache and latents."""
+    mock_ops.install(monkeypatch)
+    cfg = CFGS[name]
+    g = golden(f"{name}_t2i")
+    model = cpu_model(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    gi, newlens, newrope = model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+    for i in range(L):
+        assert rel(cache.key_cache[i], g["key_cache"][i]) < 1e-2, f"K cache layer {i}"
+        assert rel(cache.value_cache[i], g["value_cache"][i]) < 1e-2, f"V cache layer {i}"
+    runs = [("gen_kwargs", "latents")] + ([("gen_kwargs_channel", "latents_channel")] if "gen_kwargs_channel" in g else [])
+    for kw, key in runs:
+        lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **g[kw],
+                                   **g["latent_inputs"])
+        assert len(lat) == len(g[key])
+        for a, b in zip(lat, g[key]):
+            assert a.shape == b.shape and a.dtype == torch.float32
+            assert rel(a, b) < 2e-2, key
+
+
+def _three_stream_setup(model, cfg, sizes):
+    """cond / cfg-text / cfg-img contexts of DIFFERENT lengths from three prompts (what the edit flow produces, without the
+    ViT / VAE prefill): exercises ragged contexts and NaiveCache.concat with three live caches."""
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ids = NEW_TOKEN_IDS_TINY
+    B = len(sizes)
+    out = []
+    for prompts in (["a small red cube on the table", "sky"][:B], ["cube", "a b"][:B], ["x y z w v", "hello world again"][:B]):
+        gi, lens, ropes = model.prepare_prompts([0] * B, [0] * B, prompts, tok, ids)
+        out.append((model.forward_cache_update_text(new_cache(cfg), **gi), lens, ropes))
+    (c0, l0, r0), (c1, l1, r1), (c2, l2, r2) = out
+    torch.manual_seed(7)
+    li = model.prepare_vae_latent(l0, r0, sizes, ids)
+    ct = model.prepare_vae_latent_cfg(l1, r1, sizes)
+    ci = model.prepare_vae_latent_cfg(l2, r2, sizes)
+    return c0, li, (c1, ct), (c2, ci)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("side", [False, True], ids=["rows_in_tile_gemm", "marker_side_path"])
+@pytest.mark.parametrize("streams", [2, 3])
+def test_stream_batched_cfg_equals_sequential(monkeypatch, name, side, streams):
+    """model.cfg_batched: the cond + CFG forwards of a step as ONE forward over [stream 0 | stream 1 | ...].  With operators
+    whose row results do not depend on the batch (mock_ops) the latents must equal the sequential path BIT FOR BIT -- every
+    routing list, context offset, RoPE row and V^T column of the concatenated plan / cache is in play -- with and without the
+    dense side path for the marker rows, for 2 streams (text->image, second context empty) and 3 (edit-style ragged contexts),
+    and with CFG switched off for part of the schedule (cfg_interval) so both code paths alternate inside one run."""
+    mock_ops.install(monkeypatch)
+    cfg = CFGS[name]
+    model = cpu_model(cfg)
+    sizes = [(64, 64), (32, 64)]
+    c0, li, (c1, ct), (c2, ci) = _three_stream_setup(model, cfg, sizes)
+    if streams == 2:
+        c1, ct = new_cache(cfg), model.prepare_vae_latent_cfg([0, 0], [0, 0], sizes)     # text->image: no CFG context at all
+    kw = dict(num_timesteps=5, timestep_shift=3.0, cfg_text_scale=4.0, cfg_interval=[0.6, 1.0], cfg_renorm_min=0.0,
+              cfg_renorm_type="global" if streams == 2 else "text_channel", **cfg_kwargs("cfg_text", c1, ct))
+    if streams == 3:
+        kw.update(cfg_img_scale=2.0, **cfg_kwargs("cfg_img", c2, ci))
+    model.cfg_batched = False
+    ref = model.generate_image(past_key_values=copy.deepcopy(c0), **kw, **li)
+    model.cfg_batched, model.und_side_path = True, side
+    calls = []
+    eng = model.language_model.engine()
+    orig = eng.forward
+    monkeypatch.setattr(eng, "forward", lambda seq, plan, *a, **k: (calls.append((plan.B, plan.M, plan.und_side)), orig(seq, plan, *a, **k))[1])
+    got = model.generate_image(past_key_values=copy.deepcopy(c0), **kw, **li)
+    B, M = len(sizes), sum(int(x) for x in li["packed_seqlens"])
+    assert (streams * B, streams * M, side) in calls, "the batched forward never ran"
+    assert (B, M, False) in calls, "cfg_interval should have left single-stream steps in the schedule"
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
+def test_concat_plan_and_cache_layout(monkeypatch):
+    """Known-answer check of concat_plans / NaiveCache.concat on a hand-sized case."""
+    mock_ops.install(monkeypatch)
+    from bagel_amd.modeling.bagel.qwen2_navit import ForwardPlan, NaiveCache, concat_plans
+    dev = torch.device("cpu")
+    inv = torch.tensor([1.0, 0.5])
+    mk = lambda pos, ctx: ForwardPlan(dev, [3, 4], pos, key_values_lens=ctx, text_indexes=[0, 2, 3, 6], vae_indexes=[1, 4, 5],  # noqa: E731
+                                      inv_freq=inv)
+    a = mk(torch.tensor([5, 5, 5, 2, 2, 2, 2]), [5, 2])
+    b = mk(torch.tensor([0, 0, 0, 0, 0, 0, 0]), [0, 0])
+    p = concat_plans([a, b])
+    assert (p.B, p.M, p.q_lens, p.ctx_lens, p.max_lq) == (4, 14, [3, 4, 3, 4], [5, 2, 0, 0], 4)
+    assert p.cu_q.tolist() == [0, 3, 7, 10, 14] and p.vt_new_col.tolist() == [0, 64, 128, 192] and p.vt_cols == 256
+    assert p.text_idx.tolist() == [0, 2, 3, 6, 7, 9, 10, 13] and p.vae_idx.tolist() == [1, 4, 5, 8, 11, 12]
+    assert p.expert.tolist() == [0, 1, 0, 0, 1, 1, 0] * 2 and (p.n_text, p.n_vae) == (8, 6) and p.has_ctx
+    assert torch.equal(p.cos, torch.cat([a.cos, b.cos])) and torch.equal(p.pos_ids, torch.cat([a.pos_ids, b.pos_ids]))
+    c = NaiveCache(2)
+    k = torch.arange(7 * 8, dtype=torch.float32).view(7, 8).to(torch.bfloat16)
+    for i in range(2):
+        c.store(i, k + i, -k - i, [5, 2], [0, 0], 1, 8, 8)
+    m = NaiveCache.concat([c, NaiveCache(2), None], [2, 2, 2])
+    assert m.lens(0) == [5, 2, 0, 0, 0, 0] and m.seq_lens == 7 and m.num_layers == 2
+    assert torch.equal(m.key_cache[1], (k + 1).view(7, 1, 8)) and torch.equal(m.value_cache[0], (-k).view(7, 1, 8))
+    cu, col, cols, mx = m._meta(0, dev)
+    assert cu.tolist() == [0, 5, 7, 7, 7, 7, 7] and col.tolist() == [0, 64, 128, 192, 256, 320] and mx == 5
+    assert NaiveCache.concat([NaiveCache(2), None], [2, 2]).is_empty(0)
+    with pytest.raises(ValueError):
+        NaiveCache.concat([c, c], [2, 3])
