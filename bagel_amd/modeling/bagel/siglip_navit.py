@@ -151,8 +151,7 @@ class SiglipVisionModel(nn.Module):
         pe = vm.embeddings.patch_embedding
         if pe.weight.dim() != 2:
             raise RuntimeError("call vision_model.embeddings.convert_conv2d_to_linear(vit_config) first (app.py:66)")
-        if not pe.weight.is_cuda or pe.weight.dtype != BF16:
-            raise ops.BagelHipError("bagel_amd runs bf16 weights on an MI355X: call model.to('cuda', torch.bfloat16) first")
+        ops.require_gpu_bf16(pe.weight, "SiglipEngine")
         D, nh = cfg.hidden_size, cfg.num_attention_heads
         hd = D // nh
         dp = padded_head_dim(hd)

@@ -222,13 +222,94 @@ def argmax(logits):
     return torch.argmax(logits.float(), -1)
 
 
+def rope2d(qkv, tables, pos_ids, nheads, head_dim, head_dim_padded):
+    cos_h, sin_h, cos_w, sin_w = (t[pos_ids.long()].float()[:, None, :] for t in tables)      # [rows, 1, hd/2]
+    hd, dp, h2, q4 = head_dim, head_dim_padded, head_dim // 2, head_dim // 4
+    heads = qkv[:, :nheads * dp].view(qkv.shape[0], nheads, dp)
+    for half, (c, s_) in enumerate(((cos_h, sin_h), (cos_w, sin_w))):
+        x = heads[:, :, half * h2:(half + 1) * h2].float()
+        rot = torch.cat([-x[..., q4:], x[..., :q4]], -1)
+        heads[:, :, half * h2:(half + 1) * h2] = _bf(_bf(x * c).float() + _bf(rot * s_).float())
+    return qkv
+
+
+def taylor_update(feature, factors, n_diff, distance):
+    cur = feature.clone()
+    for i in range(n_diff):
+        old = factors[i].clone()
+        factors[i].copy_(cur)
+        cur = _bf(_r(cur.float() - old.float()) / float(distance))
+    factors[n_diff].copy_(cur)
+
+
+def taylor_eval(factors, n, x, out):
+    acc = factors[0].float()
+    fact, xp = 1.0, 1.0
+    for i in range(1, n):
+        fact *= i
+        xp *= x
+        c = torch.tensor(1.0 / fact, dtype=torch.float32)
+        acc = _r(acc + _r(_r(c * factors[i].float()) * torch.tensor(xp, dtype=torch.float32)))
+    out.copy_(_bf(acc))
+    return out
+
+
+def attn_varlen_ranges(q, k_new, vt_new, out, q_start, q_end, vt_new_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale,
+                       k_ctx=None, vt_ctx=None, ctx_start=None, ctx_end=None, vt_ctx_col=None):
+    D, grp = head_dim, nq // nkv
+    qs, qe, ncol = q_start.tolist(), q_end.tolist(), vt_new_col.tolist()
+    cs = ctx_start.tolist() if ctx_start is not None else None
+    ce = ctx_end.tolist() if ctx_end is not None else None
+    ccol = vt_ctx_col.tolist() if vt_ctx_col is not None else None
+    for b in range(batch):
+        q0, Lq = qs[b], qe[b] - qs[b]
+        C = ce[b] - cs[b] if cs is not None else 0
+        if Lq <= 0:
+            continue
+        for h in range(nq):
+            g = h // grp
+            ks = [k_new[q0:q0 + Lq, g * D:(g + 1) * D]]
+            vs = [vt_new[g * D:(g + 1) * D, ncol[b]:ncol[b] + Lq].t()]
+            if C > 0:
+                ks.insert(0, k_ctx[cs[b]:cs[b] + C, g * D:(g + 1) * D])
+                vs.insert(0, vt_ctx[g * D:(g + 1) * D, ccol[b]:ccol[b] + C].t())
+            k, v = torch.cat(ks).double(), torch.cat(vs).double()
+            s = (q[q0:q0 + Lq, h * D:(h + 1) * D].double() @ k.t()).float() * softmax_scale
+            if causal:
+                Lk = C + Lq
+                s = s.masked_fill(~torch.ones(Lq, Lk).tril(diagonal=Lk - Lq).bool(), float("-inf"))
+            out[q0:q0 + Lq, h * D:(h + 1) * D] = _bf((torch.softmax(s, -1).double() @ v).float())
+    return out
+
+
+def flow_mix(clean, noise, t):
+    tt = t.float()[:, None]
+    return _bf((1.0 - tt) * clean.float() + tt * noise.float())
+
+
+def flow_add_rows(seq, rows, temb, temb_ids, pos_table, pos_ids):
+    r = rows.long()
+    seq[r] = _bf(_bf(seq[r].float() + temb[temb_ids.long()].float()).float() + pos_table[pos_ids.long()].float())
+    return seq
+
+
+def mse_rows(pred, noise, clean, src_rows):
+    i = src_rows.long()
+    return (pred.float() - (noise[i].float() - clean[i].float())) ** 2
+
+
+def cross_entropy(logits, labels):
+    return F.cross_entropy(logits.float(), labels.long(), reduction="none")
+
+
 def require_gpu_bf16(t, what=""):
     return None
 
 
 _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
-          "argmax", "require_gpu_bf16"]
+          "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
+          "mse_rows", "cross_entropy"]
 
 
 def install(monkeypatch):

@@ -145,3 +145,60 @@ def test_concat_plan_and_cache_layout(monkeypatch):
     assert NaiveCache.concat([NaiveCache(2), None], [2, 2]).is_empty(0)
     with pytest.raises(ValueError):
         NaiveCache.concat([c, c], [2, 3])
+
+
+def cpu_model_with_vit(cfg):
+    """As cpu_model; the SigLIP RoPE tables of the rope variant are part of oracle_weights()."""
+    return cpu_model(cfg)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_rope"])
+def test_siglip_host_path_matches_reference(golden, monkeypatch, name):
+    """SiglipVisionModel (packed patches, learned position table or 2-D RoPE, head_dim 32 / 72 padded to the 64 / 128 slots) and
+    the connector: weight packing with zero-padded heads, fused qkv layout, V^T offsets."""
+    from oracle.configs import TINY_ROPE
+    mock_ops.install(monkeypatch)
+    cfg = dict(CFGS, tiny_rope=TINY_ROPE)[name]
+    g = golden(f"{name}_siglip")
+    model = cpu_model(cfg)
+    out = model.vit_model(packed_pixel_values=g["tokens"], packed_flattened_position_ids=g["pos"], cu_seqlens=g["cu"], max_seqlen=35)
+    assert out.shape == g["out"].shape and rel(out, g["out"]) < 1e-2
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_taylorseer_host_path_matches_reference(golden, monkeypatch, name):
+    """generate_image(enable_taylorseer=True): the schedule (full / Taylor steps per stream), the last-layer-only feature cache and
+    its hand-over to the final norm vs the reference's latents (tolerance as the GPU test: 4e-2)."""
+    mock_ops.install(monkeypatch)
+    cfg = CFGS[name]
+    g = golden(f"{name}_taylorseer")
+    model = cpu_model(cfg)
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    gi, _, _ = model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+    for tag, run in g["runs"].items():
+        kw = run["gen_kwargs"]
+        lat = model.generate_image(past_key_values=cache, enable_taylorseer=True, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]),
+                                   **kw, **g["latent_inputs"])
+        st = model._last_taylor_states[0]
+        assert st.full_steps + st.taylor_steps == kw["num_timesteps"] - 1 and st.taylor_steps > 0
+        for a, b in zip(lat, run["latents"]):
+            assert rel(a, b) < 4e-2, tag
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("mask_api", ["nested", "splits"])
+def test_training_forward_host_path_matches_reference(golden, monkeypatch, name, mask_api):
+    """Bagel.forward: TrainPlan (block mask decomposed into per-split sequences with overlapping clean-key prefixes), und / gen
+    routing, per-image timestep embedding rows, loss row selection -- vs the reference's per-token losses."""
+    mock_ops.install(monkeypatch)
+    cfg = CFGS[name]
+    g = golden(f"{name}_train")
+    model = cpu_model(cfg)
+    batch = dict(g["batch"])
+    if mask_api == "splits":
+        batch.pop("nested_attention_masks")
+        batch.update(split_lens=g["split_lens"], attn_modes=g["attn_modes"])
+    out = model(noise=g["noise"], **batch)
+    assert out["mse"].shape == g["mse"].shape and out["ce"].shape == g["ce"].shape
+    assert rel(out["ce"], g["ce"]) < 2e-2 and rel(out["mse"], g["mse"]) < 5e-2
