@@ -222,6 +222,64 @@ def argmax(logits):
     return torch.argmax(logits.float(), -1)
 
 
+def argmax_into(logits, out):
+    out.copy_(torch.argmax(logits.float(), -1))
+    return out
+
+
+def rope_table_into(position_ids, inv_freq, cos, sin):
+    c, s_ = rope_table(position_ids, inv_freq)
+    cos.copy_(c.view(cos.shape))
+    sin.copy_(s_.view(sin.shape))
+    return cos, sin
+
+
+def _page_row(block_table, b, j, page=64):
+    return int(block_table[b, j // page]) * page + j % page
+
+
+def decode_qkv_post(qkv, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len, batch, nq, nkv, head_dim, head_dim_padded, eps,
+                    use_norm):
+    qknorm_rope(qkv[:batch], cos, sin, q_w, k_w, None, None, None, nq, nkv, head_dim, head_dim_padded, eps, False, use_norm)
+    qw, kw = nq * head_dim_padded, nkv * head_dim_padded
+    for b in range(batch):
+        r = _page_row(block_table, b, int(kv_len[b]))
+        kpool[r, :kw] = qkv[b, qw:qw + kw]
+        vpool[r, :kw] = qkv[b, qw + kw:qw + 2 * kw]
+    return qkv
+
+
+def kv_append_paged(k_new, v_new, kpool, vpool, block_table, kv_len, batch, width):
+    for b in range(batch):
+        r = _page_row(block_table, b, int(kv_len[b]))
+        kpool[r, :width] = k_new[b, :width]
+        vpool[r, :width] = v_new[b, :width]
+
+
+def attn_decode_paged(q, kpool, vpool, block_table, kv_len, len_add, max_len, part_o, part_ml, out, batch, nq, nkv, head_dim,
+                      softmax_scale):
+    D, grp = head_dim, nq // nkv
+    for b in range(batch):
+        n = int(kv_len[b]) + len_add
+        rows = torch.tensor([_page_row(block_table, b, j) for j in range(n)], dtype=torch.long)
+        for h in range(nq):
+            g = h // grp
+            k, v = kpool[rows, g * D:(g + 1) * D].double(), vpool[rows, g * D:(g + 1) * D].double()
+            s = (q[b:b + 1, h * D:(h + 1) * D].double() @ k.t()).float() * softmax_scale
+            out[b, h * D:(h + 1) * D] = _bf((torch.softmax(s, -1).double() @ v).float())[0]
+    return out
+
+
+def decode_advance(next_tok, cur_tok32, tokens_out, pos, kv_len, step, batch, max_steps):
+    s_ = int(step[0])
+    cur_tok32.copy_(next_tok.to(torch.int32))
+    if s_ + 1 < max_steps:
+        tokens_out[s_ + 1].copy_(next_tok)
+    pos.add_(1)
+    kv_len.add_(1)
+    step.add_(1)
+
+
 def rope2d(qkv, tables, pos_ids, nheads, head_dim, head_dim_padded):
     cos_h, sin_h, cos_w, sin_w = (t[pos_ids.long()].float()[:, None, :] for t in tables)      # [rows, 1, hd/2]
     hd, dp, h2, q4 = head_dim, head_dim_padded, head_dim // 2, head_dim // 4
@@ -309,7 +367,8 @@ def require_gpu_bf16(t, what=""):
 _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
-          "mse_rows", "cross_entropy"]
+          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged",
+          "decode_advance"]
 
 
 def install(monkeypatch):

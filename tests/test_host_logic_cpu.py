@@ -202,3 +202,59 @@ def test_training_forward_host_path_matches_reference(golden, monkeypatch, name,
     out = model(noise=g["noise"], **batch)
     assert out["mse"].shape == g["mse"].shape and out["ce"].shape == g["ce"].shape
     assert rel(out["ce"], g["ce"]) < 2e-2 and rel(out["mse"], g["mse"]) < 5e-2
+
+
+def _tokens_match(ours, ref, ref_logits, what):
+    """Greedy ids equal the oracle's up to the first near tie in the oracle's logits (the rule of test_model_gpu.py)."""
+    assert ours.shape == ref.shape and ours.dtype == torch.int64
+    for s in range(1, ref.shape[0]):
+        if torch.equal(ours[s], ref[s]):
+            continue
+        row = ref_logits[s - 1].float()
+        gap = row.max(-1).values - row.gather(-1, ours[s].view(-1, 1)).squeeze(-1)
+        assert (gap <= row.abs().max().item() * 2.0 ** -6).all(), f"{what}: tokens differ at step {s} without a near tie"
+        break
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_understanding_flow_host_path_matches_oracle(monkeypatch, name, batch):
+    """BASELINE configs[1] end to end on the host logic: SigLIP + connector prefill (non-causal, und) -> prompt prefill (causal)
+    -> prepare_start_tokens -> generate_text through the DecodeSession (paged KV cache adopted from the NaiveCache, block
+    tables, device-side step bookkeeping, write-back of the decoded K/V rows) -- eager launches (no hipGraph here) -- vs the
+    oracle's restatement of the reference flow (bagel.py:299-415,232-297,909-1000): KV caches before and after the decode,
+    greedy token ids.  batch 1 = the fused-RMSNorm gemv route, batch 2 = the RMSNorm + skinny GEMM route."""
+    from oracle import bagel_oracle as O
+    from oracle import packers as P
+    mock_ops.install(monkeypatch)
+    cfg = CFGS[name]
+    model = cpu_model(cfg)
+    W, _ = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ids = NEW_TOKEN_IDS_TINY
+    ident = lambda t: t  # noqa: E731
+    g = torch.Generator().manual_seed(5)
+    images = [torch.rand(3, 28, 42, generator=g) * 2 - 1, torch.rand(3, 42, 14, generator=g) * 2 - 1][:batch]
+    prompts = ["what is in the picture", "a b c"][:batch]
+    z = [0] * batch
+    vi, l1, r1 = model.prepare_vit_images(z, z, images, ident, ids)
+    cache = model.forward_cache_update_vit(new_cache(cfg), **vi)
+    pi, l2, r2 = model.prepare_prompts(l1, r1, prompts, tok, ids)
+    cache = model.forward_cache_update_text(cache, **pi)
+    si = model.prepare_start_tokens(l2, r2, ids)
+    # the oracle on the same inputs
+    oc = O.forward_cache_update_vit(W, cfg, O.OracleCache(L), **vi)
+    oc = O.forward_cache_update_text(W, cfg, oc, **pi)
+    for i in range(L):
+        assert rel(cache.key_cache[i], oc.key_cache[i]) < 1.5e-2 and rel(cache.value_cache[i], oc.value_cache[i]) < 1.5e-2
+    n = 6
+    otoks, ologits = O.generate_text(W, cfg, oc, si["packed_key_value_indexes"], si["key_values_lens"], si["packed_start_tokens"],
+                                     si["packed_query_position_ids"], n, return_logits=True)
+    toks = model.generate_text(past_key_values=cache, max_length=n, do_sample=False, end_token_id=None, use_graph=False, **si)
+    _tokens_match(toks, otoks, ologits, f"{name} B={batch}")
+    assert cache.seq_lens == sum(l2) + n * batch and cache.lens(0) == [x + n for x in l2]
+    if torch.equal(toks, otoks):      # same prefix -> the decoded K/V rows written back to the caller's cache are comparable too
+        for i in range(L):
+            assert rel(cache.key_cache[i], oc.key_cache[i]) < 1.5e-2 and rel(cache.value_cache[i], oc.value_cache[i]) < 1.5e-2
+    del P
