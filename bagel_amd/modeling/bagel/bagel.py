@@ -116,6 +116,7 @@ class Bagel(nn.Module):
         # on the 2 marker rows per sample; see _stream_batch / MoTEngine.forward): off unless asked for
         self.cfg_batched = os.environ.get("BAGEL_CFG_BATCH", "0") == "1"
         self.und_side_path = os.environ.get("BAGEL_UND_SIDE", "1") == "1"
+        self.global_renorm_allreduce = False      # see _renorm_sums_allreduce
 
     # ------------------------------------------------------------------------------------------------
     # helpers
@@ -411,6 +412,18 @@ class Bagel(nn.Module):
                             s_t, s_i, cfg_renorm_min, mode, taylor, multi)
         return x_t.split([int(n) - 2 for n in packed_seqlens.tolist()])
 
+    def _renorm_sums_allreduce(self, partials, nparts, mode):
+        """Optional batch-global 'global' renorm across data-parallel ranks: the reference's norm spans the tokens
+        of the LOCAL pack only (bagel.py:892-895), which is also the default here; with ``model.global_renorm_allreduce = True``
+        the per-block partial sums of stage 1 are summed over the ranks (one small all-reduce per step) so that an N-rank batch
+        renormalises like the same batch in one process."""
+        if mode != 0 or not self.global_renorm_allreduce:
+            return
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from ...parallel import allreduce_renorm_sums
+            allreduce_renorm_sums(partials[: 2 * nparts])
+
     def _stream_batch(self, st, plans, caches):
         """Opt-in (``model.cfg_batched`` / BAGEL_CFG_BATCH=1): the conditional and the CFG forwards of a denoise step share the
         query sequence and differ only in position ids and context (bagel.py:820-870), so they run as ONE forward over
@@ -467,6 +480,7 @@ class Bagel(nn.Module):
                          M0=st["v"][s].shape[0])
             v, v_ct, v_ci = st["v"][0], st["v"][1], (st["v"][2] if plan_i is not None else None)
             nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
+            self._renorm_sums_allreduce(st["partials"], nparts, mode)
             ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
             return
         v = self._velocity(st, plan, cache, st["v"][0], taylor[0])
@@ -474,6 +488,7 @@ class Bagel(nn.Module):
             v_ct = self._velocity(st, plan_t, cache_t, st["v"][1], taylor[1])
             v_ci = self._velocity(st, plan_i, cache_i, st["v"][2], taylor[2]) if plan_i is not None else None
             nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
+            self._renorm_sums_allreduce(st["partials"], nparts, mode)
             ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
         else:
             ops.cfg_stage2_euler(x_t, v, None, 0, renorm_min, dt, use_global_scale=False)

@@ -67,3 +67,92 @@ def test_broadcast_cache_gloo_world2():
     for p in ps:
         p.join(timeout=60)
     assert res == {0: True, 1: True}
+
+
+# ---- data-parallel text->image end to end on the host logic (2 ranks, gloo, torch stand-ins for the launch wrappers) --------
+def _dp_setup(B):
+    """(model, cfg, prompt inputs for B identical prompts, sizes).  The launch wrappers are the CPU stand-ins of tests/mock_ops.py
+    (test infrastructure): what is under test is the host-side DP protocol, not the kernels."""
+    from oracle.configs import TINY, NEW_TOKEN_IDS_TINY, StubTokenizer
+    from tests import mock_ops
+    from tests.test_host_logic_cpu import cpu_model
+
+    class _MP:
+        def setattr(self, obj, name, val):
+            setattr(obj, name, val)
+    mock_ops.install(_MP())
+    model = cpu_model(TINY)
+    tok = StubTokenizer(TINY["llm"]["vocab_size"])
+    return model, TINY, tok, NEW_TOKEN_IDS_TINY
+
+
+def _dp_generate(model, cfg, tok, ids, cache, B, noise, renorm):
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    L = cfg["llm"]["num_hidden_layers"]
+    sizes = [(64, 32)] * B
+    _, lens, ropes = model.prepare_prompts([0] * B, [0] * B, ["a small red cube"] * B, tok, ids)
+    li = model.prepare_vae_latent(lens, ropes, sizes, ids)
+    li["packed_init_noises"] = noise
+    ci = model.prepare_vae_latent_cfg([0] * B, [0] * B, sizes)
+    return model.generate_image(past_key_values=cache, num_timesteps=4, timestep_shift=3.0, cfg_text_scale=4.0, cfg_interval=[0, 1.0],
+                                cfg_renorm_min=0.0, cfg_renorm_type=renorm, cfg_text_past_key_values=NaiveCache(L),
+                                cfg_text_packed_position_ids=ci["cfg_packed_position_ids"],
+                                cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
+                                cfg_text_key_values_lens=ci["cfg_key_values_lens"],
+                                cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"], **li)
+
+
+def _dp_worker(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    from bagel_amd.parallel import broadcast_cache, shard_range
+    B_total, n_img = 4, 4 * 2
+    per = B_total // ws
+    model, cfg, tok, ids = _dp_setup(per)
+    L = cfg["llm"]["num_hidden_layers"]
+    # the conditioning context: rank 0 prefills, everybody receives it (bench.py / SURVEY.md 8e.1)
+    cache = NaiveCache(L)
+    if rank == 0:
+        gi, _, _ = model.prepare_prompts([0] * per, [0] * per, ["a small red cube"] * per, tok, ids)
+        cache = model.forward_cache_update_text(cache, **gi)
+    cache = broadcast_cache(cache, src=0)
+    all_noise = torch.randn(B_total * n_img, 64, generator=torch.Generator().manual_seed(42))
+    lo, hi = shard_range(B_total, rank, ws)
+    mine = all_noise[lo * n_img:hi * n_img]
+    out = {}
+    for tag, renorm, allreduce in (("channel", "channel", False), ("global_local", "global", False), ("global_allreduce", "global", True)):
+        model.global_renorm_allreduce = allreduce
+        out[tag] = [t.clone() for t in _dp_generate(model, cfg, tok, ids, cache, per, mine, renorm)]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_text_to_image_world2():
+    """Two ranks x two samples vs ONE process with all four samples, identical prompts, the job-global seed-42 noise stream sharded
+    by rank: per-token renorm -> every sample bit-identical to the single-process batch (no tensor crosses a
+    rank during sampling); 'global' renorm -> per-rank statistics by default (what the reference's torchrun drivers do: differs from
+    the 4-sample batch), equal to it with model.global_renorm_allreduce (two fp32 sums all-reduced per step)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    # single-process reference: all four samples in one batch
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    model, cfg, tok, ids = _dp_setup(4)
+    gi, _, _ = model.prepare_prompts([0] * 4, [0] * 4, ["a small red cube"] * 4, tok, ids)
+    cache = model.forward_cache_update_text(NaiveCache(cfg["llm"]["num_hidden_layers"]), **gi)
+    noise = torch.randn(4 * 8, 64, generator=torch.Generator().manual_seed(42))
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    one = {r: _dp_generate(model, cfg, tok, ids, cache, 4, noise, r) for r in ("channel", "global")}
+    dp = {tag: res[0][tag] + res[1][tag] for tag in res[0]}
+    assert all(torch.equal(a, b) for a, b in zip(dp["channel"], one["channel"]))
+    assert max(rel(a, b) for a, b in zip(dp["global_allreduce"], one["global"])) < 1e-3
+    assert max(rel(a, b) for a, b in zip(dp["global_local"], one["global"])) > 1e-3, "per-rank statistics should be visible"
