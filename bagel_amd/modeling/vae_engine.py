@@ -5,7 +5,6 @@ skip adds folded into conv epilogues.  Mirrors Encoder.forward / Decoder.forward
 import torch
 
 from .. import ops
-from .._lib import check, lib
 
 F32 = torch.float32
 
@@ -26,8 +25,7 @@ def _pack3(w, cin_pad):
 class VaeEngine:
     def __init__(self, ae):
         p0 = ae.encoder.conv_in.weight
-        if not p0.is_cuda or p0.dtype != F32:
-            raise ops.BagelHipError("the VAE runs in fp32 on an MI355X (as the reference): call vae.to('cuda') and keep it fp32")
+        ops.require_gpu_f32(p0, "VaeEngine")
         self.ae = ae
         self.dev = p0.device
         self.P = ae.params
@@ -47,9 +45,6 @@ class VaeEngine:
             self._w[id(m)] = w
         return w
 
-    def _stream(self):
-        return torch.cuda.current_stream().cuda_stream
-
     def conv(self, x, m, mode, residual=None, out_hw=None):
         """x: [B,H,W,C] NHWC fp32 -> [B,Ho,Wo,Cout]."""
         B, H, W, C = x.shape
@@ -62,9 +57,7 @@ class VaeEngine:
         if residual is not None and (ldo != cout or residual.shape[-1] != cout or not residual.is_contiguous()):
             raise ValueError("residual must be a contiguous NHWC tensor with Cout % 4 == 0 channels")
         out = torch.empty((B, Ho, Wo, ldo), dtype=F32, device=x.device)
-        check(lib().bagel_conv_gemm_f32(x.data_ptr(), C, w.data_ptr(), w.shape[1], m.bias.data.data_ptr(),
-                                        None if residual is None else residual.data_ptr(), out.data_ptr(), ldo, B, H, W, C, Ho, Wo,
-                                        cout, mode, self._stream()), "bagel_conv_gemm_f32")
+        ops.conv_gemm_f32(x, C, w, w.shape[1], m.bias.data, residual, out, ldo, B, H, W, C, Ho, Wo, cout, mode)
         return out if ldo == cout else out[..., :cout]
 
     def gemm_nt(self, a, b):
@@ -72,8 +65,7 @@ class VaeEngine:
         M, K = a.shape
         N = b.shape[0]
         out = torch.empty((M, N), dtype=F32, device=a.device)
-        check(lib().bagel_conv_gemm_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), None, None, out.data_ptr(), N, 1, 1, M, K,
-                                        1, M, N, 0, self._stream()), "bagel_conv_gemm_f32")
+        ops.conv_gemm_f32(a, a.stride(0), b, b.stride(0), None, None, out, N, 1, 1, M, K, 1, M, N, 0)
         return out
 
     def gn(self, x, m, swish):
@@ -82,8 +74,7 @@ class VaeEngine:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=F32, device=x.device)
         y = torch.empty_like(x)
-        check(lib().bagel_groupnorm_f32(x.data_ptr(), y.data_ptr(), self._ws.data_ptr(), m.weight.data.data_ptr(), m.bias.data.data_ptr(),
-                                        B, H * W, C, 32, 1e-6, int(swish), self._stream()), "bagel_groupnorm_f32")
+        ops.groupnorm_f32(x, y, self._ws, m.weight.data, m.bias.data, B, H * W, C, 32, 1e-6, swish)
         return y
 
     def res(self, x, m):
@@ -99,7 +90,7 @@ class VaeEngine:
         o = torch.empty((B, N, C), dtype=F32, device=x.device)
         for b in range(B):
             s = self.gemm_nt(q[b].view(N, C), k[b].view(N, C))
-            check(lib().bagel_softmax_rows_f32(s.data_ptr(), s.stride(0), N, N, float(C) ** -0.5, self._stream()), "bagel_softmax_rows_f32")
+            ops.softmax_rows_f32(s, s.stride(0), N, N, float(C) ** -0.5)
             vt = v[b].view(N, C).t().contiguous()          # layout copy only
             o[b] = self.gemm_nt(s, vt)
         return self.conv(o.view(B, H, W, C), m.proj_out, 0, residual=x)
@@ -134,16 +125,14 @@ class VaeEngine:
             sample_noise = torch.randn(B, zc, hh, ww)     # host generator: same draw as the reference's randn_like on CPU
         noise = sample_noise.to(device=self.dev, dtype=F32).permute(0, 2, 3, 1).contiguous()
         z = torch.empty((B, hh, ww, zc), dtype=F32, device=self.dev)
-        check(lib().bagel_vae_reparam_f32(mom.data_ptr(), noise.data_ptr(), z.data_ptr(), B * hh * ww, zc, float(P.scale_factor),
-                                          float(P.shift_factor), self._stream()), "bagel_vae_reparam_f32")
+        ops.vae_reparam_f32(mom, noise, z, B * hh * ww, zc, P.scale_factor, P.shift_factor)
         return z.permute(0, 3, 1, 2).contiguous()
 
     def decode(self, z):
         P, ae = self.P, self.ae
         z = z.to(device=self.dev, dtype=F32).contiguous()
         zz = torch.empty_like(z)
-        check(lib().bagel_vae_unscale_f32(z.data_ptr(), zz.data_ptr(), z.numel(), float(P.scale_factor), float(P.shift_factor),
-                                          self._stream()), "bagel_vae_unscale_f32")
+        ops.vae_unscale_f32(z, zz, z.numel(), P.scale_factor, P.shift_factor)
         d = ae.decoder
         h = self.conv(self.to_nhwc(zz, _ceil_to(zz.shape[1], 32)), d.conv_in, 1)
         h = self.res(h, d.mid.block_1)

@@ -561,6 +561,47 @@ def cfg_stage2_euler(x_t, v_or_tmp, partials, nparts, renorm_min, dt, use_global
     return x_t
 
 
+# ---- VAE (fp32, NHWC): thin launch wrappers, tensors in / raw pointers out (bagel_amd/modeling/vae_engine.py) ---------------
+def conv_gemm_f32(x, ld_in, w, ld_w, bias, residual, out, ld_out, B, Hin, Win, Cin, Hout, Wout, Cout, mode):
+    """bagel_conv_gemm_f32: mode 0 plain GEMM rows x w^T, 1 = 3x3 s1 p1, 2 = 3x3 s2 pad (0,1,0,1), 3 = nearest-2x + 3x3."""
+    _req(x, torch.float32, "conv_gemm_f32.x"); _req(w, torch.float32, "conv_gemm_f32.w"); _req(out, torch.float32, "conv_gemm_f32.out")
+    check(lib().bagel_conv_gemm_f32(_ptr(x), ld_in, _ptr(w), ld_w, _ptr(bias), _ptr(residual), _ptr(out), ld_out, B, Hin, Win, Cin,
+                                    Hout, Wout, Cout, mode, _stream()), "bagel_conv_gemm_f32")
+    return out
+
+
+def groupnorm_f32(x, y, workspace, gamma, beta, B, HW, C, groups, eps, swish):
+    _req(x, torch.float32, "groupnorm_f32.x"); _req(y, torch.float32, "groupnorm_f32.y")
+    check(lib().bagel_groupnorm_f32(_ptr(x), _ptr(y), _ptr(workspace), _ptr(gamma), _ptr(beta), B, HW, C, groups, float(eps),
+                                    int(swish), _stream()), "bagel_groupnorm_f32")
+    return y
+
+
+def softmax_rows_f32(x, ld, rows, cols, scale):
+    _req(x, torch.float32, "softmax_rows_f32.x")
+    check(lib().bagel_softmax_rows_f32(_ptr(x), ld, rows, cols, float(scale), _stream()), "bagel_softmax_rows_f32")
+    return x
+
+
+def vae_reparam_f32(moments, noise, z, n_pix, z_channels, scale, shift):
+    _req(moments, torch.float32, "vae_reparam_f32.moments"); _req(noise, torch.float32, "vae_reparam_f32.noise")
+    check(lib().bagel_vae_reparam_f32(_ptr(moments), _ptr(noise), _ptr(z), n_pix, z_channels, float(scale), float(shift), _stream()),
+          "bagel_vae_reparam_f32")
+    return z
+
+
+def vae_unscale_f32(z, out, n, scale, shift):
+    _req(z, torch.float32, "vae_unscale_f32.z")
+    check(lib().bagel_vae_unscale_f32(_ptr(z), _ptr(out), n, float(scale), float(shift), _stream()), "bagel_vae_unscale_f32")
+    return out
+
+
+def require_gpu_f32(t, what):
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise BagelHipError(f"{what}: the VAE runs in fp32 on an MI355X (as the reference; got {t.device}, {t.dtype}): "
+                            "call vae.to('cuda') and keep it fp32")
+
+
 def argmax_into(logits, out):
     _req(logits, BF16, "argmax.logits"); _req(out, torch.int64, "argmax.out")
     check(lib().bagel_argmax_bf16(_ptr(logits), logits.stride(0), _ptr(out), logits.shape[0], logits.shape[1], _stream()),

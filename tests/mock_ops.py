@@ -364,11 +364,98 @@ def require_gpu_bf16(t, what=""):
     return None
 
 
+def require_gpu_f32(t, what=""):
+    return None
+
+
+# ---- VAE (fp32 NHWC) ----------------------------------------------------------------------------------------------------
+def conv_gemm_f32(x, ld_in, w, ld_w, bias, residual, out, ld_out, B, Hin, Win, Cin, Hout, Wout, Cout, mode):
+    M = B * Hout * Wout
+    if mode == 0:
+        a = torch.as_strided(x, (M, Cin), (ld_in, 1))
+        y = (a.double() @ w[:Cout, :Cin].double().t()).float()
+    else:
+        xi = x.reshape(B, Hin, Win, -1)[..., :Cin].permute(0, 3, 1, 2)
+        w4 = w.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)             # tap-major (dy, dx, cin) -> [Cout, Cin, 3, 3]
+        if mode == 1:
+            y = F.conv2d(xi.double(), w4.double(), padding=1)
+        elif mode == 2:
+            y = F.conv2d(F.pad(xi.double(), (0, 1, 0, 1)), w4.double(), stride=2)
+        else:
+            y = F.conv2d(F.interpolate(xi.double(), scale_factor=2.0, mode="nearest"), w4.double(), padding=1)
+        assert y.shape[2:] == (Hout, Wout), (y.shape, Hout, Wout)
+        y = y.permute(0, 2, 3, 1).reshape(M, Cout).float()
+    if bias is not None:
+        y = y + bias.float()
+    if residual is not None:
+        y = y + residual.reshape(M, -1)[:, :Cout]
+    o = torch.as_strided(out, (M, ld_out), (ld_out, 1))
+    o[:, :Cout] = y
+    o[:, Cout:] = 0
+    return out
+
+
+def groupnorm_f32(x, y, workspace, gamma, beta, B, HW, C, groups, eps, swish):
+    v = x.reshape(B, HW, C).permute(0, 2, 1)
+    o = F.group_norm(v.double(), groups, gamma.double(), beta.double(), eps).float()
+    if swish:
+        o = o * torch.sigmoid(o)
+    y.copy_(o.permute(0, 2, 1).reshape(y.shape))
+    return y
+
+
+def softmax_rows_f32(x, ld, rows, cols, scale):
+    v = torch.as_strided(x, (rows, cols), (ld, 1))
+    v.copy_(torch.softmax(v * scale, -1))
+    return x
+
+
+def vae_reparam_f32(moments, noise, z, n_pix, z_channels, scale, shift):
+    m = moments.reshape(n_pix, -1)
+    mean, logvar = m[:, :z_channels], m[:, z_channels:2 * z_channels]
+    z.copy_((scale * ((mean + torch.exp(0.5 * logvar) * noise.reshape(n_pix, z_channels)) - shift)).reshape(z.shape))
+    return z
+
+
+def vae_unscale_f32(z, out, n, scale, shift):
+    out.copy_(z / scale + shift)
+    return out
+
+
+# ---- image pre/post-processing ---------------------------------------------------------------------------------------------
+def resample_u8(src, dst, bounds, kk, vertical):
+    a = src.to(torch.int64)
+    if vertical:
+        for o in range(dst.shape[0]):
+            first, n = int(bounds[o, 0]), int(bounds[o, 1])
+            ss = (a[first:first + n] * kk[o, :n].to(torch.int64)[:, None, None]).sum(0) + (1 << 21)
+            dst[o] = (ss >> 22).clamp(0, 255).to(torch.uint8)
+    else:
+        for o in range(dst.shape[1]):
+            first, n = int(bounds[o, 0]), int(bounds[o, 1])
+            ss = (a[:, first:first + n] * kk[o, :n].to(torch.int64)[None, :, None]).sum(1) + (1 << 21)
+            dst[:, o] = (ss >> 22).clamp(0, 255).to(torch.uint8)
+    return dst
+
+
+def u8_to_chw_f32(src, mean, std):
+    v = src.permute(2, 0, 1).float() / 255.0
+    m = torch.tensor([float(x) for x in mean], dtype=torch.float32)[:, None, None]
+    s_ = torch.tensor([float(x) for x in std], dtype=torch.float32)[:, None, None]
+    return (v - m) / s_
+
+
+def chw_f32_to_u8(src):
+    v = (src.float() * 0.5 + 0.5).clamp(0.0, 1.0) * 255.0
+    return v.to(torch.uint8).permute(1, 2, 0).contiguous()
+
+
 _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
           "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged",
-          "decode_advance"]
+          "decode_advance", "require_gpu_f32", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
+          "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8"]
 
 
 def install(monkeypatch):

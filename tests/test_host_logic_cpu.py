@@ -258,3 +258,116 @@ def test_understanding_flow_host_path_matches_oracle(monkeypatch, name, batch):
         for i in range(L):
             assert rel(cache.key_cache[i], oc.key_cache[i]) < 1.5e-2 and rel(cache.value_cache[i], oc.value_cache[i]) < 1.5e-2
     del P
+
+
+def cpu_model_and_vae(cfg):
+    from bagel_amd.factory import build_bagel
+    W, VW = oracle_weights(cfg)
+    model, vae = build_bagel(cfg, device="cpu", with_vae=True)
+    model.load_state_dict(W, strict=True)
+    vae.load_state_dict(VW, strict=True)
+    return model.to(torch.bfloat16).eval(), vae.eval()
+
+
+def test_vae_host_path_matches_reference(golden, monkeypatch):
+    """VaeEngine: weight packing (tap-major 3x3, channel padding), NHWC plumbing, conv modes (3x3, strided with the (0,1,0,1) pad,
+    upsample-fused), ResnetBlock / AttnBlock residual folding -- encode / decode vs the reference, and the truncating uint8 image."""
+    mock_ops.install(monkeypatch)
+    g = golden("tiny_vae")
+    _, vae = cpu_model_and_vae(TINY)
+    dec = vae.decode(g["z"])
+    assert dec.shape == g["decoded"].shape and (dec - g["decoded"]).abs().max() / g["decoded"].abs().max() < 1e-4
+    enc = vae.encode(g["x"], sample_noise=g["enc_noise"])
+    assert enc.shape == g["encoded"].shape and (enc - g["encoded"]).abs().max() / g["encoded"].abs().max() < 1e-4
+    from bagel_amd.inferencer import InterleaveInferencer
+    model = cpu_model(TINY)
+    inf = InterleaveInferencer(model, vae, None, None, None, None)
+    u8 = inf.image_to_u8(vae.decode(inf.latent_to_chw(g["packed_latent"], (8 * 16, 12 * 16))))
+    diff = (u8.int() - g["image_u8"].int()).abs()
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 0.01
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_edit_flow_host_path_matches_reference(golden, monkeypatch, name):
+    """BASELINE configs[4] on the host logic: VAE-encode + SigLIP prefill of a source image (two cache appends on a single-sample
+    context), prompt on top, the three CFG contexts (deepcopy of the cache), the 3-forward sampler with text_channel / global
+    renorm, and the greedy decode from the same context -- vs the reference's goldens (tolerances of the GPU test)."""
+    mock_ops.install(monkeypatch)
+    cfg = CFGS[name]
+    g = golden(f"{name}_editund")
+    model, vae = cpu_model_and_vae(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ids = NEW_TOKEN_IDS_TINY
+    ident = lambda t: t  # noqa: E731
+
+    class FixedNoiseVae:   # the reference draws randn_like inside encode; feed the recorded draw
+        def encode(self, x):
+            return vae.encode(x, sample_noise=g["enc_noise"])
+    vi, l1, r1 = model.prepare_vae_images([0], [0], [g["img_vae"]], ident, ids)
+    cache = model.forward_cache_update_vae(FixedNoiseVae(), new_cache(cfg), **vi)
+    ti, l2, r2 = model.prepare_vit_images(l1, r1, [g["img_vit"]], ident, ids)
+    cache = model.forward_cache_update_vit(cache, **ti)
+    for i in range(L):
+        assert rel(cache.key_cache[i], g["key_cache_img"][i]) < 1.5e-2
+    cfg_text_cache = copy.deepcopy(cache)
+    pi, l3, r3 = model.prepare_prompts(l2, r2, [g["prompt"]], tok, ids)
+    cache = model.forward_cache_update_text(cache, **pi)
+    for i in range(L):
+        assert rel(cache.key_cache[i], g["key_cache"][i]) < 1.5e-2 and rel(cache.value_cache[i], g["value_cache"][i]) < 1.5e-2
+    assert cfg_text_cache.seq_lens == g["key_cache_img"][0].shape[0], "deepcopy must not alias the appended cache"
+    pi2, l4, r4 = model.prepare_prompts([0], [0], [g["prompt"]], tok, ids)
+    cimg = model.forward_cache_update_text(new_cache(cfg), **pi2)
+    for batched in (False, True):
+        model.cfg_batched = batched
+        for kw, key in ((g["gen_kwargs"], "latents"), (g["gen_kwargs_global"], "latents_global")):
+            lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", cfg_text_cache, g["cfg_text_inputs"]),
+                                       **cfg_kwargs("cfg_img", cimg, g["cfg_img_inputs"]), **kw, **g["latent_inputs"])
+            assert rel(lat[0], g[key][0]) < 3e-2, (key, batched)
+    toks = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=8, do_sample=False, end_token_id=None, use_graph=False,
+                               **g["start_inputs"])
+    _tokens_match(toks, g["tokens"], g["logits"], name)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_interleave_inferencer_host_path_matches_reference(golden, monkeypatch, name):
+    """bagel_amd/inferencer.py end to end (PIL / str in and out, the product's ImageTransform, the three contexts kept in step,
+    think mode) against the REFERENCE inferencer's outputs, with the image tolerances of tests/test_inferencer_gpu.py."""
+    import re
+    import numpy as np
+    from PIL import Image
+    from bagel_amd.data.transforms import ImageTransform
+    from bagel_amd.inferencer import InterleaveInferencer
+    mock_ops.install(monkeypatch)
+    monkeypatch.setenv("BAGEL_DECODE_GRAPH", "0")          # hipGraph capture needs a device; the eager launch sequence is the same
+    cfg = CFGS[name]
+    g = golden(f"{name}_inferencer")
+    model, vae = cpu_model_and_vae(cfg)
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    inf = InterleaveInferencer(model, vae, tok, ImageTransform(64, 32, 16, device="cpu"), ImageTransform(56, 28, 14, device="cpu"),
+                               NEW_TOKEN_IDS_TINY)
+    src = Image.fromarray(g["source_image"].numpy(), "RGB")
+
+    def close(img, ref, mean_tol, p99_tol, what):
+        d = np.abs(np.asarray(img).astype(np.int32) - ref.numpy().astype(np.int32))
+        assert d.shape == tuple(ref.shape) and d.mean() <= mean_tol and np.percentile(d, 99) <= p99_tol, (what, d.mean(), np.percentile(d, 99))
+
+    def ids_of(s):
+        return re.findall(r"\[(\d+)\]", s)
+    torch.manual_seed(g["t2i"]["seed"])
+    r = inf(text=g["t2i"]["text"], **g["t2i"]["kwargs"])
+    assert isinstance(r["image"], Image.Image) and r["text"] is None
+    close(r["image"], g["t2i"]["image"], 1.5, 8, "text -> image")
+    torch.manual_seed(g["edit"]["seed"])
+    r = inf(image=src, text=g["edit"]["text"], **g["edit"]["kwargs"])
+    close(r["image"], g["edit"]["image"], 3.0, 14, "image + text -> image")
+    r = inf(image=src, text=g["understanding"]["text"], **g["understanding"]["kwargs"])
+    ours, ref = ids_of(r["text"]), ids_of(g["understanding"]["answer"])
+    first = next((i for i, (a, b) in enumerate(zip(ours, ref)) if a != b), len(ref))
+    assert r["image"] is None and len(ours) == len(ref) and first >= 1 and ours[:first] == ref[:first]
+    torch.manual_seed(g["think"]["seed"])
+    r = inf(text=g["think"]["text"], **g["think"]["kwargs"])
+    ours, ref = ids_of(r["text"]), ids_of(g["think"]["thought"])
+    assert len(ours) == len(ref) and ours[0] == ref[0]
+    if ours == ref:        # same planning text -> the image conditioned on it is comparable
+        close(r["image"], g["think"]["image"], 1.5, 8, "think -> image")
