@@ -111,3 +111,16 @@ def test_product_packers_equal_live_reference_on_random_inputs():
         imgs = [torch.randn(3, 14 * rng.randint(1, 5), 14 * rng.randint(1, 5), generator=g) for _ in range(B)]
         a, b = mine.prepare_vit_images(list(kv), list(rope), imgs, ident, ids), ref.prepare_vit_images(list(kv), list(rope), imgs, ident, ids)
         _same_out(a[0], b[0], f"prepare_vit_images #{case}"); assert a[1:] == b[1:]
+
+
+def test_reference_inferencer_drives_the_product():
+    """Drop-in at the inferencer level: the UNMODIFIED /root/reference/inferencer.py (loaded by path, after
+    bagel_amd.install_as_reference()) drives the product's Bagel / AutoEncoder / ImageTransform and reproduces the reference's own
+    text->image, edit and understanding outputs (tests/scripts/reference_inferencer_dropin.py; operators = CPU stand-ins)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "reference_inferencer_dropin.py")], capture_output=True,
+                       text=True, cwd=root, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
