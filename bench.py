@@ -12,7 +12,7 @@ One "step" = one complete pass of the hot path over one batch of synthetic input
   offline), inputs synthetic but resident in HBM before the timed region starts.
 
 Prints ONE JSON line (rank 0) with the contract's fields plus:
-  roofline      achieved MFMA TFLOP/s of the dominant kernel (gemm_tn_kernel): algorithmic 2*M*N*K FLOPs of every launch
+  roofline      achieved MFMA TFLOP/s of the dominant kernel (the persistent ping-pong GEMM, gemm_pq_kernel<*>): algorithmic 2*M*N*K FLOPs of every launch
                 in the timed region / their HIP-event durations (events on the launch stream), vs the 2.5 PFLOP/s bf16 peak;
   cpu_baseline  the oracle (CPU restatement of the reference) timed on this box's host cores on a bounded sample.
 """
