@@ -154,3 +154,18 @@ def test_position_id_variants_product_equals_oracle():
         assert torch.equal(D.get_flattened_position_ids_extrapolate(h, w, p, side), P.position_ids_extrapolate(h, w, p, side))
         assert torch.equal(D.get_flattened_position_ids_interpolate(h, w, p, side), P.position_ids_interpolate(h, w, p, side))
     assert D.get_flattened_position_ids_extrapolate(32, 48, 16, 8).tolist() == [0, 1, 2, 8, 9, 10]
+
+
+def test_bench_roofline_traffic_sources_resolve():
+    """bench.py's roofline.traffic fields come from the committed PMC summary (a profiler cannot run inside the timed region): the
+    keys the bench looks up must exist, or the field silently degrades to null."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.pmc_traffic("gemm_pq_kernel<*>")
+    assert t is not None and 0.5e9 < t < 50e9            # HBM-side bytes per launch of the dominant GEMM (0.61 GB algorithmic)
+    d = bench.pmc_decode_traffic()
+    assert d is not None and 14.0e9 < d < 16.0e9         # bytes of one decode step (14.43 GB algorithmic)
+    assert bench.pmc_traffic("no_such_kernel") is None
