@@ -76,7 +76,7 @@ def compare():
     import subprocess
     import tempfile
     outs = {}
-    for v in ("0", "1"):
+    for v in ("0", "1", "2"):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
             path = f.name
         env = dict(os.environ, BAGEL_ATTN_SCHED=v, BAGEL_ATTN_PROBE_DUMP=path)
@@ -87,12 +87,16 @@ def compare():
             raise SystemExit(f"variant {v} failed")
         outs[v] = torch.load(path)
         os.unlink(path)
-    for k in ("full", "causal"):
-        same = torch.equal(outs["0"][k], outs["1"][k])
-        print(f"BAGEL_ATTN_SCHED 0 vs 1, {k}: {'bit-identical' if same else 'DIFFERENT'}", flush=True)
-        if not same:
-            d = (outs["0"][k].float() - outs["1"][k].float()).abs().max().item()
-            raise SystemExit(f"schedule variants differ ({k}): max|d| = {d}")
+    bad = []
+    for v in ("1", "2"):
+        for k in ("full", "causal"):
+            same = torch.equal(outs["0"][k], outs[v][k])
+            d = 0.0 if same else (outs["0"][k].float() - outs[v][k].float()).abs().max().item()
+            print(f"BAGEL_ATTN_SCHED 0 vs {v}, {k}: {'bit-identical' if same else f'DIFFERENT (max|d| = {d})'}", flush=True)
+            if not same:
+                bad.append((v, k, d))
+    if bad:
+        raise SystemExit(f"schedule variants differ: {bad}")
 
 
 if __name__ == "__main__":
