@@ -169,3 +169,15 @@ def test_bench_roofline_traffic_sources_resolve():
     d = bench.pmc_decode_traffic()
     assert d is not None and 14.0e9 < d < 16.0e9         # bytes of one decode step (14.43 GB algorithmic)
     assert bench.pmc_traffic("no_such_kernel") is None
+
+
+def test_attention_sched2_protocol_model():
+    """The barrier / ring / DMA protocol of the opt-in two-phase attention schedule (attn_fwd_kernel<D, 2>), as a discrete model
+    (tools/attn_sched2_model.py): equal barrier counts for every role, reads only of resident tiles, refills only of dead slots."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("attn_sched2_model", os.path.join(root, "tools", "attn_sched2_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for T in range(1, 40):
+        assert m.check(T) == 2 * T + 3
