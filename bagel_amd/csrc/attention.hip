@@ -69,7 +69,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // softmax so it lands under the exp/convert VALU work.  Waves 4-7 (the second-dispatched half, the arbitration loser on
 // every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.  Waves with no live query row
 // skip the arithmetic (1 904 workgroups at the denoise shape, 112 of them with 2 live rows of 256).
-// SCHED = 2 (BAGEL_ATTN_SCHED=2): the two halves of the workgroup alternate roles.  The loop runs in STEPS separated by one
+// SCHED = 2 / 3 (BAGEL_ATTN_SCHED=2 / 3; 3 = 2 + four V^T fragments prefetched across the barrier): the two halves of the workgroup
+// alternate roles.  The loop runs in STEPS separated by one
 // workgroup barrier each; in every step waves 0-3 are in a MATRIX block (O^T += V^T(t-1) P^T(t-1), then S^T(t) = K(t) Q^T: 32 MFMAs
 // with the LDS reads pipelined under them) while waves 4-7 are in a VECTOR block (mask, online softmax of their S^T, P -> bf16)
 // -- and the other way round in the next step: waves 4-7 run one step behind.  Each SIMD hosts one
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
     int st = 0;
     if (SCHED == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if constexpr (SCHED == 2) {
+    if constexpr (SCHED >= 2) {
         // ---- two-phase schedule (see the comment above the kernel) ----
         // Global steps gs = 0 .. 2T+2, one workgroup barrier at the end of each.  Waves 0-3 run matrix blocks in even steps and
         // vector blocks in odd steps, waves 4-7 the other way round (their program starts one step later), a wave without a live
@@ -209,8 +210,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         constexpr int NV = DB * 4;                  // V^T fragments of a tile (index 4*db + j)
         constexpr int NK = 2 * KS;                  // K fragments of a tile (index KS*kb + ks)
         constexpr int WIN = 8;                      // fragment reads kept in flight ahead of the MFMA that consumes them
+        constexpr int PRE = SCHED == 3 ? 4 : 0;     // SCHED = 3: V^T fragments of tile t fetched at the end of its vector block, so
+                                                    // the following matrix block opens with MFMAs instead of an exposed LDS round trip
         f32x16_t s[2];
-        bf16x8_t pf[4];
+        bf16x8_t pf[4], vpre[PRE > 0 ? PRE : 1];
         auto kfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx / KS) * 32 * KROW + kch[idx % KS]); };
         auto vfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx >> 2) * 4096 + vch[idx & 3]); };
         auto slot = [&](int t) { return (const char*)smem + (t % 3) * STAGE; };
@@ -253,7 +256,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
             bf16x8_t vf[NV], kf[NK];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) vf[j] = vfrag(sbp, j);
+            for (int j = 0; j < PRE; ++j) vf[j] = vpre[j];
+#pragma unroll
+            for (int j = PRE; j < NV; ++j) vf[j] = vfrag(sbp, j);
 #pragma unroll
             for (int j = 0; j < NK; ++j) kf[j] = kfrag(sbk, j);
 #pragma unroll
@@ -262,13 +267,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
 #pragma unroll
             for (int j = 0; j < NK; ++j) s[j / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j % KS], s[j / KS], 0, 0, 0);
+            // PRE fragments are already in registers: WIN reads go out first, then one more behind every MFMA while reads remain
             __builtin_amdgcn_sched_group_barrier(0x100, WIN, 0);
 #pragma unroll
-            for (int i = 0; i < NV + NK - WIN; ++i) {
+            for (int i = 0; i < NV - PRE + NK - WIN; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, WIN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, WIN + PRE, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto block_pv = [&](int t) {                                  // O^T += V^T(t-1) P^T(t-1)   (after the last tile)
@@ -276,16 +282,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
             bf16x8_t vf[NV];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) vf[j] = vfrag(sbp, j);
+            for (int j = 0; j < PRE; ++j) vf[j] = vpre[j];
+#pragma unroll
+            for (int j = PRE; j < NV; ++j) vf[j] = vfrag(sbp, j);
 #pragma unroll
             for (int j = 0; j < NV; ++j) o[j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], pf[j & 3], o[j >> 2], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, WIN, 0);
+            constexpr int R = NV - PRE, W2 = R < WIN ? R : WIN;
+            __builtin_amdgcn_sched_group_barrier(0x100, W2, 0);
 #pragma unroll
-            for (int i = 0; i < NV - WIN; ++i) {
+            for (int i = 0; i < R - W2; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, WIN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NV - (R - W2), 0);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto block_softmax = [&](int t) {                             // vector block: mask, online softmax of S^T(t), P -> bf16
@@ -336,6 +345,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
                     pf[2 * kb + c] = __builtin_bit_cast(bf16x8_t, v4);
                 }
             l_run += psum;
+            const char* sbv = slot(t);
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) vpre[j] = vfrag(sbv, j);
         };
 
         if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
@@ -601,14 +613,17 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             set = true;
         }
-        if (sched == 2)      hipLaunchKernelGGL((attn_fwd_kernel<128, 2>), grid, block, smem, stream, p);
+        if (sched == 3)      hipLaunchKernelGGL((attn_fwd_kernel<128, 3>), grid, block, smem, stream, p);
+        else if (sched == 2) hipLaunchKernelGGL((attn_fwd_kernel<128, 2>), grid, block, smem, stream, p);
         else if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<128, 1>), grid, block, smem, stream, p);
         else                 hipLaunchKernelGGL((attn_fwd_kernel<128, 0>), grid, block, smem, stream, p);
     } else if (head_dim == 64) {
         constexpr int smem = 3 * (64 * 128 + 64 * 128);
-        if (sched == 2)      hipLaunchKernelGGL((attn_fwd_kernel<64, 2>), grid, block, smem, stream, p);
+        if (sched == 3)      hipLaunchKernelGGL((attn_fwd_kernel<64, 3>), grid, block, smem, stream, p);
+        else if (sched == 2) hipLaunchKernelGGL((attn_fwd_kernel<64, 2>), grid, block, smem, stream, p);
         else if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<64, 1>), grid, block, smem, stream, p);
         else                 hipLaunchKernelGGL((attn_fwd_kernel<64, 0>), grid, block, smem, stream, p);
     } else {

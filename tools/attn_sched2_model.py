@@ -1,4 +1,4 @@
-"""Discrete model of the synchronisation protocol of attn_fwd_kernel<D, 2> (BAGEL_ATTN_SCHED=2, csrc/attention.hip): the per-role
+"""Discrete model of the synchronisation protocol of attn_fwd_kernel<D, 2 / 3> (BAGEL_ATTN_SCHED=2 / 3, csrc/attention.hip): the per-role
 step programs, the 3-slot K/V^T ring and the DMA issue / wait rules, checked for every tile count T:
   * every role executes the same number of barriers (no deadlock);
   * every LDS read of tile t happens while slot t % 3 holds tile t, completely landed, and no refill of that slot is in flight;
@@ -18,6 +18,9 @@ def programs(T):
     for t in range(1, T):
         B[2 * t + 1] += [("V", t - 1), ("K", t)]
     B[2 * T + 1].append(("V", T - 1))
+    for t in range(T):                                      # SCHED = 3: first V^T fragments of tile t at the end of its vector block
+        A[2 * t + 1].append(("V", t))
+        B[2 * t + 2].append(("V", t))
     return {"lead (waves 0-3)": A, "follow (waves 4-7)": B, "idle": {g: [] for g in range(last + 1)}}, last
 
 
