@@ -150,10 +150,42 @@ def cpu_baseline(args, cfg):
         del m1, eng, c1
     except Exception as e:
         parity = {"error": repr(e)}
-    return dict(value=1.0 / sec_per_image, unit="images/s", cores=os.cpu_count(), kind="port", parity_at_full_size=parity,
+    try:
+        config0 = cpu_config0()
+    except Exception as e:
+        config0 = {"error": repr(e)}
+    return dict(value=1.0 / sec_per_image, unit="images/s", cores=os.cpu_count(), kind="port", parity_at_full_size=parity, config0=config0,
                 sample=f"oracle MoT decoder layer (gen mode, {Lq} query tokens on a {C}-token context, 7B shapes) x{nl}, "
                        f"{dt:.2f} s/layer-forward on {os.cpu_count()} threads; extrapolated x{llm['num_hidden_layers']} layers "
                        f"x2 forwards x{steps} Euler steps (glue, prefill and VAE excluded)")
+
+
+def cpu_config0():
+    """BASELINE.json configs[0] -- the reference's own CPU-runnable case: tiny random-init BAGEL (2-layer MoT, 128-d), text -> image on a
+    64x64 latent grid (1024^2 image, 4096 latent tokens), 4 timesteps with CFG, through the oracle on the host cores (plumbing;
+    reported beside the extrapolated 7B figure)."""
+    from oracle import bagel_oracle as O
+    from oracle import packers as P
+    from oracle.configs import TINY as cfg, NEW_TOKEN_IDS_TINY as ids, StubTokenizer
+    from oracle.shapes import bagel_shapes
+    from oracle.weights import synth_state_dict
+    W = {k: v.to(torch.bfloat16) for k, v in synth_state_dict(bagel_shapes(cfg), 0).items()}
+    H, L = cfg["llm"]["hidden_size"], cfg["llm"]["num_hidden_layers"]
+    W["latent_pos_embed.pos_embed"] = O.sincos_2d_table(H, cfg["bagel"]["max_latent_size"]).to(torch.bfloat16)
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    t0 = time.time()
+    gi, lens, ropes = P.prepare_prompts([0], [0], ["a small red cube"], tok, ids)
+    cache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi)
+    torch.manual_seed(42)
+    li = P.prepare_vae_latent(lens, ropes, [(1024, 1024)], ids, 16, cfg["bagel"]["max_latent_size"], 64)
+    ci = P.prepare_vae_latent_cfg([0], [0], [(1024, 1024)], 16)
+    cfgd = dict(cache=O.OracleCache(L), position_ids=ci["cfg_packed_position_ids"], query_indexes=ci["cfg_packed_query_indexes"],
+                key_values_lens=ci["cfg_key_values_lens"], key_value_indexes=ci["cfg_packed_key_value_indexes"])
+    lat = O.generate_image(W, cfg, li, cache, cfg_text=cfgd, num_timesteps=4, timestep_shift=3.0, cfg_renorm_type="global",
+                           cfg_interval=[0.0, 1.0], cfg_text_scale=4.0)
+    dt = time.time() - t0
+    return {"seconds": dt, "latent_tokens": int(lat[0].shape[0]), "finite": bool(torch.isfinite(lat[0]).all()),
+            "what": "oracle, tiny 2-layer MoT (128-d), text -> 64x64 latent grid, 4 timesteps x [cond + CFG-text], prefill included"}
 
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md ("8 TB/s peak (spec); ~6.3 TB/s achievable")
