@@ -82,7 +82,7 @@ def _three_stream_setup(model, cfg, sizes):
     return c0, li, (c1, ct), (c2, ci)
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_dense", "tiny_moe"])
 @pytest.mark.parametrize("side", [False, True], ids=["rows_in_tile_gemm", "marker_side_path"])
 @pytest.mark.parametrize("streams", [2, 3])
 def test_stream_batched_cfg_equals_sequential(monkeypatch, name, side, streams):
@@ -111,7 +111,7 @@ def test_stream_batched_cfg_equals_sequential(monkeypatch, name, side, streams):
     monkeypatch.setattr(eng, "forward", lambda seq, plan, *a, **k: (calls.append((plan.B, plan.M, plan.und_side)), orig(seq, plan, *a, **k))[1])
     got = model.generate_image(past_key_values=copy.deepcopy(c0), **kw, **li)
     B, M = len(sizes), sum(int(x) for x in li["packed_seqlens"])
-    assert (streams * B, streams * M, side) in calls, "the batched forward never ran"
+    assert (streams * B, streams * M, side) in calls, "the batched forward never ran"     # (the flag; the side path itself is MoT-only)
     assert (B, M, False) in calls, "cfg_interval should have left single-stream steps in the schedule"
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
