@@ -181,3 +181,42 @@ def test_attention_sched2_protocol_model():
     spec.loader.exec_module(m)
     for T in range(1, 40):
         assert m.check(T) == 2 * T + 3
+
+
+def test_vae_launch_wrappers_match_the_header(monkeypatch):
+    """The fp32 VAE wrappers of bagel_amd.ops hand the C ABI exactly the argument list include/bagel_hip.h declares (count and
+    kinds: pointer / integer / float) -- checked without a GPU by swapping the library for a recorder that validates every call
+    against the parsed prototypes (the other CPU tests replace these wrappers wholesale, so nothing else executes their bodies)."""
+    import ctypes
+    from bagel_amd import _lib, ops
+    protos = _lib.parse_header()
+    calls = []
+
+    class Recorder:
+        def __getattr__(self, name):
+            restype, argtypes = protos[name]
+
+            def fn(*args):
+                assert len(args) == len(argtypes), (name, len(args), len(argtypes))
+                for i, (a, t) in enumerate(zip(args, argtypes)):
+                    if t is ctypes.c_void_p:
+                        assert a is None or isinstance(a, int), (name, i, a)
+                    elif t in (ctypes.c_int32, ctypes.c_int64):
+                        assert isinstance(a, int) and not isinstance(a, bool), (name, i, a)
+                    else:
+                        assert isinstance(a, float), (name, i, a)
+                calls.append(name)
+                return 0
+            return fn
+    monkeypatch.setattr(ops, "lib", lambda: Recorder())
+    monkeypatch.setattr(ops, "_ptr", lambda t: None if t is None else t.data_ptr())
+    monkeypatch.setattr(ops, "_stream", lambda: 0)
+    monkeypatch.setattr(ops, "_req", lambda t, dtype, name: None)
+    f = lambda *s: torch.zeros(*s)  # noqa: E731
+    ops.conv_gemm_f32(f(2, 4, 4, 32), 32, f(8, 288), 288, f(8), f(2, 4, 4, 8), f(2, 4, 4, 8), 8, 2, 4, 4, 32, 4, 4, 8, 1)
+    ops.conv_gemm_f32(f(6, 5), 5, f(7, 5), 5, None, None, f(6, 7), 7, 1, 1, 6, 5, 1, 6, 7, 0)
+    ops.groupnorm_f32(f(1, 4, 4, 32), f(1, 4, 4, 32), f(4160), f(32), f(32), 1, 16, 32, 32, 1e-6, True)
+    ops.softmax_rows_f32(f(3, 5), 5, 3, 5, 0.25)
+    ops.vae_reparam_f32(f(16, 8), f(16, 4), f(16, 4), 16, 4, 0.3611, 0.1159)
+    ops.vae_unscale_f32(f(64), f(64), 64, 0.3611, 0.1159)
+    assert calls == ["bagel_conv_gemm_f32"] * 2 + ["bagel_groupnorm_f32", "bagel_softmax_rows_f32", "bagel_vae_reparam_f32", "bagel_vae_unscale_f32"]
