@@ -371,3 +371,64 @@ def test_interleave_inferencer_host_path_matches_reference(golden, monkeypatch, 
     assert len(ours) == len(ref) and ours[0] == ref[0]
     if ours == ref:        # same planning text -> the image conditioned on it is comparable
         close(r["image"], g["think"]["image"], 1.5, 8, "think -> image")
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_interleaved_flows_match_oracle(monkeypatch, seed):
+    """Differential fuzz of the host logic beyond the golden scenarios: a random batch (1-3 samples) goes through a random
+    interleaving of prompt / ViT-image prefills (ragged lengths, multi-sample cache merges on top of existing contexts), then
+    either a CFG text->image run on random latent sizes or a greedy decode -- product engines (stand-in operators) vs the oracle's
+    restatement of the reference on identical packer outputs."""
+    import random
+    from oracle import bagel_oracle as O
+    mock_ops.install(monkeypatch)
+    rng = random.Random(seed)
+    cfg = TINY if seed % 2 == 0 else TINY_D128
+    model = cpu_model(cfg)
+    W, _ = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ids = NEW_TOKEN_IDS_TINY
+    ident = lambda t: t  # noqa: E731
+    B = rng.randint(1, 3)
+    words = ["a", "red", "cube", "on the table", "sky", "x y z", "hello world again", "what is it"]
+    lens, ropes = [0] * B, [0] * B
+    cache, oc = new_cache(cfg), O.OracleCache(L)
+    g = torch.Generator().manual_seed(seed)
+    for stage in range(rng.randint(1, 3)):
+        if rng.random() < 0.4:
+            imgs = [torch.rand(3, 14 * rng.randint(1, 3), 14 * rng.randint(1, 3), generator=g) * 2 - 1 for _ in range(B)]
+            gi, lens, ropes = model.prepare_vit_images(lens, ropes, imgs, ident, ids)
+            cache = model.forward_cache_update_vit(cache, **gi)
+            oc = O.forward_cache_update_vit(W, cfg, oc, **gi)
+        else:
+            prompts = [" ".join(rng.choice(words) for _ in range(rng.randint(1, 3))) for _ in range(B)]
+            gi, lens, ropes = model.prepare_prompts(lens, ropes, prompts, tok, ids)
+            cache = model.forward_cache_update_text(cache, **gi)
+            oc = O.forward_cache_update_text(W, cfg, oc, **gi)
+        assert cache.lens(0) == lens and cache.seq_lens == sum(lens)
+        for i in range(L):
+            assert rel(cache.key_cache[i], oc.key_cache[i]) < 1.5e-2 and rel(cache.value_cache[i], oc.value_cache[i]) < 1.5e-2, (stage, i)
+    if rng.random() < 0.5:
+        si = model.prepare_start_tokens(lens, ropes, ids)
+        n = rng.randint(2, 5)
+        otoks, ologits = O.generate_text(W, cfg, oc, si["packed_key_value_indexes"], si["key_values_lens"], si["packed_start_tokens"],
+                                         si["packed_query_position_ids"], n, return_logits=True)
+        toks = model.generate_text(past_key_values=cache, max_length=n, do_sample=False, end_token_id=None, use_graph=False, **si)
+        _tokens_match(toks, otoks, ologits, f"seed {seed}")
+        assert cache.lens(0) == [x + n for x in lens]
+    else:
+        sizes = [(16 * rng.randint(1, 4), 16 * rng.randint(1, 4)) for _ in range(B)]
+        torch.manual_seed(seed)
+        li = model.prepare_vae_latent(lens, ropes, sizes, ids)
+        ci = model.prepare_vae_latent_cfg([0] * B, [0] * B, sizes)
+        renorm = rng.choice(["global", "channel"])
+        model.cfg_batched = rng.random() < 0.5
+        lat = model.generate_image(past_key_values=cache, num_timesteps=4, timestep_shift=3.0, cfg_text_scale=4.0, cfg_interval=[0.0, 1.0],
+                                   cfg_renorm_type=renorm, **cfg_kwargs("cfg_text", new_cache(cfg), ci), **li)
+        ocfg = dict(cache=O.OracleCache(L), position_ids=ci["cfg_packed_position_ids"], query_indexes=ci["cfg_packed_query_indexes"],
+                    key_values_lens=ci["cfg_key_values_lens"], key_value_indexes=ci["cfg_packed_key_value_indexes"])
+        ref = O.generate_image(W, cfg, li, oc, cfg_text=ocfg, num_timesteps=4, timestep_shift=3.0, cfg_text_scale=4.0,
+                               cfg_interval=[0.0, 1.0], cfg_renorm_type=renorm)
+        for a, b in zip(lat, ref):
+            assert a.shape == b.shape and rel(a, b) < 3e-2, (seed, renorm, model.cfg_batched)
