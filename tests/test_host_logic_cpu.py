@@ -432,3 +432,46 @@ def test_random_interleaved_flows_match_oracle(monkeypatch, seed):
                                cfg_interval=[0.0, 1.0], cfg_renorm_type=renorm)
         for a, b in zip(lat, ref):
             assert a.shape == b.shape and rel(a, b) < 3e-2, (seed, renorm, model.cfg_batched)
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_training_batches_match_oracle(monkeypatch, seed):
+    """Differential fuzz of the training forward's host logic (TrainPlan: the causal / full / noise block mask as per-split
+    sequences with overlapping clean-key prefixes; und / gen routing; per-image timestep rows; loss row selection): random packed
+    batches (1-3 samples, 1-5 splits: prompts, ViT images, clean and noised VAE images of random sizes, CE / MSE losses anywhere)
+    through Bagel.forward (stand-in operators, both mask APIs) vs the oracle's restatement of the reference."""
+    import random
+    from oracle import bagel_oracle as O
+    from tests.util_models import pack_training_batch
+    mock_ops.install(monkeypatch)
+    rng = random.Random(1000 + seed)
+    cfg = TINY if seed % 2 == 0 else TINY_D128
+    samples = []
+    for _ in range(rng.randint(1, 3)):
+        sp = []
+        for _ in range(rng.randint(1, 5)):
+            kind = rng.choice(["text", "text", "vit", "vae", "vae"])
+            if kind == "text":
+                sp.append(("text", rng.randint(1, 7), rng.random() < 0.5))
+            elif kind == "vit":
+                sp.append(("vit", 14 * rng.randint(1, 4), 14 * rng.randint(1, 4)))
+            else:
+                sp.append(("vae", 16 * rng.randint(1, 4), 16 * rng.randint(1, 4), rng.random() < 0.6))
+        samples.append(sp)
+    if not any(s[0] == "vae" and s[3] for sp in samples for s in sp):
+        samples[-1].append(("vae", 32, 48, True))          # the oracle's restatement expects at least one MSE target
+    batch, noise, split_lens, attn_modes = pack_training_batch(cfg, samples, seed)
+    model = cpu_model(cfg)
+    W, _ = oracle_weights(cfg)
+    ref = O.bagel_forward_train(W, cfg, batch, noise, timestep_shift=cfg["bagel"]["timestep_shift"])
+    for api in ("nested", "splits"):
+        b = dict(batch)
+        if api == "splits":
+            b.pop("nested_attention_masks")
+            b.update(split_lens=split_lens, attn_modes=attn_modes)
+        out = model(noise=noise, **b)
+        assert out["mse"].shape == ref["mse"].shape and rel(out["mse"], ref["mse"]) < 5e-2, (seed, api, samples)
+        if ref["ce"] is not None:
+            assert out["ce"].shape == ref["ce"].shape and rel(out["ce"], ref["ce"]) < 2e-2, (seed, api, samples)
+        else:
+            assert out["ce"] is None

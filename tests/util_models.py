@@ -48,3 +48,95 @@ def _product(name):
 def product_model(cfg):
     """(Bagel, AutoEncoder) on cuda:0 carrying exactly the oracle's synthetic weights."""
     return _product(cfg["name"])
+
+
+def pack_training_batch(cfg, samples, seed):
+    """Hand-pack a training batch the way data/dataset_base.py:306-476 does (the recipe of oracle/make_golden.py::scenario_train,
+    parameterised): ``samples`` = list of samples, each a list of splits ("text", n_tokens, with_ce_loss) | ("vit", H, W) |
+    ("vae", H, W, with_mse_loss).  Attention modes follow the dataset code: text causal, ViT image full, clean VAE image full,
+    noised VAE image noise.  Returns (batch dict for Bagel.forward, noise, split_lens, attn_modes)."""
+    from oracle import packers as P
+    from oracle.configs import NEW_TOKEN_IDS_TINY as ids
+    g = torch.Generator().manual_seed(seed)
+    V = cfg["llm"]["vocab_size"]
+    ps = cfg["vit"]["patch_size"]
+    ds = cfg["vae"]["downsample"] * cfg["bagel"]["latent_patch_size"]
+    text_ids, text_idx, pos, vit_idx, vae_idx, ce_idx, labels, mse_idx, timesteps = [], [], [], [], [], [], [], [], []
+    vit_tokens, vit_pos, vit_lens, lat_pos, lat_shapes, latents = [], [], [], [], [], []
+    sample_lens, masks, all_splits, all_modes = [], [], [], []
+    curr = 0
+    for sample in samples:
+        splits, modes, rope = [], [], 0
+        for sp in sample:
+            if sp[0] == "text":
+                _, n_tok, loss = sp
+                tokens = torch.randint(8, V, (n_tok,), generator=g).tolist()
+                shifted = [ids["bos_token_id"]] + tokens
+                text_ids.extend(shifted)
+                text_idx.extend(range(curr, curr + len(shifted)))
+                if loss:
+                    ce_idx.extend(range(curr, curr + len(shifted)))
+                    labels.extend(tokens + [ids["eos_token_id"]])
+                curr += len(shifted)
+                text_ids.append(ids["eos_token_id"]); text_idx.append(curr); curr += 1
+                n = len(shifted) + 1
+                pos.extend(range(rope, rope + n))
+                rope += n
+                mode = "causal"
+            elif sp[0] == "vit":
+                _, H, Wd = sp
+                img = torch.rand(3, H, Wd, generator=g) * 2 - 1
+                text_ids.append(ids["start_of_image"]); text_idx.append(curr); curr += 1
+                toks = P.patchify(img, ps)
+                vit_idx.extend(range(curr, curr + toks.shape[0])); curr += toks.shape[0]
+                vit_tokens.append(toks); vit_lens.append(toks.shape[0])
+                vit_pos.append(P.position_ids_extrapolate(H, Wd, ps, cfg["bagel"]["vit_max_num_patch_per_side"]))
+                text_ids.append(ids["end_of_image"]); text_idx.append(curr); curr += 1
+                n = toks.shape[0] + 2
+                pos.extend([rope] * n)
+                rope += 1
+                mode = "full"
+            else:
+                _, H, Wd, loss = sp
+                h, w = H // ds, Wd // ds
+                text_ids.append(ids["start_of_image"]); text_idx.append(curr); curr += 1
+                n_img = h * w
+                vae_idx.extend(range(curr, curr + n_img))
+                if loss:
+                    mse_idx.extend(range(curr, curr + n_img))
+                    t = float(torch.randn(1, generator=g))
+                else:
+                    t = float("-inf")
+                timesteps.extend([t] * n_img)
+                curr += n_img
+                lat_pos.append(P.position_ids_extrapolate(H, Wd, ds, cfg["bagel"]["max_latent_size"]))
+                lat_shapes.append((h, w))
+                latents.append(torch.randn(cfg["vae"]["z_channels"], H // cfg["vae"]["downsample"], Wd // cfg["vae"]["downsample"], generator=g))
+                text_ids.append(ids["end_of_image"]); text_idx.append(curr); curr += 1
+                n = n_img + 2
+                pos.extend([rope] * n)
+                rope = rope if loss else rope + 1
+                mode = "noise" if loss else "full"
+            splits.append(n); modes.append(mode)
+        sample_lens.append(sum(splits))
+        masks.append(O.attention_mask_per_sample(splits, modes))
+        all_splits += splits; all_modes += modes
+    batch = dict(sequence_length=curr, packed_text_ids=torch.tensor(text_ids), packed_text_indexes=torch.tensor(text_idx),
+                 sample_lens=sample_lens, packed_position_ids=torch.tensor(pos), nested_attention_masks=masks)
+    if ce_idx:
+        batch.update(ce_loss_indexes=torch.tensor(ce_idx), packed_label_ids=torch.tensor(labels))
+    if vit_tokens:
+        batch.update(packed_vit_tokens=torch.cat(vit_tokens, 0), packed_vit_token_indexes=torch.tensor(vit_idx),
+                     packed_vit_position_ids=torch.cat(vit_pos, 0), vit_token_seqlens=torch.tensor(vit_lens, dtype=torch.int))
+    noise = None
+    if latents:
+        Hm = max(l.shape[1] for l in latents); Wm = max(l.shape[2] for l in latents)
+        padded = torch.zeros(len(latents), cfg["vae"]["z_channels"], Hm, Wm)
+        for i, l in enumerate(latents):
+            padded[i, :, :l.shape[1], :l.shape[2]] = l
+        batch.update(padded_latent=padded, patchified_vae_latent_shapes=lat_shapes, packed_latent_position_ids=torch.cat(lat_pos, 0),
+                     packed_vae_token_indexes=torch.tensor(vae_idx), packed_timesteps=torch.tensor(timesteps))
+        if mse_idx:
+            batch["mse_loss_indexes"] = torch.tensor(mse_idx)
+        noise = torch.randn(len(vae_idx), cfg["bagel"]["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"], generator=g)
+    return batch, noise, all_splits, all_modes
