@@ -124,3 +124,114 @@ def test_reference_inferencer_drives_the_product():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "reference_inferencer_dropin.py")], capture_output=True,
                        text=True, cwd=root, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_oracle_training_forward_bit_exact_on_random_batches(seed):
+    """The oracle's Bagel.forward restatement vs the LIVE reference on random packed training batches (random mixtures of prompts,
+    ViT images, clean / noised VAE images, CE / MSE losses; masks from the reference's own prepare_attention_mask_per_sample):
+    per-token losses bit for bit -- the pin behind tests/test_host_logic_cpu.py::test_random_training_batches_match_oracle."""
+    import contextlib
+    import random
+    from oracle import bagel_oracle as O
+    from oracle import make_golden as G
+    from tests.util_models import pack_training_batch
+    cfg = TINY if seed % 2 == 0 else TINY_D128
+    model, _, W, _ = G.build(cfg)
+    import modeling.bagel.qwen2_navit as qn
+    from data.data_utils import prepare_attention_mask_per_sample
+    rng = random.Random(2000 + seed)
+    samples = []
+    for _ in range(rng.randint(1, 3)):
+        sp = []
+        for _ in range(rng.randint(1, 5)):
+            kind = rng.choice(["text", "text", "vit", "vae", "vae"])
+            if kind == "text":
+                sp.append(("text", rng.randint(1, 7), rng.random() < 0.5))
+            elif kind == "vit":
+                sp.append(("vit", 14 * rng.randint(1, 4), 14 * rng.randint(1, 4)))
+            else:
+                sp.append(("vae", 16 * rng.randint(1, 4), 16 * rng.randint(1, 4), rng.random() < 0.6))
+        samples.append(sp)
+    # the reference's forward needs every modality present in the pack (bagel.py:150-226 indexes them unconditionally)
+    samples[0] = [("text", 3, True), ("vit", 28, 42)] + samples[0]
+    samples[-1].append(("vae", 32, 48, True))
+    batch, _, split_lens, attn_modes = pack_training_batch(cfg, samples, seed)
+    i = 0
+    for n, m in zip(batch["sample_lens"], batch["nested_attention_masks"]):      # the masks are the reference's own, too
+        lens, modes, tot = [], [], 0
+        while tot < n:
+            lens.append(split_lens[i]); modes.append(attn_modes[i]); tot += lens[-1]; i += 1
+        assert torch.equal(prepare_attention_mask_per_sample(lens, modes), m)
+    qn.sdpa_kernel = lambda *a, **k: contextlib.nullcontext()
+    n_lat = batch["packed_vae_token_indexes"].numel()
+    model.train()
+    try:
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            torch.manual_seed(47)
+            ref = model(**batch)
+    finally:
+        model.eval()
+    torch.manual_seed(47)
+    noise = torch.randn(n_lat, cfg["bagel"]["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"])
+    mine = O.bagel_forward_train(W, cfg, batch, noise, timestep_shift=cfg["bagel"]["timestep_shift"])
+    G.same(ref["mse"], mine["mse"], "train mse")
+    G.same(ref["ce"], mine["ce"], "train ce")
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_oracle_inference_flows_bit_exact_on_random_requests(seed):
+    """The oracle vs the LIVE reference on random interleaved requests (1-3 samples; prompt / ViT-image prefills in random order on
+    top of one another; then CFG text->image on random latent sizes with a random renorm type, or a greedy decode): KV caches
+    after every prefill, latents and token ids bit for bit -- the pin behind test_random_interleaved_flows_match_oracle."""
+    import random
+    from oracle import bagel_oracle as O
+    from oracle import make_golden as G
+    from oracle.configs import NEW_TOKEN_IDS_TINY as ids, StubTokenizer
+    cfg = TINY if seed % 2 == 0 else TINY_D128
+    model, _, W, _ = G.build(cfg)
+    from modeling.bagel.qwen2_navit import NaiveCache
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ident = lambda t: t  # noqa: E731
+    rng = random.Random(3000 + seed)
+    B = rng.randint(1, 3)
+    words = ["a", "red", "cube", "on the table", "sky", "x y z", "hello world again", "what is it"]
+    lens, ropes = [0] * B, [0] * B
+    cache, oc = NaiveCache(L), O.OracleCache(L)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        for stage in range(rng.randint(1, 3)):
+            if rng.random() < 0.4:
+                imgs = [torch.rand(3, 14 * rng.randint(1, 3), 14 * rng.randint(1, 3), generator=g) * 2 - 1 for _ in range(B)]
+                gi, lens, ropes = model.prepare_vit_images(lens, ropes, imgs, ident, ids)
+                cache = model.forward_cache_update_vit(cache, **gi)
+                oc = O.forward_cache_update_vit(W, cfg, oc, **gi)
+            else:
+                prompts = [" ".join(rng.choice(words) for _ in range(rng.randint(1, 3))) for _ in range(B)]
+                gi, lens, ropes = model.prepare_prompts(lens, ropes, prompts, tok, ids)
+                cache = model.forward_cache_update_text(cache, **gi)
+                oc = O.forward_cache_update_text(W, cfg, oc, **gi)
+            G.same(G.cache_to_lists(cache, L), G.cache_to_lists(oc, L), f"cache after stage {stage}")
+        if rng.random() < 0.5:
+            si = model.prepare_start_tokens(lens, ropes, ids)
+            n = rng.randint(2, 5)
+            otoks = O.generate_text(W, cfg, oc, si["packed_key_value_indexes"], si["key_values_lens"], si["packed_start_tokens"],
+                                    si["packed_query_position_ids"], n)
+            toks = model.generate_text(past_key_values=cache, max_length=n, do_sample=False, end_token_id=None, **si)
+            G.same(toks, otoks, "greedy tokens")
+        else:
+            sizes = [(16 * rng.randint(1, 4), 16 * rng.randint(1, 4)) for _ in range(B)]
+            torch.manual_seed(seed)
+            li = model.prepare_vae_latent(lens, ropes, sizes, ids)
+            ci = model.prepare_vae_latent_cfg([0] * B, [0] * B, sizes)
+            kw = dict(num_timesteps=4, timestep_shift=3.0, cfg_text_scale=4.0, cfg_interval=[0.0, 1.0],
+                      cfg_renorm_type=rng.choice(["global", "channel"]), cfg_renorm_min=rng.choice([0.0, 0.3]))
+            lat = model.generate_image(past_key_values=cache, cfg_text_past_key_values=NaiveCache(L),
+                                       cfg_text_packed_position_ids=ci["cfg_packed_position_ids"],
+                                       cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
+                                       cfg_text_key_values_lens=ci["cfg_key_values_lens"],
+                                       cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"], **kw, **li)
+            ocfg = dict(cache=O.OracleCache(L), position_ids=ci["cfg_packed_position_ids"], query_indexes=ci["cfg_packed_query_indexes"],
+                        key_values_lens=ci["cfg_key_values_lens"], key_value_indexes=ci["cfg_packed_key_value_indexes"])
+            G.same(list(lat), list(O.generate_image(W, cfg, li, oc, cfg_text=ocfg, **kw)), "latents")
