@@ -475,3 +475,64 @@ def test_random_training_batches_match_oracle(monkeypatch, seed):
             assert out["ce"].shape == ref["ce"].shape and rel(out["ce"], ref["ce"]) < 2e-2, (seed, api, samples)
         else:
             assert out["ce"] is None
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_edit_flows_match_oracle(monkeypatch, seed):
+    """Differential fuzz of the edit-style flow: 1-2 requests with source images of random (different) sizes -> VAE-encode prefill
+    (padded image batch, per-image latent grids, gen-mode prefill with t = 0) [+ SigLIP prefill] + prompt, the three CFG contexts,
+    then the 3-forward sampler (random renorm type, sequential or stream-batched) -- product engines vs the oracle."""
+    import random
+    from oracle import bagel_oracle as O
+    mock_ops.install(monkeypatch)
+    rng = random.Random(500 + seed)
+    cfg = TINY if seed % 2 == 0 else TINY_D128
+    model, vae = cpu_model_and_vae(cfg)
+    W, VW = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ids = NEW_TOKEN_IDS_TINY
+    ident = lambda t: t  # noqa: E731
+    B = rng.randint(1, 2)
+    g = torch.Generator().manual_seed(seed)
+    z = [0] * B
+    imgs = [torch.rand(3, 16 * rng.randint(1, 3), 16 * rng.randint(1, 3), generator=g) * 2 - 1 for _ in range(B)]
+    Hm, Wm = max(i.shape[1] for i in imgs), max(i.shape[2] for i in imgs)
+    enc_noise = torch.randn(B, cfg["vae"]["z_channels"], Hm // 8, Wm // 8, generator=g)
+
+    class FixedNoiseVae:
+        def encode(self, x):
+            return vae.encode(x, sample_noise=enc_noise)
+    vi, l1, r1 = model.prepare_vae_images(z, z, imgs, ident, ids)
+    cache = model.forward_cache_update_vae(FixedNoiseVae(), new_cache(cfg), **vi)
+    oc = O.forward_cache_update_vae(W, cfg, VW, O.OracleCache(L), sample_noise=enc_noise, **vi)
+    if rng.random() < 0.6:
+        vimgs = [torch.rand(3, 14 * rng.randint(1, 3), 14 * rng.randint(1, 3), generator=g) * 2 - 1 for _ in range(B)]
+        ti, l1, r1 = model.prepare_vit_images(l1, r1, vimgs, ident, ids)
+        cache = model.forward_cache_update_vit(cache, **ti)
+        oc = O.forward_cache_update_vit(W, cfg, oc, **ti)
+    for i in range(L):
+        assert rel(cache.key_cache[i], oc.key_cache[i]) < 1.5e-2 and rel(cache.value_cache[i], oc.value_cache[i]) < 1.5e-2
+    ctext, octext = copy.deepcopy(cache), oc.clone()
+    prompts = [rng.choice(["make it blue", "a b", "remove the cube please"]) for _ in range(B)]
+    pi, l3, r3 = model.prepare_prompts(l1, r1, prompts, tok, ids)
+    cache = model.forward_cache_update_text(cache, **pi)
+    oc = O.forward_cache_update_text(W, cfg, oc, **pi)
+    pi2, l4, r4 = model.prepare_prompts(z, z, prompts, tok, ids)
+    cimg = model.forward_cache_update_text(new_cache(cfg), **pi2)
+    ocimg = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **pi2)
+    sizes = [(16 * rng.randint(1, 3), 16 * rng.randint(1, 3)) for _ in range(B)]
+    torch.manual_seed(seed)
+    li = model.prepare_vae_latent(l3, r3, sizes, ids)
+    ct, cim = model.prepare_vae_latent_cfg(l1, r1, sizes), model.prepare_vae_latent_cfg(l4, r4, sizes)
+    kw = dict(num_timesteps=4, timestep_shift=3.0, cfg_text_scale=4.0, cfg_img_scale=2.0, cfg_interval=[0.0, 1.0],
+              cfg_renorm_type=rng.choice(["text_channel", "global", "channel"]))
+    model.cfg_batched = rng.random() < 0.5
+    lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", ctext, ct), **cfg_kwargs("cfg_img", cimg, cim), **kw, **li)
+
+    def od(c, d):
+        return dict(cache=c, position_ids=d["cfg_packed_position_ids"], query_indexes=d["cfg_packed_query_indexes"],
+                    key_values_lens=d["cfg_key_values_lens"], key_value_indexes=d["cfg_packed_key_value_indexes"])
+    ref = O.generate_image(W, cfg, li, oc, cfg_text=od(octext, ct), cfg_img=od(ocimg, cim), **kw)
+    for a, b in zip(lat, ref):
+        assert a.shape == b.shape and rel(a, b) < 4e-2, (seed, kw["cfg_renorm_type"], model.cfg_batched)
