@@ -235,3 +235,16 @@ def test_oracle_inference_flows_bit_exact_on_random_requests(seed):
             ocfg = dict(cache=O.OracleCache(L), position_ids=ci["cfg_packed_position_ids"], query_indexes=ci["cfg_packed_query_indexes"],
                         key_values_lens=ci["cfg_key_values_lens"], key_value_indexes=ci["cfg_packed_key_value_indexes"])
             G.same(list(lat), list(O.generate_image(W, cfg, li, oc, cfg_text=ocfg, **kw)), "latents")
+
+
+def test_reference_batch_driver_drives_the_product():
+    """Drop-in at the batch-driver level (BASELINE configs 3/4): the UNMODIFIED eval/gen/gen_images_mp.py is loaded by
+    path after bagel_amd.install_as_reference() and its generate_image() runs the product's model and VAE end to end
+    (tests/scripts/reference_gen_images_dropin.py); the images must match the oracle's restatement of the same pipeline."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "reference_gen_images_dropin.py")], capture_output=True,
+                       text=True, cwd=root, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
