@@ -69,6 +69,17 @@ def _framed_image_layout(n_tokens):
     return marker_rows, token_rows
 
 
+def _bf16_weights(fn):
+    """Entry points of the hot path: fp32 master weights are cast to bf16 once, in place (Bagel._ensure_bf16)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        self._ensure_bf16()
+        return fn(self, *a, **k)
+    return wrapped
+
+
 def _lt(x):
     return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int64))
 
@@ -131,6 +142,16 @@ class Bagel(nn.Module):
         if not torch.is_tensor(t):
             t = torch.tensor(t)
         return t.to(device=self.device, dtype=dtype if dtype is not None else t.dtype).contiguous()
+
+    def _ensure_bf16(self):
+        """The engines run bf16 weights (the app.py:111 / inferencer.py:233 configuration).  A caller that keeps fp32 master weights
+        and relies on autocast -- eval/gen/gen_images_mp.py:174 does -- gets them cast ONCE, in place, with a warning: under the
+        reference's autocast every matmul already rounds the weights to bf16 on the fly; what changes is that the residual stream
+        and the norms are bf16 here (fp32 there)."""
+        if self.language_model.model.embed_tokens.weight.dtype == torch.float32:
+            import warnings
+            warnings.warn("bagel_amd: fp32 weights cast to bfloat16 in place (the MI355X engines run bf16 weights and activations)")
+            self.to(torch.bfloat16)
 
     def _embed_into(self, seq, token_ids, rows):
         """seq[rows] = embed_tokens[token_ids]  (bagel.py:277/377/508/796-798)."""
@@ -286,6 +307,7 @@ class Bagel(nn.Module):
     # prefill
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
+    @_bf16_weights
     def forward_cache_update_text(self, past_key_values, packed_text_ids, packed_text_position_ids, text_token_lens,
                                   packed_text_indexes, packed_key_value_indexes, key_values_lens):
         lm = self.language_model
@@ -300,6 +322,7 @@ class Bagel(nn.Module):
         return out.past_key_values
 
     @torch.no_grad()
+    @_bf16_weights
     def forward_cache_update_vit(self, past_key_values, packed_text_ids, packed_text_indexes, packed_vit_tokens,
                                  packed_vit_token_indexes, packed_vit_position_ids, vit_token_seqlens, packed_position_ids,
                                  packed_seqlens, packed_indexes, packed_key_value_indexes, key_values_lens):
@@ -328,6 +351,7 @@ class Bagel(nn.Module):
         return out.past_key_values
 
     @torch.no_grad()
+    @_bf16_weights
     def forward_cache_update_vae(self, vae_model, past_key_values, padded_images, patchified_vae_latent_shapes,
                                  packed_vae_position_ids, packed_timesteps, packed_vae_token_indexes, packed_text_ids,
                                  packed_text_indexes, packed_position_ids, packed_seqlens, packed_indexes, key_values_lens,
@@ -366,6 +390,7 @@ class Bagel(nn.Module):
         return t[:-1], t[:-1] - t[1:]
 
     @torch.no_grad()
+    @_bf16_weights
     def generate_image(self, packed_text_ids, packed_text_indexes, packed_init_noises, packed_vae_position_ids,
                        packed_vae_token_indexes, packed_seqlens, packed_position_ids, packed_indexes, past_key_values,
                        key_values_lens, packed_key_value_indexes, num_timesteps=24, timestep_shift=1.0,
@@ -494,6 +519,7 @@ class Bagel(nn.Module):
             ops.cfg_stage2_euler(x_t, v, None, 0, renorm_min, dt, use_global_scale=False)
 
     @torch.no_grad()
+    @_bf16_weights
     def _forward_flow(self, x_t, timestep, packed_vae_token_indexes, packed_vae_position_ids, packed_text_ids,
                       packed_text_indexes, packed_indexes, packed_position_ids, packed_seqlens, key_values_lens,
                       past_key_values, packed_key_value_indexes, cfg_renorm_min=0.0, cfg_renorm_type="global",
@@ -537,6 +563,7 @@ class Bagel(nn.Module):
     # autoregressive text
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
+    @_bf16_weights
     def generate_text(self, past_key_values, packed_key_value_indexes, key_values_lens, packed_start_tokens,
                       packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None,
                       use_graph=None, weight_quant=None):
@@ -603,6 +630,7 @@ class Bagel(nn.Module):
         return torch.nonzero(t, as_tuple=False).flatten() if t.dtype == torch.bool else t.to(torch.long)
 
     @torch.no_grad()
+    @_bf16_weights
     def forward(self, sequence_length, packed_text_ids, packed_text_indexes, sample_lens, packed_position_ids,
                 nested_attention_masks=None, split_lens=None, attn_modes=None, ce_loss_indexes=None, packed_label_ids=None,
                 packed_vit_tokens=None, packed_vit_token_indexes=None, packed_vit_position_ids=None, vit_token_seqlens=None,

@@ -34,7 +34,13 @@ from oracle.configs import TINY as cfg, NEW_TOKEN_IDS_TINY, StubTokenizer  # noq
 from tests.test_host_logic_cpu import cpu_model_and_vae  # noqa: E402
 from tests.util_models import oracle_weights  # noqa: E402
 
-model, vae = cpu_model_and_vae(cfg)
+from bagel_amd.factory import build_bagel  # noqa: E402
+
+_, vae = cpu_model_and_vae(cfg)
+# fp32 master weights, exactly as gen_images_mp.py:174 leaves them (`model.to(device)`, no dtype): the product casts them once
+model, _ = build_bagel(cfg, device="cpu", dtype=torch.float32, with_vae=False)
+model.load_state_dict(oracle_weights(cfg)[0], strict=True)
+model = model.eval()
 tok = StubTokenizer(cfg["llm"]["vocab_size"])
 R.gen_model = R.model = model          # the module-level names its generate_image() reads (gen_images_mp.py:137-176)
 R.vae_model, R.tokenizer, R.new_token_ids = vae, tok, NEW_TOKEN_IDS_TINY

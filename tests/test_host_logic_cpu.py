@@ -536,3 +536,29 @@ def test_random_edit_flows_match_oracle(monkeypatch, seed):
     ref = O.generate_image(W, cfg, li, oc, cfg_text=od(octext, ct), cfg_img=od(ocimg, cim), **kw)
     for a, b in zip(lat, ref):
         assert a.shape == b.shape and rel(a, b) < 4e-2, (seed, kw["cfg_renorm_type"], model.cfg_batched)
+
+
+def test_fp32_master_weights_are_cast_once(golden, monkeypatch):
+    """eval/gen/gen_images_mp.py:174 keeps fp32 weights and relies on autocast: the first hot-path call casts them to bf16 in place
+    (with a warning) and the run equals the bf16-weights run bit for bit."""
+    from bagel_amd.factory import build_bagel
+    mock_ops.install(monkeypatch)
+    cfg = TINY
+    g = golden("tiny_t2i")
+    W, _ = oracle_weights(cfg)
+    model32, _ = build_bagel(cfg, device="cpu", dtype=torch.float32, with_vae=False)
+    model32.load_state_dict(W, strict=True)
+    assert model32.llm2vae.weight.dtype == torch.float32
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    outs = []
+    for m in (model32.eval(), cpu_model(cfg)):
+        gi, _, _ = m.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+        if m is model32:
+            with pytest.warns(UserWarning, match="cast to bfloat16"):
+                cache = m.forward_cache_update_text(new_cache(cfg), **gi)
+            assert m.llm2vae.weight.dtype == torch.bfloat16
+        else:
+            cache = m.forward_cache_update_text(new_cache(cfg), **gi)
+        outs.append(m.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **g["gen_kwargs"],
+                                     **g["latent_inputs"]))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
