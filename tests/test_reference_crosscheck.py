@@ -237,6 +237,19 @@ def test_oracle_inference_flows_bit_exact_on_random_requests(seed):
             G.same(list(lat), list(O.generate_image(W, cfg, li, oc, cfg_text=ocfg, **kw)), "latents")
 
 
+def test_reference_edit_driver_drives_the_product():
+    """Drop-in at the image-edit batch driver (BASELINE configs[4]): the UNMODIFIED eval/gen/gen_images_mp_imgedit.py, loaded by path
+    after bagel_amd.install_as_reference(); its editing_image() runs the product's model, VAE and ImageTransforms end to end
+    (tests/scripts/reference_edit_driver_dropin.py) and must match the oracle's restatement on the same random draws."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "reference_edit_driver_dropin.py")], capture_output=True,
+                       text=True, cwd=root, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_reference_batch_driver_drives_the_product():
     """Drop-in at the batch-driver level (BASELINE configs 3/4): the UNMODIFIED eval/gen/gen_images_mp.py is loaded by
     path after bagel_amd.install_as_reference() and its generate_image() runs the product's model and VAE end to end
