@@ -562,3 +562,35 @@ def test_fp32_master_weights_are_cast_once(golden, monkeypatch):
         outs.append(m.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **g["gen_kwargs"],
                                      **g["latent_inputs"]))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_chat_entry_matches_oracle(monkeypatch):
+    """Bagel.chat (bagel.py:1004-1074, the eval entry): ViT prefill per image -> prompt prefill -> greedy decode until <|im_end|> ->
+    tokenizer.decode and the marker split -- vs the same chain restated with the oracle's functions."""
+    from oracle import bagel_oracle as O
+    mock_ops.install(monkeypatch)
+    monkeypatch.setenv("BAGEL_DECODE_GRAPH", "0")
+    cfg = TINY
+    model = cpu_model(cfg)
+    W, _ = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    ids = NEW_TOKEN_IDS_TINY
+    ident = lambda t: t  # noqa: E731
+    g = torch.Generator().manual_seed(11)
+    images = [torch.rand(3, 28, 28, generator=g) * 2 - 1, torch.rand(3, 14, 42, generator=g) * 2 - 1]
+    out = model.chat(tok, ids, ident, images, "what is it", max_length=6)
+    oc, lens, ropes = O.OracleCache(L), [0], [0]
+    for im in images:
+        gi, lens, ropes = model.prepare_vit_images(lens, ropes, [im], ident, ids)
+        oc = O.forward_cache_update_vit(W, cfg, oc, **gi)
+    gi, lens, ropes = model.prepare_prompts(lens, ropes, ["what is it"], tok, ids)
+    oc = O.forward_cache_update_text(W, cfg, oc, **gi)
+    si = model.prepare_start_tokens(lens, ropes, ids)
+    toks, logits = O.generate_text(W, cfg, oc, si["packed_key_value_indexes"], si["key_values_lens"], si["packed_start_tokens"],
+                                   si["packed_query_position_ids"], 6, end_token_id=ids["eos_token_id"], return_logits=True)
+    ref = tok.decode(toks[:, 0]).split("<|im_end|>")[0].split("<|im_start|>")[1]
+    import re
+    a, b = re.findall(r"\[(\d+)\]", out), re.findall(r"\[(\d+)\]", ref)
+    first = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+    assert isinstance(out, str) and first >= 1 and a[:first] == b[:first], (out, ref)
