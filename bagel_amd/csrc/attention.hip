@@ -69,8 +69,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // softmax so it lands under the exp/convert VALU work.  Waves 4-7 (the second-dispatched half, the arbitration loser on
 // every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.  Waves with no live query row
 // skip the arithmetic (1 904 workgroups at the denoise shape, 112 of them with 2 live rows of 256).
-// SCHED = 2 / 3 (BAGEL_ATTN_SCHED=2 / 3; 3 = 2 + four V^T fragments prefetched across the barrier): the two halves of the workgroup
-// alternate roles.  The loop runs in STEPS separated by one
+// SCHED = 2 / 3 / 4 (BAGEL_ATTN_SCHED; 3 = 2 + four V^T fragments prefetched across the barrier; 4 = 2 with a 4-slot ring and every
+// wave issuing its LDS-DMA pieces from its own vector blocks): the two halves of the workgroup alternate roles.  The loop runs in STEPS separated by one
 // workgroup barrier each; in every step waves 0-3 are in a MATRIX block (O^T += V^T(t-1) P^T(t-1), then S^T(t) = K(t) Q^T: 32 MFMAs
 // with the LDS reads pipelined under them) while waves 4-7 are in a VECTOR block (mask, online softmax of their S^T, P -> bf16)
 // -- and the other way round in the next step: waves 4-7 run one step behind.  Each SIMD hosts one
@@ -216,17 +216,34 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         bf16x8_t pf[4], vpre[PRE > 0 ? PRE : 1];
         auto kfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx / KS) * 32 * KROW + kch[idx % KS]); };
         auto vfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx >> 2) * 4096 + vch[idx & 3]); };
-        auto slot = [&](int t) { return (const char*)smem + (t % 3) * STAGE; };
-        // step bookkeeping: the ring slot of tile u-3 was last read in step 2u-3, so tile u is requested at the start of step 2u-2
-        // and waited for at the end of step 2u-1 (it is first read in step 2u)
+        constexpr int NS = SCHED == 4 ? 4 : 3;      // ring slots
+        auto slot = [&](int t) { return (const char*)smem + (t % NS) * STAGE; };
+        // Step bookkeeping.  Tile u is first read in step 2u and last in step 2u+3.
+        //   SCHED 2/3 (3 slots): the slot of tile u-3 is free after step 2u-3; every wave requests its share of tile u at the start of
+        //     step 2u-2 and waits for it (vmcnt(0)) at the end of step 2u-1.
+        //   SCHED 4 (4 slots): a wave requests its share of a tile at the start of one of ITS OWN vector blocks, where an LDS-DMA
+        //     instruction costs a fraction of what it costs among LDS reads and MFMAs (MI355X_MICROARCH.md, LDS-DMA issue cost):
+        //     waves 0-3 request tile u in step 2u-3, waves 4-7 in step 2u-4 (the slot of tile u-4 is free after step 2u-5); at the end
+        //     of step 2u-1 a wave has exactly the NL pieces of tile u+1 in flight behind tile u -> vmcnt(NL).
+        const bool lead = wave < 4;
         auto step_begin = [&](int gs) {
-            if ((gs & 1) == 0 && gs >= 2) {
-                const int u = (gs >> 1) + 1;
-                if (u < T) issue(u % 3, u);
+            if constexpr (SCHED == 4) {
+                int u = -1;
+                if (lead) { if (gs & 1) u = (gs + 3) >> 1; }
+                else      { if ((gs & 1) == 0) u = (gs + 4) >> 1; }
+                if (u >= 2 && u < T) issue(u % NS, u);
+            } else {
+                if ((gs & 1) == 0 && gs >= 2) {
+                    const int u = (gs >> 1) + 1;
+                    if (u < T) issue(u % NS, u);
+                }
             }
         };
         auto step_end = [&](int gs) {
-            if (gs & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (gs & 1) {
+                if (SCHED == 4 && ((gs + 1) >> 1) + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+                else                                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             asm volatile("s_barrier" ::: "memory");
         };
         // matrix blocks.  Source order = all fragment reads, then all MFMAs; the sched_group_barrier sequence turns it into
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         };
         auto block_pv_qk = [&](int t) {                               // O^T += V^T(t-1) P^T(t-1);  S^T(t) = K(t) Q^T
-            const char* sbp = slot(t + 2);                            // (t - 1) mod 3
+            const char* sbp = slot(t + NS - 1);                       // tile t - 1
             const char* sbk = slot(t);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8_t vf[NV], kf[NK];
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         };
         auto block_pv = [&](int t) {                                  // O^T += V^T(t-1) P^T(t-1)   (after the last tile)
-            const char* sbp = slot(t + 2);
+            const char* sbp = slot(t + NS - 1);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8_t vf[NV];
 #pragma unroll
@@ -607,22 +624,28 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     const dim3 grid(8 * pairs_per_xcd * nbpp), block(512);
     static const int sched = [] { const char* e = getenv("BAGEL_ATTN_SCHED"); return e ? atoi(e) : 0; }();   // read-once tuning knob
     if (head_dim == 128) {
-        constexpr int smem = 3 * (64 * 256 + 128 * 128);
+        constexpr int smem3 = 3 * (64 * 256 + 128 * 128);
+        const int smem = (sched == 4 ? 4 : 3) * (64 * 256 + 128 * 128);
         static bool set = false;
         if (!set) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3 / 3 * 4);
             set = true;
         }
-        if (sched == 3)      hipLaunchKernelGGL((attn_fwd_kernel<128, 3>), grid, block, smem, stream, p);
+        if (sched == 4)      hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), grid, block, smem, stream, p);
+        else if (sched == 3) hipLaunchKernelGGL((attn_fwd_kernel<128, 3>), grid, block, smem, stream, p);
         else if (sched == 2) hipLaunchKernelGGL((attn_fwd_kernel<128, 2>), grid, block, smem, stream, p);
         else if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<128, 1>), grid, block, smem, stream, p);
         else                 hipLaunchKernelGGL((attn_fwd_kernel<128, 0>), grid, block, smem, stream, p);
     } else if (head_dim == 64) {
-        constexpr int smem = 3 * (64 * 128 + 64 * 128);
-        if (sched == 3)      hipLaunchKernelGGL((attn_fwd_kernel<64, 3>), grid, block, smem, stream, p);
+        const int smem = (sched == 4 ? 4 : 3) * (64 * 128 + 64 * 128);
+        static bool set64 = false;
+        if (!set64) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 128 + 64 * 128)); set64 = true; }
+        if (sched == 4)      hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), grid, block, smem, stream, p);
+        else if (sched == 3) hipLaunchKernelGGL((attn_fwd_kernel<64, 3>), grid, block, smem, stream, p);
         else if (sched == 2) hipLaunchKernelGGL((attn_fwd_kernel<64, 2>), grid, block, smem, stream, p);
         else if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<64, 1>), grid, block, smem, stream, p);
         else                 hipLaunchKernelGGL((attn_fwd_kernel<64, 0>), grid, block, smem, stream, p);

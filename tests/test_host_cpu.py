@@ -181,6 +181,7 @@ def test_attention_sched2_protocol_model():
     spec.loader.exec_module(m)
     for T in range(1, 40):
         assert m.check(T) == 2 * T + 3
+        assert m.check4(T)          # the 4-slot variant with role-split DMA issue and counted waits
 
 
 def test_vae_launch_wrappers_match_the_header(monkeypatch):

@@ -55,7 +55,52 @@ def check(T):
     return nbar["idle"]
 
 
+def check4(T):
+    """SCHED = 4: 4-slot ring; waves 0-3 request their share of tile u at the start of step 2u-3 (one of their vector blocks),
+    waves 4-7 at the start of step 2u-4; at the end of every odd step 2u-1 a wave waits until only the pieces of tile u+1 are
+    still in flight (vmcnt(NL)), i.e. its share of tile u has landed."""
+    progs, last = programs(T)
+    NS = 4
+    issue = {"lead": {0: -1, 1: -1}, "follow": {0: -1, 1: -1}}
+    for g in range(last + 1):
+        if g % 2 == 1:
+            u = (g + 3) // 2
+            if 2 <= u < T:
+                issue["lead"][u] = g
+        else:
+            u = (g + 4) // 2
+            if 2 <= u < T:
+                issue["follow"][u] = g
+    for half in issue:
+        assert sorted(issue[half]) == list(range(T)) or T == 1 and sorted(issue[half]) == [0, 1], (T, half, issue[half])
+    # the wait rule: at the end of odd step g, tile u = (g + 1) / 2 must be the OLDEST incomplete tile of the wave and exactly
+    # the pieces of tile u + 1 (if it exists) may be newer
+    ready = {}
+    for half, iss in issue.items():
+        for g in range(1, last + 1, 2):
+            u = (g + 1) // 2
+            if u >= T:
+                continue
+            newer = [v for v, gi in iss.items() if v > u and gi <= g and v < T]
+            assert newer == ([u + 1] if u + 1 < T else []), (T, half, g, u, newer)
+            ready[(half, u)] = g
+    ready_all = {u: max(ready.get(("lead", u), -1), ready.get(("follow", u), -1)) for u in range(1, T)}
+    ready_all[0] = -1
+    reads = {}
+    for role, prog in progs.items():
+        for g, ops in prog.items():
+            for kind, t in ops:
+                assert ready_all[t] < g, (T, role, g, kind, t)
+                f, l_ = reads.get(t, (g, g))
+                reads[t] = (min(f, g), max(l_, g))
+    for u in range(NS, T):
+        for half in issue:
+            assert issue[half][u] > reads[u - NS][1], (T, half, u, issue[half][u], reads[u - NS])
+    return True
+
+
 if __name__ == "__main__":
     for T in range(1, 70):
         check(T)
-    print("attn SCHED=2 protocol model: barrier counts equal, ring reads/refills consistent for T = 1..69")
+        check4(T)
+    print("attn SCHED=2/3/4 protocol models: barrier counts equal, ring reads / refills / waits consistent for T = 1..69")
