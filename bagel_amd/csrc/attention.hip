@@ -70,7 +70,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.  Waves with no live query row
 // skip the arithmetic (1 904 workgroups at the denoise shape, 112 of them with 2 live rows of 256).
 // SCHED = 2 / 3 / 4 (BAGEL_ATTN_SCHED; 3 = 2 + four V^T fragments prefetched across the barrier; 4 = 2 with a 4-slot ring and every
-// wave issuing its LDS-DMA pieces from its own vector blocks): the two halves of the workgroup alternate roles.  The loop runs in STEPS separated by one
+// wave issuing its LDS-DMA pieces from its own vector blocks; 5 = 4 + the prefetch of 3): the two halves of the workgroup alternate roles.  The loop runs in STEPS separated by one
 // workgroup barrier each; in every step waves 0-3 are in a MATRIX block (O^T += V^T(t-1) P^T(t-1), then S^T(t) = K(t) Q^T: 32 MFMAs
 // with the LDS reads pipelined under them) while waves 4-7 are in a VECTOR block (mask, online softmax of their S^T, P -> bf16)
 // -- and the other way round in the next step: waves 4-7 run one step behind.  Each SIMD hosts one
@@ -210,13 +210,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         constexpr int NV = DB * 4;                  // V^T fragments of a tile (index 4*db + j)
         constexpr int NK = 2 * KS;                  // K fragments of a tile (index KS*kb + ks)
         constexpr int WIN = 8;                      // fragment reads kept in flight ahead of the MFMA that consumes them
-        constexpr int PRE = SCHED == 3 ? 4 : 0;     // SCHED = 3: V^T fragments of tile t fetched at the end of its vector block, so
+        constexpr int PRE = (SCHED == 3 || SCHED == 5) ? 4 : 0;     // SCHED = 3 / 5: V^T fragments of tile t fetched at the end of its vector block, so
                                                     // the following matrix block opens with MFMAs instead of an exposed LDS round trip
         f32x16_t s[2];
         bf16x8_t pf[4], vpre[PRE > 0 ? PRE : 1];
         auto kfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx / KS) * 32 * KROW + kch[idx % KS]); };
         auto vfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx >> 2) * 4096 + vch[idx & 3]); };
-        constexpr int NS = SCHED == 4 ? 4 : 3;      // ring slots
+        constexpr int NS = SCHED >= 4 ? 4 : 3;      // ring slots
         auto slot = [&](int t) { return (const char*)smem + (t % NS) * STAGE; };
         // Step bookkeeping.  Tile u is first read in step 2u and last in step 2u+3.
         //   SCHED 2/3 (3 slots): the slot of tile u-3 is free after step 2u-3; every wave requests its share of tile u at the start of
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         //     of step 2u-1 a wave has exactly the NL pieces of tile u+1 in flight behind tile u -> vmcnt(NL).
         const bool lead = wave < 4;
         auto step_begin = [&](int gs) {
-            if constexpr (SCHED == 4) {
+            if constexpr (SCHED >= 4) {
                 int u = -1;
                 if (lead) { if (gs & 1) u = (gs + 3) >> 1; }
                 else      { if ((gs & 1) == 0) u = (gs + 4) >> 1; }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         };
         auto step_end = [&](int gs) {
             if (gs & 1) {
-                if (SCHED == 4 && ((gs + 1) >> 1) + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+                if (SCHED >= 4 && ((gs + 1) >> 1) + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
                 else                                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             asm volatile("s_barrier" ::: "memory");
@@ -625,7 +625,7 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     static const int sched = [] { const char* e = getenv("BAGEL_ATTN_SCHED"); return e ? atoi(e) : 0; }();   // read-once tuning knob
     if (head_dim == 128) {
         constexpr int smem3 = 3 * (64 * 256 + 128 * 128);
-        const int smem = (sched == 4 ? 4 : 3) * (64 * 256 + 128 * 128);
+        const int smem = (sched >= 4 ? 4 : 3) * (64 * 256 + 128 * 128);
         static bool set = false;
         if (!set) {
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
@@ -633,18 +633,25 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3 / 3 * 4);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3 / 3 * 4);
             set = true;
         }
-        if (sched == 4)      hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), grid, block, smem, stream, p);
+        if (sched == 5)      hipLaunchKernelGGL((attn_fwd_kernel<128, 5>), grid, block, smem, stream, p);
+        else if (sched == 4) hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), grid, block, smem, stream, p);
         else if (sched == 3) hipLaunchKernelGGL((attn_fwd_kernel<128, 3>), grid, block, smem, stream, p);
         else if (sched == 2) hipLaunchKernelGGL((attn_fwd_kernel<128, 2>), grid, block, smem, stream, p);
         else if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<128, 1>), grid, block, smem, stream, p);
         else                 hipLaunchKernelGGL((attn_fwd_kernel<128, 0>), grid, block, smem, stream, p);
     } else if (head_dim == 64) {
-        const int smem = (sched == 4 ? 4 : 3) * (64 * 128 + 64 * 128);
+        const int smem = (sched >= 4 ? 4 : 3) * (64 * 128 + 64 * 128);
         static bool set64 = false;
-        if (!set64) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 128 + 64 * 128)); set64 = true; }
-        if (sched == 4)      hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), grid, block, smem, stream, p);
+        if (!set64) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 128 + 64 * 128));
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 128 + 64 * 128));
+            set64 = true;
+        }
+        if (sched == 5)      hipLaunchKernelGGL((attn_fwd_kernel<64, 5>), grid, block, smem, stream, p);
+        else if (sched == 4) hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), grid, block, smem, stream, p);
         else if (sched == 3) hipLaunchKernelGGL((attn_fwd_kernel<64, 3>), grid, block, smem, stream, p);
         else if (sched == 2) hipLaunchKernelGGL((attn_fwd_kernel<64, 2>), grid, block, smem, stream, p);
         else if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<64, 1>), grid, block, smem, stream, p);

@@ -76,7 +76,7 @@ def compare():
     import subprocess
     import tempfile
     outs = {}
-    for v in ("0", "1", "2", "3", "4"):
+    for v in ("0", "1", "2", "3", "4", "5"):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
             path = f.name
         env = dict(os.environ, BAGEL_ATTN_SCHED=v, BAGEL_ATTN_PROBE_DUMP=path)
@@ -88,7 +88,7 @@ def compare():
         outs[v] = torch.load(path)
         os.unlink(path)
     bad = []
-    for v in ("1", "2", "3", "4"):
+    for v in ("1", "2", "3", "4", "5"):
         for k in ("full", "causal"):
             same = torch.equal(outs["0"][k], outs[v][k])
             d = 0.0 if same else (outs["0"][k].float() - outs[v][k].float()).abs().max().item()
