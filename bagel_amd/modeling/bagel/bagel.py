@@ -424,7 +424,7 @@ class Bagel(nn.Module):
         timesteps, dts = self.flow_schedule(num_timesteps, timestep_shift)
         mode = ops.RENORM_MODES[cfg_renorm_type]
         multi = None
-        if self.cfg_batched and plan_t is not None and not enable_taylorseer:
+        if self.cfg_batched and plan_t is not None:
             multi = self._stream_batch(st, [plan, plan_t] + ([plan_i] if plan_i is not None else []),
                                        [past_key_values, cfg_text_past_key_values] + ([cfg_img_past_key_values] if plan_i is not None else []))
         for i, t in enumerate(timesteps):
@@ -499,7 +499,7 @@ class Bagel(nn.Module):
             for s in range(S):
                 multi["seq"][s * M:(s + 1) * M].copy_(seq)
             h = self.language_model.engine().forward(multi["seq"], multi["plan"], "gen" if self.use_moe else "und", multi["cache"],
-                                                     update=False, causal=False)
+                                                     update=False, causal=False, taylor=list(taylor[:S]) if taylor[0] is not None else None)
             for s in range(S):
                 ops.gemm(h, self.llm2vae.weight.data, st["v"][s], bias0=self.llm2vae.bias.data, a_rows0=multi["vae_rows"][s],
                          M0=st["v"][s].shape[0])

@@ -708,7 +708,17 @@ class MoTEngine:
         gen_attn = gen and self.mot
         ws = self.workspace(plan.M, plan.vt_cols)
         x, h, qkv, att, act, vt = ws["x"], ws["h"], ws["qkv"], ws["attn"], ws["act"], ws["vt"]
-        skip_layers = taylor is not None and taylor.next_type() == "Taylor"
+        # ``taylor`` may be a list of states, one per forward stream of a stream-batched plan (concat_plans; stream s = rows
+        # [s*M/S, (s+1)*M/S)).  The streams advance separately (a step without CFG moves only the first one), so their step types can
+        # differ: the layers run unless EVERY stream extrapolates; afterwards each stream either refreshes its cache from its slice or
+        # replaces its slice by its extrapolation -- per stream exactly what the sequential forwards do.
+        streams = list(taylor) if isinstance(taylor, (list, tuple)) else None
+        if streams is not None:
+            kinds = [st.next_type() for st in streams]
+            skip_layers = all(k == "Taylor" for k in kinds)
+            taylor = None
+        else:
+            skip_layers = taylor is not None and taylor.next_type() == "Taylor"
         if skip_layers and update:
             raise ValueError("a TaylorSeer-skipped forward cannot update the KV cache")
         if not skip_layers:
@@ -730,7 +740,8 @@ class MoTEngine:
         nl = len(self.layers) if num_layers is None else num_layers
         if skip_layers:
             nl = 0
-            taylor.eval_into(x)
+            if streams is None:
+                taylor.eval_into(x)
         # Marker-row side path (plan.und_side, MoT gen mode).  The und group of a denoise forward is 2 rows per sample; as a row
         # group of the tile GEMM it costs a whole 256-row tile row in every projection.  With the gen rows alone the tile count of
         # a stream-batched forward (concat_plans) is an exact multiple of the 256 persistent workgroups (2 x 4 x 4096 rows = 128
@@ -798,6 +809,15 @@ class MoTEngine:
             if not skip_layers:
                 taylor.update(x)
             taylor.advance()
+        if streams is not None:
+            rows = plan.M // len(streams)
+            for si, (st, kind) in enumerate(zip(streams, kinds)):
+                xs = x[si * rows:(si + 1) * rows]
+                if kind == "Taylor":
+                    st.eval_into(xs)
+                else:
+                    st.update(xs)
+                st.advance()
         if not final_norm:
             return x.clone()          # the raw residual stream after the last executed layer (full-size parity probes)
         out = torch.empty_like(x)

@@ -594,3 +594,29 @@ def test_chat_entry_matches_oracle(monkeypatch):
     a, b = re.findall(r"\[(\d+)\]", out), re.findall(r"\[(\d+)\]", ref)
     first = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
     assert isinstance(out, str) and first >= 1 and a[:first] == b[:first], (out, ref)
+
+
+@pytest.mark.parametrize("interval", [[0.0, 1.0], [0.45, 1.0]], ids=["cfg_everywhere", "cfg_off_late"])
+def test_stream_batched_cfg_with_taylorseer_equals_sequential(monkeypatch, interval):
+    """enable_taylorseer=True under model.cfg_batched: one TaylorSeer state per stream inside the batched forward (full steps refresh
+    every stream's cache from its slice, Taylor steps replace the slice by the stream's extrapolation; with cfg_interval switching
+    CFG off for the late steps the streams' schedules drift apart and a batched forward mixes both kinds) == the sequential path
+    bit for bit, and the schedules (full / Taylor counts per stream) are the same."""
+    mock_ops.install(monkeypatch)
+    cfg = TINY
+    model = cpu_model(cfg)
+    sizes = [(32, 32), (16, 48)]
+    c0, li, (c1, ct), _ = _three_stream_setup(model, cfg, sizes)
+    kw = dict(num_timesteps=14, timestep_shift=3.0, cfg_text_scale=4.0, cfg_interval=interval, cfg_renorm_min=0.0,
+              cfg_renorm_type="global", enable_taylorseer=True, **cfg_kwargs("cfg_text", c1, ct))
+    model.cfg_batched = False
+    ref = model.generate_image(past_key_values=copy.deepcopy(c0), **kw, **li)
+    sched_ref = [(s.full_steps, s.taylor_steps) for s in model._last_taylor_states[:2]]
+    model.cfg_batched, model.und_side_path = True, True
+    got = model.generate_image(past_key_values=copy.deepcopy(c0), **kw, **li)
+    sched = [(s.full_steps, s.taylor_steps) for s in model._last_taylor_states[:2]]
+    assert sched == sched_ref and sched[0][1] > 0, (sched, sched_ref)
+    if interval[0] > 0:
+        assert sched[0] != sched[1], "the streams were meant to drift apart"
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
