@@ -622,7 +622,9 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     const int nbpp = (nq / nkv) * p.nqt;
     const int pairs_per_xcd = ceil_div((long)batch * nkv, 8);
     const dim3 grid(8 * pairs_per_xcd * nbpp), block(512);
-    static const int sched = [] { const char* e = getenv("BAGEL_ATTN_SCHED"); return e ? atoi(e) : 0; }();   // read-once tuning knob
+    // tuning knob, read at every launch (a getenv is noise beside a launch) so that one process can sweep the schedules
+    const char* sched_env = getenv("BAGEL_ATTN_SCHED");
+    const int sched = sched_env ? atoi(sched_env) : 0;
     if (head_dim == 128) {
         constexpr int smem3 = 3 * (64 * 256 + 128 * 128);
         const int smem = (sched >= 4 ? 4 : 3) * (64 * 256 + 128 * 128);

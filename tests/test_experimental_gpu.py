@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_attention_schedule_variant_is_bit_identical():
-    """BAGEL_ATTN_SCHED is read once per process: tools/attn_probe.py --compare runs both schedules in child processes on the same
-    seeded denoise-shape inputs (full and causal) and fails unless the outputs are bit-identical."""
+    """tools/attn_probe.py --compare runs every schedule in its own child process (a misbehaving variant cannot take the suite
+    down) on the same seeded denoise-shape inputs (full and causal) and fails unless the outputs are bit-identical."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "attn_probe.py"), "--compare"], capture_output=True, text=True,
                        cwd=ROOT, timeout=900)
     print(r.stdout[-1500:])

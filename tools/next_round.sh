@@ -1,7 +1,7 @@
 #!/bin/bash
 # First GPU visit of the next round: evaluate the opt-in variants that were written without a GPU (round 1 ran out of
 # GPU-minutes): BAGEL_ATTN_SCHED=1 (attention.hip), BAGEL_CFG_BATCH=1 (+ BAGEL_UND_SIDE) (bagel.py / qwen2_navit.py).
-# Everything is wrapped in timeouts; logs under gpurun_out/.  ~20 GPU-minutes.  (attn_probe runs each schedule in its own child
+# Everything is wrapped in timeouts; logs under gpurun_out/.  ~15 GPU-minutes.  (attn_probe runs each schedule in its own child
 # process under a 600 s timeout: a variant that hangs cannot take the visit down with it.)
 set -x
 mkdir -p gpurun_out
@@ -12,13 +12,8 @@ for sv in 1 2 3 4 5; do ( BAGEL_ATTN_SCHED=$sv timeout 600 python -m pytest test
 ( BAGEL_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_experimental_gpu.py -m gpu -q --timeout 800 ) > gpurun_out/pytest_experimental.log 2>&1; tail -4 gpurun_out/pytest_experimental.log
 ( timeout 900 python tools/check_stream_batch.py --bench ) > gpurun_out/stream_batch.log 2>&1; tail -12 gpurun_out/stream_batch.log
 ( BAGEL_CFG_BATCH=1 timeout 600 python -m pytest tests/test_model_gpu.py tests/test_inferencer_gpu.py -m gpu -q --timeout 300 ) > gpurun_out/pytest_cfg_batch.log 2>&1; tail -4 gpurun_out/pytest_cfg_batch.log
-# relative comparison on a reduced denoise (10 timesteps, no VAE: flagged invalid by bench.py, ~10 s each) ...
-Q="--steps 1 --warmup 1 --no-understanding --no-taylorseer --no-cpu-baseline --num-timesteps 10 --no-vae"
-for v in "" "BAGEL_ATTN_SCHED=1" "BAGEL_ATTN_SCHED=2" "BAGEL_ATTN_SCHED=3" "BAGEL_ATTN_SCHED=4" "BAGEL_ATTN_SCHED=5" "BAGEL_CFG_BATCH=1" "BAGEL_CFG_BATCH=1 BAGEL_UND_SIDE=0"; do
-  tag=$(echo "${v:-default}" | tr ' =' '__')
-  ( env $v timeout 400 python bench.py $Q ) > gpurun_out/quick_$tag.log 2>&1
-  echo "$tag: $(tail -1 gpurun_out/quick_$tag.log | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(round(d["ms_per_step"]), "ms/step, gemm", round(d["roofline"]["achieved"]), "TF")' 2>/dev/null)"
-done
+# (the relative comparison of all variants is the in-process sweep of check_stream_batch.py --bench above: one 7B model build,
+# 5 Euler steps per mode)
 # ... then the full bench line for the default and for the combination expected to win (re-run with the measured best if it differs)
 for v in "" "BAGEL_ATTN_SCHED=2 BAGEL_CFG_BATCH=1"; do
   tag=$(echo "${v:-default}" | tr ' =' '__')
