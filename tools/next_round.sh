@@ -10,7 +10,7 @@ B="--steps 1 --warmup 1 --no-understanding --no-taylorseer --no-cpu-baseline"
 ( timeout 300 python tools/attn_probe.py --compare ) > gpurun_out/attn_sched.log 2>&1; tail -8 gpurun_out/attn_sched.log
 for sv in 1 2 3 4 5; do ( BAGEL_ATTN_SCHED=$sv timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_train_gpu.py tests/test_model_gpu.py -m gpu -q --timeout 300 ) > gpurun_out/pytest_attn_sched$sv.log 2>&1; tail -4 gpurun_out/pytest_attn_sched$sv.log; done
 ( BAGEL_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_experimental_gpu.py -m gpu -q --timeout 800 ) > gpurun_out/pytest_experimental.log 2>&1; tail -4 gpurun_out/pytest_experimental.log
-( timeout 900 python tools/check_stream_batch.py --bench ) > gpurun_out/stream_batch.log 2>&1; tail -12 gpurun_out/stream_batch.log
+( timeout 900 python tools/check_stream_batch.py --bench ) > gpurun_out/stream_batch.log 2>&1; tail -32 gpurun_out/stream_batch.log
 ( BAGEL_CFG_BATCH=1 timeout 600 python -m pytest tests/test_model_gpu.py tests/test_inferencer_gpu.py -m gpu -q --timeout 300 ) > gpurun_out/pytest_cfg_batch.log 2>&1; tail -4 gpurun_out/pytest_cfg_batch.log
 # (the relative comparison of all variants is the in-process sweep of check_stream_batch.py --bench above: one 7B model build,
 # 5 Euler steps per mode)
