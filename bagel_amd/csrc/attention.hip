@@ -43,6 +43,7 @@ struct AttnParams {
     int nq, nkv, causal;
     int batch, nqt;          // samples, 256-row query tiles per sample (from max_lq)
     float scale_log2;
+    int prio;                // SCHED >= 2 only (BAGEL_ATTN_PRIO=1): s_setprio 1 inside the matrix blocks
 };
 
 // 16 bytes per lane HBM -> LDS (destination = wave-uniform LDS byte address + lane*16).  Issued from inline asm on
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         // WIN reads | (MFMA, read) ... | WIN MFMAs: every read is issued WIN MFMAs ahead of its consumer.
         auto block_qk = [&](int t) {                                  // S^T(t) = K(t) Q^T   (first tile)
             const char* sbk = slot(t);
+            if (p.prio) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8_t kf[NK];
 #pragma unroll
@@ -266,10 +268,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, WIN, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (p.prio) __builtin_amdgcn_s_setprio(0);
         };
         auto block_pv_qk = [&](int t) {                               // O^T += V^T(t-1) P^T(t-1);  S^T(t) = K(t) Q^T
             const char* sbp = slot(t + NS - 1);                       // tile t - 1
             const char* sbk = slot(t);
+            if (p.prio) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8_t vf[NV], kf[NK];
 #pragma unroll
@@ -293,9 +297,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, WIN + PRE, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (p.prio) __builtin_amdgcn_s_setprio(0);
         };
         auto block_pv = [&](int t) {                                  // O^T += V^T(t-1) P^T(t-1)   (after the last tile)
             const char* sbp = slot(t + NS - 1);
+            if (p.prio) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8_t vf[NV];
 #pragma unroll
@@ -313,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NV - (R - W2), 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (p.prio) __builtin_amdgcn_s_setprio(0);
         };
         auto block_softmax = [&](int t) {                             // vector block: mask, online softmax of S^T(t), P -> bf16
             const bool is_ctx = t < nt_ctx;
@@ -619,6 +626,7 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     p.nq = nq; p.nkv = nkv; p.causal = causal;
     p.batch = batch; p.nqt = ceil_div(max_lq, 256);
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    { const char* e = getenv("BAGEL_ATTN_PRIO"); p.prio = e ? atoi(e) : 0; }
     const int nbpp = (nq / nkv) * p.nqt;
     const int pairs_per_xcd = ceil_div((long)batch * nkv, 8);
     const dim3 grid(8 * pairs_per_xcd * nbpp), block(512);
