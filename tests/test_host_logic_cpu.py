@@ -147,11 +147,6 @@ def test_concat_plan_and_cache_layout(monkeypatch):
         NaiveCache.concat([c, c], [2, 3])
 
 
-def cpu_model_with_vit(cfg):
-    """As cpu_model; the SigLIP RoPE tables of the rope variant are part of oracle_weights()."""
-    return cpu_model(cfg)
-
-
 @pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_rope"])
 def test_siglip_host_path_matches_reference(golden, monkeypatch, name):
     """SiglipVisionModel (packed patches, learned position table or 2-D RoPE, head_dim 32 / 72 padded to the 64 / 128 slots) and
@@ -225,7 +220,6 @@ def test_understanding_flow_host_path_matches_oracle(monkeypatch, name, batch):
     oracle's restatement of the reference flow (bagel.py:299-415,232-297,909-1000): KV caches before and after the decode,
     greedy token ids.  batch 1 = the fused-RMSNorm gemv route, batch 2 = the RMSNorm + skinny GEMM route."""
     from oracle import bagel_oracle as O
-    from oracle import packers as P
     mock_ops.install(monkeypatch)
     cfg = CFGS[name]
     model = cpu_model(cfg)
@@ -257,7 +251,6 @@ def test_understanding_flow_host_path_matches_oracle(monkeypatch, name, batch):
     if torch.equal(toks, otoks):      # same prefix -> the decoded K/V rows written back to the caller's cache are comparable too
         for i in range(L):
             assert rel(cache.key_cache[i], oc.key_cache[i]) < 1.5e-2 and rel(cache.value_cache[i], oc.value_cache[i]) < 1.5e-2
-    del P
 
 
 def cpu_model_and_vae(cfg):
