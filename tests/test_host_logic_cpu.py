@@ -613,3 +613,34 @@ def test_stream_batched_cfg_with_taylorseer_equals_sequential(monkeypatch, inter
         assert sched[0] != sched[1], "the streams were meant to drift apart"
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+def test_understanding_only_model_chat(monkeypatch):
+    """The construction recipe of eval/vlm/utils.py:30-63 -- BagelConfig(visual_gen=False, visual_und=True) (no VAE config, no
+    latent modules), fp32 weights from a full checkpoint via load_state_dict(strict=False), .eval() -- then model.chat with a PIL
+    image through the ImageTransform, as the VLM benchmark drivers call it (eval/vlm/eval/mme/eval.py:61-68).  The answer must equal
+    the full model's (the und path does not touch the generation modules)."""
+    import numpy as np
+    from PIL import Image
+    from bagel_amd.data.transforms import ImageTransform
+    from bagel_amd.modeling.bagel import Bagel, BagelConfig, Qwen2Config, Qwen2ForCausalLM, SiglipVisionConfig, SiglipVisionModel
+    mock_ops.install(monkeypatch)
+    monkeypatch.setenv("BAGEL_DECODE_GRAPH", "0")
+    cfg = TINY
+    W, _ = oracle_weights(cfg)
+    llm_config, vit_config = Qwen2Config(**cfg["llm"]), SiglipVisionConfig(**cfg["vit"])
+    config = BagelConfig(visual_gen=False, visual_und=True, llm_config=llm_config, vit_config=vit_config,
+                         vit_max_num_patch_per_side=cfg["bagel"]["vit_max_num_patch_per_side"], connector_act="gelu_pytorch_tanh")
+    model = Bagel(Qwen2ForCausalLM(llm_config), SiglipVisionModel(vit_config), config)
+    model.vit_model.vision_model.embeddings.convert_conv2d_to_linear(vit_config)
+    msg = model.load_state_dict(W, strict=False)
+    assert not msg.missing_keys and all(k.split(".")[0] in ("vae2llm", "llm2vae", "time_embedder", "latent_pos_embed") for k in msg.unexpected_keys)
+    assert not hasattr(model, "vae2llm")
+    model = model.eval()
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    tf = ImageTransform(56, 28, 14, device="cpu")
+    img = Image.fromarray(np.random.default_rng(3).integers(0, 256, (60, 80, 3), dtype=np.uint8), "RGB")
+    with pytest.warns(UserWarning, match="cast to bfloat16"):
+        out = model.chat(tok, NEW_TOKEN_IDS_TINY, tf, images=[img], prompt="what is it", max_length=6)
+    full = cpu_model(cfg).chat(tok, NEW_TOKEN_IDS_TINY, tf, images=[img], prompt="what is it", max_length=6)
+    assert isinstance(out, str) and out == full and out.startswith("[")
