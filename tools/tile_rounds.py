@@ -40,6 +40,11 @@ def main():
         print(f"layer GEMM cost, {mode:28}: {v / base:6.3f} x")
     lq = n_img + 2
     qt = math.ceil(lq / 256)
+    for mode, samples in (("sequential (per forward)", a.batch), ("batched", a.batch * a.streams)):
+        wgs = samples * NQ * qt
+        full = samples * NQ * (qt - 1 if lq - (qt - 1) * 256 < 32 else qt)
+        print(f"attention workgroups (one per CU at a time), {mode:26}: {wgs:5d} = {wgs / CUS:6.2f} rounds (paid {math.ceil(wgs / CUS)}); "
+              f"full-cost ones {full} = {full / CUS:.2f} rounds")
     print(f"attention: {qt} query tiles of 256 rows per (sample, head); the last one has {lq - (qt - 1) * 256} live rows "
           f"-> {a.batch * a.streams * NQ * qt} workgroups per step-forward pair, {a.batch * a.streams * NQ} of them nearly empty "
           f"({1 / qt:.1%} of the tile count)")
