@@ -51,7 +51,67 @@ def parse():
     ap.add_argument("--und-new-tokens", type=int, default=256)
     ap.add_argument("--und-batch", type=int, default=1, help="requests decoded together per GPU (reference: 1, bagel.py:996)")
     ap.add_argument("--und-image", type=int, default=980, help="side of the understanding image (980 -> 4900 ViT tokens)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="debug only: rendezvous + barrier + max-over-ranks timing + the JSON line, no model (gloo when there is no GPU)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` outside torchrun: re-exec this file as N ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1, which is how gen_images_mp.py is started (scripts/eval/run_geneval.sh:10-16).
+    Rank 0 of the child job prints the JSON line; its exit code is ours."""
+    import socket
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus and not args.launch_check:
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args, rank, world, local):
+    """The distributed skeleton of main() without the model: process group, fence, timed region, MAX over ranks, one line."""
+    import torch.distributed as dist
+    cuda = torch.cuda.is_available() and torch.cuda.device_count() > local
+    dev = torch.device("cuda", local) if cuda else torch.device("cpu")
+    if cuda:
+        torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if cuda else "gloo", rank=rank, world_size=world, **({"device_id": dev} if cuda else {}))
+
+    def fence():
+        if cuda:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    fence()
+    t0 = time.perf_counter()
+    x = torch.full((1 << 20,), float(rank + 1), device=dev)
+    for _ in range(args.steps):
+        if world > 1:
+            dist.all_reduce(x)
+            x /= world
+    fence()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    ranks = torch.ones(1, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no model)", "valid": False, "value": 0.0, "unit": "images/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(tt.item()) / max(args.steps, 1) * 1e3,
+                          "backend": ("nccl(RCCL)" if cuda else "gloo") if world > 1 else None, "ranks_seen": int(ranks.item()),
+                          "config": {"workload": "launch check", "global_batch": world * args.batch, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 class FixedTokenizer:
@@ -382,8 +442,12 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                     # does not return
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.launch_check:
+        return launch_check(args, rank, world, local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist

@@ -156,3 +156,31 @@ def test_data_parallel_text_to_image_world2():
     assert all(torch.equal(a, b) for a, b in zip(dp["channel"], one["channel"]))
     assert max(rel(a, b) for a, b in zip(dp["global_allreduce"], one["global"])) < 1e-3
     assert max(rel(a, b) for a, b in zip(dp["global_local"], one["global"])) > 1e-3, "per-rank statistics should be visible"
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` outside torchrun re-execs itself as 2 ranks (torch.distributed.run on 127.0.0.1) and rank 0
+    prints ONE JSON line with n_gpus = 2; the same command line under an existing torchrun environment must not fork again.
+    (--launch-check = the distributed skeleton of bench.main() without the model; gloo on a box without GPUs.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""        # the skeleton's gloo leg, also on a GPU box
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--launch-check"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["steps"] == 2 and out["ms_per_step"] > 0
+    # N = 1 stays in-process
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--launch-check"],
+                        env=env, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+    # a WORLD_SIZE that contradicts --gpus is still refused (the driver's torchrun line always agrees)
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE" in r2.stderr
