@@ -636,15 +636,14 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     if (head_dim == 128) {
         constexpr int smem3 = 3 * (64 * 256 + 128 * 128);
         const int smem = (sched >= 4 ? 4 : 3) * (64 * 256 + 128 * 128);
-        static bool set = false;
-        if (!set) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3 / 3 * 4);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3 / 3 * 4);
-            set = true;
+        {
+            int rc = sched == 5 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 5>, smem, "attn_fwd_kernel<128,5>")
+                   : sched == 4 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 4>, smem, "attn_fwd_kernel<128,4>")
+                   : sched == 3 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 3>, smem, "attn_fwd_kernel<128,3>")
+                   : sched == 2 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 2>, smem, "attn_fwd_kernel<128,2>")
+                   : sched == 1 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 1>, smem, "attn_fwd_kernel<128,1>")
+                                : bagel_enable_lds((const void*)attn_fwd_kernel<128, 0>, smem, "attn_fwd_kernel<128,0>");
+            if (rc != BAGEL_OK) return rc;
         }
         if (sched == 5)      hipLaunchKernelGGL((attn_fwd_kernel<128, 5>), grid, block, smem, stream, p);
         else if (sched == 4) hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), grid, block, smem, stream, p);
@@ -654,11 +653,10 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
         else                 hipLaunchKernelGGL((attn_fwd_kernel<128, 0>), grid, block, smem, stream, p);
     } else if (head_dim == 64) {
         const int smem = (sched >= 4 ? 4 : 3) * (64 * 128 + 64 * 128);
-        static bool set64 = false;
-        if (!set64) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 128 + 64 * 128));
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 128 + 64 * 128));
-            set64 = true;
+        if (sched >= 4) {
+            int rc = sched == 5 ? bagel_enable_lds((const void*)attn_fwd_kernel<64, 5>, smem, "attn_fwd_kernel<64,5>")
+                                : bagel_enable_lds((const void*)attn_fwd_kernel<64, 4>, smem, "attn_fwd_kernel<64,4>");
+            if (rc != BAGEL_OK) return rc;
         }
         if (sched == 5)      hipLaunchKernelGGL((attn_fwd_kernel<64, 5>), grid, block, smem, stream, p);
         else if (sched == 4) hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), grid, block, smem, stream, p);

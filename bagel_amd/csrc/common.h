@@ -17,6 +17,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 int bagel_set_error(int code, const char* fmt, ...);
 int bagel_check_launch(const char* what);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): a process that drives several GPUs must enable
+// the > 64 KB LDS kernels on each of them; the return code is checked and reported through bagel_set_error.
+int bagel_enable_lds(const void* func, int bytes, const char* what);
 
 #define BAGEL_REQUIRE(cond, ...)                                  \
     do {                                                          \

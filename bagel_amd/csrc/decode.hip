@@ -362,12 +362,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) { gemv_body<MR,
 template <int MR, int WPP>
 static int launch_gemv(const GemvParams& p, hipStream_t stream) {
     const size_t smem = WPP == 1 ? (size_t)MR * p.K * sizeof(bf16_t) : 0;     // the split-K path stages nothing
-    static size_t attr_bytes = 0;   // largest dynamic-LDS size this instantiation has been enabled for
-    if (smem > 48 * 1024 && smem > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)gemv_kernel<MR, WPP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMV_MAX_LDS) != hipSuccess)
-            return bagel_set_error(BAGEL_ERR_LAUNCH, "gemv: cannot enable %zu bytes of LDS", smem);
-        attr_bytes = GEMV_MAX_LDS;
-    }
+    if (smem > 48 * 1024)
+        if (int rc = bagel_enable_lds((const void*)gemv_kernel<MR, WPP>, (int)GEMV_MAX_LDS, "gemv_kernel")) return rc;
     const int NP = p.N / 2;
     GemvParams q = p;
     int grid;

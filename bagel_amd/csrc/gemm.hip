@@ -561,11 +561,7 @@ static int launch_gemm_pp(const GemmParams& p0, hipStream_t stream) {
     }
     p.gm = gm;
     constexpr int smem = 2 * 4 * 128 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    if (int rc = bagel_enable_lds((const void*)gemm_pp_kernel<ABL>, smem, "gemm_pp_kernel")) return rc;
     hipLaunchKernelGGL(gemm_pp_kernel<ABL>, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, stream, p);
     return bagel_check_launch("gemm_pp_kernel");
 }
@@ -961,24 +957,25 @@ static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream) {
     p.tiles_m = t;
     p.tiles_n = ceil_div(p.N, 256);
     if (t == 0) return BAGEL_OK;
-    static int gm = 0, wgs = 0;
+    static int gm = 0, wgs_of_dev[16] = {0};   // read-once tuning knobs; the CU count is cached per device
     if (gm == 0) {
         const char* e = getenv("BAGEL_GEMM_GM");
         gm = (e && atoi(e) > 0) ? atoi(e) : 4;
-        int dev = 0, cus = 0;
-        (void)hipGetDevice(&dev);
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    if (wgs_of_dev[dev] == 0) {
+        int cus = 0;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const char* w = getenv("BAGEL_GEMM_PERSIST_WGS");
-        wgs = (w && atoi(w) > 0) ? atoi(w) : cus;
-        wgs = wgs < 8 ? 8 : (wgs & ~7);            // a multiple of 8 keeps every work item of a workgroup on its XCD
+        int v = (w && atoi(w) > 0) ? atoi(w) : cus;
+        wgs_of_dev[dev] = v < 8 ? 8 : (v & ~7);    // a multiple of 8 keeps every work item of a workgroup on its XCD
     }
+    const int wgs = wgs_of_dev[dev];
     p.gm = gm;
     constexpr int smem = 2 * 4 * 128 * 128 + 3 * 2048;   // two k-tile stages + the three-deep row-table ring
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_pq_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<MODE>, smem, "gemm_pq_kernel")) return rc;
     const int nblk = p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL(gemm_pq_kernel<MODE>, dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
     return bagel_check_launch("gemm_pq_kernel");
@@ -996,11 +993,7 @@ static int launch_gemm(const GemmParams& p0, hipStream_t stream) {
     p.tiles_n = ceil_div(p.N, BN);
     if (t == 0) return BAGEL_OK;
     constexpr int smem = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    if (int rc = bagel_enable_lds((const void*)gemm_tn_kernel<BM, BN, WM, WN>, smem, "gemm_tn_kernel")) return rc;
     hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), smem, stream, p);
     return bagel_check_launch("gemm_tn_kernel");
 }
@@ -1045,7 +1038,9 @@ extern "C" int bagel_gemm_bf16(const void* A, int64_t lda,
             if (has_bias) return launch_gemm_pq<2>(p, stream);
             return launch_gemm_pq<3>(p, stream);
         }
+#ifdef BAGEL_ENABLE_ABLATIONS
         case 13: return launch_gemm_pp<1>(p, stream);   // timing-only ablation (results are garbage): no DMA in the k-loop
+#endif
         default: return bagel_set_error(BAGEL_ERR_ARG, "gemm: unknown variant %d", variant);
     }
 }

@@ -233,12 +233,8 @@ __global__ __launch_bounds__(256) void gemv_w8_kernel(GemvW8Params p) {
 template <int MR>
 static int launch_gemv_w8(const GemvW8Params& p, hipStream_t stream) {
     const size_t smem = (size_t)MR * p.K * sizeof(bf16_t);
-    static size_t attr_bytes = 0;
-    if (smem > 48 * 1024 && smem > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)gemv_w8_kernel<MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W8_MAX_LDS) != hipSuccess)
-            return bagel_set_error(BAGEL_ERR_LAUNCH, "gemv_w8: cannot enable %zu bytes of LDS", smem);
-        attr_bytes = W8_MAX_LDS;
-    }
+    if (smem > 48 * 1024)
+        if (int rc = bagel_enable_lds((const void*)gemv_w8_kernel<MR>, (int)W8_MAX_LDS, "gemv_w8_kernel")) return rc;
     hipLaunchKernelGGL((gemv_w8_kernel<MR>), dim3(ceil_div(p.N / 2, 4)), dim3(256), smem, stream, p);
     return bagel_check_launch("gemv_w8_kernel");
 }

@@ -4,6 +4,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -18,6 +19,29 @@ int bagel_set_error(int code, const char* fmt, ...) {
 int bagel_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bagel_set_error(BAGEL_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return BAGEL_OK;
+}
+
+int bagel_enable_lds(const void* func, int bytes, const char* what) {
+    constexpr int MAXF = 128, MAXDEV = 16;
+    static std::mutex mu;
+    static const void* funcs[MAXF];
+    static int enabled[MAXF][MAXDEV];      // largest size enabled for (kernel, device); 0 = never
+    static int nfuncs = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return bagel_set_error(BAGEL_ERR_LAUNCH, "%s: no current device", what);
+    std::lock_guard<std::mutex> lock(mu);
+    int i = 0;
+    while (i < nfuncs && funcs[i] != func) ++i;
+    if (i == nfuncs) {
+        if (nfuncs == MAXF) return bagel_set_error(BAGEL_ERR_LAUNCH, "%s: LDS attribute table full", what);
+        funcs[nfuncs++] = func;
+    }
+    if (enabled[i][dev] >= bytes) return BAGEL_OK;
+    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess)
+        return bagel_set_error(BAGEL_ERR_LAUNCH, "%s: cannot enable %d bytes of LDS on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+    enabled[i][dev] = bytes;
     return BAGEL_OK;
 }
 

@@ -207,8 +207,7 @@ extern "C" int bagel_conv_gemm_f32(const float* in, int64_t ld_in, const float* 
     p.tiles_m = ceil_div(p.M, 128);
     p.tiles_n = ceil_div(Cout, 128);
     constexpr int smem = 2 * 256 * 128;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv_gemm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set = true; }
+    if (int rc = bagel_enable_lds((const void*)conv_gemm_f32_kernel, smem, "conv_gemm_f32_kernel")) return rc;
     hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, stream, p);
     return bagel_check_launch("conv_gemm_f32_kernel");
 }

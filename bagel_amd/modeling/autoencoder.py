@@ -7,6 +7,8 @@ from typing import List
 import torch
 from torch import nn
 
+from .packed import PackedWeights
+
 
 @dataclass
 class AutoEncoderParams:
@@ -108,7 +110,7 @@ class _Decoder(nn.Module):
         self.conv_out = _conv(bi, p.out_ch, 3)
 
 
-class AutoEncoder(nn.Module):
+class AutoEncoder(PackedWeights):
     def __init__(self, params: AutoEncoderParams):
         super().__init__()
         self.params = params
@@ -118,18 +120,15 @@ class AutoEncoder(nn.Module):
         self.shift_factor = params.shift_factor
         self._engine = None
 
-    def _apply(self, fn, *a, **k):
+    def _drop_packed(self):
         self._engine = None
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._engine = None
-        return super().load_state_dict(*a, **k)
 
     def _eng(self):
+        self._check_packed()
         if self._engine is None:
             from .vae_engine import VaeEngine
             self._engine = VaeEngine(self)
+            self._packed_fresh()
         return self._engine
 
     @torch.no_grad()

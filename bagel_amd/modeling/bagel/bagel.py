@@ -402,6 +402,7 @@ class Bagel(nn.Module):
                        cfg_type="parallel", enable_taylorseer=False):
         # bagel.py:680-689: one TaylorSeer state per forward stream (cond, cfg-text, cfg-img)
         self.language_model.model.enable_taylorseer = False     # the engine gets the state explicitly (see _velocity)
+        self.language_model.engine(check=True)                  # re-pack if the parameters changed since the last call
         taylor = [TaylorSeerState(num_timesteps) for _ in range(3)] if enable_taylorseer else [None, None, None]
         self._last_taylor_states = taylor
         if cfg_renorm_type not in ops.RENORM_MODES:
@@ -441,13 +442,22 @@ class Bagel(nn.Module):
         """Optional batch-global 'global' renorm across data-parallel ranks: the reference's norm spans the tokens
         of the LOCAL pack only (bagel.py:892-895), which is also the default here; with ``model.global_renorm_allreduce = True``
         the per-block partial sums of stage 1 are summed over the ranks (one small all-reduce per step) so that an N-rank batch
-        renormalises like the same batch in one process."""
+        renormalises like the same batch in one process.  The collective always carries the WHOLE fixed-size partials buffer
+        (2 x 256 fp32, the unused tail zeroed): ``nparts`` depends on the local row count, and ranks with different pack sizes
+        must not enter an all-reduce with different tensor sizes.  Returns the number of partial pairs stage 2 has to sum.
+        Every rank of the group has to run the same number of denoise steps (a rank with an empty shard must not skip
+        generate_image while the others wait in the collective)."""
         if mode != 0 or not self.global_renorm_allreduce:
-            return
+            return nparts
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from ...parallel import allreduce_renorm_sums
-            allreduce_renorm_sums(partials[: 2 * nparts])
+            full = partials.numel() // 2
+            if nparts < full:
+                partials[2 * nparts:].zero_()
+            allreduce_renorm_sums(partials)
+            return full
+        return nparts
 
     def _stream_batch(self, st, plans, caches):
         """Opt-in (``model.cfg_batched`` / BAGEL_CFG_BATCH=1): the conditional and the CFG forwards of a denoise step share the
@@ -505,7 +515,7 @@ class Bagel(nn.Module):
                          M0=st["v"][s].shape[0])
             v, v_ct, v_ci = st["v"][0], st["v"][1], (st["v"][2] if plan_i is not None else None)
             nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
-            self._renorm_sums_allreduce(st["partials"], nparts, mode)
+            nparts = self._renorm_sums_allreduce(st["partials"], nparts, mode)
             ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
             return
         v = self._velocity(st, plan, cache, st["v"][0], taylor[0])
@@ -513,7 +523,7 @@ class Bagel(nn.Module):
             v_ct = self._velocity(st, plan_t, cache_t, st["v"][1], taylor[1])
             v_ci = self._velocity(st, plan_i, cache_i, st["v"][2], taylor[2]) if plan_i is not None else None
             nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
-            self._renorm_sums_allreduce(st["partials"], nparts, mode)
+            nparts = self._renorm_sums_allreduce(st["partials"], nparts, mode)
             ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
         else:
             ops.cfg_stage2_euler(x_t, v, None, 0, renorm_min, dt, use_global_scale=False)
@@ -585,7 +595,7 @@ class Bagel(nn.Module):
             return torch.empty((0, len(kv_lens)), dtype=torch.long, device=self.device)
         if weight_quant is None:
             weight_quant = getattr(self, "decode_weight_quant", None)    # model-level switch, like the reference's load-time modes (app.py:114-131)
-        sess = DecodeSession(lm.engine(), lm.model.embed_tokens.weight.data, lm.lm_head.weight.data, past_key_values, kv_lens,
+        sess = DecodeSession(lm.engine(check=True), lm.model.embed_tokens.weight.data, lm.lm_head.weight.data, past_key_values, kv_lens,
                              packed_start_tokens, packed_query_position_ids, max_length, weight_quant=weight_quant)
         self._last_decode_session = sess
         if use_graph is None:

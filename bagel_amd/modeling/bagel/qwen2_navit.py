@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from ... import ops
+from ..packed import PackedWeights
 
 BF16 = torch.bfloat16
 
@@ -887,8 +888,10 @@ def _engine_forward_train(self, seq, tp: "TrainPlan"):
 MoTEngine.forward_train = _engine_forward_train
 
 
-class Qwen2ForCausalLM(nn.Module):
-    """Same constructor, attribute names and ``forward_inference`` signature as qwen2_navit.py:1095-1188."""
+class Qwen2ForCausalLM(PackedWeights):
+    """Same constructor, attribute names and ``forward_inference`` signature as qwen2_navit.py:1095-1188.  The engine's packed
+    weight copies follow the parameters (modeling/packed.py): ``.to()``, any ``load_state_dict`` incl. one on the parent Bagel,
+    and in-place rewrites all drop them."""
 
     def __init__(self, config):
         super().__init__()
@@ -908,21 +911,18 @@ class Qwen2ForCausalLM(nn.Module):
                 param.data.copy_(sd[name.replace("_moe_gen", "")].data)
         self.invalidate_packed()
 
-    def invalidate_packed(self):
+    def _drop_packed(self):
         self._engine = None
         self._plans = {}
 
-    def _apply(self, fn, *a, **k):
-        self.invalidate_packed()
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self.invalidate_packed()
-        return super().load_state_dict(*a, **k)
-
-    def engine(self) -> MoTEngine:
+    def engine(self, check=False) -> MoTEngine:
+        """``check=True`` (the public entry points: once per prefill / generate_image / generate_text call) compares the
+        parameters' (data_ptr, version) signature with the one the packed copies were built from."""
+        if check:
+            self._check_packed()
         if self._engine is None:
             self._engine = MoTEngine(self.model, self.lm_head)
+            self._packed_fresh()
         return self._engine
 
     def get_input_embeddings(self):
@@ -946,7 +946,7 @@ class Qwen2ForCausalLM(nn.Module):
         # TaylorSeer (qwen2_navit.py:1034-1037): the caller parks the stream's state on the model, like the reference's
         # model.cache_dic / model.current (bagel.py:816-818)
         taylor = getattr(self.model, "current", None) if getattr(self.model, "enable_taylorseer", False) else None
-        eng = self.engine()
+        eng = self.engine(check=True)
         if plan is None:
             gen = mode == "gen" and eng.moe_mlp
             plan = self.make_plan(query_lens, packed_query_position_ids, packed_query_indexes, key_values_lens,
@@ -963,7 +963,7 @@ class Qwen2ForCausalLM(nn.Module):
                       packed_gen_token_indexes=None, split_lens=None, attn_modes=None):
         """qwen2_navit.py:1124-1143 (forward only: no autograd graph is built).  ``attention_mask``: the list of per-sample
         additive masks of the non-flex path, or None with flat ``split_lens`` / ``attn_modes`` (the flex path's inputs)."""
-        eng = self.engine()
+        eng = self.engine(check=True)
         sample_lens = [int(x) for x in sample_lens]
         if isinstance(attention_mask, (list, tuple)):
             splits = [splits_from_mask(m) for m in attention_mask]

@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from ... import ops
+from ..packed import PackedWeights
 from .qwen2_navit import _ceil_to, _pad_heads_cols, _pad_heads_rows, padded_head_dim
 
 BF16 = torch.bfloat16
@@ -125,7 +126,7 @@ class SiglipVisionTransformer(nn.Module):
         self.post_layernorm = _P(config.hidden_size)
 
 
-class SiglipVisionModel(nn.Module):
+class SiglipVisionModel(PackedWeights):
     main_input_name = "packed_pixel_values"
 
     def __init__(self, config: SiglipVisionConfig):
@@ -134,15 +135,7 @@ class SiglipVisionModel(nn.Module):
         self.vision_model = SiglipVisionTransformer(config)
         self._packed = None
 
-    def _apply(self, fn, *a, **k):
-        self._packed = None
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._packed = None
-        return super().load_state_dict(*a, **k)
-
-    def invalidate_packed(self):
+    def _drop_packed(self):
         self._packed = None
 
     def _pack(self):
@@ -151,6 +144,8 @@ class SiglipVisionModel(nn.Module):
         pe = vm.embeddings.patch_embedding
         if pe.weight.dim() != 2:
             raise RuntimeError("call vision_model.embeddings.convert_conv2d_to_linear(vit_config) first (app.py:66)")
+        if cfg.hidden_act != "gelu_pytorch_tanh":     # the encoder MLP's activation is the GEMM's tanh-GELU epilogue (siglip_navit.py:273)
+            raise NotImplementedError(f"SigLIP hidden_act {cfg.hidden_act!r} (BAGEL's so400m config uses gelu_pytorch_tanh)")
         ops.require_gpu_bf16(pe.weight, "SiglipEngine")
         D, nh = cfg.hidden_size, cfg.num_attention_heads
         hd = D // nh
@@ -174,10 +169,12 @@ class SiglipVisionModel(nn.Module):
             r = vm.rope
             rope = tuple(getattr(r, n).to(device=w.device, dtype=BF16).contiguous() for n in ("cos_h", "sin_h", "cos_w", "sin_w"))
         self._packed = dict(wpatch=w, bpatch=pe.bias.data, kin=kin, kpad=kpad, layers=layers, hd=hd, dp=dp, nh=nh, rope=rope)
+        self._packed_fresh()
         return self._packed
 
     @torch.no_grad()
     def forward(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
+        self._check_packed()
         P = self._packed or self._pack()
         cfg = self.config
         dev = P["wpatch"].device

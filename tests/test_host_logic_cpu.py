@@ -644,3 +644,51 @@ def test_understanding_only_model_chat(monkeypatch):
         out = model.chat(tok, NEW_TOKEN_IDS_TINY, tf, images=[img], prompt="what is it", max_length=6)
     full = cpu_model(cfg).chat(tok, NEW_TOKEN_IDS_TINY, tf, images=[img], prompt="what is it", max_length=6)
     assert isinstance(out, str) and out == full and out.startswith("[")
+
+
+def test_packed_weights_follow_a_reload_through_the_parent(monkeypatch):
+    """The engines keep packed copies of the weights (fused Wqkv, interleaved gate/up).  After a forward, loading ANOTHER checkpoint
+    through the parent Bagel (gen_images_mp.py:165-176 does exactly that), or rewriting parameters in place (EMA swap), must be
+    seen by the next call: the result has to equal a fresh model built from the new weights -- not a mixture of old packed and
+    new plain tensors."""
+    mock_ops.install(monkeypatch)
+    cfg = TINY
+    from bagel_amd.factory import build_bagel
+    W, _ = oracle_weights(cfg)
+    g = torch.Generator().manual_seed(11)
+    W2 = {k: (v.float() + 0.05 * v.float().std().nan_to_num(0.0).clamp_min(1e-3) * torch.randn(v.shape, generator=g)).to(v.dtype) if v.is_floating_point() and "pos_embed" not in k else v
+          for k, v in W.items()}
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+
+    def prefill(model):
+        gi, _, _ = model.prepare_prompts([0, 0], [0, 0], ["a small red cube", "sky"], tok, NEW_TOKEN_IDS_TINY)
+        c = model.forward_cache_update_text(new_cache(cfg), **gi)
+        return [c.key_cache[i].clone() for i in range(cfg["llm"]["num_hidden_layers"])]
+
+    def fresh(weights):
+        m, _ = build_bagel(cfg, device="cpu", with_vae=False)
+        m.load_state_dict(weights, strict=True)
+        return m.to(torch.bfloat16).eval()
+
+    want1, want2 = prefill(fresh(W)), prefill(fresh(W2))
+    assert not torch.equal(want1[-1], want2[-1])
+    model = fresh(W)
+    assert all(torch.equal(a, b) for a, b in zip(prefill(model), want1))
+    model.load_state_dict({k: v.to(torch.bfloat16) if v.is_floating_point() else v for k, v in W2.items()}, strict=True)   # parent load
+    assert all(torch.equal(a, b) for a, b in zip(prefill(model), want2)), "stale packed weights after Bagel.load_state_dict"
+    with torch.no_grad():                                                                 # in-place rewrite (EMA swap)
+        sd = {k: v.to(torch.bfloat16) if v.is_floating_point() else v for k, v in W.items()}
+        for k, p in model.named_parameters():
+            p.copy_(sd[k])
+    assert all(torch.equal(a, b) for a, b in zip(prefill(model), want1)), "stale packed weights after an in-place parameter rewrite"
+    sd2 = {k: v.to(torch.bfloat16) if v.is_floating_point() else v for k, v in W2.items()}
+    for k, p in model.named_parameters():                                                 # re-seated storage
+        p.data = sd2[k].clone()
+    assert all(torch.equal(a, b) for a, b in zip(prefill(model), want2)), "stale packed weights after param.data = ..."
+    # writes through a detached alias (param.data.copy_) bump no version counter and keep the pointer: the documented route for
+    # those is an explicit invalidate_packed() (what init_moe does itself)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.data.copy_(sd[k])
+    model.language_model.invalidate_packed()
+    assert all(torch.equal(a, b) for a, b in zip(prefill(model), want1))
