@@ -70,7 +70,7 @@ def test_broadcast_cache_gloo_world2():
 
 
 # ---- data-parallel text->image end to end on the host logic (2 ranks, gloo, torch stand-ins for the launch wrappers) --------
-def _dp_setup(B):
+def _dp_setup(B, monkeypatch=None):
     """(model, cfg, prompt inputs for B identical prompts, sizes).  The launch wrappers are the CPU stand-ins of tests/mock_ops.py
     (test infrastructure): what is under test is the host-side DP protocol, not the kernels."""
     from oracle.configs import TINY, NEW_TOKEN_IDS_TINY, StubTokenizer
@@ -80,7 +80,7 @@ def _dp_setup(B):
     class _MP:
         def setattr(self, obj, name, val):
             setattr(obj, name, val)
-    mock_ops.install(_MP())
+    mock_ops.install(monkeypatch or _MP())      # worker processes keep the stand-ins for life; the pytest process restores them
     model = cpu_model(TINY)
     tok = StubTokenizer(TINY["llm"]["vocab_size"])
     return model, TINY, tok, NEW_TOKEN_IDS_TINY
@@ -130,7 +130,7 @@ def _dp_worker(rank, ws, port, q):
     dist.destroy_process_group()
 
 
-def test_data_parallel_text_to_image_world2():
+def test_data_parallel_text_to_image_world2(monkeypatch):
     """Two ranks x two samples vs ONE process with all four samples, identical prompts, the job-global seed-42 noise stream sharded
     by rank: per-token renorm -> every sample bit-identical to the single-process batch (no tensor crosses a
     rank during sampling); 'global' renorm -> per-rank statistics by default (what the reference's torchrun drivers do: differs from
@@ -146,7 +146,7 @@ def test_data_parallel_text_to_image_world2():
         p.join(timeout=60)
     # single-process reference: all four samples in one batch
     from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
-    model, cfg, tok, ids = _dp_setup(4)
+    model, cfg, tok, ids = _dp_setup(4, monkeypatch)
     gi, _, _ = model.prepare_prompts([0] * 4, [0] * 4, ["a small red cube"] * 4, tok, ids)
     cache = model.forward_cache_update_text(NaiveCache(cfg["llm"]["num_hidden_layers"]), **gi)
     noise = torch.randn(4 * 8, 64, generator=torch.Generator().manual_seed(42))
