@@ -43,7 +43,6 @@ struct AttnParams {
     int nq, nkv, causal;
     int batch, nqt;          // samples, 256-row query tiles per sample (from max_lq)
     float scale_log2;
-    int prio;                // SCHED >= 2 only (BAGEL_ATTN_PRIO=1): s_setprio 1 inside the matrix blocks
 };
 
 // 16 bytes per lane HBM -> LDS (destination = wave-uniform LDS byte address + lane*16).  Issued from inline asm on
@@ -63,23 +62,16 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 
 #define ATTN_DEFER_LOG2 8.0f
 
-// SCHED = 0: hipcc's own instruction order.  SCHED = 1 (BAGEL_ATTN_SCHED=1): the same arithmetic in the same order -- results
-// are bit-identical -- with the LDS fragment reads software-pipelined by hand (sched_group_barrier): hipcc's schedule reads one
-// K / V^T fragment, waits for it, issues its MFMA, reads the next ... (a full LDS round trip in front of every MFMA: 32 per
-// tile); SCHED = 1 keeps 8 fragment reads in flight under the MFMAs and fetches the first half of the V^T tile before the
-// softmax so it lands under the exp/convert VALU work.  Waves 4-7 (the second-dispatched half, the arbitration loser on
-// every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.  Waves with no live query row
-// skip the arithmetic (1 904 workgroups at the denoise shape, 112 of them with 2 live rows of 256).
-// SCHED = 2 / 3 / 4 (BAGEL_ATTN_SCHED; 3 = 2 + four V^T fragments prefetched across the barrier; 4 = 2 with a 4-slot ring and every
-// wave issuing its LDS-DMA pieces from its own vector blocks; 5 = 4 + the prefetch of 3): the two halves of the workgroup alternate roles.  The loop runs in STEPS separated by one
-// workgroup barrier each; in every step waves 0-3 are in a MATRIX block (O^T += V^T(t-1) P^T(t-1), then S^T(t) = K(t) Q^T: 32 MFMAs
-// with the LDS reads pipelined under them) while waves 4-7 are in a VECTOR block (mask, online softmax of their S^T, P -> bf16)
-// -- and the other way round in the next step: waves 4-7 run one step behind.  Each SIMD hosts one
-// wave of either half, so its matrix pipe and its VALU are both busy in every step instead of being contended for in one
-// phase and idle in the other (MI355X_MICROARCH.md, "Two waves per SIMD").  Per wave the arithmetic and its order are those of
-// SCHED = 0 (the accumulation of tile t-1 simply moves behind the barrier), so results are bit-identical; every wave executes the
-// same 2T + 3 barriers whatever its role.  Ring: tile t is read in steps 2t .. 2t+3, its slot is refilled (tile t+3) at the start of
-// step 2t+4 and waited for at the end of step 2t+5.
+// SCHED = 1 (the default since round 2: 787 -> 870 TFLOP/s at the denoise shape, profiles/r02_attn_schedules.log): the LDS fragment
+// reads are software-pipelined by hand (sched_group_barrier) -- hipcc's own order (SCHED = 0, kept as the bit-identity yardstick,
+// BAGEL_ATTN_SCHED=0) reads one K / V^T fragment, waits for it, issues its MFMA, reads the next ...: a full LDS round trip in
+// front of each of the 32 MFMAs of a tile.  SCHED = 1 keeps 8 fragment reads in flight under the MFMAs and fetches the first half
+// of the V^T tile before the softmax so it lands under the exp/convert VALU work.  Waves 4-7 (the second-dispatched half, the
+// arbitration loser on every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.  Waves with
+// no live query row skip the arithmetic (1 904 workgroups at the denoise shape, 112 of them with 2 live rows of 256).  Same
+// instructions on the same operands in the same per-accumulator order as SCHED = 0: results are bit-identical.
+// (Round 1 also carried four "role alternation" schedules -- the two wave halves swapping matrix and softmax blocks per step, 3- and
+// 4-slot rings: all bit-identical, all measured at 768-837 TFLOP/s, i.e. below this one, and removed.)
 template <int D, int SCHED>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = D / 16;              // k-steps of the QK^T contraction
@@ -202,208 +194,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
     int st = 0;
     if (SCHED == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if constexpr (SCHED >= 2) {
-        // ---- two-phase schedule (see the comment above the kernel) ----
-        // Global steps gs = 0 .. 2T+2, one workgroup barrier at the end of each.  Waves 0-3 run matrix blocks in even steps and
-        // vector blocks in odd steps, waves 4-7 the other way round (their program starts one step later), a wave without a live
-        // query row only keeps the DMA ring and the barriers going.  Every wave executes exactly 2T+3 barriers.  The per-role
-        // programs are written out linearly (first block | steady loop | last block) so that the loop bodies are unconditional.
-        constexpr int NV = DB * 4;                  // V^T fragments of a tile (index 4*db + j)
-        constexpr int NK = 2 * KS;                  // K fragments of a tile (index KS*kb + ks)
-        constexpr int WIN = 8;                      // fragment reads kept in flight ahead of the MFMA that consumes them
-        constexpr int PRE = (SCHED == 3 || SCHED == 5) ? 4 : 0;     // SCHED = 3 / 5: V^T fragments of tile t fetched at the end of its vector block, so
-                                                    // the following matrix block opens with MFMAs instead of an exposed LDS round trip
-        f32x16_t s[2];
-        bf16x8_t pf[4], vpre[PRE > 0 ? PRE : 1];
-        auto kfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx / KS) * 32 * KROW + kch[idx % KS]); };
-        auto vfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx >> 2) * 4096 + vch[idx & 3]); };
-        constexpr int NS = SCHED >= 4 ? 4 : 3;      // ring slots
-        auto slot = [&](int t) { return (const char*)smem + (t % NS) * STAGE; };
-        // Step bookkeeping.  Tile u is first read in step 2u and last in step 2u+3.
-        //   SCHED 2/3 (3 slots): the slot of tile u-3 is free after step 2u-3; every wave requests its share of tile u at the start of
-        //     step 2u-2 and waits for it (vmcnt(0)) at the end of step 2u-1.
-        //   SCHED 4 (4 slots): a wave requests its share of a tile at the start of one of ITS OWN vector blocks, where an LDS-DMA
-        //     instruction costs a fraction of what it costs among LDS reads and MFMAs (MI355X_MICROARCH.md, LDS-DMA issue cost):
-        //     waves 0-3 request tile u in step 2u-3, waves 4-7 in step 2u-4 (the slot of tile u-4 is free after step 2u-5); at the end
-        //     of step 2u-1 a wave has exactly the NL pieces of tile u+1 in flight behind tile u -> vmcnt(NL).
-        const bool lead = wave < 4;
-        auto step_begin = [&](int gs) {
-            if constexpr (SCHED >= 4) {
-                int u = -1;
-                if (lead) { if (gs & 1) u = (gs + 3) >> 1; }
-                else      { if ((gs & 1) == 0) u = (gs + 4) >> 1; }
-                if (u >= 2 && u < T) issue(u % NS, u);
-            } else {
-                if ((gs & 1) == 0 && gs >= 2) {
-                    const int u = (gs >> 1) + 1;
-                    if (u < T) issue(u % NS, u);
-                }
-            }
-        };
-        auto step_end = [&](int gs) {
-            if (gs & 1) {
-                if (SCHED >= 4 && ((gs + 1) >> 1) + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-                else                                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            asm volatile("s_barrier" ::: "memory");
-        };
-        // matrix blocks.  Source order = all fragment reads, then all MFMAs; the sched_group_barrier sequence turns it into
-        // WIN reads | (MFMA, read) ... | WIN MFMAs: every read is issued WIN MFMAs ahead of its consumer.
-        auto block_qk = [&](int t) {                                  // S^T(t) = K(t) Q^T   (first tile)
-            const char* sbk = slot(t);
-            if (p.prio) __builtin_amdgcn_s_setprio(1);
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8_t kf[NK];
-#pragma unroll
-            for (int j = 0; j < NK; ++j) kf[j] = kfrag(sbk, j);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
-#pragma unroll
-            for (int j = 0; j < NK; ++j) s[j / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j % KS], s[j / KS], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, WIN, 0);
-#pragma unroll
-            for (int i = 0; i < NK - WIN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, WIN, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (p.prio) __builtin_amdgcn_s_setprio(0);
-        };
-        auto block_pv_qk = [&](int t) {                               // O^T += V^T(t-1) P^T(t-1);  S^T(t) = K(t) Q^T
-            const char* sbp = slot(t + NS - 1);                       // tile t - 1
-            const char* sbk = slot(t);
-            if (p.prio) __builtin_amdgcn_s_setprio(1);
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8_t vf[NV], kf[NK];
-#pragma unroll
-            for (int j = 0; j < PRE; ++j) vf[j] = vpre[j];
-#pragma unroll
-            for (int j = PRE; j < NV; ++j) vf[j] = vfrag(sbp, j);
-#pragma unroll
-            for (int j = 0; j < NK; ++j) kf[j] = kfrag(sbk, j);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) o[j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], pf[j & 3], o[j >> 2], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
-#pragma unroll
-            for (int j = 0; j < NK; ++j) s[j / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j % KS], s[j / KS], 0, 0, 0);
-            // PRE fragments are already in registers: WIN reads go out first, then one more behind every MFMA while reads remain
-            __builtin_amdgcn_sched_group_barrier(0x100, WIN, 0);
-#pragma unroll
-            for (int i = 0; i < NV - PRE + NK - WIN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, WIN + PRE, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (p.prio) __builtin_amdgcn_s_setprio(0);
-        };
-        auto block_pv = [&](int t) {                                  // O^T += V^T(t-1) P^T(t-1)   (after the last tile)
-            const char* sbp = slot(t + NS - 1);
-            if (p.prio) __builtin_amdgcn_s_setprio(1);
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8_t vf[NV];
-#pragma unroll
-            for (int j = 0; j < PRE; ++j) vf[j] = vpre[j];
-#pragma unroll
-            for (int j = PRE; j < NV; ++j) vf[j] = vfrag(sbp, j);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) o[j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], pf[j & 3], o[j >> 2], 0, 0, 0);
-            constexpr int R = NV - PRE, W2 = R < WIN ? R : WIN;
-            __builtin_amdgcn_sched_group_barrier(0x100, W2, 0);
-#pragma unroll
-            for (int i = 0; i < R - W2; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NV - (R - W2), 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (p.prio) __builtin_amdgcn_s_setprio(0);
-        };
-        auto block_softmax = [&](int t) {                             // vector block: mask, online softmax of S^T(t), P -> bf16
-            const bool is_ctx = t < nt_ctx;
-            const int ti = is_ctx ? t : t - nt_ctx;
-            const int seglen = is_ctx ? C : Lq;
-            const int kbase = ti * 64;
-            const bool need_mask = (kbase + 64 > seglen) || (p.causal && !is_ctx && (kbase + 63 > wrow0));
-            if (need_mask) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kbase + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
-                        const bool ok = key < seglen && (!p.causal || is_ctx || key <= qrow);
-                        s[kb][r] = ok ? s[kb][r] : -INFINITY;
-                    }
-            }
-            float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
-            if (__any(mx > m_run + ATTN_DEFER_LOG2)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - (m_new == -INFINITY ? 0.f : m_new));
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < DB; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            }
-            const float m_use = m_run == -INFINITY ? 0.f : m_run;
-            float psum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    unsigned wv[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * c + 2 * e], p.scale_log2, -m_use));
-                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * c + 2 * e + 1], p.scale_log2, -m_use));
-                        psum += p0 + p1;
-                        wv[e] = pack2bf(p0, p1);
-                    }
-                    u32x4_t v4 = {wv[0], wv[1], wv[2], wv[3]};
-                    pf[2 * kb + c] = __builtin_bit_cast(bf16x8_t, v4);
-                }
-            l_run += psum;
-            const char* sbv = slot(t);
-#pragma unroll
-            for (int j = 0; j < PRE; ++j) vpre[j] = vfrag(sbv, j);
-        };
-
-        if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-        else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");     // tile 0 is resident
-        const int last = 2 * T + 2;                 // last global step
-        if (wrow0 >= Lq) {
-            for (int gs = 0; gs <= last; ++gs) { step_begin(gs); step_end(gs); }
-        } else if (wave < 4) {
-            // waves 0-3: matrix block of tile t in step 2t, vector block in step 2t+1
-            step_begin(0); block_qk(0); step_end(0);
-            step_begin(1); block_softmax(0); step_end(1);
-            for (int t = 1; t < T; ++t) {
-                step_begin(2 * t); block_pv_qk(t); step_end(2 * t);
-                step_begin(2 * t + 1); block_softmax(t); step_end(2 * t + 1);
-            }
-            step_begin(2 * T); block_pv(T); step_end(2 * T);
-            step_begin(2 * T + 1); step_end(2 * T + 1);
-            step_begin(2 * T + 2); step_end(2 * T + 2);
-        } else {
-            // waves 4-7: one step behind -- matrix block of tile t in step 2t+1, vector block in step 2t+2
-            step_begin(0); step_end(0);
-            step_begin(1); block_qk(0); step_end(1);
-            step_begin(2); block_softmax(0); step_end(2);
-            for (int t = 1; t < T; ++t) {
-                step_begin(2 * t + 1); block_pv_qk(t); step_end(2 * t + 1);
-                step_begin(2 * t + 2); block_softmax(t); step_end(2 * t + 2);
-            }
-            step_begin(2 * T + 1); block_pv(T); step_end(2 * T + 1);
-            step_begin(2 * T + 2); step_end(2 * T + 2);
-        }
-    } else
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
         else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -626,44 +416,22 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     p.nq = nq; p.nkv = nkv; p.causal = causal;
     p.batch = batch; p.nqt = ceil_div(max_lq, 256);
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    { const char* e = getenv("BAGEL_ATTN_PRIO"); p.prio = e ? atoi(e) : 0; }
     const int nbpp = (nq / nkv) * p.nqt;
     const int pairs_per_xcd = ceil_div((long)batch * nkv, 8);
     const dim3 grid(8 * pairs_per_xcd * nbpp), block(512);
-    // tuning knob, read at every launch (a getenv is noise beside a launch) so that one process can sweep the schedules
+    // read at every launch (a getenv is noise beside a launch) so that one process can compare the two instruction orders
     const char* sched_env = getenv("BAGEL_ATTN_SCHED");
-    const int sched = sched_env ? atoi(sched_env) : 0;
+    const int sched = sched_env ? atoi(sched_env) : 1;
     if (head_dim == 128) {
-        constexpr int smem3 = 3 * (64 * 256 + 128 * 128);
-        const int smem = (sched >= 4 ? 4 : 3) * (64 * 256 + 128 * 128);
-        {
-            int rc = sched == 5 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 5>, smem, "attn_fwd_kernel<128,5>")
-                   : sched == 4 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 4>, smem, "attn_fwd_kernel<128,4>")
-                   : sched == 3 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 3>, smem, "attn_fwd_kernel<128,3>")
-                   : sched == 2 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 2>, smem, "attn_fwd_kernel<128,2>")
-                   : sched == 1 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 1>, smem, "attn_fwd_kernel<128,1>")
-                                : bagel_enable_lds((const void*)attn_fwd_kernel<128, 0>, smem, "attn_fwd_kernel<128,0>");
-            if (rc != BAGEL_OK) return rc;
-        }
-        if (sched == 5)      hipLaunchKernelGGL((attn_fwd_kernel<128, 5>), grid, block, smem, stream, p);
-        else if (sched == 4) hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), grid, block, smem, stream, p);
-        else if (sched == 3) hipLaunchKernelGGL((attn_fwd_kernel<128, 3>), grid, block, smem, stream, p);
-        else if (sched == 2) hipLaunchKernelGGL((attn_fwd_kernel<128, 2>), grid, block, smem, stream, p);
-        else if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<128, 1>), grid, block, smem, stream, p);
-        else                 hipLaunchKernelGGL((attn_fwd_kernel<128, 0>), grid, block, smem, stream, p);
+        constexpr int smem = 3 * (64 * 256 + 128 * 128);
+        if (int rc = sched == 0 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 0>, smem, "attn_fwd_kernel<128,0>")
+                                : bagel_enable_lds((const void*)attn_fwd_kernel<128, 1>, smem, "attn_fwd_kernel<128,1>")) return rc;
+        if (sched == 0) hipLaunchKernelGGL((attn_fwd_kernel<128, 0>), grid, block, smem, stream, p);
+        else            hipLaunchKernelGGL((attn_fwd_kernel<128, 1>), grid, block, smem, stream, p);
     } else if (head_dim == 64) {
-        const int smem = (sched >= 4 ? 4 : 3) * (64 * 128 + 64 * 128);
-        if (sched >= 4) {
-            int rc = sched == 5 ? bagel_enable_lds((const void*)attn_fwd_kernel<64, 5>, smem, "attn_fwd_kernel<64,5>")
-                                : bagel_enable_lds((const void*)attn_fwd_kernel<64, 4>, smem, "attn_fwd_kernel<64,4>");
-            if (rc != BAGEL_OK) return rc;
-        }
-        if (sched == 5)      hipLaunchKernelGGL((attn_fwd_kernel<64, 5>), grid, block, smem, stream, p);
-        else if (sched == 4) hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), grid, block, smem, stream, p);
-        else if (sched == 3) hipLaunchKernelGGL((attn_fwd_kernel<64, 3>), grid, block, smem, stream, p);
-        else if (sched == 2) hipLaunchKernelGGL((attn_fwd_kernel<64, 2>), grid, block, smem, stream, p);
-        else if (sched == 1) hipLaunchKernelGGL((attn_fwd_kernel<64, 1>), grid, block, smem, stream, p);
-        else                 hipLaunchKernelGGL((attn_fwd_kernel<64, 0>), grid, block, smem, stream, p);
+        constexpr int smem = 3 * (64 * 128 + 64 * 128);
+        if (sched == 0) hipLaunchKernelGGL((attn_fwd_kernel<64, 0>), grid, block, smem, stream, p);
+        else            hipLaunchKernelGGL((attn_fwd_kernel<64, 1>), grid, block, smem, stream, p);
     } else {
         return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn: head_dim %d not in {64,128} (pad the head)", head_dim);
     }

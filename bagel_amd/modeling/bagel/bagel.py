@@ -123,9 +123,12 @@ class Bagel(nn.Module):
             nn.init.constant_(self.llm2vae.weight, 0)
             nn.init.constant_(self.llm2vae.bias, 0)
         self._k64 = {}
-        # opt-in execution options of generate_image (results agree with the default path within bf16 accumulation-order noise
-        # on the 2 marker rows per sample; see _stream_batch / MoTEngine.forward): off unless asked for
-        self.cfg_batched = os.environ.get("BAGEL_CFG_BATCH", "0") == "1"
+        # execution options of generate_image.  cfg_batched (default since round 2: 417.2 -> 399.4 ms per Euler step at config 3,
+        # profiles/r02_stream_batch.log): the cond + CFG forwards of a step run as ONE forward (see _stream_batch); und_side_path
+        # sends the 2 marker rows per sample through the skinny GEMM beside it so the latent rows fill whole 256-row tiles.
+        # Without the side path the result is bit-identical to sequential forwards; with it the marker rows see another
+        # accumulation order (bf16 noise).  BAGEL_CFG_BATCH=0 / BAGEL_UND_SIDE=0 switch them off.
+        self.cfg_batched = os.environ.get("BAGEL_CFG_BATCH", "1") == "1"
         self.und_side_path = os.environ.get("BAGEL_UND_SIDE", "1") == "1"
         self.global_renorm_allreduce = False      # see _renorm_sums_allreduce
 
@@ -460,7 +463,7 @@ class Bagel(nn.Module):
         return nparts
 
     def _stream_batch(self, st, plans, caches):
-        """Opt-in (``model.cfg_batched`` / BAGEL_CFG_BATCH=1): the conditional and the CFG forwards of a denoise step share the
+        """``model.cfg_batched`` (default on; BAGEL_CFG_BATCH=0 turns it off): the conditional and the CFG forwards of a denoise step share the
         query sequence and differ only in position ids and context (bagel.py:820-870), so they run as ONE forward over
         [stream 0's samples | stream 1's | ...] -- row-wise operators and per-sample attention make every row's arithmetic the
         same as in separate forwards.  What it buys is tile quantisation: 4 x 4096 latent rows per stream are 64 row tiles of

@@ -641,10 +641,10 @@ def main():
                                    f"BAGEL-7B-MoT text->image {R}x{R}, {T} timesteps ({T - 1} Euler steps x [cond + CFG-text 4.0]), "
                                    f"global renorm, timestep_shift 3, prompt {args.prompt_tokens}+2 tokens, {B} samples/GPU, VAE decode included",
                        "global_batch": world * B, "query_tokens_per_sample": n_img + 2, "parallelism": f"dp{world}",
-                       # opt-in execution variants; all off in the default configuration
+                       # execution options in force (promoted in round 2 after measurement)
                        "options": {"cfg_batched": bool(getattr(model, "cfg_batched", False)),
                                    "und_side_path": bool(getattr(model, "cfg_batched", False) and getattr(model, "und_side_path", False)),
-                                   "attn_sched": int(os.environ.get("BAGEL_ATTN_SCHED", "0"))}},
+                                   "attn_sched": int(os.environ.get("BAGEL_ATTN_SCHED", "1"))}},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                          "traffic": pmc_traffic(names.get(dom, str(dom))) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None, "kernel": names.get(dom, str(dom)), "launches": len(records),
                          "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},

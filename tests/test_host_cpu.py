@@ -171,19 +171,6 @@ def test_bench_roofline_traffic_sources_resolve():
     assert bench.pmc_traffic("no_such_kernel") is None
 
 
-def test_attention_sched2_protocol_model():
-    """The barrier / ring / DMA protocol of the opt-in two-phase attention schedule (attn_fwd_kernel<D, 2>), as a discrete model
-    (tools/attn_sched2_model.py): equal barrier counts for every role, reads only of resident tiles, refills only of dead slots."""
-    import importlib.util
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("attn_sched2_model", os.path.join(root, "tools", "attn_sched2_model.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
-    for T in range(1, 40):
-        assert m.check(T) == 2 * T + 3
-        assert m.check4(T)          # the 4-slot variant with role-split DMA issue and counted waits
-
-
 def test_vae_launch_wrappers_match_the_header(monkeypatch):
     """The fp32 VAE wrappers of bagel_amd.ops hand the C ABI exactly the argument list include/bagel_hip.h declares (count and
     kinds: pointer / integer / float) -- checked without a GPU by swapping the library for a recorder that validates every call

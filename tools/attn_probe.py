@@ -64,7 +64,7 @@ def main():
         torch.save({"full": full, "causal": out.cpu().clone()}, dump)
     ms = timeit(run)
     fl = 4.0 * B * Lq * (Lq + C_ctx) * nq * D
-    tag = f"[BAGEL_ATTN_SCHED={os.environ.get('BAGEL_ATTN_SCHED', '0')}] "
+    tag = f"[BAGEL_ATTN_SCHED={os.environ.get('BAGEL_ATTN_SCHED', '1')}] "
     print(f"{tag}attn_denoise: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  max_rel_err {worst:.3e}", flush=True)
     ms_c = timeit(lambda: run(True))
     print(f"{tag}attn_causal : {ms_c:.3f} ms  {fl / 2 / ms_c / 1e9:.1f} TFLOP/s (half the work)", flush=True)
@@ -76,7 +76,7 @@ def compare():
     import subprocess
     import tempfile
     outs = {}
-    for v in ("0", "1", "2", "3", "4", "5"):
+    for v in ("0", "1"):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
             path = f.name
         env = dict(os.environ, BAGEL_ATTN_SCHED=v, BAGEL_ATTN_PROBE_DUMP=path)
@@ -88,7 +88,7 @@ def compare():
         outs[v] = torch.load(path)
         os.unlink(path)
     bad = []
-    for v in ("1", "2", "3", "4", "5"):
+    for v in ("1",):
         for k in ("full", "causal"):
             same = torch.equal(outs["0"][k], outs[v][k])
             d = 0.0 if same else (outs["0"][k].float() - outs[v][k].float()).abs().max().item()

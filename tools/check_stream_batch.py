@@ -71,13 +71,11 @@ def bench():
     li = model.prepare_vae_latent(lens, ropes, [(R, R)] * B, ids)
     ci = model.prepare_vae_latent_cfg([0] * B, [0] * B, [(R, R)] * B)
     res = {}
-    modes = [("sequential", False, False, "0", "0"), ("batched", True, False, "0", "0"), ("batched+side", True, True, "0", "0")]
-    modes += [(f"sequential, attn sched {v}", False, False, v, "0") for v in ("1", "2", "3", "4", "5")]
-    modes += [(f"sequential, attn sched {v} + matrix-block priority", False, False, v, "1") for v in ("2", "4")]
-    modes += [(f"batched+side, attn sched {v}", True, True, v, "0") for v in ("2", "4")]
-    for tag, batched, side, sched, prio in modes:
+    modes = [("sequential", False, False, "1"), ("batched", True, False, "1"), ("batched+side", True, True, "1")]
+    modes += [("sequential, attn sched 0", False, False, "0"), ("batched+side, attn sched 0", True, True, "0")]
+    for tag, batched, side, sched in modes:
         model.cfg_batched, model.und_side_path = batched, side
-        os.environ["BAGEL_ATTN_SCHED"], os.environ["BAGEL_ATTN_PRIO"] = sched, prio     # read by the library at every attention launch
+        os.environ["BAGEL_ATTN_SCHED"] = sched     # read by the library at every attention launch
 
         def run(T):
             return model.generate_image(past_key_values=cache, num_timesteps=T, cfg_text_scale=4.0, cfg_interval=[0, 1.0],
@@ -95,7 +93,7 @@ def bench():
         res[tag] = (ms, lat)
         print(f"7B text->image B=4 1024^2, {tag}: {ms:.1f} ms per Euler step (2 forwards)  -> {4 / (49 * ms * 1e-3):.4f} images/s (denoise only)",
               flush=True)
-    os.environ["BAGEL_ATTN_SCHED"], os.environ["BAGEL_ATTN_PRIO"] = "0", "0"
+    os.environ.pop("BAGEL_ATTN_SCHED", None)
     for tag, (ms, lat) in res.items():
         if "attn sched" in tag:
             base = res["batched+side" if tag.startswith("batched") else "sequential"][1]
