@@ -87,3 +87,12 @@ class StubTokenizer:
             else:
                 out.append(f"[{t}]")
         return "".join(out)
+
+# BAGEL-7B-MoT WIDTH (hidden 3584, intermediate 18944, 28 / 4 heads of 128, MoT) at 2 layers and a 512-token vocabulary: the shapes
+# the benchmark's kernels actually run (M = 4098 rows per 1024^2 sample, K = 3584 / 18944, GQA 7) at a size the unmodified
+# reference finishes on 8 CPU cores in about a minute -- tests/golden/wide7b_t2i.pt (oracle/make_golden_wide.py).
+WIDE7B = dict(
+    name="wide7b",
+    llm=dict(BAGEL_7B["llm"], vocab_size=512, num_hidden_layers=2),
+    vit=TINY["vit"], vae=_VAE_TINY, bagel=TINY["bagel"], llm2vae_std=0.02,
+)
