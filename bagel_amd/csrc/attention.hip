@@ -16,16 +16,31 @@
 //                 as the B operand.  The MFMA row -> key assignment inside each 32-key block is permuted (quads
 //                 1<->2 of every 16) when K fragments are read, which makes each lane's 8 k-slots 8 CONSECUTIVE
 //                 keys, so the V^T fragment is one ds_read_b128.
-//   K / V^T tiles (64 keys) stream HBM -> LDS by global_load_lds_dwordx4 into a 3-deep ring, XOR-swizzled on the
-//   source side; ONE barrier per tile, counted vmcnt keeps two tiles in flight across it.
+//   K / V^T tiles (64 keys) stream HBM -> LDS by global_load_lds_dwordx4 (wave-uniform base + lane-constant offset) into a
+//   3-slot ring, XOR-swizzled on the source side; ONE barrier per tile.
+//   Every wave is SOFTWARE-PIPELINED over the KV tiles (round 2): while the matrix pipe runs S^T(t+1) = K(t+1) Q^T (phase A) the
+//   VALU turns S^T(t) into P(t) (exp2, row sums, bf16 pack), and while it runs O^T += V^T(t) P^T(t) (phase B) the VALU takes the
+//   row max of S^T(t+1).  Scores live in two named register sets that swap roles per tile (the tile loop is unrolled by two).
+//   The issue order is written out by hand, one chunk per MFMA (see `step`).
 //   Online softmax in base 2 with the scale folded into the exponent's fma; the running max is only raised (and O
 //   rescaled) when some row's tile max exceeds it by more than 2^8 ("deferred max": P <= 256, exact in fp32/bf16
-//   range; the final O/l normalisation makes the result independent of which max was used).
+//   range; the final O/l normalisation makes the result independent of which max was used).  The decision for tile t+1 is
+//   taken after P(t) V(t) has been issued -- O and l are rescaled behind those MFMAs, P(t+1) is exponentiated against the new max:
+//   every term of O and l is scaled exactly once (cdna_hip_programming.md T13).
 //   Block order is XCD-aware: the (sample, kv-head) pairs are dealt round-robin to the 8 XCDs (blockIdx % 8), and all
 //   q-heads x q-tiles of one pair run back to back on that XCD, so its K/V (2.1 MB at 4098 keys) stays in the
 //   XCD's 4 MiB L2 while ~119 workgroups stream it.
+//
+// Measured history of this kernel at the denoise shape (4 x 4098 rows, 28/4 heads, D 128; profiles/r02_attn_*.{log,txt}):
+//   hipcc's own order, no pipelining 787 TFLOP/s -> LDS reads pipelined by sched_group_barrier 850-876 -> this form 867-904.
+//   PMC of the previous form: matrix pipe busy 42 %, waves parked on waitcnt/barrier 27 %, issue-stalled 35 %, issuing 38 %.
+//   Tried and removed: role alternation between the wave halves (four variants, 768-837); a one-wave-per-SIMD form with 64 query
+//   rows per wave, O / Q / S in the accumulation registers and inline-asm MFMAs (correct, 155 VGPR + 256 AGPR, 787 TFLOP/s: a
+//   single wave per SIMD issues every one of its ~590 instructions per tile itself -- 60 % of its cycles -- and nothing hides its
+//   22 % of waitcnt/barrier time); timing-only ablations of this form: no barrier +5 %, no DMA +8 %, neither +11 %.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct AttnParams {
     const bf16_t* q; long ldq;
@@ -56,34 +71,32 @@ __device__ __forceinline__ void glds16a(const void* gsrc, unsigned lds_dst_unifo
                  : "v"(gsrc), "s"(lds_dst_uniform)
                  : "memory");
 }
+// the same with the address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16s(unsigned voff, const void* sbase_uniform, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
+                 : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
 }
 
 #define ATTN_DEFER_LOG2 8.0f
 
-// SCHED = 1 (the default since round 2: 787 -> 870 TFLOP/s at the denoise shape, profiles/r02_attn_schedules.log): the LDS fragment
-// reads are software-pipelined by hand (sched_group_barrier) -- hipcc's own order (SCHED = 0, kept as the bit-identity yardstick,
-// BAGEL_ATTN_SCHED=0) reads one K / V^T fragment, waits for it, issues its MFMA, reads the next ...: a full LDS round trip in
-// front of each of the 32 MFMAs of a tile.  SCHED = 1 keeps 8 fragment reads in flight under the MFMAs and fetches the first half
-// of the V^T tile before the softmax so it lands under the exp/convert VALU work.  Waves 4-7 (the second-dispatched half, the
-// arbitration loser on every segment: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run at a static s_setprio 1.  Waves with
-// no live query row skip the arithmetic (1 904 workgroups at the denoise shape, 112 of them with 2 live rows of 256).  Same
-// instructions on the same operands in the same per-accumulator order as SCHED = 0: results are bit-identical.
-// (Round 1 also carried four "role alternation" schedules -- the two wave halves swapping matrix and softmax blocks per step, 3- and
-// 4-slot rings: all bit-identical, all measured at 768-837 TFLOP/s, i.e. below this one, and removed.)
-template <int D, int SCHED>
+template <int D>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int NQB = 1;                  // 32-row q-blocks per wave (the loops below are written for any number)
     constexpr int KS = D / 16;              // k-steps of the QK^T contraction
     constexpr int DB = D / 32;              // 32-row blocks of O^T
     constexpr int KROW = D * 2;             // bytes per K row in LDS
     constexpr int KT_BYTES = 64 * KROW;
     constexpr int VT_BYTES = D * 128;
     constexpr int STAGE = KT_BYTES + VT_BYTES;
-    constexpr int NW = 8;
-    constexpr int NLK = KT_BYTES / 1024 / NW;   // glds per wave for K   (2 @128, 1 @64)
-    constexpr int NLV = VT_BYTES / 1024 / NW;   // glds per wave for V^T
-    constexpr int NL = NLK + NLV;
+    constexpr int NW = 8 / NQB;              // waves per workgroup; a wave owns NQB 32-row q-blocks
+    constexpr int NLK = KT_BYTES / 1024 / NW;   // LDS-DMA pieces per wave for K   (4 @128)
+    constexpr int NLV = VT_BYTES / 1024 / NW;   // ... for V^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 
     // ---- XCD-aware work mapping ----
     const int grp = p.nq / p.nkv;
-    const int nbpp = grp * p.nqt;                 // workgroups per (sample, kv-head) pair
+    const int nbpp = grp * p.nqt;
     const int npairs = p.batch * p.nkv;
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
     const int pair = (kk / nbpp) * 8 + xcd;
@@ -109,16 +122,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     const int vcol_ctx = C > 0 ? p.vt_ctx_col[b] : 0;
 
     const int qi = lane & 31, hi = lane >> 5;
-    const int wrow0 = qt * 256 + wave * 32;                // first row of this wave inside the sample
-    const int qrow = wrow0 + qi;                           // may exceed Lq-1: padding row
-    const int qrow_c = qrow < Lq ? qrow : Lq - 1;
-
-    // ---- Q fragments (B operand): Q[qrow][16*ks + 8*hi .. +8) ----
-    bf16x8_t qf[KS];
-    {
-        const bf16_t* qp = p.q + (long)(q0 + qrow_c) * p.ldq + (long)h * D + 8 * hi;
+    const int wrow0 = qt * 256 + wave * (32 * NQB);               // first row of this wave inside the sample
+    const bool live = wrow0 < Lq;                          // wave-uniform
+    int qrow[NQB];
+    bf16x8_t qf[NQB][KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qp + 16 * ks);
+    for (int qb = 0; qb < NQB; ++qb) {
+        qrow[qb] = wrow0 + 32 * qb + qi;                   // may exceed Lq-1: padding row
+        const int rc = qrow[qb] < Lq ? qrow[qb] : Lq - 1;
+        const bf16_t* qp = p.q + (long)(q0 + rc) * p.ldq + (long)h * D + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = *(const bf16x8_t*)(qp + 16 * ks);
     }
 
     // ---- tile schedule: ctx tiles then new tiles ----
@@ -128,133 +142,92 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     const int nt_new = (new_needed + 63) >> 6;
     const int T = nt_ctx + nt_new;
 
-    // K tile: D=128: 256-B rows, instr j -> rows 4j + lane/16, chunk lane%16 ^ (row&15)
-    //         D=64 : 128-B rows, instr j -> rows 8j + lane/8 , chunk lane%8  ^ ((row>>1)&7)
-    // V^T tile: 128-B rows (64 keys), instr j -> d rows 8j + lane/8, chunk lane%8 ^ ((d>>1)&7)
+    // ---- LDS-DMA of one 64-key tile: every address = wave-uniform base (SGPR pair) + a lane-constant 32-bit offset ----
+    // piece i of this wave (global piece j = wave + NW*i): K rows RS*j + lane/(16|8), V^T rows 8*j + lane/8; the XOR swizzle of the
+    // 16-byte chunk depends on the row only mod 16 (resp. (d>>1) mod 8), which the piece stride preserves -- so one lane offset per
+    // operand and segment serves all pieces and all tiles, and the per-tile work is scalar arithmetic.
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    constexpr int RS = D == 128 ? 4 : 8;          // K rows per LDS-DMA piece
+    const int rowk = RS * wave + (D == 128 ? (lane >> 4) : (lane >> 3));
+    const int gchk = D == 128 ? ((lane & 15) ^ (rowk & 15)) : ((lane & 7) ^ ((rowk >> 1) & 7));
+    const int dv = 8 * wave + (lane >> 3);
+    const int gchv = (lane & 7) ^ ((dv >> 1) & 7);
+    const unsigned kcol = (unsigned)(g * D + gchk * 8) * 2u;
+    const unsigned koff_ctx = (unsigned)rowk * (unsigned)p.ldk_ctx * 2u + kcol, koff_new = (unsigned)rowk * (unsigned)p.ldk_new * 2u + kcol;
+    const unsigned voff_ctx = ((unsigned)(g * D + dv) * (unsigned)p.ldvt_ctx + gchv * 8) * 2u;
+    const unsigned voff_new = ((unsigned)(g * D + dv) * (unsigned)p.ldvt_new + gchv * 8) * 2u;
     auto issue = [&](int stage, int t) {
-        const unsigned sb = smem_base + __builtin_amdgcn_readfirstlane(stage) * STAGE;
+        const unsigned sb = smem_base + __builtin_amdgcn_readfirstlane(stage) * STAGE + wave * 1024u;
         const bool is_ctx = t < nt_ctx;
         const int ti = is_ctx ? t : t - nt_ctx;
         const int seglen = is_ctx ? C : Lq;
-        const bf16_t* kbase = is_ctx ? p.k_ctx + (long)c0 * p.ldk_ctx : p.k_new + (long)q0 * p.ldk_new;
         const long ldk = is_ctx ? p.ldk_ctx : p.ldk_new;
-        const bf16_t* vbase = is_ctx ? p.vt_ctx : p.vt_new;
         const long ldvt = is_ctx ? p.ldvt_ctx : p.ldvt_new;
-        const int vcol = (is_ctx ? vcol_ctx : vcol_new) + ti * 64;
+        const char* kseg = (const char*)(is_ctx ? p.k_ctx + (long)c0 * p.ldk_ctx : p.k_new + (long)q0 * p.ldk_new);
+        const char* vseg = (const char*)(is_ctx ? p.vt_ctx : p.vt_new) + (long)((is_ctx ? vcol_ctx : vcol_new) + ti * 64) * 2;
+        const unsigned vo = is_ctx ? voff_ctx : voff_new;
+        if (ti * 64 + 64 <= seglen) {
+            const char* kt = kseg + (long)ti * 64 * ldk * 2;
+            const unsigned ko = is_ctx ? koff_ctx : koff_new;
 #pragma unroll
-        for (int i = 0; i < NLK; ++i) {
-            const int j = wave + NW * i;
-            int row, gch;
-            if (D == 128) { row = 4 * j + (lane >> 4); gch = (lane & 15) ^ (row & 15); }
-            else          { row = 8 * j + (lane >> 3); gch = (lane & 7) ^ ((row >> 1) & 7); }
-            int key = ti * 64 + row;
-            key = key < seglen ? key : seglen - 1;
-            glds16a(kbase + (long)key * ldk + (long)g * D + gch * 8, sb + j * 1024u);
+            for (int i = 0; i < NLK; ++i) glds16s(ko, kt + (long)i * (RS * NW) * ldk * 2, sb + i * (NW * 1024u));
+        } else {
+            // the segment's last tile: rows past its end re-read the last key (masked in the scores); per-lane offsets
+#pragma unroll
+            for (int i = 0; i < NLK; ++i) {
+                int key = ti * 64 + rowk + RS * NW * i;
+                key = key < seglen ? key : seglen - 1;
+                glds16s((unsigned)key * (unsigned)ldk * 2u + kcol, kseg, sb + i * (NW * 1024u));
+            }
         }
 #pragma unroll
-        for (int i = 0; i < NLV; ++i) {
-            const int j = wave + NW * i;
-            const int d = 8 * j + (lane >> 3);
-            const int gch = (lane & 7) ^ ((d >> 1) & 7);
-            glds16a(vbase + ((long)g * D + d) * ldvt + vcol + gch * 8, sb + KT_BYTES + j * 1024u);
-        }
+        for (int i = 0; i < NLV; ++i) glds16s(vo, vseg + (long)i * (8 * NW) * ldvt * 2, sb + KT_BYTES + i * (NW * 1024u));
     };
 
     // ---- per-lane constants for fragment reads ----
     // MFMA row i = lane&31 reads key pi(i): swap quads 1<->2 inside each 16
     const int quad = (qi >> 2) & 3;
     const int pkey = (qi & 16) | ((((quad & 1) << 1) | (quad >> 1)) << 2) | (qi & 3);
-    int kswz;      // XOR mask applied to the chunk index
-    if (D == 128) { kswz = pkey & 15; }          // (32*kb + pkey) & 15 == pkey & 15
-    else          { kswz = (pkey >> 1) & 7; }    // ((32*kb + pkey) >> 1) & 7
+    int kswz;
+    if (D == 128) { kswz = pkey & 15; }
+    else          { kswz = (pkey >> 1) & 7; }
     const int koff0 = pkey * KROW;
-    const int vswz = (qi >> 1) & 7;   // d = 32*db + qi  ->  ((d>>1)&7) == ((qi>>1)&7)
+    const int vswz = (qi >> 1) & 7;
     const int voff = KT_BYTES + qi * 128;
-    // chunk byte offsets, loop invariant
     int kch[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kch[ks] = koff0 + (((2 * ks + hi) ^ kswz) << 4);
     int vch[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vch[j] = voff + (((2 * j + hi) ^ vswz) << 4);   // j = 2*kb + c
+    for (int j = 0; j < 4; ++j) vch[j] = voff + (((2 * j + hi) ^ vswz) << 4);
 
-    f32x16_t o[DB];
+    f32x16_t o[NQB][DB];
 #pragma unroll
-    for (int i = 0; i < DB; ++i)
+    for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;   // m_run in log2 units (already multiplied by scale_log2)
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+    float m_run[NQB], l_run[NQB], m_use[NQB];                          // m_run in log2 units
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; m_use[qb] = 0.f; }
 
     if (T > 0) issue(0, 0);
     if (T > 1) issue(1, 1);
-    // Make hipcc retire ITS loads (the Q fragments) here: otherwise it places their counted vmcnt waits at the first
-    // use inside the tile loop, where they would also drain this file's in-flight DMA on every iteration.
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
-    int st = 0;
-    if (SCHED == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-        else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // every wave's DMA of tile t has landed, and every wave is done reading tile t-1 (ring slot (t+2)%3)
-        asm volatile("s_barrier" ::: "memory");
-        if (t + 2 < T) issue(st >= 1 ? st - 1 : 2, t + 2);
-        const char* sb = smem + st * STAGE;
-        st = st == 2 ? 0 : st + 1;
-        // SCHED = 1: a wave whose 32 query rows all lie past the end of the sample (the last 256-row tile of a 4098-row sample
-        // has 2 live rows: 7 of its 8 waves) keeps feeding the DMA ring and the barrier but skips the arithmetic -- it stores nothing.
-        if (SCHED == 1 && wrow0 >= Lq) continue;
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[qb][ks]));
 
-        // ---- S^T = K Q^T ----
-        f32x16_t s[2];
-        bf16x8_t vpre[2][4];   // SCHED = 1: V^T fragments of O^T blocks 0 and 1, fetched ahead of the softmax
-        if (SCHED == 0) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                bf16x8_t kf[KS];
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8_t*)(sb + kb * 32 * KROW + kch[ks]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kb], 0, 0, 0);
-            }
-        } else {
-            // order pinned below: KS reads | KS x (MFMA, read) | KS x (MFMA, V read) -- every MFMA has KS reads in flight behind it
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8_t kf0[KS], kf1[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf0[ks] = *(const bf16x8_t*)(sb + kch[ks]);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf1[ks] = *(const bf16x8_t*)(sb + 32 * KROW + kch[ks]);
-#pragma unroll
-            for (int db = 0; db < 2 && db < DB; ++db)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) vpre[db][j] = *(const bf16x8_t*)(sb + db * 4096 + vch[j]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s[0], 0, 0, 0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s[1], 0, 0, 0);
-            constexpr int NVPRE = (DB < 2 ? DB : 2) * 4;
-            __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);                 // kf0 reads
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // QK MFMA (block 0)
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // one kf1 read
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // QK MFMA (block 1)
-                if (ks < NVPRE) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one V^T read
-            }
-            if (NVPRE > KS) __builtin_amdgcn_sched_group_barrier(0x100, NVPRE - KS, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    constexpr int NK = 2 * KS;                  // K fragments of a tile  (index KS*kb + ks)
+    constexpr int NV = DB * 4;                  // V^T fragments of a tile (index 4*db + j)
+    auto slot = [&](int t) { return (const char*)smem + (t % 3) * STAGE; };
+    auto kfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx / KS) * 32 * KROW + kch[idx % KS]); };
+    auto vfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx >> 2) * 4096 + vch[idx & 3]); };
 
-        // ---- mask (tile tails, causal), row max ----
+    // mask (tile tails, causal) of the scores of tile t, then the row max and the deferred-max decision -> m_run / m_use (and the
+    // rescale of O, l -- the caller guarantees every MFMA into O has been issued before)
+    auto mask_tile = [&](f32x16_t (&s)[NQB][2], int t) {
         const bool is_ctx = t < nt_ctx;
         const int ti = is_ctx ? t : t - nt_ctx;
         const int seglen = is_ctx ? C : Lq;
@@ -262,103 +235,215 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         const bool need_mask = (kbase + 64 > seglen) || (p.causal && !is_ctx && (kbase + 63 > wrow0));
         if (need_mask) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kbase + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    const bool ok = key < seglen && (!p.causal || is_ctx || key <= qrow);
-                    s[kb][r] = ok ? s[kb][r] : -INFINITY;
-                }
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kbase + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
+                        const bool ok = key < seglen && (!p.causal || is_ctx || key <= qrow[qb]);
+                        s[qb][kb][r] = ok ? s[qb][kb][r] : -INFINITY;
+                    }
         }
-        float mx = fmaxf(s[0][0], s[1][0]);
+    };
+    auto row_max = [&](f32x16_t (&s)[NQB][2], float (&mx)[NQB]) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;    // scale > 0: max commutes with it
-        // ---- deferred running max: raise it (and rescale O, l) only when some row outgrew it by > 2^8 ----
-        if (__any(mx > m_run + ATTN_DEFER_LOG2)) {
-            const float m_new = fmaxf(m_run, mx);
-            // a row with no visible key so far keeps m = -inf; use 0 in the exponent so nothing becomes NaN
-            const float alpha = __builtin_amdgcn_exp2f(m_run - (m_new == -INFINITY ? 0.f : m_new));
-            m_run = m_new;
-            l_run *= alpha;
+        for (int qb = 0; qb < NQB; ++qb) {
+            float a = fmaxf(s[qb][0][0], s[qb][1][0]), c = fmaxf(s[qb][0][1], s[qb][1][1]);
 #pragma unroll
-            for (int i = 0; i < DB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-        const float m_use = m_run == -INFINITY ? 0.f : m_run;
-        float psum = 0.f;
-        bf16x8_t pf[4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                unsigned wv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * c + 2 * e], p.scale_log2, -m_use));
-                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * c + 2 * e + 1], p.scale_log2, -m_use));
-                    psum += p0 + p1;
-                    wv[e] = pack2bf(p0, p1);
-                }
-                u32x4_t v4 = {wv[0], wv[1], wv[2], wv[3]};
-                pf[2 * kb + c] = __builtin_bit_cast(bf16x8_t, v4);
+            for (int r = 2; r < 16; r += 2) {
+                a = fmaxf(fmaxf(a, s[qb][0][r]), s[qb][1][r]);
+                c = fmaxf(fmaxf(c, s[qb][0][r + 1]), s[qb][1][r + 1]);
             }
-        l_run += psum;
+            a = fmaxf(a, c);
+            mx[qb] = fmaxf(a, __shfl_xor(a, 32, 64)) * p.scale_log2;
+        }
+    };
+    auto raise_max = [&](const float (&mx)[NQB]) {
+        bool grow = false;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) grow = grow || (mx[qb] > m_run[qb] + ATTN_DEFER_LOG2);
+        if (__any(grow)) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                const float m_new = fmaxf(m_run[qb], mx[qb]);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - (m_new == -INFINITY ? 0.f : m_new));
+                m_run[qb] = m_new;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+                m_use[qb] = m_new == -INFINITY ? 0.f : m_new;
+            }
+        }
+    };
 
-        // ---- O^T += V^T P^T ----
-        if (SCHED == 0) {
+    // One pipeline step: phase A = [S^T(t+1) -> sn] || [exp2 / pack of sc -> pf] ; phase B = [O^T += V^T(t) P^T(t)] || [row sum of
+    // P(t), row max of sn].  LAST: there is no tile t+1.
+    auto step = [&](f32x16_t (&sc)[NQB][2], f32x16_t (&sn)[NQB][2], int t, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        if (!LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t+1 have landed
+        asm volatile("s_barrier" ::: "memory");          // ... everyone's; and everyone is done with tile t-1
+        if (t + 2 < T) issue((t + 2) % 3, t + 2);
+        if (!live) return;
+        const char* sbv = slot(t);
+        const char* sbk = slot(t + 1);
+        // Issue order is written out by hand: one CHUNK per MFMA = the MFMA, the fragment read WIN chunks ahead, and a 1/16 slice of the
+        // softmax work; a sched_barrier(0) closes every chunk, so hipcc orders instructions inside a chunk only.  Consecutive MFMAs hit
+        // different accumulators (a VALU slot between two MFMAs of one accumulation chain costs ~43 cycles: MI355X_MICROARCH.md).
+        constexpr int WIN = 4;
+        constexpr int NMA = NQB * NK, NMB = NQB * NV;          // MFMAs of phase A / phase B
+        constexpr int SPA = 16 * NQB / NMA, SPB = 16 * NQB / NMB;   // softmax / row-max slices per chunk (1 at D = 128, 2 at D = 64)
+        unsigned pw[NQB][16];                                  // P(t) as packed bf16 pairs: pw[qb][4 * f + e] = word e of fragment f
+        float acc[NQB][4];
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                bf16x8_t vf[4];
+        for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) vf[j] = *(const bf16x8_t*)(sb + db * 4096 + vch[j]);
+            for (int i = 0; i < 4; ++i) acc[qb][i] = 0.f;
+        // slice m of the softmax of tile t: scores (2 pi, 2 pi + 1) of q-block qbv -> exp2, partial row sums, one packed word
+        auto softmax_slice = [&](int m) {
+            const int qbv = m / 16, pi = m % 16;
+            const int kb = pi / 8, r = (2 * pi) % 16;
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qbv][kb][r], p.scale_log2, -m_use[qbv]));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qbv][kb][r + 1], p.scale_log2, -m_use[qbv]));
+            acc[qbv][2 * (pi & 1)] += p0;
+            acc[qbv][2 * (pi & 1) + 1] += p1;
+            pw[qbv][pi] = pack2bf(p0, p1);
+            // opaque re-definitions: these values have no consumer before phase B, and LLVM would otherwise sink the whole slice below
+            // the mask branch, out of the chunk it is meant to fill
+            asm volatile("" : "+v"(pw[qbv][pi]), "+v"(acc[qbv][2 * (pi & 1)]), "+v"(acc[qbv][2 * (pi & 1) + 1]));
+        };
+        auto kidx = [&](int j) { return (j & 1) * KS + (j >> 1); };          // K fragments alternate between the two key blocks
+        auto vidx = [&](int f) { return 4 * (f % DB) + f / DB; };            // V^T fragments round-robin over the O^T blocks
+        bf16x8_t vf[NV];
+        // ---------------- phase A:  S^T(t+1) = K(t+1) Q^T  ||  P(t) = exp2(S^T(t) - m) ----------------
+        __builtin_amdgcn_sched_barrier(0);
+        if (!LAST) {
+            bf16x8_t kf[NK];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], pf[j], o[db], 0, 0, 0);
+            for (int j = 0; j < WIN; ++j) kf[j] = kfrag(sbk, kidx(j));
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sn[qb][kb][r] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NMA; ++m) {
+                const int j = m / NQB, qb = m % NQB, kb = j & 1, ks = j >> 1;
+                sn[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[qb][ks], sn[qb][kb], 0, 0, 0);
+                if (qb == NQB - 1) {
+                    if (j + WIN < NK) kf[j + WIN] = kfrag(sbk, kidx(j + WIN));
+                    else if (j + WIN - NK < WIN) vf[j + WIN - NK] = vfrag(sbv, vidx(j + WIN - NK));     // the first V^T fragments of phase B
+                }
+#pragma unroll
+                for (int u = 0; u < SPA; ++u) softmax_slice(m * SPA + u);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            // blocks 0/1 from the prefetched fragments while the fragments of blocks 2/3 are read; then blocks 2/3
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8_t vlate[2][4];
-            if (DB > 2) {
 #pragma unroll
-                for (int db = 2; db < DB; ++db)
+            for (int j = 0; j < WIN; ++j) vf[j] = vfrag(sbv, vidx(j));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) vlate[db - 2][j] = *(const bf16x8_t*)(sb + db * 4096 + vch[j]);
+            for (int m = 0; m < 16 * NQB; ++m) softmax_slice(m);
+        }
+        bf16x8_t pf[NQB][4];
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            l_run[qb] += (acc[qb][0] + acc[qb][1]) + (acc[qb][2] + acc[qb][3]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                u32x4_t v4 = {pw[qb][4 * f], pw[qb][4 * f + 1], pw[qb][4 * f + 2], pw[qb][4 * f + 3]};
+                pf[qb][f] = __builtin_bit_cast(bf16x8_t, v4);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!LAST) mask_tile(sn, t + 1);
+        // ---------------- phase B:  O^T += V^T(t) P^T(t)  ||  row max of S^T(t+1) ----------------
+        __builtin_amdgcn_sched_barrier(0);
+        float mx[NQB];
 #pragma unroll
-            for (int db = 0; db < 2 && db < DB; ++db)
+        for (int qb = 0; qb < NQB; ++qb) mx[qb] = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vpre[db][j], pf[j], o[db], 0, 0, 0);
-            if (DB > 2) {
+        for (int m = 0; m < NMB; ++m) {
+            const int f = m / NQB, qb = m % NQB, db = f % DB, jj = f / DB;
+            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[f], pf[qb][jj], o[qb][db], 0, 0, 0);
+            if (qb == NQB - 1 && f + WIN < NV) vf[f + WIN] = vfrag(sbv, vidx(f + WIN));
+            if (!LAST) {
 #pragma unroll
-                for (int db = 2; db < DB; ++db)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlate[db - 2][j], pf[j], o[db], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // PV MFMA (blocks 0/1)
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one V^T read (blocks 2/3)
+                for (int u = 0; u < SPB; ++u) {
+                    const int c = m * SPB + u, qbv = c / 16, i = c % 16, kb = i / 8, r = (2 * i) % 16;
+                    mx[qbv] = fmaxf(fmaxf(mx[qbv], sn[qbv][kb][r]), sn[qbv][kb][r + 1]);
+                    asm volatile("" : "+v"(mx[qbv]));
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!LAST) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 32, 64)) * p.scale_log2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!LAST) raise_max(mx);
+    };
+
+    // f32x16_t x[2][2] twice: the two score sets
+    f32x16_t sA[NQB][2], sB[NQB][2];
+    if (T > 0) {
+        // prologue: tile 0 resident; S^T(0) -> sA with nothing to overlap, its mask / max / first m
+        if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLK + NLV) : "memory");
+        else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (live) {
+            const char* sbk = slot(0);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sA[qb][kb][r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+                const bf16x8_t kf = kfrag(sbk, j);
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb)
+                    sA[qb][j / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][j % KS], sA[qb][j / KS], 0, 0, 0);
+            }
+            mask_tile(sA, 0);
+            float mx[NQB];
+            row_max(sA, mx);
+            raise_max(mx);
+        }
+        int t = 0;
+        for (; t + 2 <= T - 1; t += 2) {
+            step(sA, sB, t, std::false_type{});
+            step(sB, sA, t + 1, std::false_type{});
+        }
+        if (t < T - 1) {
+            step(sA, sB, t, std::false_type{});
+            step(sB, sA, t + 1, std::true_type{});
+        } else {
+            step(sA, sB, t, std::true_type{});
         }
     }
 
     // ---- epilogue: O[q][d] = O^T / l ; lane owns d = 32*db + 8*u + 4*hi + (0..3) ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (qrow < Lq) {
-        bf16_t* op = p.out + (long)(q0 + qrow) * p.ldo + (long)h * D + 4 * hi;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+    for (int qb = 0; qb < NQB; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (qrow[qb] < Lq) {
+            bf16_t* op = p.out + (long)(q0 + qrow[qb]) * p.ldo + (long)h * D + 4 * hi;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                u32x2_t v = {pack2bf(o[db][4 * u] * inv, o[db][4 * u + 1] * inv),
-                             pack2bf(o[db][4 * u + 2] * inv, o[db][4 * u + 3] * inv)};
-                *(u32x2_t*)(op + 32 * db + 8 * u) = v;
-            }
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    u32x2_t v = {pack2bf(o[qb][db][4 * u] * inv, o[qb][db][4 * u + 1] * inv),
+                                 pack2bf(o[qb][db][4 * u + 2] * inv, o[qb][db][4 * u + 3] * inv)};
+                    *(u32x2_t*)(op + 32 * db + 8 * u) = v;
+                }
+        }
     }
 }
 
@@ -419,19 +504,13 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     const int nbpp = (nq / nkv) * p.nqt;
     const int pairs_per_xcd = ceil_div((long)batch * nkv, 8);
     const dim3 grid(8 * pairs_per_xcd * nbpp), block(512);
-    // read at every launch (a getenv is noise beside a launch) so that one process can compare the two instruction orders
-    const char* sched_env = getenv("BAGEL_ATTN_SCHED");
-    const int sched = sched_env ? atoi(sched_env) : 1;
     if (head_dim == 128) {
         constexpr int smem = 3 * (64 * 256 + 128 * 128);
-        if (int rc = sched == 0 ? bagel_enable_lds((const void*)attn_fwd_kernel<128, 0>, smem, "attn_fwd_kernel<128,0>")
-                                : bagel_enable_lds((const void*)attn_fwd_kernel<128, 1>, smem, "attn_fwd_kernel<128,1>")) return rc;
-        if (sched == 0) hipLaunchKernelGGL((attn_fwd_kernel<128, 0>), grid, block, smem, stream, p);
-        else            hipLaunchKernelGGL((attn_fwd_kernel<128, 1>), grid, block, smem, stream, p);
+        if (int rc = bagel_enable_lds((const void*)attn_fwd_kernel<128>, smem, "attn_fwd_kernel<128>")) return rc;
+        hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, smem, stream, p);
     } else if (head_dim == 64) {
         constexpr int smem = 3 * (64 * 128 + 64 * 128);
-        if (sched == 0) hipLaunchKernelGGL((attn_fwd_kernel<64, 0>), grid, block, smem, stream, p);
-        else            hipLaunchKernelGGL((attn_fwd_kernel<64, 1>), grid, block, smem, stream, p);
+        hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, smem, stream, p);
     } else {
         return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn: head_dim %d not in {64,128} (pad the head)", head_dim);
     }

@@ -824,8 +824,7 @@ def main():
                        "global_batch": world * B, "query_tokens_per_sample": n_img + 2, "parallelism": f"dp{world}",
                        # execution options in force (promoted in round 2 after measurement)
                        "options": {"cfg_batched": bool(getattr(model, "cfg_batched", False)),
-                                   "und_side_path": bool(getattr(model, "cfg_batched", False) and getattr(model, "und_side_path", False)),
-                                   "attn_sched": int(os.environ.get("BAGEL_ATTN_SCHED", "1"))}},
+                                   "und_side_path": bool(getattr(model, "cfg_batched", False) and getattr(model, "und_side_path", False))}},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                          "traffic": pmc_traffic(names.get(dom, str(dom))) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None, "kernel": names.get(dom, str(dom)), "launches": len(records),
                          "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},

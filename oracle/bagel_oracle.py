@@ -45,9 +45,21 @@ attn_varlen = _fa.flash_attn_varlen_func   # definition of flash_attn_varlen_fun
 # ----------------------------------------------------------------------------------------------
 # elementary ops
 # ----------------------------------------------------------------------------------------------
+# Noise-floor probe (oracle/make_golden_wide.py): with LINEAR_FP32_ACCUM the SAME bf16-rounded operands are multiplied with an fp32
+# matmul and the result is rounded to bf16 once -- the same mathematics and rounding points as the reference's bf16 F.linear, another
+# summation order (what a different CPU backend, or a GPU, does).  How far the reference's outputs move under this switch is the
+# size of its own accumulation-order noise; the parity tolerances at 7B width are derived from it.  Never on in a parity check.
+LINEAR_FP32_ACCUM = False
+
+
 @_explicit_casts
 def linear(x, w, b=None):
     """F.linear under bf16 autocast: inputs cast to the (bf16) weight dtype, bf16 result."""
+    if LINEAR_FP32_ACCUM:
+        y = x.to(w.dtype).float() @ w.float().t()
+        if b is not None:
+            y = y + b.to(w.dtype).float()
+        return y.to(w.dtype)
     return F.linear(x.to(w.dtype), w, None if b is None else b.to(w.dtype))
 
 

@@ -72,12 +72,28 @@ def main():
         ts, _ = O.flow_schedule(KW["num_timesteps"], KW["timestep_shift"])
         timestep = torch.tensor([ts[0]] * li["packed_init_noises"].shape[0])
         v0 = O.forward_flow(W, cfg, oli["packed_init_noises"], timestep, oli, ocache, ocfg, None, 4.0, 1.0, 0.0, "global")
+        # the reference's own accumulation-order noise at this width: the oracle again with fp32-accumulating linears (same operands,
+        # same rounding points, another summation order) -- prefill, first-step velocity and the whole Euler loop
+        O.LINEAR_FP32_ACCUM = True
+        try:
+            ocache32 = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **ogi)
+            ocfg32 = dict(ocfg, cache=O.OracleCache(L))
+            v0_32 = O.forward_flow(W, cfg, oli["packed_init_noises"], timestep, oli, ocache32, ocfg32, None, 4.0, 1.0, 0.0, "global")
+            olat32 = O.generate_image(W, cfg, oli, ocache32, cfg_text=ocfg32, **KW)
+        finally:
+            O.LINEAR_FP32_ACCUM = False
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
+    kc32, vc32 = MG.cache_to_lists(ocache32, L)
     kc, vc = MG.cache_to_lists(cache, L)
     x0 = li["packed_init_noises"]
+    noise = dict(kv=max(max(rel(a, b) for a, b in zip(kc32, kc)), max(rel(a, b) for a, b in zip(vc32, vc))), v_first_step=rel(v0_32, v0),
+                 latents=rel(olat32[0], lat[0]), displacement=rel(olat32[0] - x0, lat[0] - x0))
+    print("reference accumulation-order noise floor at 7B width (fp32-accumulating oracle vs reference, rel-L2):", noise)
     print(f"latents: |x0| rms {x0.float().pow(2).mean().sqrt():.3f}, |x_T| rms {lat[0].float().pow(2).mean().sqrt():.3f}, "
           f"|x_T - x0| rms {(lat[0] - x0).float().pow(2).mean().sqrt():.3f}, |v0| rms {v0.float().pow(2).mean().sqrt():.3f}")
     out = dict(prompt=PROMPT, image_sizes=SIZES, prompt_inputs=gi, newlens=newlens, newrope=newrope, key_cache=kc, value_cache=vc,
                latent_inputs=li, cfg_inputs=ci, gen_kwargs=KW, latents=list(lat), v_first_step=v0,
+               noise_floor=noise, v_first_step_f32acc=v0_32, latents_f32acc=list(olat32),
                host=dict(torch=torch.__version__, cpu_bf16_backend="mkldnn" if torch.backends.mkldnn.is_available() else "native"))
     path = os.path.join(MG.GOLD, "wide7b_t2i.pt")
     torch.save(out, path)

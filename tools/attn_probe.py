@@ -64,43 +64,11 @@ def main():
         torch.save({"full": full, "causal": out.cpu().clone()}, dump)
     ms = timeit(run)
     fl = 4.0 * B * Lq * (Lq + C_ctx) * nq * D
-    tag = f"[BAGEL_ATTN_SCHED={os.environ.get('BAGEL_ATTN_SCHED', '1')}] "
+    tag = ""
     print(f"{tag}attn_denoise: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  max_rel_err {worst:.3e}", flush=True)
     ms_c = timeit(lambda: run(True))
     print(f"{tag}attn_causal : {ms_c:.3f} ms  {fl / 2 / ms_c / 1e9:.1f} TFLOP/s (half the work)", flush=True)
 
 
-def compare():
-    """python tools/attn_probe.py --compare: the kernel's schedule variants (BAGEL_ATTN_SCHED, read once per process) in child
-    processes on the same seeded inputs -- outputs must be BIT-IDENTICAL (the variants only reorder instructions) -- and timed."""
-    import subprocess
-    import tempfile
-    outs = {}
-    for v in ("0", "1"):
-        with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
-            path = f.name
-        env = dict(os.environ, BAGEL_ATTN_SCHED=v, BAGEL_ATTN_PROBE_DUMP=path)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
-        sys.stdout.write(r.stdout)
-        if r.returncode != 0:
-            sys.stdout.write(r.stderr[-2000:])
-            raise SystemExit(f"variant {v} failed")
-        outs[v] = torch.load(path)
-        os.unlink(path)
-    bad = []
-    for v in ("1",):
-        for k in ("full", "causal"):
-            same = torch.equal(outs["0"][k], outs[v][k])
-            d = 0.0 if same else (outs["0"][k].float() - outs[v][k].float()).abs().max().item()
-            print(f"BAGEL_ATTN_SCHED 0 vs {v}, {k}: {'bit-identical' if same else f'DIFFERENT (max|d| = {d})'}", flush=True)
-            if not same:
-                bad.append((v, k, d))
-    if bad:
-        raise SystemExit(f"schedule variants differ: {bad}")
-
-
 if __name__ == "__main__":
-    if "--compare" in sys.argv:
-        compare()
-    else:
-        main()
+    main()

@@ -71,11 +71,9 @@ def bench():
     li = model.prepare_vae_latent(lens, ropes, [(R, R)] * B, ids)
     ci = model.prepare_vae_latent_cfg([0] * B, [0] * B, [(R, R)] * B)
     res = {}
-    modes = [("sequential", False, False, "1"), ("batched", True, False, "1"), ("batched+side", True, True, "1")]
-    modes += [("sequential, attn sched 0", False, False, "0"), ("batched+side, attn sched 0", True, True, "0")]
-    for tag, batched, side, sched in modes:
+    modes = [("sequential", False, False), ("batched", True, False), ("batched+side", True, True)]
+    for tag, batched, side in modes:
         model.cfg_batched, model.und_side_path = batched, side
-        os.environ["BAGEL_ATTN_SCHED"] = sched     # read by the library at every attention launch
 
         def run(T):
             return model.generate_image(past_key_values=cache, num_timesteps=T, cfg_text_scale=4.0, cfg_interval=[0, 1.0],
@@ -93,12 +91,6 @@ def bench():
         res[tag] = (ms, lat)
         print(f"7B text->image B=4 1024^2, {tag}: {ms:.1f} ms per Euler step (2 forwards)  -> {4 / (49 * ms * 1e-3):.4f} images/s (denoise only)",
               flush=True)
-    os.environ.pop("BAGEL_ATTN_SCHED", None)
-    for tag, (ms, lat) in res.items():
-        if "attn sched" in tag:
-            base = res["batched+side" if tag.startswith("batched") else "sequential"][1]
-            same = all(torch.equal(a, b) for a, b in zip(lat, base))
-            print(f"{tag}: latents {'bit-identical to' if same else 'DIFFERENT from'} the default schedule's", flush=True)
     e = max(rel_l2(a, b) for a, b in zip(res["batched"][1], res["sequential"][1]))
     e2 = max(rel_l2(a, b) for a, b in zip(res["batched+side"][1], res["sequential"][1]))
     print(f"latents after 5 steps: batched vs sequential rel-L2 {e:.3e} (expected 0), batched+side vs sequential {e2:.3e}", flush=True)
