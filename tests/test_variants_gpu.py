@@ -4,7 +4,6 @@ import pytest
 import torch
 
 pytestmark = [pytest.mark.gpu]
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
