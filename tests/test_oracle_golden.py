@@ -212,3 +212,16 @@ def test_dense_and_moe_layer_kinds_match_reference(golden, name):
     lat = O.generate_image(W, cfg, g["latent_inputs"], cache, cfg_text=_cfgd(O.OracleCache(L), g["cfg_inputs"]), **g["gen_kwargs"])
     for a, b in zip(lat, g["latents"]):
         same(a, b, TOL_LATENT, "latents")
+
+
+def test_fp32_master_reference_run_is_a_stated_distance_away(golden):
+    """The reference's two deployed precisions -- bf16 weights (app.py:105-113, every other fixture) and fp32 master weights under autocast
+    (eval/gen/gen_images_mp.py:165-176) -- give different latents on identical inputs; the fixture written by
+    oracle/make_golden_fp32master.py states by how much (~1e-2 rel-L2), and the numbers are re-derived here from the stored tensors."""
+    import torch
+    for name in ("tiny", "tiny_d128"):
+        g, gm = golden(f"{name}_t2i"), golden(f"{name}_t2i_fp32master")
+        for key in ("latents", "latents_channel"):
+            d = max(float((a - b).norm() / b.norm()) for a, b in zip(gm[key], g[key]))
+            assert abs(d - gm["deviation_of_bf16_weights_reference"][key]) < 1e-6
+            assert 5e-3 < d < 2e-2, (name, key, d)
