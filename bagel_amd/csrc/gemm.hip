@@ -18,6 +18,7 @@
 // A/W panels they share stay in that XCD's 4 MiB L2.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define EPI_NONE 0
 #define EPI_GELU_TANH 1
@@ -981,6 +982,13 @@ static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream) {
     return bagel_check_launch("gemm_pq_kernel");
 }
 
+// Round-2 experiments that did NOT beat the persistent ping-pong kernel and were removed (tools/gemm_v5_check.py history):
+//   variant 5: one wave per SIMD (4 waves, 128 x 128 per wave, 256 accumulators in AGPRs through inline-asm MFMAs), 4-stage ring of
+//              32-deep k-stages, one barrier per stage: 1 248 TFLOP/s at M 32768 / K 18944 (variant 4: 1 355-1 389), 1 698 with the
+//              in-loop LDS-DMA switched off -- a single wave pays the 60-180 cycle issue cost of every global_load_lds itself;
+//   variant 6: the same ring with two free-running waves per SIMD (8 waves, 64 x 128 each): 1 232; 1 350 with the DMA re-reading
+//              L2-hot data, 1 616 without DMA.  So ~16 % of this structure goes to DMA issue / LDS write traffic and ~9 % to L2 misses;
+//              the ping-pong kernels hide the DMA issue in the partner group's MFMA slot, which is why they stay.
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
