@@ -45,6 +45,9 @@ struct GemmParams {
     int epi;
     int ngroups;
     GemmGroup g[2];
+    // FP8 operands (gemm_pq_kernel<MODE, true>): A / W are e4m3 bytes, sa[physical A row] and sw[n] the fp32 de-quantisation scales
+    const float* sa;
+    const float* sw;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -596,7 +599,19 @@ __device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_dst_uni
 
 // MODE fixes the epilogue at compile time (0 SwiGLU pairing, 1 residual add, 2 bias, 3 plain) so that no load of hipcc's sits
 // behind a run-time branch: after such a join its wait counting turns conservative and drains the DMA pipe.
-template <int MODE>
+// FP8 = true: the operands are OCP e4m3 bytes with per-row fp32 scales (A: per activation row, W: per output column).  The LDS
+// image, the DMA and the whole pipeline are byte-for-byte those of the bf16 kernel -- a 128-byte LDS row is 128 fp8 values instead of
+// 64 bf16 (the host passes K, lda, ldw in 2-byte units) -- and one v_mfma_scale_f32_16x16x128_f8f6f4 (block scales fixed at 2^0)
+// replaces the two 16x16x32 bf16 MFMAs of a fragment pair at the same pipe time: twice the arithmetic per k-tile, per LDS byte and
+// per DMA byte.  The epilogue multiplies every accumulator by sa[row] * sw[col] before the bf16 roundings of the bf16 kernel.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__device__ __forceinline__ i32x8_t cat_frag(const bf16x8_t& lo, const bf16x8_t& hi) {
+    const i32x4_t a = __builtin_bit_cast(i32x4_t, lo), b = __builtin_bit_cast(i32x4_t, hi);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int MODE, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     constexpr bool SWIGLU = MODE == 0, HAS_R = MODE == 1, HAS_BIAS = MODE == 2;
     constexpr int BM = 256, BN = 256;
@@ -680,8 +695,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 
     const int fr = lane & 15;
     const int sw = fr >> 1;
-    const int ch0 = ((lane >> 4) ^ sw) << 4;
-    const int ch1 = (((lane >> 4) + 4) ^ sw) << 4;
+    // bf16: fragment kh = chunks (lane/16) + 4 kh (k = 32 kh + 8 (lane/16) ..);  fp8: ONE fragment = the 32 bytes k = 32 (lane/16) ..,
+    // i.e. chunks 2 (lane/16) and 2 (lane/16) + 1, kept in the same two registers quads
+    const int ch0 = ((FP8 ? 2 * (lane >> 4) : (lane >> 4)) ^ sw) << 4;
+    const int ch1 = ((FP8 ? 2 * (lane >> 4) + 1 : (lane >> 4) + 4) ^ sw) << 4;
     const int a_row = (grp * 64 + fr) * 128;
     const int b_row = (wj * 32 + fr) * 128;
 
@@ -703,6 +720,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     };
     auto mma = [&](int ma, bf16x8_t (&bf0)[2][2], bf16x8_t (&bf1)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (FP8) {
+            // 16 MFMAs of K = 128 (32 pipe cycles each) = the pipe time of the 32 bf16 MFMAs below, twice their arithmetic
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ma][i][0][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat_frag(bf0[j][0], bf0[j][1]), cat_frag(af[i][0], af[i][1]),
+                                                                                        acc[ma][i][0][j], 0, 0, 0, 127, 0, 127);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ma][i][1][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat_frag(bf1[j][0], bf1[j][1]), cat_frag(af[i][0], af[i][1]),
+                                                                                        acc[ma][i][1][j], 0, 0, 0, 127, 0, 127);
+        } else
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
@@ -813,6 +845,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
             const int rb = ewave * 4 + (elane >> 4);          // store row of iteration `it` = it*32 + rb, rb < 32
 #pragma unroll
             for (int it = 0; it < 8; ++it) crow[it] = ctab[it * 32 + rb];
+            float sa_r[2][4];
+            f32x4_t sw_c[2][2];
+            if constexpr (FP8) {                   // de-quantisation scales: hipcc's own loads, retired before the next tile's DMA
+                const int* atab = (const int*)(smem + TBL + slot * 2048);
+#pragma unroll
+                for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sa_r[ma][i] = p.sa[atab[egrp * 128 + ma * 64 + i * 16 + efr]];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) {
+                        const int n = n0 + ewj * 64 + nb * 32 + jn * 16 + ensub;
+                        sw_c[nb][jn] = *(const f32x4_t*)(p.sw + min(n, p.N - 4));
+                    }
+#pragma unroll
+                for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(sa_r[ma][i]));
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+v"(sw_c[nb][jn]));
+            }
             start_next();
 #pragma unroll
             for (int ma = 0; ma < 2; ++ma)
@@ -826,8 +882,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
                         float o[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float g = bfround(acc[ma][i][nb][0][e]);
-                            const float u = bfround(acc[ma][i][nb][1][e]);
+                            const float g = bfround(FP8 ? acc[ma][i][nb][0][e] * (sa_r[ma][i] * sw_c[nb][0][e]) : acc[ma][i][nb][0][e]);
+                            const float u = bfround(FP8 ? acc[ma][i][nb][1][e] * (sa_r[ma][i] * sw_c[nb][1][e]) : acc[ma][i][nb][1][e]);
                             o[e] = bfround(silu_f(g)) * u;
                         }
                         u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
@@ -876,6 +932,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+v"(bv[nb][jn]));
             }
+            float sa_r[2][4];
+            f32x4_t sw_c[2][2];
+            if constexpr (FP8) {                   // de-quantisation scales (see the SwiGLU branch)
+                const int* atab = (const int*)(smem + TBL + slot * 2048);
+#pragma unroll
+                for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sa_r[ma][i] = p.sa[atab[egrp * 128 + ma * 64 + i * 16 + efr]];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) {
+                        const int n = n0 + ewj * 64 + nb * 32 + jn * 16 + ensub;
+                        sw_c[nb][jn] = *(const f32x4_t*)(p.sw + min(n, p.N - 4));
+                    }
+#pragma unroll
+                for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(sa_r[ma][i]));
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+v"(sw_c[nb][jn]));
+            }
             u32x4_t rv[8];
             if constexpr (HAS_R) {
 #pragma unroll
@@ -905,7 +985,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
                             const int c = ewj * 64 + nb * 32 + jn * 16 + ensub;
                             float o[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = acc[ma][i][nb][jn][e];
+                            for (int e = 0; e < 4; ++e) o[e] = FP8 ? acc[ma][i][nb][jn][e] * (sa_r[ma][i] * sw_c[nb][jn][e]) : acc[ma][i][nb][jn][e];
                             if constexpr (HAS_BIAS) {
                                 o[0] += lo2f(bv[nb][jn][0]); o[1] += hi2f(bv[nb][jn][0]);
                                 o[2] += lo2f(bv[nb][jn][1]); o[3] += hi2f(bv[nb][jn][1]);
@@ -947,7 +1027,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     }
 }
 
-template <int MODE>
+template <int MODE, bool FP8 = false>
 static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
     int t = 0;
@@ -976,9 +1056,9 @@ static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream) {
     const int wgs = wgs_of_dev[dev];
     p.gm = gm;
     constexpr int smem = 2 * 4 * 128 * 128 + 3 * 2048;   // two k-tile stages + the three-deep row-table ring
-    if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<MODE>, smem, "gemm_pq_kernel")) return rc;
+    if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<MODE, FP8>, smem, "gemm_pq_kernel")) return rc;
     const int nblk = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(gemm_pq_kernel<MODE>, dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
+    hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8>), dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
     return bagel_check_launch("gemm_pq_kernel");
 }
 
@@ -1051,4 +1131,33 @@ extern "C" int bagel_gemm_bf16(const void* A, int64_t lda,
 #endif
         default: return bagel_set_error(BAGEL_ERR_ARG, "gemm: unknown variant %d", variant);
     }
+}
+
+// FP8 (OCP e4m3) operands with per-row fp32 scales: C[c_rows[i], :] = epilogue((sa[a_rows[i]] * sw[n]) * sum_k Aq[a_rows[i], k] Wq[n, k]).
+// One row group (the MoT gen expert: the und marker rows take the bf16 side path).  The same persistent kernel, DMA and LDS image as
+// the bf16 path; K % 128 == 0 (one fp8 k-tile = 128 bytes), leading dimensions in BYTES and even.
+extern "C" int bagel_gemm_fp8_bf16(const void* Aq, int64_t lda_bytes, const float* sa, const void* Wq, int64_t ldw_bytes, const float* sw,
+                                   const void* bias, const int32_t* a_rows, const int32_t* c_rows, int32_t M, const void* R,
+                                   int64_t ldr, void* C, int64_t ldc, int32_t N, int32_t K, int32_t epilogue, hipStream_t stream) {
+    BAGEL_REQUIRE(Aq && Wq && sa && sw && C, "gemm_fp8: null pointer");
+    BAGEL_REQUIRE(K >= 256 && (K % 128) == 0, "gemm_fp8: K=%d must be a multiple of 128 (>= 256)", K);
+    BAGEL_REQUIRE(N > 0 && (N % 8) == 0, "gemm_fp8: N=%d must be a multiple of 8", N);
+    BAGEL_REQUIRE((lda_bytes % 16) == 0 && (ldw_bytes % 16) == 0 && (ldc % 8) == 0 && (ldr % 8) == 0 && (((uintptr_t)C | (uintptr_t)R) & 15) == 0,
+                  "gemm_fp8: leading dims must keep rows 16-byte aligned");
+    BAGEL_REQUIRE(epilogue == EPI_NONE || epilogue == EPI_SWIGLU16, "gemm_fp8: epilogue %d not built", epilogue);
+    BAGEL_REQUIRE(epilogue != EPI_SWIGLU16 || ((N % 32) == 0 && !bias && !R), "gemm_fp8: swiglu needs N%%32==0, no bias/residual");
+    BAGEL_REQUIRE(!(bias && R), "gemm_fp8: bias + residual not built");
+    if (M <= 0) return BAGEL_OK;
+    GemmParams p;
+    p.A = (const bf16_t*)Aq; p.R = (const bf16_t*)R; p.C = (bf16_t*)C;
+    p.lda = lda_bytes / 2; p.ldw = ldw_bytes / 2; p.ldr = ldr; p.ldc = ldc;      // the kernel addresses operands in 2-byte units
+    p.N = N; p.K = K / 2; p.epi = epilogue;
+    p.sa = sa; p.sw = sw;
+    p.ngroups = 1;
+    p.g[0] = GemmGroup{(const bf16_t*)Wq, (const bf16_t*)bias, a_rows, c_rows, M, 0};
+    p.g[1] = p.g[0];
+    if (epilogue == EPI_SWIGLU16) return launch_gemm_pq<0, true>(p, stream);
+    if (R) return launch_gemm_pq<1, true>(p, stream);
+    if (bias) return launch_gemm_pq<2, true>(p, stream);
+    return launch_gemm_pq<3, true>(p, stream);
 }

@@ -269,3 +269,52 @@ extern "C" int bagel_gemv_w8_bf16(const void* A, int64_t lda, const void* Wq, in
     }
     return BAGEL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// FP8 (OCP e4m3) row quantisation for the gen-expert GEMMs (bagel_gemm_fp8_bf16, gemm.hip): the MI355X-native counterpart of the
+// reference's quantised load modes (app.py:114-131) on the DENOISE side, where the time goes.
+//   q[r, k] = e4m3(x[r, k] / s_r)  (round to nearest even, v_cvt_pk_fp8_f32),   s_r = max_k |x[r, k]| / 448   (448 = largest e4m3)
+// Used once per weight matrix at pack time and once per activation matrix per GEMM input.  One wave per row, 16-byte lanes,
+// two passes over the row (the second one hits L2): HBM-bound, 3 bytes moved per element.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __restrict__ x, long ldx, unsigned char* __restrict__ q,
+                                                                long ldq, float* __restrict__ scale, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (long)row * ldx;
+    const int nch = cols >> 3;                       // 8-element chunks (16 bytes in, 8 bytes out)
+    float amax = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+        const u32x4_t v = *(const u32x4_t*)(xr + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo2f(v[e])), fabsf(hi2f(v[e]))));
+    }
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? amax / 448.0f : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) scale[row] = s;
+    unsigned char* qr = q + (long)row * ldq;
+    for (int c = lane; c < nch; c += 64) {
+        const u32x4_t v = *(const u32x4_t*)(xr + 8 * c);
+        u32x2_t o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(lo2f(v[2 * h]) * inv, hi2f(v[2 * h]) * inv, w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(lo2f(v[2 * h + 1]) * inv, hi2f(v[2 * h + 1]) * inv, w, true);
+            o[h] = (unsigned)w;
+        }
+        *(u32x2_t*)(qr + 8 * c) = o;
+    }
+}
+
+extern "C" int bagel_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq_bytes, float* scale, int32_t rows, int32_t cols,
+                                       hipStream_t stream) {
+    BAGEL_REQUIRE(x && q && scale, "quantize_rows_fp8: null pointer");
+    BAGEL_REQUIRE((cols % 8) == 0 && (ldx % 8) == 0 && (ldq_bytes % 8) == 0, "quantize_rows_fp8: cols / leading dims must be multiples of 8");
+    if (rows <= 0 || cols <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, (long)ldx,
+                       (unsigned char*)q, (long)ldq_bytes, scale, rows, cols);
+    return bagel_check_launch("quantize_rows_fp8_kernel");
+}

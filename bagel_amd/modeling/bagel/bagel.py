@@ -131,6 +131,10 @@ class Bagel(nn.Module):
         self.cfg_batched = os.environ.get("BAGEL_CFG_BATCH", "1") == "1"
         self.und_side_path = os.environ.get("BAGEL_UND_SIDE", "1") == "1"
         self.global_renorm_allreduce = False      # see _renorm_sums_allreduce
+        # option (changes results; off by default, reported beside the bf16 numbers): "fp8" = the gen expert's four projections of the
+        # denoise forwards run on the OCP-e4m3 MFMA with row-wise scales -- the MI355X counterpart of the reference's quantised load
+        # modes (app.py:114-131).  BAGEL_GEN_QUANT=fp8 sets it for a whole process.
+        self.gen_weight_quant = os.environ.get("BAGEL_GEN_QUANT") or None
 
     # ------------------------------------------------------------------------------------------------
     # helpers
@@ -494,7 +498,7 @@ class Bagel(nn.Module):
     def _velocity(self, st, plan, cache, out, taylor=None):
         """llm2vae(backbone(seq))[latent rows] -> out (bagel.py:820-833)."""
         h = self.language_model.engine().forward(st["seq"], plan, "gen" if self.use_moe else "und", cache, update=False,
-                                                 causal=False, taylor=taylor)
+                                                 causal=False, taylor=taylor, gen_quant=self.gen_weight_quant)
         ops.gemm(h, self.llm2vae.weight.data, out, bias0=self.llm2vae.bias.data, a_rows0=st["vae_rows"], M0=out.shape[0])
         return out
 
@@ -512,7 +516,8 @@ class Bagel(nn.Module):
             for s in range(S):
                 multi["seq"][s * M:(s + 1) * M].copy_(seq)
             h = self.language_model.engine().forward(multi["seq"], multi["plan"], "gen" if self.use_moe else "und", multi["cache"],
-                                                     update=False, causal=False, taylor=list(taylor[:S]) if taylor[0] is not None else None)
+                                                     update=False, causal=False, taylor=list(taylor[:S]) if taylor[0] is not None else None,
+                                                     gen_quant=self.gen_weight_quant)
             for s in range(S):
                 ops.gemm(h, self.llm2vae.weight.data, st["v"][s], bias0=self.llm2vae.bias.data, a_rows0=multi["vae_rows"][s],
                          M0=st["v"][s].shape[0])

@@ -652,6 +652,8 @@ class MoTEngine:
         self.layers = [self._pack_layer(l) for l in model.layers]
         self._ws = {}
         self._ws_side = {}
+        self._fp8 = None
+        self._ws_fp8 = {}
 
     def _pack_layer(self, L):
         nq, nkv, hd, dp = self.nq, self.nkv, self.hd, self.dp
@@ -695,8 +697,21 @@ class MoTEngine:
     def plan(self, query_lens, position_ids, **kw):
         return ForwardPlan(self.device, query_lens, position_ids, inv_freq=self.model.rotary_emb.inv_freq(self.device), **kw)
 
+    def fp8_weights(self):
+        """OCP e4m3 copies (row-wise absmax scales) of the gen expert's four projections, quantised on first use (option
+        ``gen_weight_quant = "fp8"``: the MI355X counterpart of the reference's quantised load modes, app.py:114-131)."""
+        if self._fp8 is None:
+            if not self.mot:
+                raise NotImplementedError("gen_weight_quant='fp8' is built for the MoT layer kind (a separate gen expert)")
+            for n, k in (("H", self.H), ("I", self.I), ("nq*dp", self.nq * self.dp)):
+                if k % 128:
+                    raise NotImplementedError(f"gen_weight_quant='fp8' needs {n} = {k} to be a multiple of 128 (one fp8 k-tile)")
+            self._fp8 = [dict(wqkv=ops.quantize_rows_fp8(P.wqkv[1]), wo=ops.quantize_rows_fp8(P.wo[1]), wgu=ops.quantize_rows_fp8(P.wgu[1]),
+                              wd=ops.quantize_rows_fp8(P.wd[1])) for P in self.layers]
+        return self._fp8
+
     def forward(self, seq, plan: ForwardPlan, mode="und", cache: NaiveCache = None, update=True, causal=True,
-                num_layers=None, taylor=None, final_norm=True):
+                num_layers=None, taylor=None, final_norm=True, gen_quant=None):
         """Qwen2Model.forward_inference (qwen2_navit.py:1018-1092).  ``seq`` is not modified.
         ``taylor``: a TaylorSeerState (cache_utils/taylorseer.py) -> the TaylorSeer hooks of :1034-1037,1057-1061,
         1086-1087 are active: a 'full' step runs the layers and refreshes the feature cache, a 'Taylor' step replaces
@@ -749,7 +764,21 @@ class MoTEngine:
         # row tiles), so the marker rows travel beside it as a small dense matrix [n_text, H]: their projections are weight-streaming
         # skinny GEMMs, their q/k/v rows are scattered into the fused projection buffer before the attention and their attention
         # rows gathered after it.  Same operators, same rounding points; only the GEMM kernel that serves those rows differs.
-        side = bool(gen_attn and plan.und_side and nl > 0 and 2 <= plan.n_text <= ops.SKINNY_MAX_ROWS)
+        fp8 = None
+        if gen_quant is not None and nl > 0 and gen:
+            if gen_quant != "fp8":
+                raise NotImplementedError(f"gen_weight_quant={gen_quant!r}: only 'fp8' (OCP e4m3, row-wise scales) is built")
+            if not (gen_attn and 2 <= plan.n_text <= ops.SKINNY_MAX_ROWS):
+                raise NotImplementedError("gen_weight_quant='fp8' needs the MoT layer kind and 2..64 marker rows (they take the bf16 side path)")
+            fp8 = self.fp8_weights()
+            fw = self._ws_fp8.get(plan.M)
+            if fw is None:
+                u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=self.device)  # noqa: E731
+                f32 = lambda: torch.empty((plan.M,), dtype=torch.float32, device=self.device)  # noqa: E731
+                if len(self._ws_fp8) > 3:
+                    self._ws_fp8.pop(next(iter(self._ws_fp8)))
+                fw = self._ws_fp8[plan.M] = dict(hq=u8(plan.M, self.H), sh=f32(), aq=u8(plan.M, nq * dp), sa=f32(), cq=u8(plan.M, self.I), sc=f32())
+        side = bool(gen_attn and (plan.und_side or fp8 is not None) and nl > 0 and 2 <= plan.n_text <= ops.SKINNY_MAX_ROWS)
         if side:
             nt = plan.n_text
             sw = self._ws_side.get(nt)
@@ -764,12 +793,20 @@ class MoTEngine:
                 return dict(W0=w[1], bias0=None if b is None else b[1], a_rows0=plan.vae_idx, c_rows0=plan.vae_idx, M0=plan.n_vae)
         for li in range(nl):
             P = self.layers[li]
-            ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if gen_attn else None, expert=expert if gen_attn else None)
+            if fp8 is None:
+                ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if gen_attn else None, expert=expert if gen_attn else None)
             if side:
                 ops.rmsnorm(xu, P.ln_in[0], hu, self.eps)
                 ops.gemm(hu, P.wqkv[0], qu, bias0=P.bqkv[0])
                 ops.copy_rows(qu, qkv, nt, qu.shape[1], dst_rows=plan.text_idx)
-                ops.gemm(h, C=qkv, **gen_only(P.wqkv, P.bqkv))
+                if fp8 is not None:
+                    # FP8 option: the latent rows' operands are e4m3 with row scales (the marker rows stay on the bf16 side path).  The
+                    # norm writes the quantised operand directly; attention output and SwiGLU output get one quantiser pass each.
+                    Q = fp8[li]
+                    ops.rmsnorm_fp8(x, P.ln_in[1], fw["hq"], fw["sh"], self.eps)
+                    ops.gemm_fp8(fw["hq"], fw["sh"], Q["wqkv"][0], Q["wqkv"][1], qkv, bias=P.bqkv[1], rows=plan.vae_idx, M=plan.n_vae)
+                else:
+                    ops.gemm(h, C=qkv, **gen_only(P.wqkv, P.bqkv))
             else:
                 ops.gemm(h, C=qkv, **groups(P.wqkv, P.bqkv, gen_attn))
             ops.qknorm_rope(qkv, plan.cos, plan.sin, P.qn[0] if self.use_norm else None, P.kn[0] if self.use_norm else None,
@@ -792,6 +829,17 @@ class MoTEngine:
             if side:
                 ops.copy_rows(att, au, nt, au.shape[1], src_rows=plan.text_idx)
                 ops.gemm(au, P.wo[0], xu, residual=xu)
+                if fp8 is not None:
+                    ops.quantize_rows_fp8(att, fw["aq"], fw["sa"])
+                    ops.gemm_fp8(fw["aq"], fw["sa"], Q["wo"][0], Q["wo"][1], x, rows=plan.vae_idx, M=plan.n_vae, residual=x)
+                    ops.rmsnorm(xu, P.ln_post[0], hu, self.eps)
+                    ops.rmsnorm_fp8(x, P.ln_post[1], fw["hq"], fw["sh"], self.eps)
+                    ops.gemm(hu, P.wgu[0], actu, epilogue=ops.EPI_SWIGLU16)
+                    ops.gemm_fp8(fw["hq"], fw["sh"], Q["wgu"][0], Q["wgu"][1], act, rows=plan.vae_idx, M=plan.n_vae, epilogue=ops.EPI_SWIGLU16)
+                    ops.gemm(actu, P.wd[0], xu, residual=xu)
+                    ops.quantize_rows_fp8(act, fw["cq"], fw["sc"])
+                    ops.gemm_fp8(fw["cq"], fw["sc"], Q["wd"][0], Q["wd"][1], x, rows=plan.vae_idx, M=plan.n_vae, residual=x)
+                    continue
                 ops.gemm(att, C=x, residual=x, **gen_only(P.wo))
                 ops.rmsnorm(xu, P.ln_post[0], hu, self.eps)
                 ops.rmsnorm(x, P.ln_post[0], h, self.eps, w1=P.ln_post[1], expert=expert)

@@ -153,6 +153,48 @@ def quantize_rows_i8(W):
     return q, s
 
 
+def quantize_rows_fp8(X, q=None, scale=None):
+    """bf16 [rows, K] -> (u8 [rows, K] holding OCP e4m3 bytes, fp32 scale [rows] = rowwise absmax / 448); see bagel_quantize_rows_fp8.
+    ``q`` / ``scale``: optional preallocated outputs (the activation buffers of the engine)."""
+    _req(X, BF16, "quantize_rows_fp8.X")
+    rows, K = X.shape
+    if q is None:
+        q = torch.empty((rows, K), dtype=torch.uint8, device=X.device)
+    if scale is None:
+        scale = torch.empty((rows,), dtype=torch.float32, device=X.device)
+    _req(q, torch.uint8, "quantize_rows_fp8.q"); _req(scale, torch.float32, "quantize_rows_fp8.scale")
+    check(lib().bagel_quantize_rows_fp8(_ptr(X), X.stride(0), _ptr(q), q.stride(0), _ptr(scale), rows, K, _stream()), "bagel_quantize_rows_fp8")
+    return q, scale
+
+
+def rmsnorm_fp8(x, w, q, scale, eps):
+    """q, scale = quantize_rows_fp8(rmsnorm(x, w)) in one pass; see bagel_rmsnorm_fp8."""
+    _req(x, BF16, "rmsnorm_fp8.x"); _req(w, BF16, "rmsnorm_fp8.w"); _req(q, torch.uint8, "rmsnorm_fp8.q"); _req(scale, torch.float32, "rmsnorm_fp8.scale")
+    rows, cols = x.shape
+    check(lib().bagel_rmsnorm_fp8(_ptr(x), _ld(x), _ptr(w), _ptr(q), q.stride(0), _ptr(scale), rows, cols, float(eps), _stream()), "bagel_rmsnorm_fp8")
+    return q, scale
+
+
+def gemm_fp8(Aq, sa, Wq, sw, C, *, bias=None, rows=None, M=None, residual=None, epilogue=EPI_NONE):
+    """C[rows] = epilogue(sa[rows] * sw * (Aq[rows] @ Wq^T)) on the fp8 MFMA (fp32 accumulate); ``rows`` = the row list of the one
+    row group (gather of A / scatter of C and the residual); see bagel_gemm_fp8_bf16."""
+    _req(Aq, torch.uint8, "gemm_fp8.Aq"); _req(Wq, torch.uint8, "gemm_fp8.Wq"); _req(C, BF16, "gemm_fp8.C")
+    _req(sa, torch.float32, "gemm_fp8.sa"); _req(sw, torch.float32, "gemm_fp8.sw")
+    N, K = Wq.shape
+    if Aq.shape[-1] != K or sw.numel() != N or sa.numel() < Aq.shape[0]:
+        raise BagelHipError("gemm_fp8: shape mismatch")
+    if rows is not None:
+        _req(rows, torch.int32, "gemm_fp8.rows")
+    if M is None:
+        M = rows.numel() if rows is not None else Aq.shape[0]
+    if residual is not None:
+        _req(residual, BF16, "gemm_fp8.residual")
+    check(lib().bagel_gemm_fp8_bf16(_ptr(Aq), Aq.stride(0), _ptr(sa), _ptr(Wq), Wq.stride(0), _ptr(sw), _ptr(bias), _ptr(rows), _ptr(rows), M,
+                                    _ptr(residual), _ld(residual) if residual is not None else 0, _ptr(C), _ld(C), N, K, epilogue, _stream()),
+          "bagel_gemm_fp8_bf16")
+    return C
+
+
 def gemv_w8(A, Wq, scale, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0):
     """``gemv`` on row-wise INT8 weights (u8 + fp32 scales), activations bf16; see bagel_gemv_w8_bf16."""
     _req(A, BF16, "gemv_w8.A"); _req(Wq, torch.uint8, "gemv_w8.Wq"); _req(scale, torch.float32, "gemv_w8.scale"); _req(C, BF16, "gemv_w8.C")

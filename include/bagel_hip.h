@@ -158,6 +158,23 @@ int bagel_gemv_w8_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldw, 
                        const void* R, int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M,
                        int32_t N, int32_t K, int32_t epilogue, bagel_stream_t stream);
 
+/* FP8 (OCP e4m3) path for the gen-expert GEMMs of the denoise forward (the MI355X-native counterpart of the reference's quantised
+ * load modes, app.py:114-131 -- an OPTION that changes results; bf16 is the default).
+ * quantize: q[r,k] = e4m3_rne(x[r,k] / scale[r]), scale[r] = max_k |x[r,k]| / 448.  cols % 8 == 0; ldq in bytes. */
+int bagel_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq_bytes, float* scale, int32_t rows, int32_t cols,
+                            bagel_stream_t stream);
+/* Qwen2RMSNorm (modeling_qwen2.py:54-59) with the FP8 quantiser fused behind it: q, scale = quantize_rows_fp8(rmsnorm(x, w)),
+ * bit-identical to the two calls, 3 instead of 7 bytes of traffic per element. */
+int bagel_rmsnorm_fp8(const void* x, int64_t ldx, const void* w, void* q, int64_t ldq_bytes, float* scale, int32_t rows,
+                      int32_t cols, float eps, bagel_stream_t stream);
+/* C[c_rows[i], :] = epilogue((sa[a_rows[i]] * sw[n]) * sum_k Aq[a_rows[i], k] * Wq[n, k]) on v_mfma_scale_f32_16x16x128_f8f6f4 with
+ * fp32 accumulation; epilogues EPI_NONE (+bias | +residual) and EPI_SWIGLU16 with the roundings of bagel_gemm_bf16.
+ * Replaces the *_moe_gen F.linear calls of qwen2_navit.py:529-536,593-594 and modeling_qwen2.py:200-201 when the model is built
+ * with gen_weight_quant="fp8".  K % 128 == 0; leading dimensions of Aq / Wq in bytes. */
+int bagel_gemm_fp8_bf16(const void* Aq, int64_t lda_bytes, const float* sa, const void* Wq, int64_t ldw_bytes, const float* sw,
+                        const void* bias, const int32_t* a_rows, const int32_t* c_rows, int32_t M, const void* R, int64_t ldr,
+                        void* C, int64_t ldc, int32_t N, int32_t K, int32_t epilogue, bagel_stream_t stream);
+
 /* Paged KV cache (64-token pages; token j of sample b at pool row block_table[b*bt_stride + j/64]*64 + j%64).
  * Appends this step's K/V row of every sample at slot kv_len[b] (device memory) -- the in-place form of the
  * per-layer cache rebuild at qwen2_navit.py:563-575. */

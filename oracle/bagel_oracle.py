@@ -51,10 +51,27 @@ attn_varlen = _fa.flash_attn_varlen_func   # definition of flash_attn_varlen_fun
 # size of its own accumulation-order noise; the parity tolerances at 7B width are derived from it.  Never on in a parity check.
 LINEAR_FP32_ACCUM = False
 
+# FP8 option of the product (model.gen_weight_quant = "fp8", oracle/fp8.py): data_ptr()s of the weight tensors whose linear runs on
+# e4m3 operands with row-wise scales (the gen expert's q/k/v/o/gate/up/down projections).  Empty = the reference's arithmetic.
+FP8_WEIGHT_PTRS = set()
+
+
+def fp8_gen_weight_ptrs(W):
+    """The weights the product quantises under gen_weight_quant='fp8': every *_moe_gen projection of the decoder layers."""
+    names = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+    return {v.data_ptr() for k, v in W.items() if k.endswith(".weight") and "language_model.model.layers." in k
+            and any(k.endswith(f"{n}_moe_gen.weight") or (f"mlp_moe_gen.{n}.weight" in k) for n in names)}
+
 
 @_explicit_casts
 def linear(x, w, b=None):
     """F.linear under bf16 autocast: inputs cast to the (bf16) weight dtype, bf16 result."""
+    if FP8_WEIGHT_PTRS and w.data_ptr() in FP8_WEIGHT_PTRS:
+        from oracle import fp8 as F8
+        x2 = x.to(w.dtype).reshape(-1, x.shape[-1])
+        qa, sa = F8.quantize_rows_fp8(x2)
+        qw, sw = F8.quantize_rows_fp8(w)
+        return F8.gemm_fp8(qa, sa, qw, sw, bias=None if b is None else b.to(w.dtype)).reshape(*x.shape[:-1], w.shape[0])
     if LINEAR_FP32_ACCUM:
         y = x.to(w.dtype).float() @ w.float().t()
         if b is not None:

@@ -1,0 +1,123 @@
+"""GPU parity of the FP8 (OCP e4m3) option of the gen-expert GEMMs against its CPU restatement (oracle/fp8.py): the row quantiser
+bit for bit, the fp8 MFMA GEMM (persistent ping-pong kernel, every epilogue the layer uses, MoT row list) to fp32-accumulation accuracy."""
+import pytest
+import torch
+
+from oracle import fp8 as F8
+from tests.test_ops_gpu import BF16, DEV, close, ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 128), (300, 3584), (64, 18944)])
+def test_quantize_rows_fp8_bit_exact(rows, cols):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, cols, generator=g) * torch.rand(rows, 1, generator=g) * 4).to(BF16)
+    x[0, :8] = 0
+    if rows > 4:
+        x[3] = 0                                              # an all-zero row: scale 1, codes 0
+    q, s = ops().quantize_rows_fp8(x.to(DEV))
+    qr, sr = F8.quantize_rows_fp8(x)
+    assert torch.equal(s.cpu(), sr), (s.cpu() - sr).abs().max()
+    same = (q.cpu() == qr)
+    # +0 / -0 are distinct codes with the same value
+    val_same = q.cpu().view(torch.float8_e4m3fn).float() == qr.view(torch.float8_e4m3fn).float()
+    assert bool(val_same.all()), f"{(~val_same).sum().item()} of {val_same.numel()} codes differ ({(~same).sum().item()} bytes)"
+
+
+@pytest.mark.parametrize("mode", ["plain", "bias", "residual", "swiglu"])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (2500, 1024, 3584), (4096 + 77, 256, 18944)])
+def test_gemm_fp8_matches_dequantised_product(M, N, K, mode):
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M + 6, K, generator=g).to(BF16)            # the row list skips a few rows of the buffer
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(BF16)
+    rows = torch.tensor([i for i in range(M + 6) if i not in (0, 7, 100, 101, 255, 256)][:M], dtype=torch.int32)
+    qa, sa = F8.quantize_rows_fp8(A)
+    qw, sw = F8.quantize_rows_fp8(W)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF16) if mode == "bias" else None
+    Nout = N // 2 if mode == "swiglu" else N
+    R = torch.randn(M + 6, Nout, generator=g).to(BF16) if mode == "residual" else None
+    C = R.to(DEV).clone() if R is not None else torch.full((M + 6, Nout), float("nan"), dtype=BF16, device=DEV)
+    o = ops()
+    o.gemm_fp8(qa.to(DEV), sa.to(DEV), qw.to(DEV), sw.to(DEV), C, bias=None if bias is None else bias.to(DEV), rows=rows.to(DEV),
+               residual=C if R is not None else None, epilogue=o.EPI_SWIGLU16 if mode == "swiglu" else o.EPI_NONE)
+    torch.cuda.synchronize()
+    r = rows.long()
+    ref = F8.gemm_fp8(qa[r], sa[r], qw, sw, bias=bias, residual=None if R is None else R[r], swiglu=mode == "swiglu")
+    close(C.cpu()[r], ref, ulps=2, what=f"gemm_fp8 {mode} M={M} N={N} K={K}")
+    untouched = [i for i in range(M + 6) if i not in set(rows.tolist())]
+    if R is None:
+        assert torch.isnan(C.cpu()[untouched].float()).all(), "rows outside the row list were written"
+    # and the quantisation itself costs what e4m3 costs: a few percent against the bf16 product
+    if mode == "plain":
+        full = (A[r].float() @ W.float().t())
+        e = ((C.cpu()[r].float() - full).norm() / full.norm()).item()
+        assert e < 6e-2, e
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 128), (257, 3584)])
+def test_rmsnorm_fp8_equals_rmsnorm_then_quantise(rows, cols):
+    g = torch.Generator().manual_seed(cols)
+    x = (torch.randn(rows, cols, generator=g) * 3).to(BF16).to(DEV)
+    w = (1 + 0.1 * torch.randn(cols, generator=g)).to(BF16).to(DEV)
+    o = ops()
+    y = torch.empty_like(x)
+    o.rmsnorm(x, w, y, 1e-6)
+    q_ref, s_ref = o.quantize_rows_fp8(y)
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=DEV)
+    s = torch.empty((rows,), dtype=torch.float32, device=DEV)
+    o.rmsnorm_fp8(x, w, q, s, 1e-6)
+    assert torch.equal(s, s_ref) and torch.equal(q, q_ref)
+
+
+def _fp8_oracle_latents(cfg, W, g, kw):
+    from oracle import bagel_oracle as O
+    from oracle import packers as P
+    from oracle.configs import NEW_TOKEN_IDS_TINY, StubTokenizer
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    prompts = g["prompts"] if "prompts" in g else [g["prompt"]]
+    n = len(prompts)
+    gi, _, _ = P.prepare_prompts([0] * n, [0] * n, prompts, tok, NEW_TOKEN_IDS_TINY)
+    cache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi)       # the context prefill is und mode: bf16
+    ci = g["cfg_inputs"]
+    cfgd = dict(cache=O.OracleCache(L), position_ids=ci["cfg_packed_position_ids"], query_indexes=ci["cfg_packed_query_indexes"],
+                key_values_lens=ci["cfg_key_values_lens"], key_value_indexes=ci["cfg_packed_key_value_indexes"])
+    O.FP8_WEIGHT_PTRS = O.fp8_gen_weight_ptrs(W)
+    assert len(O.FP8_WEIGHT_PTRS) == 7 * L
+    try:
+        return O.generate_image(W, cfg, g["latent_inputs"], cache, cfg_text=cfgd, **kw)
+    finally:
+        O.FP8_WEIGHT_PTRS = set()
+
+
+def test_model_fp8_gen_expert_matches_its_restatement(golden):
+    """text->image on the tiny D=128 model with model.gen_weight_quant='fp8' against the oracle with the SAME quantisation scheme
+    switched into its gen-expert linears (oracle/fp8.py) -- parity of the option with its own CPU statement -- and, for the record,
+    how far the option moves the result from the bf16 reference (~5e-2 on this model).
+    Tolerance: the operators are pinned above (quantiser bit for bit, GEMM to fp32-accumulation accuracy); through the sampler the
+    bf16-level differences between GPU and CPU activations (~1e-3) flip e4m3 codes next to a rounding boundary (step 2^-3 relative), a
+    noise source the bf16 path does not have: measured 4.3e-2 after 4 Euler steps with CFG 4.0, frozen at 8e-2 (2x)."""
+    from oracle.configs import TINY_D128 as cfg, NEW_TOKEN_IDS_TINY, StubTokenizer
+    from tests.test_model_gpu import cfg_kwargs, new_cache, rel_l2
+    from tests.util_models import oracle_weights, product_model
+    g = golden("tiny_d128_t2i")
+    W, _ = oracle_weights(cfg)
+    kw = g["gen_kwargs"]
+    ref8 = _fp8_oracle_latents(cfg, W, g, kw)
+    model, _ = product_model(cfg)
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    gi, _, _ = model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+    try:
+        for batched in (True, False):
+            model.gen_weight_quant, model.cfg_batched = "fp8", batched
+            lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **kw, **g["latent_inputs"])
+            for a, b, c in zip(lat, ref8, g["latents"]):
+                assert torch.isfinite(a).all()
+                e8, e16 = rel_l2(a, b), rel_l2(a, c)
+                print(f"fp8 gen expert (cfg_batched={batched}): vs its CPU restatement {e8:.3e}; vs the bf16 reference {e16:.3e}")
+                assert e8 <= 8e-2, e8
+                assert 1e-3 < e16 < 0.5, e16            # it IS a different result, and not a wild one
+    finally:
+        model.gen_weight_quant, model.cfg_batched = None, True
