@@ -6,7 +6,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbagel_hip.so")
+# BAGEL_HIP_LIB: an alternative build of the same sources (tools/ab_build.sh: A/B measurements of compile-time variants on one GPU box)
+LIB_PATH = os.environ.get("BAGEL_HIP_LIB") or os.path.join(_HERE, "libbagel_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bagel_hip.h")
 
 

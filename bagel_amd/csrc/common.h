@@ -62,6 +62,37 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return 0.5f * x * (1.0f + tanhf(inner));
 }
 
+// Streaming loads of data that ONE workgroup reads ONCE per launch (decode weights, KV pages): non-temporal cache policy
+// (global_load_dwordx4 ... nt).  MI355X_MICROARCH.md, row nt-weights: issue -> landed -18 %, decode layer 5-10 % faster.
+// BAGEL_NT_WEIGHTS=0 at build time restores plain loads (tools/ab_build.sh: same-box A/B).  Measured on one box (tools/ab_decode_nt.sh,
+// profiles/r02_decode_nt_ab.log): batch-1 decode 280.2 tok/s plain -> 294.0 with nt on the gemv weight stream; nt on the KV pages is
+// neutral (kept plain); nt on the skinny MFMA GEMM's weight fragments is SLOWER (batch 8: 1 169 vs 1 284 tok/s: kept plain).
+#ifndef BAGEL_NT_WEIGHTS
+#define BAGEL_NT_WEIGHTS 1
+#endif
+template <typename T>
+__device__ __forceinline__ T ld_stream(const void* ptr) {
+#if BAGEL_NT_WEIGHTS
+    return __builtin_nontemporal_load((const T*)ptr);
+#else
+    return *(const T*)ptr;
+#endif
+}
+#ifndef BAGEL_NT_KV
+#define BAGEL_NT_KV 0
+#endif
+template <typename T>
+__device__ __forceinline__ T ld_stream_kv(const void* ptr) {
+#if BAGEL_NT_KV
+    return __builtin_nontemporal_load((const T*)ptr);
+#else
+    return *(const T*)ptr;
+#endif
+}
+#ifndef BAGEL_NT_SKINNY
+#define BAGEL_NT_SKINNY 0
+#endif
+
 // 16 zero bytes a lane can DMA from when its chunk lies outside the operand (K tail, conv padding)
 static __device__ __attribute__((aligned(16), used)) unsigned int bagel_zero16[4] = {0u, 0u, 0u, 0u};
 

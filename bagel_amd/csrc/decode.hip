@@ -72,6 +72,8 @@ __device__ __forceinline__ void gemv_fma_reg(float (&a0)[MR][2], float (&a1)[MR]
     }
 }
 
+__device__ __forceinline__ u32x4_t ldw_nt(const bf16_t* ptr) { return ld_stream<u32x4_t>(ptr); }
+
 template <int U>
 __device__ __forceinline__ void gemv_load_batch(u32x4_t (&wa)[U], u32x4_t (&wb)[U], const bf16_t* w0, const bf16_t* w1, int g,
                                                 int lane, int nch) {
@@ -79,8 +81,8 @@ __device__ __forceinline__ void gemv_load_batch(u32x4_t (&wa)[U], u32x4_t (&wb)[
     for (int u = 0; u < U; ++u) {
         const int ch = (g + u) * 64 + lane;
         const long off = (long)(ch < nch ? ch : 0) * 8;     // out-of-range chunks re-read chunk 0 and are multiplied by 0
-        wa[u] = *(const u32x4_t*)(w0 + off);
-        wb[u] = *(const u32x4_t*)(w1 + off);
+        wa[u] = ldw_nt(w0 + off);
+        wb[u] = ldw_nt(w1 + off);
     }
 }
 
@@ -91,8 +93,8 @@ __device__ __forceinline__ void gemv_load_full(u32x4_t (&wa)[U], u32x4_t (&wb)[U
     const bf16_t* b = w1 + ((long)g * 64 + lane) * 8;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        wa[u] = *(const u32x4_t*)(a + u * 512);
-        wb[u] = *(const u32x4_t*)(b + u * 512);
+        wa[u] = ldw_nt(a + u * 512);
+        wb[u] = ldw_nt(b + u * 512);
     }
 }
 
@@ -666,8 +668,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int i = 0; i < KU; ++i) {
         const long off = (long)pg[i] * ldp + (long)kvh * DP + sub * 8;
-        kr[i] = *(const u32x4_t*)(kpool + off);
-        vr[i] = *(const u32x4_t*)(vpool + off);
+        kr[i] = ld_stream_kv<u32x4_t>(kpool + off);
+        vr[i] = ld_stream_kv<u32x4_t>(vpool + off);
     }
     float qf[G][8];
     if (!FUSED) {

@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void gemv_w8_kernel(GemvW8Params p) {
         for (int u = 0; u < U; ++u) {
             const int ch = (g + u) * 64 + lane;
             const long off = (long)(ch < nch ? ch : 0) * 16;
-            wa[u] = *(const u32x4_t*)(p.W + (long)r0 * p.ldw + off);
-            wb[u] = *(const u32x4_t*)(p.W + (long)r1 * p.ldw + off);
+            wa[u] = ld_stream<u32x4_t>(p.W + (long)r0 * p.ldw + off);
+            wb[u] = ld_stream<u32x4_t>(p.W + (long)r1 * p.ldw + off);
         }
     };
     if (live) load_batch(0);

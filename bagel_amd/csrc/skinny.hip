@@ -74,8 +74,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int k = (k0 + u < k_hi) ? k0 + u : k_hi - 1;          // tail: re-read the last step, masked below
+#if BAGEL_NT_SKINNY
+            wf[0][u] = __builtin_nontemporal_load((const bf16x8_t*)(wg + (long)k * 32));          // weights: read once, non-temporal
+            if (SWIGLU) wf[NACC - 1][u] = __builtin_nontemporal_load((const bf16x8_t*)(wu + (long)k * 32));
+#else
             wf[0][u] = *(const bf16x8_t*)(wg + (long)k * 32);
             if (SWIGLU) wf[NACC - 1][u] = *(const bf16x8_t*)(wu + (long)k * 32);
+#endif
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[mt][u] = *(const bf16x8_t*)(xa[mt] + (long)k * 32);
         }

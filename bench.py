@@ -50,6 +50,7 @@ def parse():
                     help="t2i = BASELINE configs[2]/[3] (the headline metric); edit = configs[4] image-edit (VAE enc + ViT + 3-forward CFG)")
     ap.add_argument("--no-taylorseer", action="store_true", help="skip the extra enable_taylorseer=True measurement")
     ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the extra gen_weight_quant='fp8' measurement")
     ap.add_argument("--no-edit", action="store_true", help="skip the extra configs[4] measurement (one image-edit request per GPU)")
     ap.add_argument("--only-understanding", action="store_true", help="debug only: skip the text->image leg (result flagged invalid)")
     ap.add_argument("--und-new-tokens", type=int, default=256)
@@ -757,6 +758,33 @@ def main():
         ts = {"value": world * B / dt_ts, "unit": "images/s", "ms_per_step": dt_ts * 1e3, "full_forwards_per_stream": st.full_steps,
               "extrapolated_forwards_per_stream": st.taylor_steps, "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_ts),
               "note": "enable_taylorseer=True (reference option, changes the samples): not the headline metric"}
+    fp8 = None
+    if args.workload == "t2i" and not args.no_fp8 and not args.only_understanding:
+        # option model.gen_weight_quant = "fp8": the gen expert's projections on the OCP-e4m3 MFMA with row-wise scales (SURVEY.md 8f.4;
+        # the MI355X counterpart of the reference's quantised load modes).  It CHANGES the samples (a few percent, tests/test_fp8_gpu.py):
+        # reported beside the headline number, never as it.
+        try:
+            model.gen_weight_quant = "fp8"
+            one_step()                                  # warm-up: quantises the 28 x 4 gen-expert matrices once
+            fence()
+            t1 = time.perf_counter()
+            lat_8, _ = one_step()
+            fence()
+            dt_8 = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([dt_8], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt_8 = float(tt.item())
+            dev_l2 = max(float(((a.float() - b.float()).norm() / b.float().norm()).item()) for a, b in zip(lat_8, latents))
+            fp8 = {"value": world * B / dt_8, "unit": "images/s", "ms_per_step": dt_8 * 1e3, "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_8),
+                   "latents_rel_l2_vs_bf16_run": dev_l2, "weights": "gen expert q/k/v/o/gate/up/down in OCP e4m3, row-wise absmax scales; activations "
+                   "quantised per row on the fly; und expert, attention, norms, residual stream bf16",
+                   "note": "gen_weight_quant='fp8' option (changes results): not the headline metric"}
+        except Exception as e:
+            import traceback
+            fp8 = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
+        finally:
+            model.gen_weight_quant = None
     edit = None
     if args.workload == "t2i" and not args.no_edit and vae is not None:
         # BASELINE configs[4] beside the headline: ONE image-edit request per GPU (VAE-encode + SigLIP + prompt -> ~9 k-token
@@ -832,6 +860,7 @@ def main():
             "understanding": und,
             "edit": edit,
             "taylorseer": ts,
+            "fp8_gen_expert": fp8,
         }
         if args.workload == "t2i":
             # the whole path against the MFMA roof: denoise FLOPs (linear + attention of the 98 forwards, SURVEY.md 8d: 5.904 PFLOP
