@@ -50,6 +50,7 @@ def parse():
                     help="t2i = BASELINE configs[2]/[3] (the headline metric); edit = configs[4] image-edit (VAE enc + ViT + 3-forward CFG)")
     ap.add_argument("--no-taylorseer", action="store_true", help="skip the extra enable_taylorseer=True measurement")
     ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
+    ap.add_argument("--no-int8", action="store_true", help="understanding leg: skip the extra weight_quant='int8' decode")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra gen_weight_quant='fp8' measurement")
     ap.add_argument("--no-edit", action="store_true", help="skip the extra configs[4] measurement (one image-edit request per GPU)")
     ap.add_argument("--only-understanding", action="store_true", help="debug only: skip the text->image leg (result flagged invalid)")
@@ -462,7 +463,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     # option: row-wise INT8 layer weights (the analogue of the reference's quantised load modes; changes results) -- reported
     # beside the bf16 number, never as it
     w8 = None
-    if UB == 1:
+    if UB == 1 and not args.no_int8:
         try:
             cache8, lens8, ropes8, _ = prefill()
             st8 = model.prepare_start_tokens(lens8, ropes8, ids)
@@ -563,7 +564,8 @@ def understanding_subprocess(args, local):
     env = dict(os.environ)
     env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding"] + (["--no-cpu-baseline"] if args.no_cpu_baseline or int(os.environ.get("WORLD_SIZE", 1)) != 1 else []) + [
-           "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image), "--und-batch", str(args.und_batch)]
+           "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image), "--und-batch", str(args.und_batch)] + (
+           ["--no-int8"] if args.no_int8 else [])
     if args.layers is not None:
         cmd += ["--layers", str(args.layers)]
     try:
