@@ -37,7 +37,9 @@
 //   Tried and removed: role alternation between the wave halves (four variants, 768-837); a one-wave-per-SIMD form with 64 query
 //   rows per wave, O / Q / S in the accumulation registers and inline-asm MFMAs (correct, 155 VGPR + 256 AGPR, 787 TFLOP/s: a
 //   single wave per SIMD issues every one of its ~590 instructions per tile itself -- 60 % of its cycles -- and nothing hides its
-//   22 % of waitcnt/barrier time); timing-only ablations of this form: no barrier +5 %, no DMA +8 %, neither +11 %.
+//   22 % of waitcnt/barrier time); timing-only ablations of this form: no barrier +5 %, no DMA +8 %, neither +11 %; same-box A/B
+//   builds (tools/ab_attn.sh): fragment prefetch distance 3 / 5 / 6 instead of 4 and a static s_setprio 1 for waves 4-7: all within
+//   1 % of 895 TFLOP/s (prefetch distance 5: -4 %).
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         // Issue order is written out by hand: one CHUNK per MFMA = the MFMA, the fragment read WIN chunks ahead, and a 1/16 slice of the
         // softmax work; a sched_barrier(0) closes every chunk, so hipcc orders instructions inside a chunk only.  Consecutive MFMAs hit
         // different accumulators (a VALU slot between two MFMAs of one accumulation chain costs ~43 cycles: MI355X_MICROARCH.md).
-        constexpr int WIN = 4;
+        constexpr int WIN = 4;        // 3 .. 6 measure the same (894-899 TFLOP/s, same-box A/B): LDS latency is not what this kernel waits for
         constexpr int NMA = NQB * NK, NMB = NQB * NV;          // MFMAs of phase A / phase B
         constexpr int SPA = 16 * NQB / NMA, SPB = 16 * NQB / NMB;   // softmax / row-max slices per chunk (1 at D = 128, 2 at D = 64)
         unsigned pw[NQB][16];                                  // P(t) as packed bf16 pairs: pw[qb][4 * f + e] = word e of fragment f
