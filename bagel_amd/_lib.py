@@ -53,6 +53,11 @@ def lib():
             raise BagelHipError(
                 f"{LIB_PATH} not found: build it with `python -m bagel_amd.build` (hipcc, gfx950). "
                 "bagel_amd has no CPU or eager fallback by design.")
+        # ONE HIP runtime per process: torch bundles its own libamdhip64 and the kernels have to launch into the context, the streams
+        # and the allocations torch owns.  Loading this library first would bind it to the system ROCm's runtime instead (a second,
+        # separate runtime: every launch then fails with "no ROCm-capable device is detected").  Importing torch first makes the
+        # dynamic loader resolve libbagel_hip.so's libamdhip64 dependency to the copy that is already mapped.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in parse_header().items():
             fn = getattr(L, name)   # AttributeError here == header/library drift
