@@ -26,7 +26,7 @@ def test_quantize_rows_fp8_bit_exact(rows, cols):
 
 
 @pytest.mark.parametrize("mode", ["plain", "bias", "residual", "swiglu"])
-@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (2500, 1024, 3584), (4096 + 77, 256, 18944)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (2500, 1024, 3584), (4096 + 77, 256, 18944), (32768, 512, 3584)])
 def test_gemm_fp8_matches_dequantised_product(M, N, K, mode):
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M + 6, K, generator=g).to(BF16)            # the row list skips a few rows of the buffer

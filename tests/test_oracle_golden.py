@@ -225,3 +225,30 @@ def test_fp32_master_reference_run_is_a_stated_distance_away(golden):
             d = max(float((a - b).norm() / b.norm()) for a, b in zip(gm[key], g[key]))
             assert abs(d - gm["deviation_of_bf16_weights_reference"][key]) < 1e-6
             assert 5e-3 < d < 2e-2, (name, key, d)
+
+
+def test_fp8_restatement_known_answers():
+    """oracle/fp8.py (the CPU statement of the product's gen_weight_quant='fp8' option) on hand-checkable values: the row scale is
+    absmax / 448, codes are OCP e4m3fn with round-to-nearest-even, and the GEMM restatement equals the fp32 product of the de-quantised
+    operands."""
+    import torch
+    from oracle import fp8 as F8
+    x = torch.tensor([[448.0, 224.0, 1.0, -0.4375, 0.0, 3.25, 17.0, 18.0]], dtype=torch.float32)
+    q, s = F8.quantize_rows_fp8(x)
+    assert float(s[0]) == 1.0
+    back = F8.dequant(q, s)[0].tolist()
+    # e4m3: 3 mantissa bits -> 17 lies between 16 and 18 (tie -> even mantissa = 16), 3.25 is exact, 0.4375 = 7 * 2^-4 is exact
+    assert back == [448.0, 224.0, 1.0, -0.4375, 0.0, 3.25, 16.0, 18.0]
+    y = torch.tensor([[100.0, -50.0, 25.0, 0.0, 0.0, 0.0, 0.0, 0.0]])
+    q2, s2 = F8.quantize_rows_fp8(y)
+    assert abs(float(s2[0]) - 100.0 / 448.0) < 1e-7          # fp32 division
+    assert torch.allclose(F8.dequant(q2, s2)[0, :3], torch.tensor([100.0, -50.0, 25.0]), rtol=2 ** -4)
+    g = torch.Generator().manual_seed(0)
+    a, w = torch.randn(5, 64, generator=g), torch.randn(7, 64, generator=g)
+    qa, sa = F8.quantize_rows_fp8(a)
+    qw, sw = F8.quantize_rows_fp8(w)
+    ref = (F8.dequant(qa, sa) @ F8.dequant(qw, sw).t()).to(torch.bfloat16)
+    assert torch.equal(F8.gemm_fp8(qa, sa, qw, sw), ref) or (F8.gemm_fp8(qa, sa, qw, sw).float() - ref.float()).abs().max() <= 2 ** -7 * ref.float().abs().max()
+    z = torch.zeros(2, 16)
+    qz, sz = F8.quantize_rows_fp8(z)
+    assert sz.tolist() == [1.0, 1.0] and int(qz.view(torch.uint8).max()) == 0
