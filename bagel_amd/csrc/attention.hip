@@ -39,7 +39,11 @@
 //   single wave per SIMD issues every one of its ~590 instructions per tile itself -- 60 % of its cycles -- and nothing hides its
 //   22 % of waitcnt/barrier time); timing-only ablations of this form: no barrier +5 %, no DMA +8 %, neither +11 %; same-box A/B
 //   builds (tools/ab_attn.sh): fragment prefetch distance 3 / 5 / 6 instead of 4 and a static s_setprio 1 for waves 4-7: all within
-//   1 % of 895 TFLOP/s (prefetch distance 5: -4 %).
+//   1 % of 895 TFLOP/s (prefetch distance 5: -4 %).  A second one-wave-per-SIMD form (both score sets in VGPRs, separate 2-slot K / V^T
+//   rings with compile-time LDS offsets, 438 instead of 590 instructions per tile, zero spills in the loop): correct, 877 TFLOP/s;
+//   without barrier and DMA 987.  PMC (profiles/r02_attn_pmc_64row_v2.txt): the lone wave is issuing 55 % of its cycles -- ~5.8 cycles
+//   per instruction (v_exp_f32 is quarter rate) = ~2 500 cycles per tile against 2 048 of matrix time -- so it cannot be matrix-bound
+//   even with zero stalls, and it stalls another 45 %.  Removed as well; the two-waves-per-SIMD kernel below stays the only one.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
