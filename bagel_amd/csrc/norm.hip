@@ -11,7 +11,9 @@
 //                             gen: everything fp32 on the bf16-rounded projection, ONE final bf16 rounding
 #include "common.h"
 
-// One wave per row; each lane streams 16-byte (8 x bf16) chunks.
+// One wave per row; each lane streams 16-byte (8 x bf16) chunks.  Rows of up to 4096 columns (every hidden size on the path) are
+// held in registers: all of a lane's loads are issued back to back (one latency per row instead of one per chunk) and the second
+// pass re-reads nothing.  Same summation order as the streaming form, so the two are bit-identical.
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w0,
                                                       const bf16_t* __restrict__ w1, const int* __restrict__ expert,
                                                       bf16_t* __restrict__ y, long ldy, int rows, int cols, float eps) {
@@ -21,6 +23,43 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     const bf16_t* xr = x + (long)row * ldx;
     const bf16_t* w = (expert && expert[row]) ? w1 : w0;
     const int nch = cols >> 3;
+    bf16_t* yr = y + (long)row * ldy;
+    if (nch <= 512) {
+        u32x4_t v[8], g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < nch ? *(const u32x4_t*)(xr + c * 8) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            g[i] = c < nch ? *(const u32x4_t*)(w + c * 8) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = lo2f(v[i][e]), b = hi2f(v[i][e]);
+                ss += a * a + b * b;
+            }
+        ss = wave_sum(ss);
+        const float inv = rsqrtf(ss / (float)cols + eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bfround(lo2f(v[i][e]) * inv) * lo2f(g[i][e]);
+                const float b = bfround(hi2f(v[i][e]) * inv) * hi2f(g[i][e]);
+                o[e] = pack2bf(a, b);
+            }
+            if (c < nch) *(u32x4_t*)(yr + c * 8) = o;
+        }
+        return;
+    }
     float ss = 0.f;
     for (int c = lane; c < nch; c += 64) {
         const u32x4_t v = *(const u32x4_t*)(xr + c * 8);
@@ -32,7 +71,6 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     }
     ss = wave_sum(ss);
     const float inv = rsqrtf(ss / (float)cols + eps);
-    bf16_t* yr = y + (long)row * ldy;
     for (int c = lane; c < nch; c += 64) {
         const u32x4_t v = *(const u32x4_t*)(xr + c * 8);   // L2/L1 hit: the row was just streamed
         const u32x4_t g = *(const u32x4_t*)(w + c * 8);
@@ -61,17 +99,31 @@ extern "C" int bagel_rmsnorm_bf16(const void* x, int64_t ldx, const void* w0, co
 // Qwen2RMSNorm whose output goes straight to the FP8 (OCP e4m3) operand of the following gen-expert GEMM (bagel_gemm_fp8_bf16):
 // q[r, :] = e4m3(y[r, :] / s_r), s_r = max |y[r, :]| / 448, y = the bf16 result of rmsnorm_kernel -- bit-identical to running
 // rmsnorm_kernel and bagel_quantize_rows_fp8 one after the other, with 3 instead of 7 bytes of HBM traffic per element.
-__global__ __launch_bounds__(256) void rmsnorm_fp8_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
-                                                          unsigned char* __restrict__ q, long ldq, float* __restrict__ scale, int rows,
-                                                          int cols, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const bf16_t* xr = x + (long)row * ldx;
-    const int nch = cols >> 3;
+template <bool REG>
+__device__ __forceinline__ void rmsnorm_fp8_row(const bf16_t* __restrict__ xr, const bf16_t* __restrict__ w, unsigned char* __restrict__ qr,
+                                                float* __restrict__ scale_out, int nch, int cols, float eps, int lane) {
+    // REG: the row (<= 4096 columns) lives in registers across the three passes; otherwise it is re-read from L2
+    constexpr int NI = 8;
+    u32x4_t vr[NI], gr[NI];
+    const u32x4_t zero = u32x4_t{0u, 0u, 0u, 0u};
+    if (REG) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = lane + 64 * i;
+            vr[i] = c < nch ? *(const u32x4_t*)(xr + c * 8) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = lane + 64 * i;
+            gr[i] = c < nch ? *(const u32x4_t*)(w + c * 8) : zero;
+        }
+    }
+    const int niter = REG ? NI : (nch + 63) >> 6;
     float ss = 0.f;
-    for (int c = lane; c < nch; c += 64) {
-        const u32x4_t v = *(const u32x4_t*)(xr + c * 8);
+#pragma unroll
+    for (int i = 0; i < niter; ++i) {
+        const int c = lane + 64 * i;
+        const u32x4_t v = REG ? vr[REG ? i : 0] : (c < nch ? *(const u32x4_t*)(xr + c * 8) : zero);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a = lo2f(v[e]), b = hi2f(v[e]);
@@ -81,9 +133,12 @@ __global__ __launch_bounds__(256) void rmsnorm_fp8_kernel(const bf16_t* __restri
     ss = wave_sum(ss);
     const float inv = rsqrtf(ss / (float)cols + eps);
     float amax = 0.f;
-    for (int c = lane; c < nch; c += 64) {
-        const u32x4_t v = *(const u32x4_t*)(xr + c * 8);
-        const u32x4_t g = *(const u32x4_t*)(w + c * 8);
+#pragma unroll
+    for (int i = 0; i < niter; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = c < nch;
+        const u32x4_t v = REG ? vr[REG ? i : 0] : (ok ? *(const u32x4_t*)(xr + c * 8) : zero);
+        const u32x4_t g = REG ? gr[REG ? i : 0] : (ok ? *(const u32x4_t*)(w + c * 8) : zero);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a = bfround(bfround(lo2f(v[e]) * inv) * lo2f(g[e]));
@@ -94,11 +149,13 @@ __global__ __launch_bounds__(256) void rmsnorm_fp8_kernel(const bf16_t* __restri
     amax = wave_max(amax);
     const float s = amax > 0.f ? amax / 448.0f : 1.0f;
     const float qinv = 1.0f / s;
-    if (lane == 0) scale[row] = s;
-    unsigned char* qr = q + (long)row * ldq;
-    for (int c = lane; c < nch; c += 64) {
-        const u32x4_t v = *(const u32x4_t*)(xr + c * 8);
-        const u32x4_t g = *(const u32x4_t*)(w + c * 8);
+    if (lane == 0) *scale_out = s;
+#pragma unroll
+    for (int i = 0; i < niter; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = c < nch;
+        const u32x4_t v = REG ? vr[REG ? i : 0] : (ok ? *(const u32x4_t*)(xr + c * 8) : zero);
+        const u32x4_t g = REG ? gr[REG ? i : 0] : (ok ? *(const u32x4_t*)(w + c * 8) : zero);
         u32x2_t o;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -113,8 +170,19 @@ __global__ __launch_bounds__(256) void rmsnorm_fp8_kernel(const bf16_t* __restri
             wd = __builtin_amdgcn_cvt_pk_fp8_f32(y[2] * qinv, y[3] * qinv, wd, true);
             o[h] = (unsigned)wd;
         }
-        *(u32x2_t*)(qr + 8 * c) = o;
+        if (ok) *(u32x2_t*)(qr + 8 * c) = o;
     }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_fp8_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                          unsigned char* __restrict__ q, long ldq, float* __restrict__ scale, int rows,
+                                                          int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = cols >> 3;
+    if (nch <= 512) rmsnorm_fp8_row<true>(x + (long)row * ldx, w, q + (long)row * ldq, scale + row, nch, cols, eps, lane);
+    else rmsnorm_fp8_row<false>(x + (long)row * ldx, w, q + (long)row * ldq, scale + row, nch, cols, eps, lane);
 }
 
 extern "C" int bagel_rmsnorm_fp8(const void* x, int64_t ldx, const void* w, void* q, int64_t ldq_bytes, float* scale, int32_t rows,
