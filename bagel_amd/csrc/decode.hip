@@ -636,177 +636,208 @@ __device__ __forceinline__ void dec_post_head(const u32x4_t raw, const bf16_t* _
     }
 }
 
-template <int DP, int G, int CH, bool FUSED>
+// The kernel.  4 waves x 32 keys.  Both products run on the matrix pipe (mfma_f32_16x16x32_bf16), the GQA group padded to 16 columns:
+//   S^T[key, head] = K[16 keys, DP] Q^T[DP, 16 heads]   K fragments straight from the page rows (lane = key l%16, 16 bytes at
+//                                                        chunk 4kk + l/16), Q fragments from the projection row (or from LDS, FUSED);
+//                                                        a lane ends up with the scores of ONE head (l%16) for keys 4g..4g+3 of both
+//                                                        16-key blocks -- exactly the 8 keys an MFMA B operand of PV wants per lane;
+//   O^T[d, head]   = V^T[16 d, 32 keys] P^T[32 keys, 16 heads]   P from the score registers (bf16, like flash-attn), V^T fragments by
+//                                                        2-byte LDS reads of the wave's row-major V tile (row stride DP + 8: the four
+//                                                        lane groups hit banks 16 apart).
+// The VALU form this replaces spent 7.5 of its 12.3 us on 7 heads x 8 keys of FMA chains and ~360 ds_bpermute per lane
+// (profiles/r02_decode_attn_ablation.log); here the softmax is 8 values per lane and two cross-group exchanges.
+// FUSED: the q/k norm + RoPE of decode_qkv_post_kernel runs in the prologue -- 16-lane groups own one head each (G query heads + the
+// new key: 8 items = two waves at 7B), same arithmetic (dec_post_head), results handed to all waves through LDS; the workgroup whose
+// chunk holds position kv_len[b] uses the new K/V row from LDS / the projection and stores both into the page.
+template <int DP, bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kpool,
                                                           const bf16_t* __restrict__ vpool, long ldp,
                                                           const int* __restrict__ block_table, int bt_stride,
                                                           const int* __restrict__ kv_len, int len_add, float* __restrict__ part_o,
-                                                          float* __restrict__ part_ml, int nq, int nsplit, float scale_log2e, DecFuse fu) {
-    constexpr int LPK = DP / 8;          // lanes per key row
-    constexpr int NG = 256 / LPK;        // key rows per workgroup pass
-    constexpr int KU = CH / NG;          // keys of one lane group in the chunk: all of them are loaded before any is used
+                                                          float* __restrict__ part_ml, int nq, int G, int nsplit, float scale_log2e,
+                                                          DecFuse fu) {
+    constexpr int CH = DEC_CH;           // keys per workgroup
+    constexpr int KS = DP / 32;          // k-steps of S^T
+    constexpr int NDB = DP / 16;         // 16-wide d blocks of O^T
+    constexpr int VST = DP + 8;          // LDS row stride of the V tile, elements
+    constexpr int CPR = DP / 8;          // 16-byte chunks per K/V row
+    constexpr int RPI = 64 / CPR;        // rows one wave-wide load covers
+    constexpr int NVL = 32 / RPI;        // V loads per lane
     const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int L = kv_len[b] + len_add;
     const int j0 = split * CH;
     const int j1 = (L < j0 + CH) ? L : j0 + CH;
     if (j0 >= j1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = tid % LPK, grp = tid / LPK;
-    __shared__ float sm_o[4][G][DP];
-    __shared__ float sm_m[4][G], sm_l[4][G];
+    const int g = lane >> 4, c16 = lane & 15;
+    const int jw = j0 + 32 * wave;
+    __shared__ __attribute__((aligned(16))) bf16_t sm_v[4][32 * VST];      // V tiles; afterwards the waves' O partials [16][DP] fp32
+    __shared__ __attribute__((aligned(16))) bf16_t sm_q[17][DP];           // FUSED: finished q heads [0, G) and the new key [G]
+    __shared__ float sm_m[4][16], sm_l[4][16];
+    static_assert(16 * DP * 4 <= 32 * VST * 2, "O partial must fit the V tile");
 
-    // one latency round: block-table entries -> K/V rows (16 bytes per lane each), then the query heads
     const int* bt = block_table + (long)b * bt_stride;
-    int pg[KU];
+    const int jn = L - 1;                // FUSED: the position this step appends
+    // ---- one latency round: block-table entries -> K fragments and V rows (clamped past the range), the query heads beside them
+    long krow[2];
 #pragma unroll
-    for (int i = 0; i < KU; ++i) {
-        const int j = j0 + grp + i * NG;
+    for (int blk = 0; blk < 2; ++blk) {
+        const int j = jw + 16 * blk + c16;
         const int jc = j < j1 ? j : j1 - 1;
-        pg[i] = bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
+        krow[blk] = (long)bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
     }
-    u32x4_t kr[KU], vr[KU];
+    long vrow[NVL];
 #pragma unroll
-    for (int i = 0; i < KU; ++i) {
-        const long off = (long)pg[i] * ldp + (long)kvh * DP + sub * 8;
-        kr[i] = ld_stream_kv<u32x4_t>(kpool + off);
-        vr[i] = ld_stream_kv<u32x4_t>(vpool + off);
+    for (int i = 0; i < NVL; ++i) {
+        const int j = jw + lane / CPR + RPI * i;
+        const int jc = j < j1 ? j : j1 - 1;
+        vrow[i] = (long)bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
     }
-    float qf[G][8];
+    u32x4_t kf[2][KS], vr[NVL];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            kf[blk][kk] = ld_stream_kv<u32x4_t>(kpool + krow[blk] * ldp + (long)kvh * DP + 32 * kk + 8 * g);
+    const bf16_t* qrow = q + (long)b * ldq;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+        const bf16_t* src = vpool + vrow[i] * ldp + (long)kvh * DP + (lane % CPR) * 8;
+        if (FUSED) {         // the new V row is not in the page yet: take it from the projection
+            const int j = jw + lane / CPR + RPI * i;
+            if (j == jn || (j >= j1 && j1 - 1 == jn)) src = qrow + (long)(nq + fu.nkv + kvh) * DP + (lane % CPR) * 8;
+        }
+        vr[i] = ld_stream_kv<u32x4_t>(src);
+    }
+    u32x4_t qf[KS];
     if (!FUSED) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const u32x4_t v = *(const u32x4_t*)(q + (long)b * ldq + (long)(kvh * G + g) * DP + sub * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                qf[g][2 * e] = lo2f(v[e]) * scale_log2e;
-                qf[g][2 * e + 1] = hi2f(v[e]) * scale_log2e;
-            }
+        for (int kk = 0; kk < KS; ++kk) {
+            qf[kk] = u32x4_t{0u, 0u, 0u, 0u};
+            if (c16 < G) qf[kk] = *(const u32x4_t*)(qrow + (long)(kvh * G + c16) * DP + 32 * kk + 8 * g);
         }
     } else {
+        constexpr int LPK = DP / 8, IPW = 64 / LPK;
+        const int sub = lane % LPK, item = wave * IPW + lane / LPK;      // items [0, G): query heads; G: the new key
         const int hd = fu.hd, half = hd >> 1;
-        const bool real = sub * 8 < hd;
-        float cs[8], sn[8];
-        {
-            const int c0 = (sub * 8) % half;     // element e of the head uses table column e mod HD/2
-            u32x4_t cv = {0u, 0u, 0u, 0u}, sv = {0u, 0u, 0u, 0u};
-            if (real) {
-                cv = *(const u32x4_t*)(fu.cosb + (long)b * half + c0);
-                sv = *(const u32x4_t*)(fu.sinb + (long)b * half + c0);
+        if (item <= G) {     // whole 16-lane groups take this branch together: the shuffles of dec_post_head stay inside a group
+            const bool real = sub * 8 < hd;
+            float cs[8], sn[8];
+            {
+                const int c0 = (sub * 8) % half;     // element e of the head uses table column e mod HD/2
+                u32x4_t cv = {0u, 0u, 0u, 0u}, sv = {0u, 0u, 0u, 0u};
+                if (real) {
+                    cv = *(const u32x4_t*)(fu.cosb + (long)b * half + c0);
+                    sv = *(const u32x4_t*)(fu.sinb + (long)b * half + c0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cs[2 * e] = lo2f(cv[e]); cs[2 * e + 1] = hi2f(cv[e]); sn[2 * e] = lo2f(sv[e]); sn[2 * e + 1] = hi2f(sv[e]); }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { cs[2 * e] = lo2f(cv[e]); cs[2 * e + 1] = hi2f(cv[e]); sn[2 * e] = lo2f(sv[e]); sn[2 * e + 1] = hi2f(sv[e]); }
-        }
-        const bf16_t* row = q + (long)b * ldq;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const u32x4_t raw = *(const u32x4_t*)(row + (long)(kvh * G + g) * DP + sub * 8);
-            float qv[8];
-            dec_post_head<LPK>(raw, fu.qw, cs, sn, sub, hd, fu.eps, fu.use_norm, qv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[g][e] = qv[e] * scale_log2e;
-        }
-        // the new key (position L-1 = kv_len[b]): built from the projection row by every group, used/stored by its owner
-        const u32x4_t kraw = *(const u32x4_t*)(row + (long)(nq + kvh) * DP + sub * 8);
-        const u32x4_t vnew = *(const u32x4_t*)(row + (long)(nq + fu.nkv + kvh) * DP + sub * 8);
-        float kv8[8];
-        dec_post_head<LPK>(kraw, fu.kw, cs, sn, sub, hd, fu.eps, fu.use_norm, kv8);
-        const u32x4_t knew = {pack2bf(kv8[0], kv8[1]), pack2bf(kv8[2], kv8[3]), pack2bf(kv8[4], kv8[5]), pack2bf(kv8[6], kv8[7])};
-        const int jn = L - 1;
-#pragma unroll
-        for (int i = 0; i < KU; ++i)
-            if (j0 + grp + i * NG == jn) { kr[i] = knew; vr[i] = vnew; }
-        if (jn >= j0 && jn < j1 && grp == (jn - j0) % NG) {
-            const long off = ((long)bt[jn / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jn % BAGEL_KV_PAGE)) * ldp + (long)kvh * DP + sub * 8;
-            *(u32x4_t*)(fu.kpool + off) = knew;
-            *(u32x4_t*)(fu.vpool + off) = vnew;
-        }
-    }
-    // two passes over the KU keys held in registers: all scores first, then ONE max per head, so the accumulators are
-    // never rescaled (the online form costs 8 extra multiplies per key and head on a VALU-bound kernel)
-    float sc[KU][G];
-#pragma unroll
-    for (int i = 0; i < KU; ++i) {
-        float kf[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { kf[2 * e] = lo2f(kr[i][e]); kf[2 * e + 1] = hi2f(kr[i][e]); }
-        const bool valid = (j0 + grp + i * NG) < j1;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0 = fmaf(qf[g][2 * e], kf[2 * e], s0);
-                s1 = fmaf(qf[g][2 * e + 1], kf[2 * e + 1], s1);
+            const bool is_k = item == G;
+            const u32x4_t raw = *(const u32x4_t*)(qrow + (long)(is_k ? nq + kvh : kvh * G + item) * DP + sub * 8);
+            float o8[8];
+            dec_post_head<LPK>(raw, is_k ? fu.kw : fu.qw, cs, sn, sub, hd, fu.eps, fu.use_norm, o8);
+            const u32x4_t fin = {pack2bf(o8[0], o8[1]), pack2bf(o8[2], o8[3]), pack2bf(o8[4], o8[5]), pack2bf(o8[6], o8[7])};
+            *(u32x4_t*)(&sm_q[item][sub * 8]) = fin;
+            if (is_k && jn >= j0 && jn < j1) {       // this workgroup owns the new position: K and V into the page slot
+                const long off = ((long)bt[jn / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jn % BAGEL_KV_PAGE)) * ldp + (long)kvh * DP + sub * 8;
+                *(u32x4_t*)(fu.kpool + off) = fin;
+                *(u32x4_t*)(fu.vpool + off) = *(const u32x4_t*)(qrow + (long)(nq + fu.nkv + kvh) * DP + sub * 8);
             }
-            float sv = s0 + s1;
-#pragma unroll
-            for (int off = 1; off < LPK; off <<= 1) sv += __shfl_xor(sv, off, 64);
-            sc[i][g] = valid ? sv : -1e30f;
         }
-    }
-    float mx[G], ls[G], o[G][8];
+        __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        float m = sc[0][g];
-#pragma unroll
-        for (int i = 1; i < KU; ++i) m = fmaxf(m, sc[i][g]);
-        mx[g] = m;                          // -1e30 when this lane group holds no key of the chunk
-        ls[g] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < KU; ++i) {
-        const bool valid = (j0 + grp + i * NG) < j1;
-        float vf[8];       // a key past the range contributes exactly nothing, whatever its (clamped, possibly never-written) slot holds
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { vf[2 * e] = valid ? lo2f(vr[i][e]) : 0.f; vf[2 * e + 1] = valid ? hi2f(vr[i][e]) : 0.f; }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float pw = valid ? exp2f(sc[i][g] - mx[g]) : 0.f;
-            ls[g] += pw;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[g][e] = fmaf(pw, vf[e], o[g][e]);
+        for (int kk = 0; kk < KS; ++kk) {
+            qf[kk] = u32x4_t{0u, 0u, 0u, 0u};
+            if (c16 < G) qf[kk] = *(const u32x4_t*)(&sm_q[c16][32 * kk + 8 * g]);
         }
-    }
-    // merge the lane groups of this wave (group id differs in the lane bits >= log2(LPK))
 #pragma unroll
-    for (int off = LPK; off < 64; off <<= 1) {
+        for (int blk = 0; blk < 2; ++blk) {
+            const int j = jw + 16 * blk + c16;
+            if (j == jn || (j >= j1 && j1 - 1 == jn)) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float m2 = __shfl_xor(mx[g], off, 64);
-            const float l2 = __shfl_xor(ls[g], off, 64);
-            const float mn = fmaxf(mx[g], m2);
-            const float c1 = exp2f(mx[g] - mn), c2 = exp2f(m2 - mn);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float o2 = __shfl_xor(o[g][e], off, 64);
-                o[g][e] = o[g][e] * c1 + o2 * c2;
+                for (int kk = 0; kk < KS; ++kk) kf[blk][kk] = *(const u32x4_t*)(&sm_q[G][32 * kk + 8 * g]);
             }
-            ls[g] = ls[g] * c1 + l2 * c2;
-            mx[g] = mn;
         }
     }
-    if (lane < LPK) {
+
+    // ---- S^T = K Q^T: lane (head c16) gets keys 4g + r of both blocks
+    f32x4_t sacc[2];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+    for (int blk = 0; blk < 2; ++blk) {
+        sacc[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sm_o[wave][g][sub * 8 + e] = o[g][e];
-            if (sub == 0) { sm_m[wave][g] = mx[g]; sm_l[wave][g] = ls[g]; }
+        for (int kk = 0; kk < KS; ++kk)
+            sacc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[blk][kk]), __builtin_bit_cast(bf16x8_t, qf[kk]),
+                                                               sacc[blk], 0, 0, 0);
+    }
+    // ---- V tile -> LDS (row major), while the scores settle
+    bf16_t* svw = sm_v[wave];
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) *(u32x4_t*)(svw + (lane / CPR + RPI * i) * VST + (lane % CPR) * 8) = vr[i];
+    // ---- softmax over the wave's 32 keys, base 2, one max per head
+    float sc[2][4];
+    bool ok[2][4];
+    float mx = -1e30f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ok[blk][r] = (jw + 16 * blk + 4 * g + r) < j1;
+            sc[blk][r] = ok[blk][r] ? sacc[blk][r] * scale_log2e : -1e30f;
+            mx = fmaxf(mx, sc[blk][r]);
         }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // -1e30 when the wave holds no key of the chunk
+    float pw[2][4], ls = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pw[blk][r] = ok[blk][r] ? exp2f(sc[blk][r] - mx) : 0.f;
+            ls += pw[blk][r];
+        }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    const u32x4_t pfrag = {pack2bf(pw[0][0], pw[0][1]), pack2bf(pw[0][2], pw[0][3]), pack2bf(pw[1][0], pw[1][1]), pack2bf(pw[1][2], pw[1][3])};
+    // ---- O^T = V^T P^T: the lane's 8 keys are rows 4g..4g+3 and 16+4g..16+4g+3 of the tile, column = d
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own ds_writes above (other lanes' rows) have landed
+    __builtin_amdgcn_wave_barrier();
+    f32x4_t oacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        const bf16_t* col = svw + 16 * db + c16;
+        unsigned short e[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            e[t] = col[(4 * g + t) * VST];
+            e[4 + t] = col[(16 + 4 * g + t) * VST];
+        }
+        const u32x4_t vfrag = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                               (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+        oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vfrag), __builtin_bit_cast(bf16x8_t, pfrag),
+                                                          f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    // ---- the wave's (max, sum, O) -> LDS (O over its own V tile: every read of the tile is older than these writes), merge
+    float* so = (float*)svw;
+    if (c16 < G) {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) *(f32x4_t*)(so + c16 * DP + 16 * db + 4 * g) = oacc[db];
+        if (g == 0) { sm_m[wave][c16] = mx; sm_l[wave][c16] = ls; }
     }
     __syncthreads();
     for (int idx = tid; idx < G * DP; idx += 256) {
-        const int g = idx / DP, d = idx - g * DP;
-        const float m0 = sm_m[0][g], m1 = sm_m[1][g], m2 = sm_m[2][g], m3 = sm_m[3][g];
+        const int h = idx / DP, d = idx - h * DP;
+        const float m0 = sm_m[0][h], m1 = sm_m[1][h], m2 = sm_m[2][h], m3 = sm_m[3][h];
         const float mn = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         const float c0 = exp2f(m0 - mn), c1 = exp2f(m1 - mn), c2 = exp2f(m2 - mn), c3 = exp2f(m3 - mn);
-        const float acc = sm_o[0][g][d] * c0 + sm_o[1][g][d] * c1 + sm_o[2][g][d] * c2 + sm_o[3][g][d] * c3;
-        const long slot = ((long)b * nq + kvh * G + g) * nsplit + split;
+        const float acc = ((const float*)sm_v[0])[idx] * c0 + ((const float*)sm_v[1])[idx] * c1 + ((const float*)sm_v[2])[idx] * c2 +
+                          ((const float*)sm_v[3])[idx] * c3;
+        const long slot = ((long)b * nq + kvh * G + h) * nsplit + split;
         part_o[slot * DP + d] = acc;
         if (d == 0) {
             part_ml[slot * 2] = mn;
-            part_ml[slot * 2 + 1] = sm_l[0][g] * c0 + sm_l[1][g] * c1 + sm_l[2][g] * c2 + sm_l[3][g] * c3;
+            part_ml[slot * 2 + 1] = sm_l[0][h] * c0 + sm_l[1][h] * c1 + sm_l[2][h] * c2 + sm_l[3][h] * c3;
         }
     }
 }
@@ -861,31 +892,13 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
     }
 }
 
-template <int DP, int CH, bool FUSED>
+template <int DP, bool FUSED>
 static int launch_attn_decode(int G, dim3 grid, hipStream_t stream, const bf16_t* q, long ldq, const bf16_t* kpool, const bf16_t* vpool,
                               long ldp, const int* bt, int bt_stride, const int* kv_len, int len_add, float* po, float* pml, int nq,
                               int nsplit, float sl2e, DecFuse fu) {
-#define DEC_CASE(GG)                                                                                                                   \
-    case GG:                                                                                                                           \
-        hipLaunchKernelGGL((attn_decode_kernel<DP, GG, CH, FUSED>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, \
-                           kv_len, len_add, po, pml, nq, nsplit, sl2e, fu);                                                            \
-        break
-    switch (G) {
-        DEC_CASE(1); DEC_CASE(2); DEC_CASE(3); DEC_CASE(4); DEC_CASE(5); DEC_CASE(6); DEC_CASE(7); DEC_CASE(8);
-        default: return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_decode: GQA group %d > 8", G);
-    }
-#undef DEC_CASE
+    hipLaunchKernelGGL((attn_decode_kernel<DP, FUSED>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, kv_len,
+                       len_add, po, pml, nq, G, nsplit, sl2e, fu);
     return bagel_check_launch("attn_decode_kernel");
-}
-
-// keys per split: 128 (default) or 64 (BAGEL_DEC_CH=64: twice the workgroups, half the serial work per lane group)
-static int decode_chunk() {
-    static int ch = 0;
-    if (ch == 0) {
-        const char* e = getenv("BAGEL_DEC_CH");
-        ch = (e && atoi(e) == 64) ? 64 : DEC_CH;
-    }
-    return ch;
 }
 
 static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
@@ -898,7 +911,7 @@ static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, con
     BAGEL_REQUIRE((ldq % 8) == 0 && (ld_pool % 8) == 0 && (ldo % 4) == 0 && (((uintptr_t)out) & 7) == 0, "attn_decode: leading dims / out alignment");
     BAGEL_REQUIRE((((uintptr_t)q | (uintptr_t)kpool | (uintptr_t)vpool) & 15) == 0, "attn_decode: 16-byte alignment");
     if (batch <= 0 || max_len <= 0) return BAGEL_OK;
-    const int ch = decode_chunk();
+    const int ch = DEC_CH;
     const int nsplit = ceil_div(max_len, ch);
     const float sl2e = softmax_scale * 1.4426950408889634f;
     const dim3 grid(nsplit, nkv, batch);
@@ -906,16 +919,15 @@ static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, con
     DecFuse fu = {};
     if (fuse) fu = *fuse;
     const int G = nq / nkv;
+    BAGEL_REQUIRE(G <= 16, "attn_decode: GQA group %d > 16", G);
     int rc;
-#define DEC_GO(DPV, CHV)                                                                                                           \
-    rc = fuse ? launch_attn_decode<DPV, CHV, true>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
-                                                   len_add, part_o, part_ml, nq, nsplit, sl2e, fu)                                  \
-              : launch_attn_decode<DPV, CHV, false>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
-                                                    len_add, part_o, part_ml, nq, nsplit, sl2e, fu)
-    if (head_dim == 128 && ch == 128) { DEC_GO(128, 128); }
-    else if (head_dim == 128) { DEC_GO(128, 64); }
-    else if (ch == 128) { DEC_GO(64, 128); }
-    else { DEC_GO(64, 64); }
+#define DEC_GO(DPV)                                                                                                              \
+    rc = fuse ? launch_attn_decode<DPV, true>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
+                                              len_add, part_o, part_ml, nq, nsplit, sl2e, fu)                                    \
+              : launch_attn_decode<DPV, false>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
+                                               len_add, part_o, part_ml, nq, nsplit, sl2e, fu)
+    if (head_dim == 128) { DEC_GO(128); }
+    else { DEC_GO(64); }
 #undef DEC_GO
     if (rc != BAGEL_OK) return rc;
     if (head_dim == 128)

@@ -122,10 +122,11 @@ class DecodeSession:
         self.step_ctr = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.inv_freq = eng.model.rotary_emb.inv_freq(dev)
         import os
-        # BAGEL_DECODE_FUSED=1: q/k norm + RoPE + page append inside the attention workgroups (one launch fewer per layer,
-        # bit-identical).  Measured SLOWER on MI355X (3.69 vs 3.61 ms/token at 7B: every workgroup redoes the 7 query heads and
-        # gains a dependent load round), so the two-kernel form stays the default; needs head_dim/2 % 8 == 0.
-        self.fused_attention = os.environ.get("BAGEL_DECODE_FUSED", "0") == "1" and (eng.hd // 2) % 8 == 0
+        # q/k norm + RoPE + page append run in the prologue of the attention workgroups (16-lane groups own one head each, results
+        # handed round through LDS): one launch fewer per layer, bit-identical to the two-kernel form, 3.31 -> 3.23 ms/token under
+        # the profiler at 7B (profiles/r02_decode_mfma_attention.log).  BAGEL_DECODE_FUSED=0 keeps decode_qkv_post as its own launch;
+        # head dims whose rotate half is not a multiple of 8 elements always take that path.
+        self.fused_attention = os.environ.get("BAGEL_DECODE_FUSED", "1") == "1" and (eng.hd // 2) % 8 == 0
         # weight-only INT8 for the four projections of every layer (option; lm_head stays bf16 like the reference's quantised
         # modes keep it): the engine caches the quantised copies next to the bf16 ones
         if weight_quant not in (None, "int8"):
