@@ -15,6 +15,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef BAGEL_GEMV_U4
+#define BAGEL_GEMV_U4 10
+#endif
 #define EPI_NONE 0
 #define EPI_GELU_TANH 1
 #define EPI_SILU 2
@@ -108,7 +111,9 @@ __device__ __forceinline__ void gemv_load_full(u32x4_t (&wa)[U], u32x4_t (&wb)[U
 // by which time the weights have landed.
 template <int MR, int WPP>
 __device__ __forceinline__ void gemv_body(const GemvParams& p) {
-    constexpr int U = 7;   // chunk groups in flight per row: K = 3584 -> exactly one batch, K = 18944 / 4 waves -> 7 + 3
+    // chunk groups in flight per row: K = 3584 -> exactly one batch of 7; split-K (K = 18944 over 4 waves = 10, 10, 10, 7 groups): the
+    // whole quarter row in ONE batch (with 7 + 3 every wave streamed in two bursts with its FMAs in between)
+    constexpr int U = (WPP == 4) ? BAGEL_GEMV_U4 : 7;
     extern __shared__ __attribute__((aligned(16))) unsigned char gemv_smem[];
     bf16_t* xs = (bf16_t*)gemv_smem;   // [MR][K]
     __shared__ float red[MR][4];
