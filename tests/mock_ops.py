@@ -270,6 +270,15 @@ def attn_decode_paged(q, kpool, vpool, block_table, kv_len, len_add, max_len, pa
     return out
 
 
+def attn_decode_fused(qkv, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len, max_len, part_o, part_ml, out, batch, nq, nkv,
+                      head_dim, head_dim_padded, eps, use_norm, softmax_scale):
+    """decode_qkv_post + attn_decode_paged in one launch; the projection buffer stays untouched (the kernel works on copies in LDS)."""
+    tmp = qkv.clone()
+    decode_qkv_post(tmp, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len, batch, nq, nkv, head_dim, head_dim_padded, eps, use_norm)
+    return attn_decode_paged(tmp, kpool, vpool, block_table, kv_len, 1, max_len, part_o, part_ml, out, batch, nq, nkv, head_dim_padded,
+                             softmax_scale)
+
+
 def decode_advance(next_tok, cur_tok32, tokens_out, pos, kv_len, step, batch, max_steps):
     s_ = int(step[0])
     cur_tok32.copy_(next_tok.to(torch.int32))
@@ -453,7 +462,7 @@ def chw_f32_to_u8(src):
 _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
-          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged",
+          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused",
           "decode_advance", "require_gpu_f32", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8"]
 
