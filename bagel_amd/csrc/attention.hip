@@ -44,6 +44,10 @@
 //   without barrier and DMA 987.  PMC (profiles/r02_attn_pmc_64row_v2.txt): the lone wave is issuing 55 % of its cycles -- ~5.8 cycles
 //   per instruction (v_exp_f32 is quarter rate) = ~2 500 cycles per tile against 2 048 of matrix time -- so it cannot be matrix-bound
 //   even with zero stalls, and it stalls another 45 %.  Removed as well; the two-waves-per-SIMD kernel below stays the only one.
+//   Four waves per SIMD (two workgroups per CU) is not reachable from here: the wave's state is 64 O^T accumulators + two 32-register
+//   score sets + 32 Q registers + fragment windows = 256 unified registers (the second __launch_bounds__ argument is waves per SIMD,
+//   not workgroups per CU), so shrinking the LDS ring to 64 KB (separate 2-slot K and V^T rings: written, compiled, dropped) buys no
+//   occupancy; 128 registers would need 16-row waves, i.e. twice the LDS fragment traffic per FLOP.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
