@@ -211,6 +211,39 @@ def gemv_w8(A, Wq, scale, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=N
     return C
 
 
+def quantize_rows_mxfp4(W):
+    """bf16 [N, K] (K % 128 == 0) -> (u8 [N, K/2] E2M1 codes, two per byte; u8 [N, 16 * ceil(K/512)] E8M0 block scales in device order);
+    see bagel_quantize_rows_mxfp4 / oracle/mxfp4.py."""
+    _req(W, BF16, "quantize_rows_mxfp4.W")
+    N, K = W.shape
+    if K % 128:
+        raise BagelHipError(f"quantize_rows_mxfp4: K={K} is not a multiple of 128")
+    q = torch.empty((N, K // 2), dtype=torch.uint8, device=W.device)
+    s = torch.empty((N, ((K // 128 + 3) // 4) * 16), dtype=torch.uint8, device=W.device)
+    check(lib().bagel_quantize_rows_mxfp4(_ptr(W), W.stride(0), _ptr(q), q.stride(0), _ptr(s), s.stride(0), N, K, _stream()),
+          "bagel_quantize_rows_mxfp4")
+    return q, s
+
+
+def gemv_w4(A, Wq, Ws, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0):
+    """``gemv`` on MXFP4 weights (codes + block scales of ``quantize_rows_mxfp4``): activations quantised to FP8 inside the kernel, the
+    product on the block-scaled MFMA; M <= 4 rows; see bagel_gemv_w4_bf16."""
+    _req(A, BF16, "gemv_w4.A"); _req(Wq, torch.uint8, "gemv_w4.Wq"); _req(Ws, torch.uint8, "gemv_w4.Ws"); _req(C, BF16, "gemv_w4.C")
+    N, K = Wq.shape[0], Wq.shape[1] * 2
+    if A.shape[-1] != K or Ws.shape[0] != N:
+        raise BagelHipError("gemv_w4: shape mismatch")
+    if M is None:
+        M = A.shape[0]
+    if residual is not None:
+        _req(residual, BF16, "gemv_w4.residual")
+    if norm_w is not None:
+        _req(norm_w, BF16, "gemv_w4.norm_w")
+    check(lib().bagel_gemv_w4_bf16(_ptr(A), _ld(A), _ptr(Wq), Wq.stride(0), _ptr(Ws), Ws.stride(0), _ptr(bias), _ptr(residual),
+                                   _ld(residual) if residual is not None else 0, _ptr(C), _ld(C), _ptr(norm_w), float(eps), M, N, K,
+                                   epilogue, _stream()), "bagel_gemv_w4_bf16")
+    return C
+
+
 KV_PAGE = 64          # tokens per KV page (BAGEL_KV_PAGE in decode.hip)
 DECODE_CHUNK = 64     # smallest keys-per-split the library may use (DEC_CH 128, or 64 with BAGEL_DEC_CH=64): sizes the workspace
 

@@ -158,6 +158,20 @@ int bagel_gemv_w8_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldw, 
                        const void* R, int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M,
                        int32_t N, int32_t K, int32_t epilogue, bagel_stream_t stream);
 
+/* MXFP4 weight-only projections for the decode path: the 4-bit counterpart of the reference's bitsandbytes NF4 load mode
+ * (app.py:114-125) on the chip's own block-scaled MFMA operand -- an OPTION that changes results.  OCP-MX FP4: codes E2M1, two per
+ * byte (element 2i in the low nibble of byte i), one E8M0 scale byte per 32 elements along K (2^(b-127), b = max(exp(max|w|) - 2, 0)),
+ * stored per row in groups of 16 bytes = 4 k-steps of 128 elements: byte 4q + j = block q of step j (oracle/mxfp4.py permute_scales).
+ * cols % 128 == 0; ldq_bytes % 16 == 0 and >= cols/2; lds_bytes % 4 == 0 and >= 16 * ceil(cols / 512). */
+int bagel_quantize_rows_mxfp4(const void* W, int64_t ldw, void* q, int64_t ldq_bytes, void* scales, int64_t lds_bytes, int32_t rows,
+                              int32_t cols, bagel_stream_t stream);
+/* C[M <= 4, N] = epilogue(A W^T) on those weights: the A rows are (optionally RMS-normalised, modeling_qwen2.py:54-59, and) quantised
+ * to FP8 e4m3 with one scale per row inside the kernel, the product runs on v_mfma_scale_f32_16x16x128_f8f6f4, epilogues none / bias /
+ * residual / SwiGLU16 (3) with the rounding points of bagel_gemm_bf16.  Replaces the F.linear sites of bagel_gemv_bf16 at Lq = 1. */
+int bagel_gemv_w4_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldq_bytes, const void* Ws, int64_t lds_bytes, const void* bias,
+                       const void* R, int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N,
+                       int32_t K, int32_t epilogue, bagel_stream_t stream);
+
 /* FP8 (OCP e4m3) path for the gen-expert GEMMs of the denoise forward (the MI355X-native counterpart of the reference's quantised
  * load modes, app.py:114-131 -- an OPTION that changes results; bf16 is the default).
  * quantize: q[r,k] = e4m3_rne(x[r,k] / scale[r]), scale[r] = max_k |x[r,k]| / 448.  cols % 8 == 0; ldq in bytes. */
