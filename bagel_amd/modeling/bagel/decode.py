@@ -129,23 +129,33 @@ class DecodeSession:
         self.fused_attention = os.environ.get("BAGEL_DECODE_FUSED", "1") == "1" and (eng.hd // 2) % 8 == 0
         # weight-only INT8 for the four projections of every layer (option; lm_head stays bf16 like the reference's quantised
         # modes keep it): the engine caches the quantised copies next to the bf16 ones
-        if weight_quant not in (None, "int8"):
-            raise NotImplementedError(f"weight_quant={weight_quant!r}: only 'int8' (row-wise absmax, W8A16) is built")
+        # weight-only quantisation of the four projections of every layer (options; lm_head stays bf16 like the reference's quantised
+        # modes keep it): "int8" = row-wise absmax W8A16, de-quantised on the VALU (csrc/quant.hip); "mxfp4" = OCP-MX FP4 blocks of 32
+        # with E8M0 scales x FP8 activations on the block-scaled MFMA (csrc/mxfp4.hip), the counterpart of the reference's NF4 mode.
+        # The engine caches the quantised copies next to the bf16 ones.
+        if weight_quant not in (None, "int8", "mxfp4"):
+            raise NotImplementedError(f"weight_quant={weight_quant!r}: 'int8' (row-wise absmax, W8A16) and 'mxfp4' (OCP-MX FP4, W4A8) are built")
         self.weight_quant = weight_quant
-        self.w8 = self._quantised_weights() if weight_quant else None
-        if self.w8 is not None and (eng.H % 16 or eng.I % 16 or (nq * dp) % 16):
+        if weight_quant == "int8" and (eng.H % 16 or eng.I % 16 or (nq * dp) % 16):
             raise NotImplementedError("int8 weights need row lengths that are multiples of 16")
+        if weight_quant == "mxfp4":
+            if eng.H % 128 or eng.I % 128 or (nq * dp) % 128:
+                raise NotImplementedError("mxfp4 weights need row lengths that are multiples of 128")
+            if B > 4:
+                raise NotImplementedError("mxfp4 weights: the projection kernel quantises at most 4 activation rows per launch (batch <= 4)")
+        self.w8 = self._quantised_weights() if weight_quant else None
         self.steps_done = 0
         self.graph = None
         self.graph_error = None
 
     def _quantised_weights(self):
         eng = self.eng
-        cache = getattr(eng, "_w8_cache", None)
+        attr = "_w8_cache" if self.weight_quant == "int8" else "_w4_cache"
+        cache = getattr(eng, attr, None)
         if cache is None:
-            cache = [dict(wqkv=ops.quantize_rows_i8(P.wqkv[0]), wo=ops.quantize_rows_i8(P.wo[0]), wgu=ops.quantize_rows_i8(P.wgu[0]),
-                          wd=ops.quantize_rows_i8(P.wd[0])) for P in eng.layers]
-            eng._w8_cache = cache
+            qz = ops.quantize_rows_i8 if self.weight_quant == "int8" else ops.quantize_rows_mxfp4
+            cache = [dict(wqkv=qz(P.wqkv[0]), wo=qz(P.wo[0]), wgu=qz(P.wgu[0]), wd=qz(P.wd[0])) for P in eng.layers]
+            setattr(eng, attr, cache)
         return cache
 
     # ---- the launch sequence of one token (no host-dependent values: safe to capture) ---------------------------
@@ -164,7 +174,9 @@ class DecodeSession:
         h = self.h
 
         def proj(inp, w, out, norm_w=None, **kw):
-            if isinstance(w, tuple):        # (u8 weights, fp32 row scales)
+            if isinstance(w, tuple):        # int8: (u8 weights, fp32 row scales); mxfp4: (E2M1 codes, E8M0 block scales)
+                if self.weight_quant == "mxfp4":
+                    return ops.gemv_w4(inp, w[0], w[1], out, norm_w=norm_w, eps=eng.eps, M=B, **kw)
                 return ops.gemv_w8(inp, w[0], w[1], out, norm_w=norm_w, eps=eng.eps, M=B, **kw)
             if fused:
                 return ops.gemv(inp, w, out, norm_w=norm_w, eps=eng.eps, **kw)

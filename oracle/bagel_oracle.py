@@ -63,9 +63,28 @@ def fp8_gen_weight_ptrs(W):
             and any(k.endswith(f"{n}_moe_gen.weight") or (f"mlp_moe_gen.{n}.weight" in k) for n in names)}
 
 
+# MXFP4 option of the product's text decode (generate_text(weight_quant="mxfp4"), oracle/mxfp4.py): data_ptr()s of the weight tensors
+# whose linear runs on OCP-MX FP4 weights x FP8 activations (the und expert's q/k/v/o/gate/up/down projections; lm_head stays bf16).
+# Only meaningful around the decode loop: the product's prefill uses the bf16 weights.
+MXFP4_WEIGHT_PTRS = set()
+
+
+def mxfp4_decode_weight_ptrs(W):
+    names = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+    return {v.data_ptr() for k, v in W.items() if "language_model.model.layers." in k and any(k.endswith(f".{n}.weight") for n in names)}
+
+
 @_explicit_casts
 def linear(x, w, b=None):
     """F.linear under bf16 autocast: inputs cast to the (bf16) weight dtype, bf16 result."""
+    if MXFP4_WEIGHT_PTRS and w.data_ptr() in MXFP4_WEIGHT_PTRS:
+        from oracle import mxfp4 as MX
+        x2 = x.to(w.dtype).reshape(-1, x.shape[-1])
+        cache = linear.__dict__.setdefault("_mx", {})
+        key = (w.data_ptr(), w._version)
+        if key not in cache:
+            cache[key] = MX.quantize_mxfp4(w)
+        return MX.gemv_w4(x2, *cache[key], bias=None if b is None else b.to(w.dtype)).reshape(*x.shape[:-1], w.shape[0])
     if FP8_WEIGHT_PTRS and w.data_ptr() in FP8_WEIGHT_PTRS:
         from oracle import fp8 as F8
         x2 = x.to(w.dtype).reshape(-1, x.shape[-1])

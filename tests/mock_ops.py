@@ -279,6 +279,24 @@ def attn_decode_fused(qkv, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len
                              softmax_scale)
 
 
+def quantize_rows_mxfp4(W):
+    from oracle import mxfp4
+    q, sb = mxfp4.quantize_mxfp4(W)
+    return q, mxfp4.permute_scales(sb)
+
+
+def gemv_w4(A, Wq, Ws, C, *, bias=None, residual=None, epilogue=0, M=None, norm_w=None, eps=0.0):
+    from oracle import mxfp4
+    N, ng = Ws.shape
+    nk = Wq.shape[1] * 2 // 128
+    v = Ws.view(N, ng // 16, 4, 4)                                   # [row, group, q, j] -> natural [row, k-step = 4 group + j, q]
+    sb = v.permute(0, 1, 3, 2).reshape(N, -1, 4)[:, :nk].reshape(N, nk * 4)
+    M = A.shape[0] if M is None else M
+    C[:M] = mxfp4.gemv_w4(A[:M], Wq, sb, bias=bias, residual=None if residual is None else residual[:M], swiglu=epilogue == 3,
+                          norm_w=norm_w, eps=eps)
+    return C
+
+
 def decode_advance(next_tok, cur_tok32, tokens_out, pos, kv_len, step, batch, max_steps):
     s_ = int(step[0])
     cur_tok32.copy_(next_tok.to(torch.int32))
@@ -462,7 +480,7 @@ def chw_f32_to_u8(src):
 _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
-          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused",
+          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4",
           "decode_advance", "require_gpu_f32", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8"]
 

@@ -602,3 +602,55 @@ def test_generate_text_int8_weights_option():
     finally:
         model.decode_weight_quant = None
     assert torch.equal(c, a)
+
+
+def test_generate_text_mxfp4_weights_option():
+    """weight_quant='mxfp4' (OCP-MX FP4 weights x FP8 activations on the block-scaled MFMA; the projection itself is pinned to its
+    restatement in tests/test_mxfp4_gpu.py): same loop, graph replay == eager bit for bit, first-step logits within the 4-bit noise of
+    the bf16 path and not equal to it, model-level switch."""
+    from oracle.configs import TINY_D128 as cfg
+    from tests.util_models import product_model
+    model, _ = product_model(cfg)
+    cache, lens, ropes, start = _context(model, cfg, ["a small red cube"])
+    ref = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=1, end_token_id=None, **start)
+    ref_logits = model._last_decode_session.logits.float().clone()
+    one = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=1, end_token_id=None, weight_quant="mxfp4", **start)
+    q_logits = model._last_decode_session.logits.float().clone()
+    assert one.shape == ref.shape and torch.isfinite(q_logits).all()
+    err = ((q_logits - ref_logits).norm() / ref_logits.norm()).item()
+    assert 1e-3 < err < 0.4, f"mxfp4-weight logits vs bf16-weight logits: rel_l2 {err:.3g}"
+    # ... and against the oracle's decode step with the MXFP4 scheme switched into the same seven linears per layer (bf16 prefill on
+    # both sides): the whole quantised step, not only the projection, is what the restatement says
+    from oracle import bagel_oracle as O
+    from oracle.configs import NEW_TOKEN_IDS_TINY, StubTokenizer
+    from tests.util_models import oracle_weights
+    W, _ = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    gi, l2, r2 = model.prepare_prompts([0], [0], ["a small red cube"], StubTokenizer(cfg["llm"]["vocab_size"]), NEW_TOKEN_IDS_TINY)
+    oc = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi)
+    O.MXFP4_WEIGHT_PTRS = O.mxfp4_decode_weight_ptrs(W)
+    try:
+        st = {k: torch.as_tensor(v).cpu() for k, v in start.items()}
+        _, ologits = O.generate_text(W, cfg, oc, st["packed_key_value_indexes"], st["key_values_lens"], st["packed_start_tokens"],
+                                     st["packed_query_position_ids"], 1, return_logits=True)
+    finally:
+        O.MXFP4_WEIGHT_PTRS = set()
+    ol = torch.as_tensor(ologits[0]).float().reshape(q_logits.shape)
+    e2 = ((q_logits.cpu() - ol).norm() / ol.norm()).item()
+    e_bf16 = ((ref_logits.cpu() - ol).norm() / ol.norm()).item()
+    # tolerance: as for the FP8 gen expert (tests/test_fp8_gpu.py) -- an e4m3 activation code next to a rounding boundary flips on a
+    # bf16-level difference of its input (one code step = 6 % of the element), a noise source the bf16 path does not have.  Measured
+    # 4.4e-2 on MI355X, with the bf16 path 2.1e-1 away from the same restatement.
+    assert e2 < 8e-2 and e2 < 0.5 * e_bf16, f"mxfp4 decode step vs its restatement: rel_l2 {e2:.3g} (bf16 path vs the same restatement: {e_bf16:.3g})"
+    n = 8
+    a = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, weight_quant="mxfp4", use_graph=True, **start)
+    sess = model._last_decode_session
+    assert sess.weight_quant == "mxfp4" and sess.graph is not None
+    b = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, weight_quant="mxfp4", use_graph=False, **start)
+    assert torch.equal(a, b)
+    model.decode_weight_quant = "mxfp4"
+    try:
+        c = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, **start)
+    finally:
+        model.decode_weight_quant = None
+    assert torch.equal(c, a)

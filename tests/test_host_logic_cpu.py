@@ -253,6 +253,38 @@ def test_understanding_flow_host_path_matches_oracle(monkeypatch, name, batch):
             assert rel(cache.key_cache[i], oc.key_cache[i]) < 1.5e-2 and rel(cache.value_cache[i], oc.value_cache[i]) < 1.5e-2
 
 
+def test_decode_mxfp4_weights_host_path_matches_oracle(monkeypatch):
+    """generate_text(weight_quant='mxfp4') on the host logic: which weights are quantised (the und expert's fused qkv / o / interleaved
+    gate+up / down; lm_head stays bf16), RMSNorm fused into the quantising projection, residual and SwiGLU epilogues -- vs the oracle's
+    decode loop with the MXFP4 scheme switched into exactly those linears (oracle/mxfp4.py).  Prefill stays bf16 on both sides."""
+    from oracle import bagel_oracle as O
+    mock_ops.install(monkeypatch)
+    cfg = CFGS["tiny_d128"]
+    model = cpu_model(cfg)
+    W, _ = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    pi, l2, r2 = model.prepare_prompts([0], [0], ["what is in the picture"], tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(new_cache(cfg), **pi)
+    oc = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **pi)
+    si = model.prepare_start_tokens(l2, r2, NEW_TOKEN_IDS_TINY)
+    n = 5
+    plain, _ = O.generate_text(W, cfg, copy.deepcopy(oc), si["packed_key_value_indexes"], si["key_values_lens"], si["packed_start_tokens"],
+                               si["packed_query_position_ids"], 1, return_logits=True)
+    O.MXFP4_WEIGHT_PTRS = O.mxfp4_decode_weight_ptrs(W)
+    try:
+        assert len(O.MXFP4_WEIGHT_PTRS) == 7 * L
+        otoks, ologits = O.generate_text(W, cfg, oc, si["packed_key_value_indexes"], si["key_values_lens"], si["packed_start_tokens"],
+                                         si["packed_query_position_ids"], n, return_logits=True)
+    finally:
+        O.MXFP4_WEIGHT_PTRS = set()
+    toks = model.generate_text(past_key_values=cache, max_length=n, do_sample=False, end_token_id=None, use_graph=False, weight_quant="mxfp4", **si)
+    assert model._last_decode_session.weight_quant == "mxfp4"
+    _tokens_match(toks, otoks, ologits, "tiny_d128 mxfp4")
+    first = model._last_decode_session
+    assert first.w8 is not None and len(first.w8) == L
+
+
 def cpu_model_and_vae(cfg):
     from bagel_amd.factory import build_bagel
     W, VW = oracle_weights(cfg)

@@ -252,3 +252,38 @@ def test_fp8_restatement_known_answers():
     z = torch.zeros(2, 16)
     qz, sz = F8.quantize_rows_fp8(z)
     assert sz.tolist() == [1.0, 1.0] and int(qz.view(torch.uint8).max()) == 0
+
+
+def test_mxfp4_restatement_known_answers():
+    """oracle/mxfp4.py (the CPU statement of the product's decode weight_quant='mxfp4' option) against the OCP Microscaling v1.0
+    definitions on hand-checkable values: the E2M1 grid and its round-to-nearest-even ties, the shared exponent max(exp(amax) - 2, 0),
+    saturation at 6 X, nibble packing, the device scale order, and that de-quantisation inverts quantisation on representable blocks."""
+    from oracle import mxfp4 as MX
+    grid = torch.tensor([0, .5, 1, 1.5, 2, 3, 4, 6, -.5, -6, .25, .75, 1.25, 1.75, 2.5, 3.5, 5, 7, -7] + [0] * 13)
+    w = (grid * 0.125).to(torch.bfloat16)[None]                        # amax = 7/8 -> exponent 126 -> scale byte 124 -> X = 1/8
+    q, sb = MX.quantize_mxfp4(w)
+    assert sb.tolist() == [[124]]
+    d = MX.dequant_mxfp4(q, sb)[0] / 0.125
+    assert d[:19].tolist() == [0, .5, 1, 1.5, 2, 3, 4, 6, -.5, -6, 0, 1, 1, 2, 2, 4, 4, 6, -6]      # ties to even, saturation
+    codes = [int(q[0, i // 2] >> (4 * (i % 2))) & 0xF for i in range(10)]
+    assert codes == [0, 1, 2, 3, 4, 5, 6, 7, 9, 15]                    # element 2i in the low nibble of byte i, sign in bit 3
+    z = torch.zeros(1, 32, dtype=torch.bfloat16)
+    qz, sz = MX.quantize_mxfp4(z)
+    assert sz.tolist() == [[0]] and int(qz.max()) == 0
+    # a block whose values are all on the grid of its own scale survives exactly
+    g = torch.Generator().manual_seed(0)
+    vals = MX.E2M1[torch.randint(0, 8, (4, 96), generator=g)] * torch.where(torch.rand(4, 96, generator=g) < 0.5, -1.0, 1.0)
+    vals[:, 0::32] = 6.0                                               # pin every block's amax so its scale is 2^0 * 2^k
+    w2 = (vals * torch.tensor([1.0, 0.25, 8.0, 2.0 ** -10])[:, None]).to(torch.bfloat16)
+    q2, s2 = MX.quantize_mxfp4(w2)
+    assert torch.equal(MX.dequant_mxfp4(q2, s2), w2.float())
+    # device order of the scale bytes: byte 4q + j of a 16-byte group = block q of k-step j
+    nat = torch.arange(2 * 5 * 4, dtype=torch.uint8).view(2, 20)      # 5 k-steps -> 2 groups, 3 padded steps
+    dev = MX.permute_scales(nat)
+    assert dev.shape == (2, 32)
+    assert dev[0, :16].tolist() == [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]
+    assert dev[0, 16:].tolist() == [16, 127, 127, 127, 17, 127, 127, 127, 18, 127, 127, 127, 19, 127, 127, 127]
+    # the projection restatement reduces to the plain product when nothing is lost: grid weights, activations that are exact in e4m3
+    x = torch.tensor([[1.0, -2.0, 0.5, 448.0] + [0.0] * 92]).to(torch.bfloat16)
+    y = MX.gemv_w4(x, q2, s2)
+    assert torch.equal(y, (x.float() @ w2.float().t()).to(torch.bfloat16))
