@@ -19,6 +19,16 @@
 #define EPI_SWIGLU16 3
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+#ifndef BAGEL_W4_NT
+#define BAGEL_W4_NT 0      // a wave-wide fragment load covers 16 rows x 64 B: the half lines of two consecutive k-steps meet in L1/L2 -- nt measured slower (26.6 vs 23.6 us gate+up)
+#endif
+__device__ __forceinline__ u32x4_t w4_ld(const void* p) {
+#if BAGEL_W4_NT
+    return __builtin_nontemporal_load((const u32x4_t*)p);
+#else
+    return *(const u32x4_t*)p;
+#endif
+}
 
 // ---- quantiser: one wave per row, a lane per 32-element block ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mxfp4_quantize_rows_kernel(const bf16_t* __restrict__ w, long ldw, unsigned char* __restrict__ q,
@@ -98,7 +108,101 @@ struct W4Params {
 
 #define W4_MAX_M 4
 
-template <bool SWIGLU>
+// One activation row -> (Qwen2RMSNorm, und cast points) -> FP8 e4m3 with one scale, by the whole workgroup.  IN_REGS: a thread keeps its
+// chunks of the row in registers (K / 8 chunks over the workgroup: 2 per thread at K = 3584 / 256 threads, 5 at K = 18944 / 512): one
+// load round and two workgroup reductions; otherwise the row is re-read from L2 per pass.  Ends with a barrier.
+template <int W4_CPT>
+__device__ __forceinline__ void w4_load_row(const bf16_t* __restrict__ ar, const bf16_t* __restrict__ norm_w, int K, int tid, int nthr,
+                                            u32x4_t (&xv)[W4_CPT], u32x4_t (&gv)[W4_CPT]) {
+    const int nch = K >> 3;
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < W4_CPT; ++i) {
+        const int c = tid + i * nthr;
+        xv[i] = c < nch ? *(const u32x4_t*)(ar + (long)c * 8) : zero;
+    }
+    if (norm_w) {
+#pragma unroll
+        for (int i = 0; i < W4_CPT; ++i) {
+            const int c = tid + i * nthr;
+            gv[i] = c < nch ? *(const u32x4_t*)(norm_w + (long)c * 8) : zero;
+        }
+    }
+}
+template <bool IN_REGS, int W4_CPT>
+__device__ __forceinline__ void w4_quantise_row(const bf16_t* __restrict__ ar, const bf16_t* __restrict__ norm_w, float eps, int K,
+                                                unsigned char* __restrict__ dst, float* __restrict__ scale_out, float* __restrict__ red,
+                                                int tid, int nthr, u32x4_t (&xv)[W4_CPT], u32x4_t (&gv)[W4_CPT], bool preloaded) {
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const int nch = K >> 3;
+    const int niter = IN_REGS ? W4_CPT : (nch + nthr - 1) / nthr;
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    if (IN_REGS && !preloaded) w4_load_row<W4_CPT>(ar, norm_w, K, tid, nthr, xv, gv);
+    float inv = 1.f;
+    if (norm_w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < niter; ++i) {
+            const int c = tid + i * nthr;
+            const u32x4_t v = IN_REGS ? xv[IN_REGS ? i : 0] : (c < nch ? *(const u32x4_t*)(ar + (long)c * 8) : zero);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float a = lo2f(v[e]), b = hi2f(v[e]); ss += a * a + b * b; }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int i = 0; i < nw; ++i) tot += red[i];
+        inv = rsqrtf(tot / (float)K + eps);
+        __syncthreads();
+    }
+    auto normed = [&](u32x4_t v, const u32x4_t g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pack2bf(bfround(lo2f(v[e]) * inv) * lo2f(g[e]), bfround(hi2f(v[e]) * inv) * hi2f(g[e]));
+        return v;
+    };
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < niter; ++i) {
+        const int c = tid + i * nthr;
+        const bool ok = c < nch;
+        u32x4_t v = IN_REGS ? xv[IN_REGS ? i : 0] : (ok ? *(const u32x4_t*)(ar + (long)c * 8) : zero);
+        if (norm_w) {
+            v = normed(v, IN_REGS ? gv[IN_REGS ? i : 0] : (ok ? *(const u32x4_t*)(norm_w + (long)c * 8) : zero));
+            if (IN_REGS) xv[IN_REGS ? i : 0] = v;        // the normalised row replaces the raw one (bf16 pairs)
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo2f(v[e])), fabsf(hi2f(v[e]))));
+    }
+    amax = wave_max(amax);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    float am = 0.f;
+    for (int i = 0; i < nw; ++i) am = fmaxf(am, red[i]);
+    const float sq = am > 0.f ? am / 448.0f : 1.0f;
+    const float qinv = 1.0f / sq;
+    if (tid == 0) *scale_out = sq;
+#pragma unroll
+    for (int i = 0; i < niter; ++i) {
+        const int c = tid + i * nthr;
+        const bool ok = c < nch;
+        u32x4_t v = IN_REGS ? xv[IN_REGS ? i : 0] : (ok ? *(const u32x4_t*)(ar + (long)c * 8) : zero);
+        if (norm_w && !IN_REGS) v = normed(v, ok ? *(const u32x4_t*)(norm_w + (long)c * 8) : zero);
+        u32x2_t o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int wd = 0;
+            wd = __builtin_amdgcn_cvt_pk_fp8_f32(lo2f(v[2 * h]) * qinv, hi2f(v[2 * h]) * qinv, wd, false);
+            wd = __builtin_amdgcn_cvt_pk_fp8_f32(lo2f(v[2 * h + 1]) * qinv, hi2f(v[2 * h + 1]) * qinv, wd, true);
+            o[h] = (unsigned)wd;
+        }
+        if (ok) *(u32x2_t*)(dst + (long)c * 8) = o;
+    }
+    __syncthreads();
+}
+
+// W4_CPT: 16-byte activation chunks a thread holds (2: K <= 16 x threads, the K = 3584 projections; 5: the down projection)
+template <bool SWIGLU, int W4_CPT>
 __global__ __launch_bounds__(512) void gemv_w4_kernel(W4Params p) {
     constexpr int KU = 8;                       // 128-deep steps per batch (8 x 16 B of codes per lane in flight), two scale dwords
     constexpr int NACC = SWIGLU ? 2 : 1;
@@ -131,15 +235,20 @@ __global__ __launch_bounds__(512) void gemv_w4_kernel(W4Params p) {
     const unsigned char* sg = p.Ws + (long)(wrow + r) * p.lds + q * 4;
     const unsigned char* su = sg + (long)16 * p.lds;
 
-    // ---- first weight batch goes out before the prologue's reductions (same latency reasoning as gemv_body) ----
+    // ---- issue order = the latency chain (as in gemv_body): (1) the activation chunks and norm weights of row 0, (2) the wave's first
+    //      weight batch, (3) the reductions / quantisation, which wait only for (1) -- loads return in order: had the weights gone
+    //      first, the prologue would have waited for HBM (measured: 23.5 us = 10 + 13.5, purely additive) ----
+    const bool in_regs = (p.K >> 3) <= W4_CPT * nthr;
+    u32x4_t xv[W4_CPT], gv[W4_CPT];
+    if (in_regs) w4_load_row<W4_CPT>(p.A, p.norm_w, p.K, tid, nthr, xv, gv);
     u32x4_t wf[NACC][KU];
     unsigned sc[NACC][KU / 4];
     auto load_batch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int k = (k0 + u < k_hi) ? k0 + u : (k_hi > 0 ? k_hi - 1 : 0);
-            wf[0][u] = ld_stream<u32x4_t>(wg + (long)k * 64);
-            if (SWIGLU) wf[NACC - 1][u] = ld_stream<u32x4_t>(wu + (long)k * 64);
+            wf[0][u] = w4_ld(wg + (long)k * 64);
+            if (SWIGLU) wf[NACC - 1][u] = w4_ld(wu + (long)k * 64);
         }
 #pragma unroll
         for (int g4 = 0; g4 < KU / 4; ++g4) {
@@ -153,64 +262,9 @@ __global__ __launch_bounds__(512) void gemv_w4_kernel(W4Params p) {
     // ---- prologue: the M activation rows -> (RMSNorm) -> FP8 with one scale per row, into LDS ----
     for (int m = 0; m < p.M; ++m) {
         const bf16_t* ar = p.A + (long)m * p.lda;
-        float inv = 1.f;
-        if (p.norm_w) {
-            float ss = 0.f;
-            for (int c = tid; c < (p.K >> 3); c += nthr) {
-                const u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float a = lo2f(v[e]), b = hi2f(v[e]); ss += a * a + b * b; }
-            }
-            ss = wave_sum(ss);
-            if (lane == 0) red[wave] = ss;
-            __syncthreads();
-            float tot = 0.f;
-            for (int i = 0; i < nw; ++i) tot += red[i];
-            inv = rsqrtf(tot / (float)p.K + p.eps);
-            __syncthreads();
-        }
-        float amax = 0.f;
-        for (int c = tid; c < (p.K >> 3); c += nthr) {
-            const u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
-            u32x4_t g = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-            if (p.norm_w) g = *(const u32x4_t*)(p.norm_w + (long)c * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = lo2f(v[e]), b = hi2f(v[e]);
-                if (p.norm_w) { a = bfround(bfround(a * inv) * lo2f(g[e])); b = bfround(bfround(b * inv) * hi2f(g[e])); }
-                amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
-            }
-        }
-        amax = wave_max(amax);
-        if (lane == 0) red[wave] = amax;
-        __syncthreads();
-        float am = 0.f;
-        for (int i = 0; i < nw; ++i) am = fmaxf(am, red[i]);
-        const float s = am > 0.f ? am / 448.0f : 1.0f;
-        const float qinv = 1.0f / s;
-        if (tid == 0) sx[m] = s;
-        for (int c = tid; c < (p.K >> 3); c += nthr) {
-            const u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
-            u32x4_t g = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-            if (p.norm_w) g = *(const u32x4_t*)(p.norm_w + (long)c * 8);
-            u32x2_t o;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float y[4];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float a = lo2f(v[2 * h + e]), b = hi2f(v[2 * h + e]);
-                    if (p.norm_w) { a = bfround(bfround(a * inv) * lo2f(g[2 * h + e])); b = bfround(bfround(b * inv) * hi2f(g[2 * h + e])); }
-                    y[2 * e] = a; y[2 * e + 1] = b;
-                }
-                int wd = 0;
-                wd = __builtin_amdgcn_cvt_pk_fp8_f32(y[0] * qinv, y[1] * qinv, wd, false);
-                wd = __builtin_amdgcn_cvt_pk_fp8_f32(y[2] * qinv, y[3] * qinv, wd, true);
-                o[h] = (unsigned)wd;
-            }
-            *(u32x2_t*)(xq + (long)m * p.K + (long)c * 8) = o;
-        }
-        __syncthreads();
+        unsigned char* dst = xq + (long)m * p.K;
+        if (in_regs) w4_quantise_row<true, W4_CPT>(ar, p.norm_w, p.eps, p.K, dst, &sx[m], red, tid, nthr, xv, gv, m == 0);
+        else w4_quantise_row<false, W4_CPT>(ar, p.norm_w, p.eps, p.K, dst, &sx[m], red, tid, nthr, xv, gv, false);
     }
 
     // ---- the weight stream ----
@@ -308,22 +362,32 @@ extern "C" int bagel_gemv_w4_bf16(const void* A, int64_t lda, const void* Wq, in
     const int ncb = sw ? N / 32 : N / 16;
     const int nk = K / 128;
     // K splits: enough waves to cover the chip (~2 000) while a split keeps at least one scale group (4 steps)
+    // K splits (waves sharing one column block): as few as give every wave ONE 8-step batch -- it is issued ahead of the prologue and
+    // nothing else of the weight stream has to wait for a reduction -- at most 8 (the down projection: 148 steps = 3 batches per wave)
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("BAGEL_W4_SPLIT");     // tuning knob; the default is what bench.py measures
+        force = (e && atoi(e) > 0) ? atoi(e) : 0;
+    }
     int S = 1;
-    while (S < 8 && ncb * S < 2000 && nk / (2 * S) >= 4) S *= 2;
+    while (S < 8 && nk > 8 * S) S *= 2;
+    if (force) S = force;
+    while (S > 1 && nk / S < 1) S /= 2;
     p.split = S;
     const int nw = S > 4 ? S : 4;
     const int grid = ceil_div(ncb, nw / S);
     const size_t xq_bytes = ((size_t)M * K + 15) & ~(size_t)15;
     const size_t smem = xq_bytes + (S > 1 ? (size_t)nw * (sw ? 2 : 1) * 64 * sizeof(f32x4_t) : 0);
     BAGEL_REQUIRE(smem <= 150 * 1024, "gemv_w4: M*K = %d bytes of activations do not fit the LDS", M * K);
-    if (sw) {
-        if (smem > 48 * 1024)
-            if (int rc = bagel_enable_lds((const void*)gemv_w4_kernel<true>, 150 * 1024, "gemv_w4_kernel<true>")) return rc;
-        hipLaunchKernelGGL((gemv_w4_kernel<true>), dim3(grid), dim3(64 * nw), smem, stream, p);
-    } else {
-        if (smem > 48 * 1024)
-            if (int rc = bagel_enable_lds((const void*)gemv_w4_kernel<false>, 150 * 1024, "gemv_w4_kernel<false>")) return rc;
-        hipLaunchKernelGGL((gemv_w4_kernel<false>), dim3(grid), dim3(64 * nw), smem, stream, p);
-    }
+    const bool few = (K / 8) <= 2 * 64 * nw;            // the row fits 2 chunks per thread
+#define W4_GO(SWV, CPTV)                                                                                                              \
+    do {                                                                                                                              \
+        if (smem > 48 * 1024)                                                                                                         \
+            if (int rc = bagel_enable_lds((const void*)gemv_w4_kernel<SWV, CPTV>, 150 * 1024, "gemv_w4_kernel")) return rc;          \
+        hipLaunchKernelGGL((gemv_w4_kernel<SWV, CPTV>), dim3(grid), dim3(64 * nw), smem, stream, p);                                   \
+    } while (0)
+    if (sw) { if (few) W4_GO(true, 2); else W4_GO(true, 5); }
+    else { if (few) W4_GO(false, 2); else W4_GO(false, 5); }
+#undef W4_GO
     return bagel_check_launch("gemv_w4_kernel");
 }

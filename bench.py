@@ -50,7 +50,7 @@ def parse():
                     help="t2i = BASELINE configs[2]/[3] (the headline metric); edit = configs[4] image-edit (VAE enc + ViT + 3-forward CFG)")
     ap.add_argument("--no-taylorseer", action="store_true", help="skip the extra enable_taylorseer=True measurement")
     ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
-    ap.add_argument("--no-int8", action="store_true", help="understanding leg: skip the extra weight_quant='int8' decode")
+    ap.add_argument("--no-int8", action="store_true", help="understanding leg: skip the extra weight_quant='int8' / 'mxfp4' decodes")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra gen_weight_quant='fp8' measurement")
     ap.add_argument("--no-edit", action="store_true", help="skip the extra configs[4] measurement (one image-edit request per GPU)")
     ap.add_argument("--only-understanding", action="store_true", help="debug only: skip the text->image leg (result flagged invalid)")
@@ -462,23 +462,27 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     dt = t3 - t2
     # option: row-wise INT8 layer weights (the analogue of the reference's quantised load modes; changes results) -- reported
     # beside the bf16 number, never as it
-    w8 = None
-    if UB == 1 and not args.no_int8:
+    def quantised_decode(mode, weights):
         try:
-            cache8, lens8, ropes8, _ = prefill()
-            st8 = model.prepare_start_tokens(lens8, ropes8, ids)
-            model.generate_text(past_key_values=cache8, max_length=8, do_sample=False, end_token_id=None, weight_quant="int8", **st8)
-            cache8, lens8, ropes8, _ = prefill()
-            st8 = model.prepare_start_tokens(lens8, ropes8, ids)
+            c8, l8, r8, _ = prefill()
+            s8 = model.prepare_start_tokens(l8, r8, ids)
+            model.generate_text(past_key_values=c8, max_length=8, do_sample=False, end_token_id=None, weight_quant=mode, **s8)
+            c8, l8, r8, _ = prefill()
+            s8 = model.prepare_start_tokens(l8, r8, ids)
             fence()
             t4 = time.perf_counter()
-            model.generate_text(past_key_values=cache8, max_length=n, do_sample=False, end_token_id=None, weight_quant="int8", **st8)
+            model.generate_text(past_key_values=c8, max_length=n, do_sample=False, end_token_id=None, weight_quant=mode, **s8)
             fence()
             dt8 = time.perf_counter() - t4
-            w8 = {"value": n / dt8, "unit": "tokens/s", "decode_ms_per_token": dt8 / n * 1e3, "weights": "row-wise absmax INT8 (W8A16), lm_head bf16",
-                  "note": "weight_quant='int8' option (changes results): not the headline metric"}
+            return {"value": n / dt8, "unit": "tokens/s", "decode_ms_per_token": dt8 / n * 1e3, "weights": weights,
+                    "note": f"weight_quant='{mode}' option (changes results): not the headline metric"}
         except Exception as e:
-            w8 = {"error": repr(e)}
+            return {"error": repr(e)}
+    w8 = w4 = None
+    if UB == 1 and not args.no_int8:
+        w8 = quantised_decode("int8", "row-wise absmax INT8 (W8A16, de-quantised on the VALU), lm_head bf16")
+        # the 4-bit counterpart of the reference's NF4 load mode: OCP-MX FP4 weights x FP8 activations on the block-scaled MFMA
+        w4 = quantised_decode("mxfp4", "OCP-MX FP4 E2M1 blocks of 32 with E8M0 scales (W4A8 on v_mfma_scale_f32_16x16x128_f8f6f4), lm_head bf16")
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -502,7 +506,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
             "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
             "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer", "cpu_baseline": cpu,
-            "int8_weights": w8,
+            "int8_weights": w8, "mxfp4_weights": w4,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_decode_traffic() if (UB == 1 and args.und_image == 980) else None,
                          "kernel": "gemv_kernel (decode step)",
