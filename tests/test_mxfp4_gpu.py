@@ -26,6 +26,8 @@ def test_quantize_rows_mxfp4_bit_exact(rows, cols):
 @pytest.mark.parametrize("mode", ["plain", "bias", "residual", "swiglu", "norm", "norm_swiglu"])
 @pytest.mark.parametrize("M,N,K", [(1, 64, 128), (1, 4608, 3584), (2, 3584, 3584), (1, 3584, 18944), (1, 37888, 3584), (4, 512, 1024)])
 def test_gemv_w4_matches_restatement(M, N, K, mode):
+    if N == 37888 and mode not in ("swiglu", "norm_swiglu"):
+        pytest.skip("the gate+up shape only carries the SwiGLU epilogues in the model (and its CPU restatement takes 10 s)")
     g = torch.Generator().manual_seed(N + K + M)
     x = (torch.randn(M, K, generator=g) * 1.5).to(BF16)
     W = (torch.randn(N, K, generator=g) * K ** -0.5).to(BF16)
