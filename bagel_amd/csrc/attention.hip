@@ -67,6 +67,7 @@ struct AttnParams {
     const int* vt_ctx_col;
     int nq, nkv, causal;
     int batch, nqt;          // samples, 256-row query tiles per sample (from max_lq)
+    int qsplit;              // interleaved query-tile sets per (sample, KV head) pair: 8 / gcd(pairs, 8), see the kernel
     float scale_log2;
 };
 
@@ -113,15 +114,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- XCD-aware work mapping ----
+    // All workgroups of one (sample, KV head) pair share its K / V^T through one XCD's L2, so pairs are dealt to the 8 XCDs (block id & 7).
+    // When the pairs do not fill the XCDs evenly (batch-1 prefill: 4 pairs -> 4 idle XCDs; the 3-stream edit forward: 12 pairs -> 2/2/2/2/1/1/1/1)
+    // every pair is split into p.qsplit interleaved sets of query tiles ("virtual pairs") so that their number is a multiple of 8.
     const int grp = p.nq / p.nkv;
-    const int nbpp = grp * p.nqt;
-    const int npairs = p.batch * p.nkv;
+    const int nqs = (p.nqt + p.qsplit - 1) / p.qsplit;       // query tiles per virtual pair
+    const int nbpp = grp * nqs;
+    const int nvp = p.batch * p.nkv * p.qsplit;
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
-    const int pair = (kk / nbpp) * 8 + xcd;
-    if (pair >= npairs) return;
+    const int vp = (kk / nbpp) * 8 + xcd;
+    if (vp >= nvp) return;
     const int w = kk % nbpp;
+    const int pair = vp / p.qsplit;
     const int b = pair / p.nkv, g = pair % p.nkv;
-    const int h = g * grp + w % grp, qt = w / grp;
+    const int qts = (w / grp) * p.qsplit + vp % p.qsplit;    // this workgroup's query tile, ascending
+    if (qts >= p.nqt) return;
+    // causal: the last query tile of a sample walks the most key tiles -- hand the heavy tiles out first (longest-processing-time order)
+    const int h = g * grp + w % grp, qt = p.causal ? p.nqt - 1 - qts : qts;
 
     const int q0 = p.cu_q[b];
     const int Lq = (p.q_end ? p.q_end[b] : p.cu_q[b + 1]) - q0;
@@ -511,9 +520,14 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     p.nq = nq; p.nkv = nkv; p.causal = causal;
     p.batch = batch; p.nqt = ceil_div(max_lq, 256);
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    const int nbpp = (nq / nkv) * p.nqt;
-    const int pairs_per_xcd = ceil_div((long)batch * nkv, 8);
-    const dim3 grid(8 * pairs_per_xcd * nbpp), block(512);
+    const int npairs = batch * nkv;
+    int gcd8 = 8;
+    while (npairs % gcd8) gcd8 >>= 1;
+    p.qsplit = 8 / gcd8;
+    while (p.qsplit > 1 && p.qsplit > p.nqt) p.qsplit >>= 1;
+    const int nbpp = (nq / nkv) * ceil_div(p.nqt, p.qsplit);
+    const int vp_per_xcd = ceil_div((long)npairs * p.qsplit, 8);
+    const dim3 grid(8 * vp_per_xcd * nbpp), block(512);
     if (head_dim == 128) {
         constexpr int smem = 3 * (64 * 256 + 128 * 128);
         if (int rc = bagel_enable_lds((const void*)attn_fwd_kernel<128>, smem, "attn_fwd_kernel<128>")) return rc;
