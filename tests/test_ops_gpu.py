@@ -310,6 +310,11 @@ ATTN_CASES = [
     ([300, 257], [64, 0], 4, 2, 64, False),          # D=64 path (tiny config, padded heads)
     ([9, 120], [3, 70], 2, 2, 64, True),
     ([1026], [32], 28, 4, 128, False),               # 7B head layout, 512^2-sized latent block
+    # (sample, KV head) pair counts that do not fill the 8 XCDs: every pair is dealt out as 8 / gcd(pairs, 8) interleaved query-tile sets
+    ([1400], [300], 8, 4, 128, True),                # 4 pairs -> 2 sets of the 6 query tiles; causal: heaviest tiles first
+    ([700, 1100, 257], [64, 0, 500], 4, 4, 128, False),   # 12 pairs -> 2 sets, ragged tile counts (3 / 5 / 2)
+    ([900], [10], 3, 1, 128, True),                  # 1 pair -> 8 sets, fewer query tiles (4) than sets
+    ([600, 300, 513, 256, 1030], [0, 40, 0, 7, 0], 4, 2, 64, False),   # 10 pairs -> 4 sets, D = 64
 ]
 
 
