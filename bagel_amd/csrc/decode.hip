@@ -925,6 +925,10 @@ static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, con
     if (fuse) fu = *fuse;
     const int G = nq / nkv;
     BAGEL_REQUIRE(G <= 16, "attn_decode: GQA group %d > 16", G);
+    // FUSED prologue: one 16-byte-per-lane group per item (G query heads + the new key), 4 waves x 64 / (DP / 8) groups, one round
+    BAGEL_REQUIRE(!fuse || G + 1 <= 4 * (64 / (head_dim / 8)),
+                  "attn_decode_fused: GQA group %d + the new key do not fit the %d prologue groups at padded head_dim %d (use decode_qkv_post + attn_decode_paged)",
+                  G, 4 * (64 / (head_dim / 8)), head_dim);
     int rc;
 #define DEC_GO(DPV)                                                                                                              \
     rc = fuse ? launch_attn_decode<DPV, true>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \

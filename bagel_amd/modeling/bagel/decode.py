@@ -126,7 +126,10 @@ class DecodeSession:
         # handed round through LDS): one launch fewer per layer, bit-identical to the two-kernel form, 3.31 -> 3.23 ms/token under
         # the profiler at 7B (profiles/r02_decode_mfma_attention.log).  BAGEL_DECODE_FUSED=0 keeps decode_qkv_post as its own launch;
         # head dims whose rotate half is not a multiple of 8 elements always take that path.
-        self.fused_attention = os.environ.get("BAGEL_DECODE_FUSED", "1") == "1" and (eng.hd // 2) % 8 == 0
+        # The fused prologue serves head dims 32 / 64 / 128 and needs one 16-byte-lane group per item (G query heads + the new key) out of
+        # the 4 x 64 / (dp / 8) groups of a workgroup (G <= 15 at a padded head_dim of 128); everything else takes the two-kernel form.
+        self.fused_attention = (os.environ.get("BAGEL_DECODE_FUSED", "1") == "1" and eng.hd in (32, 64, 128)
+                                and nq // nkv + 1 <= 4 * (64 // (dp // 8)))
         # weight-only INT8 for the four projections of every layer (option; lm_head stays bf16 like the reference's quantised
         # modes keep it): the engine caches the quantised copies next to the bf16 ones
         # weight-only quantisation of the four projections of every layer (options; lm_head stays bf16 like the reference's quantised

@@ -34,8 +34,12 @@ class PackedWeights(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _signature(self):
-        sig = [(t.data_ptr(), t._version) for t in self.parameters()]
-        sig += [(t.data_ptr(), t._version) for t in self.buffers()]
+        # inference tensors (model built / loaded / moved under torch.inference_mode()) keep no version counter and cannot be
+        # rewritten in place outside inference mode: their storage pointer is the whole signature
+        def one(t):
+            return (t.data_ptr(), 0 if t.is_inference() else t._version)
+        sig = [one(t) for t in self.parameters()]
+        sig += [one(t) for t in self.buffers()]
         return hash(tuple(sig))
 
     def _packed_fresh(self):

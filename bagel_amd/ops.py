@@ -60,9 +60,11 @@ def default_gemm_variant(M, N, K):
     # combinations variant 4 does not instantiate and to the plain 256x256 kernel (variant 1) when K % 64 != 0.  Small-M
     # launches (prefill of a short prompt, decode, time embedder) keep the 128x128 tile so the grid still covers the chip.
     if M >= 2048 and N >= 512:
-        # fewer than half a round of 256x256 tiles on a long K (SigLIP fc2 at a 980^2 image: 100 tiles, K = 4304): the 128x128 kernel puts 351
-        # workgroups on the chip instead -- 92 vs 136 us (tools/gemm_prefill_shapes.py); every other prefill / edit shape stays on variant 4
-        if -(-M // 256) * -(-N // 256) <= 128 and K >= 2048:
+        # fewer than half a round of 256x256 tiles on a long K that the ping-pong kernel cannot take (K % 64 != 0 -> the plain 256x256 kernel):
+        # SigLIP fc2 at a 980^2 image, 100 tiles, K = 4304 -- the 128x128 kernel puts 351 workgroups on the chip instead, 92 vs 136 us
+        # (tools/gemm_prefill_shapes.py).  Only that measured case: the LLM's prefill / edit projections (K % 64 == 0) stay on variant 4 at
+        # every M, so neighbouring prompt lengths share one kernel and one accumulation order.
+        if -(-M // 256) * -(-N // 256) <= 128 and K >= 2048 and K % 64 != 0:
             return 0
         return 4
     return 0

@@ -724,3 +724,24 @@ def test_packed_weights_follow_a_reload_through_the_parent(monkeypatch):
             p.data.copy_(sd[k])
     model.language_model.invalidate_packed()
     assert all(torch.equal(a, b) for a, b in zip(prefill(model), want1))
+
+
+def test_model_built_under_inference_mode_runs(golden, monkeypatch):
+    """Inference tensors keep no version counter: the packed-weight signature (modeling/packed.py) must not read `_version`
+    on them -- every public entry point calls _check_packed, so a model built, loaded or moved inside torch.inference_mode()
+    would otherwise fail with 'Inference tensors do not track version counter'."""
+    mock_ops.install(monkeypatch)
+    cfg = TINY
+    g = golden("tiny_t2i")
+    with torch.inference_mode():
+        model = cpu_model(cfg)
+        assert all(p.is_inference() for p in model.parameters())
+        tok = StubTokenizer(cfg["llm"]["vocab_size"])
+        gi, _, _ = model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+        cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+        sig = model.language_model._signature()
+        cache2 = model.forward_cache_update_text(new_cache(cfg), **gi)          # second call: signature compared, packed copies kept
+        assert model.language_model._signature() == sig
+    for i in range(cfg["llm"]["num_hidden_layers"]):
+        assert rel(cache.key_cache[i], g["key_cache"][i]) < 1e-2
+        assert torch.equal(cache.key_cache[i], cache2.key_cache[i])
