@@ -48,8 +48,9 @@ def cache_from_flat(meta, flat):
     return cache
 
 
-def broadcast_cache(cache, src=0, group=None, device=None):
-    """Every rank returns a NaiveCache equal to rank ``src``'s.  Two collectives: a small int64 header, then the payload."""
+def broadcast_cache(cache, src=0, group=None, device=None, stats=None):
+    """Every rank returns a NaiveCache equal to rank ``src``'s.  Two collectives: a small int64 header, then the payload.
+    ``stats`` (optional dict) receives ``bytes`` = what this call moved to every rank."""
     rank = dist.get_rank(group)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -67,6 +68,8 @@ def broadcast_cache(cache, src=0, group=None, device=None):
     dist.broadcast(meta, src, group=group)
     meta = meta.cpu()
     L, nkv, hd, dp = (int(x) for x in meta[:4])
+    if stats is not None:
+        stats["bytes"] = stats.get("bytes", 0) + 8 * (1 + meta.numel())
     if nkv == 0:
         return NaiveCache(L)
     total = int(meta[4:].sum())
@@ -75,6 +78,8 @@ def broadcast_cache(cache, src=0, group=None, device=None):
     else:
         flat = flat.to(device)
     dist.broadcast(flat, src, group=group)
+    if stats is not None:
+        stats["bytes"] += flat.numel() * flat.element_size()
     return cache if rank == src else cache_from_flat(meta, flat)
 
 

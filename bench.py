@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="debug only: skip the VAE decode (result flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=1)
+    ap.add_argument("--no-full-depth", action="store_true",
+                    help="cpu_baseline: skip the full-depth Euler step through the oracle (~3 min of host time) and its parity check")
     ap.add_argument("--cpu-port", action="store_true", help="cpu_baseline: time the oracle port even where /root/reference exists")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="no GPU needed: time the CPU baseline on this host (the unmodified reference where /root/reference exists) and print it")
@@ -57,6 +59,9 @@ def parse():
     ap.add_argument("--und-new-tokens", type=int, default=256)
     ap.add_argument("--und-batch", type=int, default=1, help="requests decoded together per GPU (reference: 1, bagel.py:996)")
     ap.add_argument("--und-image", type=int, default=980, help="side of the understanding image (980 -> 4900 ViT tokens)")
+    ap.add_argument("--standins", action="store_true",
+                    help="TEST ONLY (tests/test_parallel_cpu.py): run main()'s own one_step() / fence / timing / JSON line on the CPU with the torch "
+                         "stand-ins of tests/mock_ops.py in place of the launch wrappers, a tiny model and the gloo backend; the line is flagged invalid")
     ap.add_argument("--launch-check", action="store_true",
                     help="debug only: rendezvous + barrier + max-over-ranks timing + the JSON line, no model (gloo when there is no GPU)")
     return ap.parse_args()
@@ -278,7 +283,76 @@ def full_size_parity(cfg, nl, k):
             "rel_l2": float((yc - xr).norm() / xr.norm()), "max_abs": float((yc - xr).abs().max()), "ref_max_abs": float(xr.abs().max())}
 
 
-def cpu_baseline(args, cfg):
+# parity_at_full_depth tolerance on the CFG-combined velocity of one Euler step at 28 layers: 1.5 x the reference's own accumulation-order
+# noise at that depth (tools/full_depth_noise_floor.py -> profiles/r03_full_depth_noise_floor.log), the rule tests/test_wide_gpu.py froze
+# at 2 layers; tests/test_full_depth_gpu.py holds the same constant to a depth-reduced run of the same function.
+FULL_DEPTH_TOL = 6.0e-2
+
+
+def full_depth_step(args, cfg, model, tok, ids, threads, layers=None):
+    """ONE full Euler step of the benchmark workload at 7B DEPTH for ONE 1024^2 sample -- text prefill of the prompt, then the cond and
+    the CFG-text forward through every MoT layer, CFG 4.0, global renorm (bagel.py:757-907) -- through the oracle on this box's host
+    cores WITH THE GPU MODEL'S OWN WEIGHTS (copied off the device), and through the HIP engine on the same inputs: the sequential
+    ``_forward_flow`` and the default stream-batched path inside ``generate_image(num_timesteps=2)`` (one step, dt = 1, so
+    v = x_0 - x_1).  Returns the measured CPU time of the step (SURVEY.md 8d ii: the measured slice of the CPU baseline) and the rel-L2
+    of the CFG-combined velocity.  Checker use of the oracle only."""
+    from oracle import bagel_oracle as O
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    L = model.config.llm_config.num_hidden_layers if layers is None else layers
+    R = args.resolution
+    torch.set_num_threads(threads)
+    t0 = time.time()
+    keep = ("language_model.model.", "time_embedder.", "vae2llm.", "llm2vae.", "latent_pos_embed.")
+    W = {}
+    for k, v in model.state_dict().items():
+        if k.startswith(keep) and not (k.startswith("language_model.model.layers.") and int(k.split(".")[3]) >= L):
+            W[k] = v.detach().to("cpu")
+    t_copy = time.time() - t0
+    ocfg_model = dict(cfg, llm=dict(cfg["llm"], num_hidden_layers=L))
+    gi, lens, ropes = model.prepare_prompts([0], [0], ["p"], tok, ids)
+    li = model.prepare_vae_latent(lens, ropes, [(R, R)], ids)
+    x0 = torch.randn(li["packed_init_noises"].shape, generator=torch.Generator().manual_seed(4242))
+    li["packed_init_noises"] = x0
+    ci = model.prepare_vae_latent_cfg([0], [0], [(R, R)])
+    ts = torch.tensor([1.0] * x0.shape[0])
+    t1 = time.time()
+    ocache = O.forward_cache_update_text(W, ocfg_model, O.OracleCache(L), **gi)
+    t_prefill = time.time() - t1
+    ocfg = dict(cache=O.OracleCache(L), position_ids=ci["cfg_packed_position_ids"], query_indexes=ci["cfg_packed_query_indexes"],
+                key_values_lens=ci["cfg_key_values_lens"], key_value_indexes=ci["cfg_packed_key_value_indexes"])
+    t1 = time.time()
+    v_cpu = O.forward_flow(W, ocfg_model, x0, ts, li, ocache, ocfg, None, 4.0, 1.0, 0.0, "global").float()
+    t_step = time.time() - t1
+    del W
+    # the HIP engine on the same weights and inputs
+    cache = model.forward_cache_update_text(NaiveCache(model.config.llm_config.num_hidden_layers), **gi)
+    kv_err = max(float(((cache.key_cache[i].float().cpu() - ocache.key_cache[i].float()).norm() / ocache.key_cache[i].float().norm())) for i in range(L))
+    ckw = dict(cfg_text_past_key_values=NaiveCache(model.config.llm_config.num_hidden_layers),
+               cfg_text_packed_position_ids=ci["cfg_packed_position_ids"], cfg_text_packed_query_indexes=ci["cfg_packed_query_indexes"],
+               cfg_text_key_values_lens=ci["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=ci["cfg_packed_key_value_indexes"])
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    out = {"what": f"one Euler step (t = 1): cond + CFG-text forward of {L} MoT layers over {x0.shape[0] + 2} tokens on a {lens[0]}-token context, CFG 4.0, "
+                   f"global renorm, 7B shapes, identical weights and inputs: CFG-combined velocity, HIP engine vs oracle (rel-L2)",
+           "layers": L, "cpu_seconds_per_euler_step": t_step, "cpu_seconds_prefill": t_prefill, "weights_copy_seconds": t_copy, "threads": threads,
+           "prefill_kv_rel_l2_max": kv_err, "v_rms": float(v_cpu.pow(2).mean().sqrt()), "tolerance": FULL_DEPTH_TOL}
+    if L == model.config.llm_config.num_hidden_layers:
+        lkw = {k: v for k, v in li.items() if k != "packed_init_noises"}
+        model.language_model.model.enable_taylorseer = False
+        v_seq = model._forward_flow(x_t=x0, timestep=ts, past_key_values=cache, cfg_text_scale=4.0, cfg_renorm_type="global", **ckw, **lkw)
+        out["rel_l2_sequential_forward_flow"] = rel(v_seq.float().cpu(), v_cpu)
+        lat = model.generate_image(past_key_values=cache, num_timesteps=2, cfg_text_scale=4.0, cfg_interval=[0, 1.0], cfg_renorm_min=0.0,
+                                   cfg_renorm_type="global", timestep_shift=3.0, **ckw, **li)
+        v_gpu = x0 - torch.cat([t.float().cpu() for t in lat])
+        out["rel_l2"] = rel(v_gpu, v_cpu)
+        out["path"] = "generate_image(num_timesteps=2): the default stream-batched cond + CFG forward with the marker-row side path"
+    else:
+        # depth-reduced run (tests): the engine stops after L layers, no final norm / llm2vae -- compare the residual stream instead
+        raise NotImplementedError("full_depth_step compares whole-model velocities: build the model with the depth to test")
+    out["within_tolerance"] = bool(out["rel_l2"] <= FULL_DEPTH_TOL and out["rel_l2_sequential_forward_flow"] <= FULL_DEPTH_TOL)
+    return out
+
+
+def cpu_baseline(args, cfg, gpu=None):
     """The reference CPU path timed on this box's host cores, on a bounded sample of the benchmark workload: one MoT decoder
     layer-forward of one 1024^2 sample at 7B shapes (2.15 TFLOP), extrapolated to images/s as 1 / (Euler steps x 2 forwards x
     layers x t_layer).  kind = "reference" (the unmodified reference classes) where /root/reference exists, else "port" (the
@@ -311,16 +385,29 @@ def cpu_baseline(args, cfg):
     steps = args.num_timesteps - 1
     sec_per_image = steps * 2 * llm["num_hidden_layers"] * dt
     fl = _layer_flops(Lq, C, llm["hidden_size"])
+    full = None
+    if gpu is not None and torch.cuda.is_available() and not args.no_full_depth:
+        try:
+            full = full_depth_step(args, cfg, gpu["model"], gpu["tok"], gpu["ids"], threads)
+            sec_per_image = steps * full["cpu_seconds_per_euler_step"]          # measured: a whole Euler step at full depth (cond + CFG)
+        except Exception as e:
+            import traceback
+            full = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
     try:
         config0 = cpu_config0()
     except Exception as e:
         config0 = {"error": repr(e)}
     out = dict(value=1.0 / sec_per_image, unit="images/s", cores=threads, threads=threads, logical_cpus=os.cpu_count(), kind=kind, warmup=1,
-               cpu_tflops=fl / dt / 1e12, seconds_per_layer_forward=dt, parity_at_full_size=parity, config0=config0,
+               cpu_tflops=fl / dt / 1e12, seconds_per_layer_forward=dt, parity_at_full_size=parity, parity_at_full_depth=full, config0=config0,
+               value_from=("one MEASURED Euler step at full depth (cond + CFG forward of all layers, B = 1) x Euler steps" if full and "error" not in full
+                           else "one measured layer-forward x layers x 2 forwards x Euler steps"),
                sample=f"{'unmodified reference (generate_image, 1 Euler step = 2 forwards' if kind == 'reference' else 'oracle MoT decoder layer (gen mode'}, "
                       f"{Lq} query tokens on a {C}-token context, 7B shapes, {nl} layer(s)), after one warm-up pass: {dt:.2f} s per layer-forward on "
                       f"{threads} threads = {fl / dt / 1e12:.2f} TFLOP/s; extrapolated x{llm['num_hidden_layers']} layers x2 forwards x{steps} Euler "
-                      f"steps (glue, prefill and VAE excluded)")
+                      f"steps (glue, prefill and VAE excluded)"
+                      + (f"; and ONE MEASURED Euler step at full depth through the oracle with the GPU model's weights (cond + CFG-text forward of "
+                         f"{full['layers']} layers, B = 1): {full['cpu_seconds_per_euler_step']:.1f} s -> value = 1 / ({steps} x that)"
+                         if full and "error" not in full else ""))
     if "reference_error" in keep:
         out["reference_error"] = keep["reference_error"]
     return out
@@ -600,12 +687,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if args.launch_check:
         return launch_check(args, rank, world, local)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     import torch.distributed as dist
+    cuda = not args.standins
+    if cuda:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if cuda:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from bagel_amd import ops
     from bagel_amd.factory import BAGEL_7B_MOT, NEW_TOKEN_IDS_QWEN25, build_bagel, init_random_
@@ -614,17 +708,40 @@ def main():
     from bagel_amd.parallel import broadcast_cache
 
     cfg = BAGEL_7B_MOT
+    if args.standins:
+        # TEST ONLY: the launch wrappers become the torch stand-ins of tests/mock_ops.py and the model a 2-layer toy, so that THIS
+        # function's sharding, broadcast, fence, timing and JSON assembly run on two gloo ranks without a GPU.  Nothing measured here
+        # is a benchmark number (the line says "valid": false).
+        from tests import mock_ops
+        from oracle.configs import TINY
+        mock_ops.install_permanently()
+        cfg = TINY
+        args.no_taylorseer = args.no_understanding = args.no_fp8 = args.no_edit = args.no_cpu_baseline = True
     model, vae = build_bagel(cfg, device=dev, num_layers=args.layers, with_vae=not args.only_understanding)
     init_random_(model, seed=0)
     if vae is not None:
         init_random_(vae, seed=0)
     model.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device=dev).manual_seed(1))
+    # who is really here: an all-reduce of ones over the job's process group (RCCL on the GPUs), and the collective library's version
+    ranks_seen, rccl_version, backend = 1, None, None
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        backend = dist.get_backend()
+    if cuda:
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:     # reported, never required
+            rccl_version = f"unavailable ({type(e).__name__})"
     L = model.config.llm_config.num_hidden_layers
     B, R, T = args.batch, args.resolution, args.num_timesteps
     g = torch.Generator().manual_seed(1)
-    prompt_ids = torch.randint(0, 151643, (args.prompt_tokens,), generator=g).tolist()
+    prompt_ids = torch.randint(0, min(151643, cfg["llm"]["vocab_size"] - 8), (args.prompt_tokens,), generator=g).tolist()
     tok = FixedTokenizer(prompt_ids)
     ids = NEW_TOKEN_IDS_QWEN25
+    if args.standins:
+        ids = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)     # inside the toy's 512-entry vocabulary
     inf = InterleaveInferencer(model, vae, tok, None, None, ids)
     noise_gen = torch.Generator().manual_seed(42)
     pdim = model.patch_latent_dim
@@ -632,6 +749,8 @@ def main():
     # global noise stream of the whole job; rank r takes rows [r*B, (r+1)*B)
     all_noise = torch.randn(world * B * n_img, pdim, generator=noise_gen)
     my_noise = all_noise[rank * B * n_img:(rank + 1) * B * n_img].to(dev)
+
+    bcast = []          # (start, end, bytes) of every conditioning-KV broadcast
 
     def one_step(taylorseer=False):
         # conditioning context: computed once (rank 0) and broadcast; every sample shares the prompt (gen_images_mp.py:43)
@@ -641,7 +760,19 @@ def main():
         else:
             cache = NaiveCache(L)
         if world > 1:
-            cache = broadcast_cache(cache, src=0)
+            # the one exchange of the data-parallel path: events on the launch stream around the collective --
+            # on rank 0 the prefill is ordered in front of the first event, so the pair brackets the broadcast itself
+            st = {}
+            if cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                cache = broadcast_cache(cache, src=0, stats=st)
+                e1.record()
+                bcast.append((e0, e1, st.get("bytes", 0)))
+            else:
+                t_b = time.perf_counter()
+                cache = broadcast_cache(cache, src=0, stats=st)
+                bcast.append((t_b, time.perf_counter(), st.get("bytes", 0)))
         li = model.prepare_vae_latent(newlens, newrope, [(R, R)] * B, ids)
         li["packed_init_noises"] = my_noise
         ci = model.prepare_vae_latent_cfg([0] * B, [0] * B, [(R, R)] * B)
@@ -711,10 +842,12 @@ def main():
         one_step = edit_step
 
     def fence():
-        torch.cuda.synchronize()
+        if cuda:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if cuda:
+                torch.cuda.synchronize()
 
     if args.only_understanding:
         # child mode (see understanding_subprocess): this process measures configs[1] only
@@ -732,8 +865,11 @@ def main():
         return
     for _ in range(args.warmup):
         one_step()
-    records, orig_gemm, timed_gemm = gemm_profile_hook()
-    ops.gemm = timed_gemm
+    records, orig_gemm = [], ops.gemm
+    if cuda:
+        records, orig_gemm, timed_gemm = gemm_profile_hook()
+        ops.gemm = timed_gemm
+    del bcast[:]
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -741,6 +877,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.gemm = orig_gemm
+    bcast_timed = list(bcast)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -863,6 +1000,13 @@ def main():
                          "traffic": pmc_traffic(names.get(dom, str(dom))) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None, "kernel": names.get(dom, str(dom)), "launches": len(records),
                          "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},
             "outputs_finite": bool(finite),
+            # the job as the collective library saw it (an all-reduce of ones at start-up) and the conditioning-KV broadcast of the timed
+            # steps as rank 0 timed it (HIP events on the launch stream; null at N = 1: there is no exchange)
+            "ranks_seen": ranks_seen, "collective_backend": backend, "rccl_version": rccl_version,
+            "broadcast": None if not bcast_timed else {
+                "calls": len(bcast_timed), "bytes_per_call": bcast_timed[0][2],
+                "ms_per_call": (sum(a.elapsed_time(b) for a, b, _ in bcast_timed) if cuda else sum((b - a) * 1e3 for a, b, _ in bcast_timed)) / len(bcast_timed),
+                "what": "conditioning KV of the shared prompt: rank 0 prefills, one flat bf16 buffer [L][2][rows][nkv*D] + an int64 header to every rank"},
             "understanding": und,
             "edit": edit,
             "taylorseer": ts,
@@ -877,14 +1021,18 @@ def main():
                                           "frac": pf * images / dt / 1e12 / world / PEAK_BF16_TFLOPS, "denoise_pflop_per_image": pf / 1e15}
         if args.workload == "edit":
             out["metric"] = "images/sec (image edit 1024^2, 50-step, 3-forward CFG), 7B-MoT"
-        if args.layers is not None or args.no_vae or R != 1024 or T != 50:
+        if args.layers is not None or args.no_vae or R != 1024 or T != 50 or args.standins:
             out["valid"] = False
             out["note"] = "debug flags reduce the workload: not a benchmark number"
+        if args.standins:
+            out["standins"] = "tests/mock_ops.py torch stand-ins on the CPU, tiny model, gloo: exercises bench.main()'s host logic only"
+            out["latents_checksum"] = [float(x.double().sum()) for x in latents]
         if world > 1:
             out["cpu_baseline"] = None      # timed on rank 0 at N=1 only: the host cores are shared by N ranks here
         elif not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, cfg)
+                gpu = None if (args.layers is not None or args.workload != "t2i") else dict(model=model, tok=tok, ids=ids)
+                out["cpu_baseline"] = cpu_baseline(args, cfg, gpu)
             except Exception as e:   # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -96,3 +96,16 @@ WIDE7B = dict(
     llm=dict(BAGEL_7B["llm"], vocab_size=512, num_hidden_layers=2),
     vit=TINY["vit"], vae=_VAE_TINY, bagel=TINY["bagel"], llm2vae_std=0.02,
 )
+
+# BASELINE.json configs[1] (image understanding) at the shapes it actually runs, cut down in DEPTH only: SigLIP so400m WIDTH (1152-d,
+# 16 heads x 72, MLP 4304, patch 14, 70 x 70 learned position table; siglip_navit.py:145-245) at 2 layers on a 980 x 980 image
+# (4900 patches) + the 7B-width LLM of WIDE7B at 2 layers -- tests/golden/wide7b_und.pt (oracle/make_golden_wide_und.py).
+WIDE7B_UND = dict(
+    name="wide7b_und",
+    llm=WIDE7B["llm"],
+    vit=dict(BAGEL_7B["vit"], num_hidden_layers=2),
+    vae=_VAE_TINY, bagel=dict(BAGEL_7B["bagel"]), llm2vae_std=0.02,
+)
+
+# the real VAE (autoencoder.py:340-351) on its own -- tests/golden/vae_full.pt
+VAE_FULL = dict(name="vae_full", vae=BAGEL_7B["vae"])

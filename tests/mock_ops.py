@@ -492,3 +492,11 @@ def install(monkeypatch):
     for n in _NAMES:
         monkeypatch.setattr(ops, n, g[n])
     assert math.isfinite(1.0)
+
+
+def install_permanently():
+    """The same replacement for a whole PROCESS (bench.py --standins: the child ranks of tests/test_parallel_cpu.py)."""
+    from bagel_amd import ops
+    g = globals()
+    for n in _NAMES:
+        setattr(ops, n, g[n])

@@ -1,0 +1,31 @@
+"""GPU: bench.py's ``full_depth_step`` -- one whole Euler step (cond + CFG-text forward, CFG 4.0, global renorm) through the oracle with
+the GPU model's own weights vs the HIP engine -- on a DEPTH-REDUCED 7B-width model (4 MoT layers instead of 28, so the oracle finishes in
+well under a minute on the GPU box's host cores), held to the tolerance the benchmark applies at full depth (bench.FULL_DEPTH_TOL =
+1.5 x the reference's own accumulation-order noise at 28 layers, profiles/r03_full_depth_noise_floor.log).  The 28-layer comparison
+itself runs inside ``bench.py`` (``cpu_baseline.parity_at_full_depth``), where its 2-3 minutes of host time are also the measured
+CPU-baseline slice (SURVEY.md 8d ii)."""
+import argparse
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_euler_step_matches_oracle_at_7b_width_depth_4():
+    import bench
+    from bagel_amd.factory import BAGEL_7B_MOT, build_bagel, init_random_
+    cfg = dict(BAGEL_7B_MOT, llm=dict(BAGEL_7B_MOT["llm"], vocab_size=512))
+    model, _ = build_bagel(cfg, device="cuda", num_layers=4, with_vae=False)
+    init_random_(model, seed=0)
+    model.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device="cuda").manual_seed(1))
+    g = torch.Generator().manual_seed(1)
+    tok = bench.FixedTokenizer(torch.randint(8, 500, (30,), generator=g).tolist())
+    ids = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
+    args = argparse.Namespace(resolution=1024)
+    out = bench.full_depth_step(args, cfg, model, tok, ids, threads=bench.physical_cores())
+    print("depth-4 Euler step parity:", {k: v for k, v in out.items() if k != "what"})
+    assert out["layers"] == 4
+    assert out["prefill_kv_rel_l2_max"] <= 1e-2
+    assert out["rel_l2"] <= bench.FULL_DEPTH_TOL and out["rel_l2_sequential_forward_flow"] <= bench.FULL_DEPTH_TOL, out
+    assert out["within_tolerance"] is True

@@ -184,3 +184,41 @@ def test_bench_self_launches_n_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode != 0 and "WORLD_SIZE" in r2.stderr
+
+
+def test_bench_one_step_on_two_gloo_ranks():
+    """bench.py's ACTUAL main() -- one_step() (prompt prefill on rank 0, conditioning-KV broadcast, rank-sharded seed-42 noise,
+    generate_image with the stream-batched CFG forward, VAE decode), the fence, the max-over-ranks timing and the JSON assembly -- on 2
+    gloo ranks with the torch stand-ins in place of the launch wrappers (``--standins``: test-only mode, line flagged invalid).
+    The line must carry what the first real 8-GPU run will be read by: n_gpus, ranks_seen (an all-reduce of ones), the collective
+    backend, the broadcast's size and time, a whole-job value; and rank 0's samples must be bit-identical to the N = 1 run's (it owns
+    the same rows of the job-global noise stream and the default `global` renorm is per rank, like the reference's torchrun drivers:
+    gen_images_mp.py:127-130,188-190)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    env["OMP_NUM_THREADS"] = "2"
+    common = ["--standins", "--batch", "2", "--resolution", "64", "--num-timesteps", "4", "--prompt-tokens", "6"]
+
+    def run(n, steps, warmup):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", str(warmup)] + common,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+    two = run(2, 2, 1)
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["collective_backend"] == "gloo" and two["valid"] is False
+    assert two["steps"] == 2 and two["warmup"] == 1 and two["scaling"] == "weak" and two["outputs_finite"] is True
+    assert two["config"]["global_batch"] == 4 and two["config"]["parallelism"] == "dp2"
+    assert abs(two["value"] - 4 * 2 / (two["ms_per_step"] * 2 / 1e3)) < 1e-6 * two["value"]          # whole-job images / max-over-ranks time
+    b = two["broadcast"]
+    # 2 layers x (K, V) x 2 samples x 8 prompt rows x (2 KV heads x 64 padded lanes) bf16 + the int64 header (count, L, nkv, hd, dp, 2 lens)
+    assert b["calls"] == 2 and b["bytes_per_call"] == 2 * 2 * 16 * 128 * 2 + 8 * (1 + 4 + 2) and b["ms_per_call"] > 0
+    assert two["cpu_baseline"] is None and two["understanding"] is None
+    one = run(1, 1, 0)
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and one["broadcast"] is None and one["collective_backend"] is None
+    assert one["latents_checksum"] == two["latents_checksum"], "rank 0 of the 2-rank job must reproduce the 1-rank job's samples"
