@@ -86,6 +86,7 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
         kn, vn = k2, v2
         vt, cols, col = None, 0, None
     vt_new, ld_new, vt_new_col = transposed(vn, cq, lq, max_seqlen_q)
+    out = torch.empty_like(q2)
     ctx_start, ctx_end = ck[:-1].contiguous(), (ck[:-1] + nctx).to(torch.int32).contiguous()
     q_start, q_end = cq[:-1].contiguous(), cq[1:].contiguous()
     _check(_L.bagel_attn_varlen_ranges_bf16(

@@ -575,6 +575,84 @@ def attn_varlen(q, k_new, vt_new, out, cu_q, vt_new_col, batch, max_lq, nq, nkv,
     return out
 
 
+class AttnPlan:
+    """Work list of the persistent attention kernel (csrc/attention2.hip) for ONE forward shape: built on the host by the library's
+    planner (``bagel_attn_plan``: pure host code, runs without a GPU), copied to the device once and reused by every layer.
+
+    ``q_start / q_len`` = first row and length of every sample's query (= new key) rows, ``ctx_start / ctx_len`` the same for its
+    context rows (None = no context), ``vt_new_col / vt_ctx_col`` the V^T column of each sample's first key -- all HOST int lists in
+    the layout ``attn_varlen`` uses."""
+
+    def __init__(self, q_start, q_len, vt_new_col, nq, nkv, head_dim, causal, device, ctx_start=None, ctx_len=None, vt_ctx_col=None,
+                 n_workers=None, split_min_tiles=0):
+        import numpy as np
+        B = len(q_len)
+        self.q_start, self.q_len, self.vt_new_col = [int(x) for x in q_start], [int(x) for x in q_len], [int(x) for x in vt_new_col]
+        self.has_ctx = ctx_len is not None and any(int(x) > 0 for x in ctx_len)
+        self.ctx_start = [int(x) for x in ctx_start] if self.has_ctx else [0] * B
+        self.ctx_len = [int(x) for x in ctx_len] if self.has_ctx else [0] * B
+        self.vt_ctx_col = [int(x) for x in vt_ctx_col] if self.has_ctx else [0] * B
+        self.nq, self.nkv, self.head_dim, self.causal = int(nq), int(nkv), int(head_dim), bool(causal)
+        if n_workers is None:
+            n_workers = torch.cuda.get_device_properties(device).multi_processor_count // 8 * 8
+        self.n_workers = int(n_workers)
+        i32 = lambda x: np.ascontiguousarray(np.asarray(x, dtype=np.int32))  # noqa: E731
+        arrs = [i32(self.q_start), i32(self.q_len), i32(self.ctx_start), i32(self.ctx_len), i32(self.vt_new_col), i32(self.vt_ctx_col)]
+        items_max = sum(-(-l // 256) for l in self.q_len) * self.nq + self.n_workers
+        cap = 8 + self.n_workers + 1 + 16 + 16 * items_max + 8 * self.n_workers
+        buf = np.zeros(cap, dtype=np.int32)
+        ptr = lambda a: a.ctypes.data  # noqa: E731
+        check(lib().bagel_attn_plan(ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), B, self.nq,
+                                    self.nkv, int(self.causal), self.n_workers, int(split_min_tiles), ptr(buf), cap), "bagel_attn_plan")
+        self.n_items, self.n_comb, self.n_slots = int(buf[1]), int(buf[2]), int(buf[3])
+        self.off_items, self.off_comb = int(buf[4]), int(buf[5])
+        self.makespan, self.total = int(buf[6]), int(buf[7])
+        used = self.off_comb + 8 * self.n_comb
+        self.host = buf[:used].copy()
+        self.dev = torch.from_numpy(self.host).to(device) if torch.device(device).type == "cuda" else None
+
+    def items(self):
+        """[n_items, 16] host view of the item table (tests)."""
+        return self.host[self.off_items:self.off_items + 16 * self.n_items].reshape(self.n_items, 16)
+
+    def worker_off(self):
+        return self.host[8:8 + self.n_workers + 1]
+
+    def combines(self):
+        return self.host[self.off_comb:self.off_comb + 8 * self.n_comb].reshape(self.n_comb, 8)
+
+
+_ATTN_PARTIALS = {}
+
+
+def _attn_partials(device, n_slots, head_dim):
+    """Shared fp32 workspace of the key-split items (one attention launch at a time per device stream)."""
+    need = n_slots * 256 * (head_dim + 2)
+    key = torch.device(device).index
+    ws = _ATTN_PARTIALS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ATTN_PARTIALS[key] = torch.empty(need, dtype=torch.float32, device=device)
+    return ws
+
+
+def attn_planned(q, k_new, vt_new, out, aplan, softmax_scale, k_ctx=None, vt_ctx=None):
+    """attn_varlen through a prebuilt AttnPlan (persistent kernel, head-per-wave tail tiles, key-split last round)."""
+    for t, n in ((q, "q"), (k_new, "k_new"), (vt_new, "vt_new"), (out, "out")):
+        _req(t, BF16, "attn_planned." + n)
+    if aplan.has_ctx and (k_ctx is None or vt_ctx is None):
+        raise BagelHipError("attn_planned: the plan has context keys but no context tensors were given")
+    if aplan.dev is None or aplan.dev.device != q.device:
+        raise BagelHipError("attn_planned: the plan was not built for this device")
+    part = _attn_partials(q.device, aplan.n_slots, aplan.head_dim) if aplan.n_comb else None
+    check(lib().bagel_attn_planned_bf16(
+        _ptr(q), q.stride(0), _ptr(k_new), k_new.stride(0), _ptr(vt_new), vt_new.stride(0),
+        _ptr(k_ctx) if aplan.has_ctx else None, k_ctx.stride(0) if aplan.has_ctx else 0,
+        _ptr(vt_ctx) if aplan.has_ctx else None, vt_ctx.stride(0) if aplan.has_ctx else 0,
+        _ptr(out), out.stride(0), _ptr(aplan.dev), aplan.n_workers, aplan.n_comb, aplan.off_items, aplan.off_comb, _ptr(part),
+        aplan.head_dim, float(softmax_scale), _stream()), "bagel_attn_planned_bf16")
+    return out
+
+
 def v_transpose(v, vt, cu_rows, col_start, batch, max_len, nkv, head_dim):
     _req(v, BF16, "v_transpose.v"); _req(vt, BF16, "v_transpose.vt")
     check(lib().bagel_v_transpose_bf16(_ptr(v), v.stride(0), _ptr(vt), vt.stride(0), _ptr(cu_rows), _ptr(col_start), batch,

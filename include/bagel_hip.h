@@ -93,6 +93,27 @@ int bagel_attn_varlen_ranges_bf16(const void* q, int64_t ldq, const void* k_new,
                                   int32_t max_lq, int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal,
                                   float softmax_scale, bagel_stream_t stream);
 
+/* The same attention for a caller that holds the sequence lengths on the HOST (the engine's ForwardPlan): a host planner + a persistent
+ * kernel (csrc/attention2.hip).  bagel_attn_plan is pure host code (no device is touched): from per-sample HOST arrays -- first
+ * query / new-key row and length, first context row and length, V^T column starts (the layout of bagel_attn_varlen_bf16) -- it
+ * writes the work list of `n_workers` persistent workgroups (a multiple of 8; the CU count) into `plan` (int32[plan_ints], host
+ * memory):  [0] n_workers [1] n_items [2] n_comb [3] n_slots [4] item table offset [5] combine table offset [6] makespan
+ * [7] total (tile steps), then worker_off[n_workers + 1], items[n_items][16], comb[n_comb][8].  Query tiles of <= 32 rows run in
+ * head-per-wave form (one item serves the whole GQA group); items of a partial last round are split along the key axis when they
+ * span >= split_min_tiles 64-key tiles (0 = default 16) and merged by a combine pass through `n_slots` partial slots of
+ * 256 * (head_dim + 2) floats.  The caller copies the plan to the device once per forward SHAPE (it is the same for every layer)
+ * and launches bagel_attn_planned_bf16 with the device copy; `partials` may be null when n_comb == 0.
+ * Replaces flash_attn_varlen_func at qwen2_navit.py:579-588 / siglip_navit.py:232-241 like bagel_attn_varlen_bf16; items that are
+ * not key-split produce bit-identical results to it. */
+int bagel_attn_plan(const int32_t* q_start, const int32_t* q_len, const int32_t* ctx_start, const int32_t* ctx_len,
+                    const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t nq, int32_t nkv,
+                    int32_t causal, int32_t n_workers, int32_t split_min_tiles, int32_t* plan, int64_t plan_ints);
+int bagel_attn_planned_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
+                            int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx, int64_t ldvt_ctx,
+                            void* out, int64_t ldo, const int32_t* plan_dev, int32_t n_workers, int32_t n_comb,
+                            int32_t off_items, int32_t off_comb, void* partials, int32_t head_dim, float softmax_scale,
+                            bagel_stream_t stream);
+
 /* V[rows][nkv][D] -> V^T[nkv][D][cols] per sample (layout consumed by bagel_attn_varlen_bf16). */
 int bagel_v_transpose_bf16(const void* v, int64_t ld_src, void* vt, int64_t ld_dst, const int32_t* cu_rows,
                            const int32_t* col_start, int32_t batch, int32_t max_len, int32_t nkv, int32_t head_dim,

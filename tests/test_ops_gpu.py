@@ -248,8 +248,10 @@ def test_qknorm_rope(hd, dp, nq, nkv, gen):
 # ------------------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------------------
-def run_attention(q_lens, ctx_lens, nq, nkv, D, causal, seed=0, scale_dim=None):
-    """Builds packed q/k/v (+context), runs v_transpose + attn_varlen, returns (got, ref)."""
+def run_attention(q_lens, ctx_lens, nq, nkv, D, causal, seed=0, scale_dim=None, planned=None):
+    """Builds packed q/k/v (+context), runs v_transpose + attn_varlen, returns (got, ref).
+    ``planned`` = dict(n_workers=, split_min_tiles=): also run the persistent planned kernel on the same device tensors and return
+    (got, ref, got_planned, plan)."""
     B = len(q_lens)
     M, Ctot = sum(q_lens), sum(ctx_lens)
     q, k, v = rnd(M, nq, D, seed=seed + 1), rnd(M, nkv, D, seed=seed + 2), rnd(M, nkv, D, seed=seed + 3)
@@ -296,7 +298,13 @@ def run_attention(q_lens, ctx_lens, nq, nkv, D, causal, seed=0, scale_dim=None):
         kwargs = dict(k_ctx=kc.reshape(Ctot, -1).to(DEV), vt_ctx=vtc, cu_ctx=i32(cu_c), vt_ctx_col=i32(ccol))
     out = torch.full((M, qw), float("nan"), dtype=BF16, device=DEV)
     o.attn_varlen(qkv[:, :qw], qkv[:, qw:qw + kw], vt, out, i32(cu_q), i32(vcol), B, max(q_lens), nq, nkv, D, causal, scale, **kwargs)
-    return out.view(M, nq, D), ref
+    if planned is None:
+        return out.view(M, nq, D), ref
+    ap = o.AttnPlan(cu_q[:-1], q_lens, vcol, nq, nkv, D, causal, DEV, ctx_start=cu_c[:-1] if Ctot > 0 else None,
+                    ctx_len=ctx_lens if Ctot > 0 else None, vt_ctx_col=ccol if Ctot > 0 else None, **planned)
+    out2 = torch.full((M, qw), float("nan"), dtype=BF16, device=DEV)
+    o.attn_planned(qkv[:, :qw], qkv[:, qw:qw + kw], vt, out2, ap, scale, k_ctx=kwargs.get("k_ctx"), vt_ctx=kwargs.get("vt_ctx"))
+    return out.view(M, nq, D), ref, out2.view(M, nq, D), ap
 
 
 ATTN_CASES = [
