@@ -62,8 +62,6 @@ struct Attn2Params {
     const bf16_t* k_ctx; long ldk_ctx;
     const bf16_t* vt_ctx; long ldvt_ctx;
     bf16_t* out; long ldo;
-    const int* worker_off;       // [n_workers + 1]
-    const AttnItem* items;
     float* part;                 // [slots][256 * (D + 2)] fp32
     float scale_log2;
 };
@@ -83,8 +81,45 @@ __device__ __forceinline__ void a2_glds16s(unsigned voff, const void* sbase_unif
 
 #define ATTN2_DEFER_LOG2 8.0f
 
-template <int D>
-__global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
+// Chunk schedules of one pipeline step (a chunk = one MFMA + its fragment read + a slice of VALU work, closed by sched_barrier).  A step has
+// 16 "slots" per phase (D = 64 folds two slots into one chunk).  The 16 softmax slices of tile t (2 scores each: fma, exp2, row-sum add,
+// bf16 pack = 7 VALU) used to sit one per slot in phase A, beside the S^T(t+1) MFMAs, while phase B carried one v_max3 per slot: phase A
+// was ISSUE-bound (~10 instructions per 32-cycle MFMA), phase B had slack.  P(t) is consumed by the PV MFMAs of phase B in quarters
+// (slot 4f .. 4f+3 reads the bf16 fragment built from slices 4f .. 4f+3), so later slices may run inside phase B:
+//   A_SL[s][slot] / B_SL[s][slot] = number of softmax slices executed in that slot (in order);  A_DMA[s][slot] = 1 + the LDS-DMA piece of
+//   tile t+2 issued in that slot of phase A (0 = none; schedule 0 issues all pieces before the phase).
+// Constraint (static_assert below): before phase-B slot m, at least 4 * (m / 4 + 1) slices are done.
+constexpr int A2_NSCHED = 4;
+#define ATTN2_DEFAULT_SCHED 0
+#ifndef A2_WIN
+#define A2_WIN 3          // fragment prefetch distance in chunks (3 .. 6 measured the same in attention.hip; 3 frees four registers)
+#endif
+constexpr int A_SL[A2_NSCHED][16] = {{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
+                                      {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
+                                      {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
+                                      {0, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1}};
+constexpr int B_SL[A2_NSCHED][16] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+                                      {1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+                                      {1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+                                      {1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+constexpr int A_DMA[A2_NSCHED][16] = {{0}, {0}, {1, 2, 3, 4}, {1, 2, 3, 4}};
+constexpr bool a2_sched_ok(int s) {
+    int done = 0;
+    for (int m = 0; m < 16; ++m) done += A_SL[s][m];
+    for (int m = 0; m < 16; ++m) {
+        if (done < 4 * (m / 4 + 1)) return false;
+        done += B_SL[s][m];
+    }
+    return done == 16;
+}
+static_assert(a2_sched_ok(0) && a2_sched_ok(1) && a2_sched_ok(2) && a2_sched_ok(3), "softmax slices must be complete before the PV MFMA that reads them");
+
+template <int D, int SCHED>
+__global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, const int* __restrict__ worker_off,
+                                                        const AttnItem* __restrict__ item_tab) {
+    // (the two tables are separate noalias kernel arguments on purpose: only then does hipcc read them with SCALAR loads -- as members of
+    // `p` they may alias the output stores, every descriptor field becomes a vector load + v_readfirstlane, and hipcc's vmcnt waits for
+    // those loads drain the asm LDS-DMA in the middle of the tile loop)
     constexpr int KS = D / 16;              // k-steps of the QK^T contraction
     constexpr int DB = D / 32;              // 32-row blocks of O^T
     constexpr int KROW = D * 2;             // bytes per K row in LDS
@@ -99,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i_begin = p.worker_off[blockIdx.x], i_end = p.worker_off[blockIdx.x + 1];
+    const int i_begin = worker_off[blockIdx.x], i_end = worker_off[blockIdx.x + 1];
     if (i_begin >= i_end) return;
     const int qi = lane & 31, hi = lane >> 5;
 
@@ -119,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
     int d_i = i_begin, d_t = 0, d_t1 = 0, d_ntc = 0, d_lc = 0, d_ln = 0, d_slot = 0;
     const char *d_kc = nullptr, *d_kn = nullptr, *d_vc = nullptr, *d_vn = nullptr;
     auto d_load = [&](int idx) {
-        const AttnItem* it = p.items + idx;
+        const AttnItem* it = item_tab + idx;
         d_lc = it->l_ctx; d_ln = it->l_new; d_ntc = (d_lc + 63) >> 6; d_t = it->t0; d_t1 = it->t1;
         const long g = it->g;
         d_kc = (const char*)(p.k_ctx + (long)it->kc_row0 * p.ldk_ctx + g * D);
@@ -127,8 +162,16 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
         d_vc = (const char*)(p.vt_ctx + g * D * p.ldvt_ctx + it->vtc_col0);
         d_vn = (const char*)(p.vt_new + g * D * p.ldvt_new + it->vtn_col0);
     };
-    auto issue_next = [&]() -> bool {
-        if (d_i >= i_end) return false;
+    // One 64-key tile = NLK + NLV LDS-DMA pieces per wave.  dma_prepare() resolves the tile under the cursor and advances the cursor; a
+    // regular tile leaves per-piece (uniform base, LDS destination) in scalars for dma_piece(i) -- the lane offsets are the lane constants
+    // koff_* / voff_* --, a segment's ragged LAST tile (per-lane clamped rows) is issued on the spot.  Returns 0 none / 1 deferred / 2 issued.
+    constexpr int NP = NLK + NLV;
+    const char* pc_base[NP];
+    unsigned pc_dst[NP];
+    bool pc_ctx = false;
+    auto dma_piece = [&](int i) { a2_glds16s(i < NLK ? (pc_ctx ? koff_ctx : koff_new) : (pc_ctx ? voff_ctx : voff_new), pc_base[i], pc_dst[i]); };
+    auto dma_prepare = [&](bool defer) -> int {
+        if (d_i >= i_end) return 0;
         const unsigned sb = __builtin_amdgcn_readfirstlane(smem_base + d_slot * STAGE + wave * 1024u);
         const bool is_ctx = d_t < d_ntc;
         const int ti = is_ctx ? d_t : d_t - d_ntc;
@@ -137,51 +180,64 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
         const long ldvt = is_ctx ? p.ldvt_ctx : p.ldvt_new;
         const char* kseg = a2_uniform(is_ctx ? d_kc : d_kn);
         const char* vseg = a2_uniform((is_ctx ? d_vc : d_vn) + (long)ti * 128);
-        const unsigned vo = is_ctx ? voff_ctx : voff_new;
+        pc_ctx = is_ctx;
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) pc_dst[i] = sb + i * (NW * 1024u);
+#pragma unroll
+        for (int i = 0; i < NLV; ++i) {
+            pc_base[NLK + i] = a2_uniform(vseg + (long)i * (8 * NW) * ldvt * 2); pc_dst[NLK + i] = sb + KT_BYTES + i * (NW * 1024u);
+        }
+        int mode = 1;
         if (ti * 64 + 64 <= seglen) {
             const char* kt = a2_uniform(kseg + (long)ti * 64 * ldk * 2);
-            const unsigned ko = is_ctx ? koff_ctx : koff_new;
 #pragma unroll
-            for (int i = 0; i < NLK; ++i) a2_glds16s(ko, kt + (long)i * (RS * NW) * ldk * 2, sb + i * (NW * 1024u));
+            for (int i = 0; i < NLK; ++i) pc_base[i] = a2_uniform(kt + (long)i * (RS * NW) * ldk * 2);
+            if (!defer) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) dma_piece(i);
+                mode = 2;
+            }
         } else {
-            // the segment's last tile: rows past its end re-read the last key (masked in the scores); per-lane offsets
+            // the segment's last tile: rows past its end re-read the last key (masked in the scores); per-lane offsets, issued here
 #pragma unroll
             for (int i = 0; i < NLK; ++i) {
                 int key = ti * 64 + rowk + RS * NW * i;
                 key = key < seglen ? key : seglen - 1;
-                a2_glds16s((unsigned)key * (unsigned)ldk * 2u + kcol, kseg, sb + i * (NW * 1024u));
+                a2_glds16s((unsigned)key * (unsigned)ldk * 2u + kcol, kseg, pc_dst[i]);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < NLV; ++i) a2_glds16s(vo, vseg + (long)i * (8 * NW) * ldvt * 2, sb + KT_BYTES + i * (NW * 1024u));
+            for (int i = NLK; i < NP; ++i) dma_piece(i);
+            mode = 2;
+        }
         d_slot = d_slot == 2 ? 0 : d_slot + 1;
         if (++d_t >= d_t1) {
             ++d_i;
             if (d_i < i_end) d_load(d_i);
         }
-        return true;
+        return mode;
     };
+    auto issue_next = [&]() -> bool { return dma_prepare(false) != 0; };
 
-    // ---- per-lane constants for fragment reads (attention.hip) ----
+    // ---- per-lane constants for fragment reads (attention.hip's layout; here as ONE address per operand) ----
+    // K fragment ks of key block kb sits at  koff0 + kb * 32 * KROW + (((2 ks + hi) ^ kswz) << 4)  and  V^T fragment (db, j) at
+    // voff + db * 4096 + (((2 j + hi) ^ vswz) << 4).  The swizzled chunk index is (hi ^ swz) ^ (2 ks), and koff0 / voff are multiples of the
+    // row size, so the address is  kb0 ^ (ks << 5)  resp.  vb0 ^ (j << 5)  (+ an immediate): two registers instead of KS + 4 address
+    // registers, and still one VALU per fragment read (the xor replaces the add of the ring-slot base, which goes into kb0 / vb0 per step).
     const int quad = (qi >> 2) & 3;
     const int pkey = (qi & 16) | ((((quad & 1) << 1) | (quad >> 1)) << 2) | (qi & 3);
     int kswz;
     if (D == 128) { kswz = pkey & 15; }
     else          { kswz = (pkey >> 1) & 7; }
-    const int koff0 = pkey * KROW;
     const int vswz = (qi >> 1) & 7;
-    const int voff = KT_BYTES + qi * 128;
-    int kch[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kch[ks] = koff0 + (((2 * ks + hi) ^ kswz) << 4);
-    int vch[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) vch[j] = voff + (((2 * j + hi) ^ vswz) << 4);
+    const unsigned kb0 = (unsigned)(pkey * KROW) | ((unsigned)(hi ^ kswz) << 4);
+    const unsigned vb0 = (unsigned)(KT_BYTES + qi * 128) | ((unsigned)((hi ^ vswz) & 7) << 4);
+    static_assert(STAGE % 256 == 0 && KT_BYTES % 128 == 0, "ring slots must keep the low address bits of the fragment offsets free");
 
     constexpr int NK = 2 * KS;                  // K fragments of a tile  (index KS*kb + ks)
     constexpr int NV = DB * 4;                  // V^T fragments of a tile (index 4*db + j)
-    auto kfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx / KS) * 32 * KROW + kch[idx % KS]); };
-    auto vfrag = [&](const char* sb, int idx) { return *(const bf16x8_t*)(sb + (idx >> 2) * 4096 + vch[idx & 3]); };
+    // kbs / vbs = kb0 / vb0 + the byte offset of the ring slot (a multiple of STAGE)
+    auto kfrag = [&](unsigned kbs, int idx) { return *(const bf16x8_t*)(smem + (kbs ^ (unsigned)((idx % KS) << 5)) + (idx / KS) * 32 * KROW); };
+    auto vfrag = [&](unsigned vbs, int idx) { return *(const bf16x8_t*)(smem + (vbs ^ (unsigned)((idx & 3) << 5)) + (idx >> 2) * 4096); };
 
     // ---- prime the tile stream: the first two tiles of this worker ----
     d_load(d_i);
@@ -192,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
 
     int cs = 0;                                 // ring slot of the compute cursor's tile (the tile stream is consumed in order)
     for (int ci = i_begin; ci < i_end; ++ci) {
-        const AttnItem* it = p.items + ci;
+        const AttnItem* it = item_tab + ci;
         const int flags = it->flags;
         const bool hpw = flags & ATTN2_HPW, causal = flags & ATTN2_CAUSAL, partial = flags & ATTN2_PARTIAL;
         const int nrows = it->nrows, C = it->l_ctx, Lnew = it->l_new, t0 = it->t0;
@@ -201,8 +257,8 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
         const int nt_ctx = (C + 63) >> 6;
         // this wave's rows and head: tile form = rows 32*wave.. of head h; head-per-wave form = rows 0.. of head h + wave
         const int wrow0 = hpw ? 0 : 32 * wave;
-        const int hw = hpw ? it->h + wave : it->h;
         const bool live = hpw ? wave < ((flags >> 8) & 255) : wrow0 < nrows;          // wave-uniform
+        const int hw = (hpw && live) ? it->h + wave : it->h;      // (idle waves still load a Q fragment: keep them on a head that exists)
         const int qrel = q_rel0 + wrow0 + qi;                                     // row index inside the sample (causal mask)
         const bool row_ok = wrow0 + qi < nrows;
         bf16x8_t qf[KS];
@@ -211,6 +267,11 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
             const bf16_t* qp = p.q + (long)(q_row0 + rc) * p.ldq + (long)hw * D + 8 * hi;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qp + 16 * ks);
+            // consume the loads HERE: hipcc then waits for them once, in front of the tile loop.  Left to itself it re-inserts counted
+            // waits for them in front of every MFMA of the loop, and its count does not know the asm LDS-DMA: vmcnt(2) inside phase A
+            // would stall every step on the tile that was just requested
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
         }
         f32x16_t o[DB];
 #pragma unroll
@@ -219,7 +280,6 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
             for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f, m_use = 0.f;            // m_run in log2 units
 
-        auto slot_ptr = [&](int s) { return (const char*)smem + s * STAGE; };
         auto next_slot = [&](int s) { return s == 2 ? 0 : s + 1; };
 
         auto mask_tile = [&](f32x16_t (&s)[2], int t) {
@@ -269,17 +329,26 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
         // [row max of sn].  LAST: there is no tile t+1 in THIS item (the stream's next tile belongs to the next item and is not waited for here).
         auto step = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int t, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
+            constexpr bool SPREAD = A_DMA[SCHED][0] != 0 && NP <= 16;      // LDS-DMA pieces inside phase A (not in a LAST step: no phase-A MFMAs)
             if (!LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t+1 have landed
             asm volatile("s_barrier" ::: "memory");          // ... everyone's; and everyone is done with tile t-1
-            const bool issued = issue_next();
-            if (LAST) newer = issued;
-            const char* sbv = slot_ptr(cs);
+            const int dmode = dma_prepare(SPREAD && !LAST);        // 0 nothing left, 1 pieces deferred into phase A, 2 issued
+            const bool issued = dmode == 1;
+            if (LAST) newer = dmode != 0;
+            const unsigned sbv = vb0 + cs * STAGE;
             cs = next_slot(cs);
-            const char* sbk = slot_ptr(cs);
-            if (!live) return;
-            constexpr int WIN = 4;
+            const unsigned sbk = kb0 + cs * STAGE;
+            if (!live) {
+                if (SPREAD && !LAST && issued) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) dma_piece(i);
+                }
+                return;
+            }
+            constexpr int WIN = A2_WIN;
             constexpr int NMA = NK, NMB = NV;
-            constexpr int SPA = 16 / NMA, SPB = 16 / NMB;   // softmax / row-max slices per chunk (1 at D = 128, 2 at D = 64)
+            constexpr int SLOTS = 16 / NMA;                 // schedule slots per chunk (1 at D = 128, 2 at D = 64)
+            constexpr int SPB = 16 / NMB;
             unsigned pw[16];
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             auto softmax_slice = [&](int pi) {
@@ -293,7 +362,12 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
             };
             auto kidx = [&](int j) { return (j & 1) * KS + (j >> 1); };
             auto vidx = [&](int f) { return 4 * (f % DB) + f / DB; };
+            auto pfrag = [&](int f) {
+                u32x4_t v4 = {pw[4 * f], pw[4 * f + 1], pw[4 * f + 2], pw[4 * f + 3]};
+                return __builtin_bit_cast(bf16x8_t, v4);
+            };
             bf16x8_t vf[NV];
+            int done = 0;                                   // softmax slices executed so far (compile-time after unrolling)
             // ---------------- phase A ----------------
             __builtin_amdgcn_sched_barrier(0);
             if (!LAST) {
@@ -312,21 +386,23 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
                     if (m + WIN < NK) kf[m + WIN] = kfrag(sbk, kidx(m + WIN));
                     else if (m + WIN - NK < WIN) vf[m + WIN - NK] = vfrag(sbv, vidx(m + WIN - NK));
 #pragma unroll
-                    for (int u = 0; u < SPA; ++u) softmax_slice(m * SPA + u);
+                    for (int u = 0; u < SLOTS; ++u) {
+                        const int slot = m * SLOTS + u;
+#pragma unroll
+                        for (int c = 0; c < A_SL[SCHED][slot]; ++c) softmax_slice(done++);
+                        if (SPREAD && A_DMA[SCHED][slot] != 0 && A_DMA[SCHED][slot] <= NP) {
+                            if (issued) dma_piece(A_DMA[SCHED][slot] - 1);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < WIN; ++j) vf[j] = vfrag(sbv, vidx(j));
 #pragma unroll
-                for (int m = 0; m < 16; ++m) softmax_slice(m);
-            }
-            bf16x8_t pf[4];
-            l_run += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                for (int slot = 0; slot < 16; ++slot)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                u32x4_t v4 = {pw[4 * f], pw[4 * f + 1], pw[4 * f + 2], pw[4 * f + 3]};
-                pf[f] = __builtin_bit_cast(bf16x8_t, v4);
+                    for (int c = 0; c < A_SL[SCHED][slot]; ++c) softmax_slice(done++);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!LAST) mask_tile(sn, t + 1);
@@ -336,18 +412,22 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
 #pragma unroll
             for (int m = 0; m < NMB; ++m) {
                 const int db = m % DB, jj = m / DB;
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[m], pf[jj], o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[m], pfrag(jj), o[db], 0, 0, 0);
                 if (m + WIN < NV) vf[m + WIN] = vfrag(sbv, vidx(m + WIN));
-                if (!LAST) {
 #pragma unroll
-                    for (int u = 0; u < SPB; ++u) {
-                        const int i = m * SPB + u, kb = i / 8, r = (2 * i) % 16;
+                for (int u = 0; u < SPB; ++u) {
+                    const int slot = m * SPB + u;
+                    if (!LAST) {
+                        const int kb = slot / 8, r = (2 * slot) % 16;
                         mx = fmaxf(fmaxf(mx, sn[kb][r]), sn[kb][r + 1]);
                         asm volatile("" : "+v"(mx));
                     }
+#pragma unroll
+                    for (int c = 0; c < B_SL[SCHED][slot]; ++c) softmax_slice(done++);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            l_run += (acc[0] + acc[1]) + (acc[2] + acc[3]);
             if (!LAST) mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
             __builtin_amdgcn_sched_barrier(0);
             if (!LAST) raise_max(mx);
@@ -357,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p) {
         // prologue: this item's first tile has landed for every wave (each waited before its previous epilogue / after the priming)
         asm volatile("s_barrier" ::: "memory");
         if (live) {
-            const char* sbk = slot_ptr(cs);
+            const unsigned sbk = kb0 + cs * STAGE;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -536,12 +616,17 @@ extern "C" int bagel_attn_plan(const int32_t* q_start, const int32_t* q_len, con
         xcd_vps[best].push_back(i);
         xload[best] += vcost[i];
     }
-    // ---- inside an XCD: its items in rounds of `wpx`, heavy items first inside a virtual pair, snake order between rounds; the
-    //      items of a last partial round are split along the key axis over the idle workers ----
+    // ---- inside an XCD: longest-processing-time dealing of its item stream (virtual pair after virtual pair, heavy items first inside
+    //      one) onto its `wpx` workers -- every item goes to the least loaded worker, which for equal costs is plain round-robin: the 32
+    //      workers then sit on the same (sample, KV head) pair at the same time.  An item that would push its worker more than `slack`
+    //      tile steps past the XCD's mean load is held back; the held-back items are cut along the key axis into contiguous tile ranges
+    //      that fill the workers up to the mean (stream-K over the leftovers, chunks of >= min_chunk tiles), each range a sub-item
+    //      that writes partials. ----
     std::vector<std::vector<AttnItem>> wl(n_workers);
     std::vector<long> wload(n_workers, 0);
     std::vector<AttnComb> combs;
     int n_slots = 0;
+    const int min_chunk = std::max(split_min_tiles / 2, 1);
     for (int x = 0; x < 8; ++x) {
         std::vector<PItem> stream;
         for (int i : xcd_vps[x]) {
@@ -549,45 +634,45 @@ extern "C" int bagel_attn_plan(const int32_t* q_start, const int32_t* q_len, con
             std::stable_sort(v.begin(), v.end(), [](const PItem& a, const PItem& b2) { return a.cost > b2.cost; });
             stream.insert(stream.end(), v.begin(), v.end());
         }
-        const int n = (int)stream.size();
-        const int full = n / wpx, rest = n % wpx;
-        auto worker = [&](int round, int j) { const int lw = (round & 1) ? wpx - 1 - j : j; return lw * 8 + x; };
-        for (int r = 0; r < full; ++r)
-            for (int j = 0; j < wpx; ++j) {
-                const int w = worker(r, j);
-                wl[w].push_back(stream[r * wpx + j].it);
-                wload[w] += stream[r * wpx + j].cost;
+        if (stream.empty()) continue;
+        long tot = 0;
+        for (auto& pi : stream) tot += pi.cost;
+        const long mean = (tot + wpx - 1) / wpx;
+        const long slack = 2;
+        auto least = [&]() { int best = x; for (int j = 1; j < wpx; ++j) if (wload[j * 8 + x] < wload[best]) best = j * 8 + x; return best; };
+        std::vector<PItem> held;
+        for (auto& pi : stream) {
+            const int w = least();
+            const bool splittable = pi.cost >= split_min_tiles && pi.cost >= 2 * min_chunk;
+            if (wload[w] + pi.cost > mean + slack && splittable) { held.push_back(pi); continue; }
+            wl[w].push_back(pi.it);
+            wload[w] += pi.cost;
+        }
+        // the held-back items as one stream of tiles: every cut gives the currently least loaded worker what it lacks to the mean
+        for (auto& pi : held) {
+            const int T = pi.it.t1 - pi.it.t0;
+            std::vector<std::pair<int, int>> cuts;      // (worker, tiles)
+            int left = T;
+            while (left > 0) {
+                const int w = least();
+                long want = mean - wload[w];
+                if (want < min_chunk) want = min_chunk;
+                int n = (int)std::min<long>(want, left);
+                if (left - n < min_chunk) n = left;                     // no crumbs
+                cuts.push_back({w, n});
+                wload[w] += n;
+                left -= n;
             }
-        if (rest > 0) {
-            // least loaded workers first
-            std::vector<int> lws(wpx);
-            for (int j = 0; j < wpx; ++j) lws[j] = j * 8 + x;
-            std::stable_sort(lws.begin(), lws.end(), [&](int a, int b2) { return wload[a] < wload[b2]; });
-            int nsplit = wpx / rest;
-            int next = 0;
-            for (int j = 0; j < rest; ++j) {
-                const PItem& pi = stream[full * wpx + j];
-                const int T = pi.it.t1 - pi.it.t0;
-                int s = std::min(nsplit, T / std::max(split_min_tiles / 2, 1));
-                if (T < split_min_tiles || s < 2) s = 1;
-                if (s == 1) {
-                    const int w = lws[next++];
-                    wl[w].push_back(pi.it);
-                    wload[w] += pi.cost;
-                    continue;
-                }
-                AttnComb c = {pi.it.q_row0, pi.it.nrows, pi.it.h, pi.it.flags, n_slots, s, 0, 0};
-                combs.push_back(c);
-                for (int k = 0; k < s; ++k) {
-                    AttnItem sub = pi.it;
-                    sub.t0 = pi.it.t0 + (int)((long)T * k / s);
-                    sub.t1 = pi.it.t0 + (int)((long)T * (k + 1) / s);
-                    sub.flags |= ATTN2_PARTIAL;
-                    sub.part = n_slots++;
-                    const int w = lws[next++];
-                    wl[w].push_back(sub);
-                    wload[w] += sub.t1 - sub.t0;
-                }
+            if (cuts.size() == 1) { wl[cuts[0].first].push_back(pi.it); continue; }
+            AttnComb c = {pi.it.q_row0, pi.it.nrows, pi.it.h, pi.it.flags, n_slots, (int)cuts.size(), 0, 0};
+            combs.push_back(c);
+            int at = pi.it.t0;
+            for (auto& cw : cuts) {
+                AttnItem sub = pi.it;
+                sub.t0 = at; sub.t1 = at + cw.second; at += cw.second;
+                sub.flags |= ATTN2_PARTIAL;
+                sub.part = n_slots++;
+                wl[cw.first].push_back(sub);
             }
         }
     }
@@ -631,21 +716,32 @@ extern "C" int bagel_attn_planned_bf16(const void* q, int64_t ldq, const void* k
     p.k_ctx = (const bf16_t*)k_ctx; p.ldk_ctx = ldk_ctx;
     p.vt_ctx = (const bf16_t*)vt_ctx; p.ldvt_ctx = ldvt_ctx;
     p.out = (bf16_t*)out; p.ldo = ldo;
-    p.worker_off = plan_dev + 8;
-    p.items = (const AttnItem*)(plan_dev + off_items);
+    const int* worker_off = plan_dev + 8;
+    const AttnItem* items = (const AttnItem*)(plan_dev + off_items);
     p.part = (float*)partials;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const dim3 grid(n_workers), block(512);
-    if (head_dim == 128) {
-        constexpr int smem = 3 * (64 * 256 + 128 * 128);
-        if (int rc = bagel_enable_lds((const void*)attn2_kernel<128>, smem, "attn2_kernel<128>")) return rc;
-        hipLaunchKernelGGL((attn2_kernel<128>), grid, block, smem, stream, p);
-    } else if (head_dim == 64) {
-        constexpr int smem = 3 * (64 * 128 + 64 * 128);
-        hipLaunchKernelGGL((attn2_kernel<64>), grid, block, smem, stream, p);
-    } else {
-        return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_planned: head_dim %d not in {64,128} (pad the head)", head_dim);
+    static int sched = -1;          // chunk schedule (see A_SL / B_SL): BAGEL_ATTN_SCHED overrides the default, for same-box A/B runs
+    if (sched < 0) {
+        const char* e = getenv("BAGEL_ATTN_SCHED");
+        const int v = e ? atoi(e) : ATTN2_DEFAULT_SCHED;
+        sched = (v >= 0 && v < A2_NSCHED) ? v : ATTN2_DEFAULT_SCHED;
     }
+#define A2_GO(DV, SV)                                                                                                              \
+    do {                                                                                                                           \
+        constexpr int smem = 3 * (64 * (DV) * 2 + (DV) * 128);                                                                      \
+        if (int rc = bagel_enable_lds((const void*)attn2_kernel<DV, SV>, smem, "attn2_kernel")) return rc;                          \
+        hipLaunchKernelGGL((attn2_kernel<DV, SV>), grid, block, smem, stream, p, worker_off, items);                                \
+    } while (0)
+#define A2_GO_D(DV)                                                                                                                \
+    do {                                                                                                                           \
+        if (sched == 1) A2_GO(DV, 1); else if (sched == 2) A2_GO(DV, 2); else if (sched == 3) A2_GO(DV, 3); else A2_GO(DV, 0);      \
+    } while (0)
+    if (head_dim == 128) A2_GO_D(128);
+    else if (head_dim == 64) A2_GO_D(64);
+    else return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_planned: head_dim %d not in {64,128} (pad the head)", head_dim);
+#undef A2_GO_D
+#undef A2_GO
     if (int rc = bagel_check_launch("attn2_kernel")) return rc;
     if (n_comb > 0) {
         const AttnComb* cb = (const AttnComb*)(plan_dev + off_comb);

@@ -23,6 +23,10 @@ from ... import ops
 from ..packed import PackedWeights
 
 BF16 = torch.bfloat16
+# attention through the planned persistent kernel (csrc/attention2.hip; default) or the one-tile-per-workgroup kernel (BAGEL_ATTN_PLANNED=0:
+# same-box A/B runs and a cross-check -- items that are not key-split are bit-identical between the two)
+import os as _os
+ATTN_PLANNED = _os.environ.get("BAGEL_ATTN_PLANNED", "1") != "0"
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -452,6 +456,7 @@ class ForwardPlan:
             raise ValueError("position ids do not cover the packed query sequence")
         self.cos, self.sin = cos_sin if cos_sin is not None else ops.rope_table(self.pos_ids, inv_freq)
         self.und_side = False      # see MoTEngine.forward: marker rows through the dense side path
+        self._attn_plans = {}
         # MoT routing
         self.text_idx = self.vae_idx = self.expert = None
         if text_indexes is not None and vae_indexes is not None:
@@ -463,6 +468,28 @@ class ForwardPlan:
             ex[torch.tensor(v, dtype=torch.long)] = 1
             self.expert = ex.to(device)
             self.n_text, self.n_vae = len(t), len(v)
+
+
+def _attn_plan_of(plan, nq, nkv, dp, causal, with_ctx, device):
+    """The persistent attention kernel's work list for this forward shape (ops.AttnPlan): built once, shared by every layer and every
+    denoise step that reuses the ForwardPlan.  Context rows / V^T columns follow NaiveCache._meta's layout."""
+    key = (nq, nkv, dp, bool(causal), bool(with_ctx))
+    ap = plan._attn_plans.get(key)
+    if ap is None:
+        q_start, vcol, c = [], [], 0
+        at = 0
+        for n in plan.q_lens:
+            q_start.append(at); at += n
+            vcol.append(c); c += _ceil_to(max(n, 1), 64)
+        kw = {}
+        if with_ctx:
+            cs, ccol, at, c = [], [], 0, 0
+            for n in plan.ctx_lens:
+                cs.append(at); at += n
+                ccol.append(c); c += _ceil_to(max(n, 1), 64)
+            kw = dict(ctx_start=cs, ctx_len=plan.ctx_lens, vt_ctx_col=ccol)
+        ap = plan._attn_plans[key] = ops.AttnPlan(q_start, plan.q_lens, vcol, nq, nkv, dp, causal, device, **kw)
+    return ap
 
 
 def concat_plans(plans):
@@ -819,9 +846,14 @@ class MoTEngine:
                 if list(cache.lens(li)) != plan.ctx_lens:
                     raise ValueError("key_values_lens does not match the KV cache contents")
                 ctx = cache.ctx_tensors(li)
-            ops.attn_varlen(q_v, k_v, vt, att, plan.cu_q, plan.vt_new_col, plan.B, plan.max_lq, nq, nkv, dp, causal, scale,
-                            k_ctx=None if ctx is None else ctx[0], vt_ctx=None if ctx is None else ctx[1],
-                            cu_ctx=None if ctx is None else ctx[2], vt_ctx_col=None if ctx is None else ctx[3])
+            if ATTN_PLANNED:
+                # persistent kernel on a host-built work list (csrc/attention2.hip): head-per-wave tail tiles, key-split leftovers
+                ap = _attn_plan_of(plan, nq, nkv, dp, causal, ctx is not None, x.device)
+                ops.attn_planned(q_v, k_v, vt, att, ap, scale, k_ctx=None if ctx is None else ctx[0], vt_ctx=None if ctx is None else ctx[1])
+            else:
+                ops.attn_varlen(q_v, k_v, vt, att, plan.cu_q, plan.vt_new_col, plan.B, plan.max_lq, nq, nkv, dp, causal, scale,
+                                k_ctx=None if ctx is None else ctx[0], vt_ctx=None if ctx is None else ctx[1],
+                                cu_ctx=None if ctx is None else ctx[2], vt_ctx_col=None if ctx is None else ctx[3])
             if update:
                 if cache is None:
                     raise ValueError("update_past_key_values=True needs a NaiveCache")

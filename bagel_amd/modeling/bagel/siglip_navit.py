@@ -200,13 +200,23 @@ class SiglipVisionModel(PackedWeights):
             ops.add_table_rows(x, self.vision_model.embeddings.position_embedding.weight.data, pos)
         qw = nh * dp
         scale = P["hd"] ** -0.5
+        from .qwen2_navit import ATTN_PLANNED
+        aplan = None
+        if ATTN_PLANNED:           # the persistent kernel's work list: one per image batch, shared by the 26 layers
+            starts, at = [], 0
+            for l in lens:
+                starts.append(at); at += int(l)
+            aplan = ops.AttnPlan(starts, [int(l) for l in lens], cols, nh, nh, dp, False, dev)
         for L in P["layers"]:
             ops.layernorm(x, L["ln1"][0], L["ln1"][1], h, eps)
             ops.gemm(h, L["wqkv"], qkv, bias0=L["bqkv"])
             if P["rope"] is not None:
                 ops.rope2d(qkv, P["rope"], pos, 2 * nh, P["hd"], dp)       # q heads then k heads
             ops.v_transpose(qkv[:, 2 * qw:], vt, cu, vcol, B, int(max_seqlen), nh, dp)
-            ops.attn_varlen(qkv[:, :qw], qkv[:, qw:2 * qw], vt, att, cu, vcol, B, int(max_seqlen), nh, nh, dp, False, scale)
+            if aplan is not None:
+                ops.attn_planned(qkv[:, :qw], qkv[:, qw:2 * qw], vt, att, aplan, scale)
+            else:
+                ops.attn_varlen(qkv[:, :qw], qkv[:, qw:2 * qw], vt, att, cu, vcol, B, int(max_seqlen), nh, nh, dp, False, scale)
             ops.gemm(att, L["wo"], x, bias0=L["bo"], residual=x)
             ops.layernorm(x, L["ln2"][0], L["ln2"][1], h, eps)
             ops.gemm(h, L["fc1"][0], mid, bias0=L["fc1"][1], epilogue=ops.EPI_GELU_TANH)

@@ -593,12 +593,12 @@ class AttnPlan:
         self.ctx_len = [int(x) for x in ctx_len] if self.has_ctx else [0] * B
         self.vt_ctx_col = [int(x) for x in vt_ctx_col] if self.has_ctx else [0] * B
         self.nq, self.nkv, self.head_dim, self.causal = int(nq), int(nkv), int(head_dim), bool(causal)
-        if n_workers is None:
-            n_workers = torch.cuda.get_device_properties(device).multi_processor_count // 8 * 8
+        if n_workers is None:      # one persistent workgroup per CU; 256 (an MI355X) when planned on the host alone
+            n_workers = torch.cuda.get_device_properties(device).multi_processor_count // 8 * 8 if torch.device(device).type == "cuda" else 256
         self.n_workers = int(n_workers)
         i32 = lambda x: np.ascontiguousarray(np.asarray(x, dtype=np.int32))  # noqa: E731
         arrs = [i32(self.q_start), i32(self.q_len), i32(self.ctx_start), i32(self.ctx_len), i32(self.vt_new_col), i32(self.vt_ctx_col)]
-        items_max = sum(-(-l // 256) for l in self.q_len) * self.nq + self.n_workers
+        items_max = 2 * sum(-(-l // 256) for l in self.q_len) * self.nq + 4 * self.n_workers      # key-split sub-items included (the planner checks)
         cap = 8 + self.n_workers + 1 + 16 + 16 * items_max + 8 * self.n_workers
         buf = np.zeros(cap, dtype=np.int32)
         ptr = lambda a: a.ctypes.data  # noqa: E731

@@ -482,7 +482,7 @@ def flow_schedule(num_timesteps, shift):
 @_explicit_casts
 def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, cfg_text_scale=1.0,
                  cfg_img_scale=1.0, cfg_renorm_min=0.0, cfg_renorm_type="global", taylor=None,
-                 taylor_last_layer_only=False):
+                 taylor_last_layer_only=False, parts=None):
     """Bagel._forward_flow, bagel.py:757-907.  ``cfg_text``/``cfg_img`` = dict(cache, position_ids,
     query_indexes, key_values_lens, key_value_indexes) or None.  ``taylor`` = (cond, cfg_text, cfg_img) TaylorStates
     (bagel.py:816-818,836-838,855-857) or None."""
@@ -516,6 +516,10 @@ def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, 
         c = cfg_img
         v_ci = run(c["cache"], c["position_ids"], c["query_indexes"], c["key_values_lens"], c["key_value_indexes"], ty[2])
 
+    if parts is not None:          # checker hook (bench.py full-depth parity): the single-forward velocities before the CFG combine
+        parts["v_cond"] = v_t
+        if cfg_text_scale > 1.0:
+            parts["v_cfg_text"] = v_ct
     if cfg_text_scale > 1.0:
         if cfg_renorm_type == "text_channel":
             v_text_ = v_ct + cfg_text_scale * (v_t - v_ct)

@@ -367,6 +367,20 @@ def attn_varlen_ranges(q, k_new, vt_new, out, q_start, q_end, vt_new_col, batch,
     return out
 
 
+def attn_planned(q, k_new, vt_new, out, aplan, softmax_scale, k_ctx=None, vt_ctx=None):
+    """Stand-in of ops.attn_planned: the attention the plan describes (its per-sample host arrays), computed densely.  (That the plan's
+    ITEMS cover exactly this is pinned by tests/test_attn_plan_cpu.py.)"""
+    t = lambda x: torch.tensor(x, dtype=torch.int32)  # noqa: E731
+    B = len(aplan.q_len)
+    q_end = [a + b for a, b in zip(aplan.q_start, aplan.q_len)]
+    kw = {}
+    if aplan.has_ctx:
+        kw = dict(k_ctx=k_ctx, vt_ctx=vt_ctx, ctx_start=t(aplan.ctx_start), ctx_end=t([a + b for a, b in zip(aplan.ctx_start, aplan.ctx_len)]),
+                  vt_ctx_col=t(aplan.vt_ctx_col))
+    return attn_varlen_ranges(q, k_new, vt_new, out, t(aplan.q_start), t(q_end), t(aplan.vt_new_col), B, max(aplan.q_len), aplan.nq, aplan.nkv,
+                              aplan.head_dim, aplan.causal, softmax_scale, **kw)
+
+
 def flow_mix(clean, noise, t):
     tt = t.float()[:, None]
     return _bf((1.0 - tt) * clean.float() + tt * noise.float())
@@ -481,7 +495,7 @@ _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
           "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4",
-          "decode_advance", "require_gpu_f32", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
+          "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8"]
 
 

@@ -165,40 +165,40 @@ def _loads(ap):
 def test_schedule_of_the_denoise_launch():
     """BASELINE configs[2] as the stream-batched forward launches it: 8 samples (4 cond on 32-token contexts + 4 CFG without) of 4098
     rows, 28 / 4 heads.  16 full query tiles x 28 heads x 8 samples = 3584 tile items = 14 per worker; the 2-row tails are 32
-    head-per-wave items, key-split 8 ways into the 15th round: the busiest worker runs 14 full items + an eighth, not 15."""
+    head-per-wave items; what does not fit 14 whole items per worker is cut along the key axis: the busiest worker runs 14 items + a
+    fraction, not 15 (the one-tile-per-workgroup kernel: 3808 workgroups = 15 rounds)."""
     ap = make_plan([4098] * 8, [32] * 4 + [0] * 4, 28, 4, False)
     items = ap.items()
     hpw = items[:, 4] & 1 == 1
-    # 3584 tile items + 32 tail items = 452 per XCD = 14 rounds of 32 + 4: those 4 (whatever they are) are key-split 8 ways
-    assert ap.n_items == 3584 + 32 - 32 + 256 and ap.n_comb == 32 and ap.n_slots == 256
     assert len({(int(i[0]), int(i[3])) for i in items[hpw]}) == 32, "one head-per-wave tail per (sample, KV head) pair"
     assert (items[hpw, 1] == 2).all() and (items[~hpw, 1] == 256).all()
+    whole = items[(items[:, 4] & 4) == 0]
+    assert len(whole) >= 3584 + 32 - 40 and ap.n_comb <= 40 and ap.n_slots <= 320
     loads = _loads(ap)
-    per_item = 65 + 1                                   # 65 new tiles (+ 1 context tile for the cond samples)
-    assert ap.makespan == max(loads) <= 14 * per_item + 10
+    assert ap.makespan == max(loads) <= 14 * 66 + 8
     assert min(loads) >= 14 * 65
     assert ap.total == sum(loads)
-    # every XCD works on whole (sample, KV head) pairs: the items of one worker round share the pair
+    # every XCD works on whole (sample, KV head) pairs: the first items of its 32 workers share the pair
     off = ap.worker_off()
     for x in range(8):
         first = [items[off[w]] for w in range(x, 256, 8)]
-        assert len({(int(i[6]), int(i[3])) for i in first}) == 1, "round 0 of an XCD must be one (sample, KV head) pair"
+        assert len({(int(i[6]), int(i[3])) for i in first}) == 1, "the first round of an XCD must be one (sample, KV head) pair"
 
 
 def test_schedule_of_the_edit_and_prefill_launches():
-    # the 3-stream edit forward: 12 (sample, KV head) pairs do not fill 8 XCDs -> interleaved halves; 1344 tile items = 5.25 rounds
+    def ratio(ap):
+        loads = _loads(ap)
+        assert ap.makespan == max(loads)
+        return max(loads) / (sum(loads) / 256)
+    # the 3-stream edit forward: 12 (sample, KV head) pairs of very different cost (contexts 9032 / 9000 / 32) -> interleaved halves per
+    # XCD, longest-first dealing, leftovers cut along the key axis: 5.25 rounds' worth of work, not 6
     ap = make_plan([4098] * 3, [9032, 9000, 32], 28, 4, False)
-    loads = _loads(ap)
-    assert max(loads) <= 1.08 * sum(loads) / 256 + 4, (max(loads), sum(loads) / 256)
-    assert ap.n_comb > 0
-    # causal LLM prefill of the understanding request (4936 tokens, batch 1): heavy tiles first, snake rounds
-    ap = make_plan([4936], [0], 28, 4, True)
-    loads = _loads(ap)
-    assert max(loads) <= 1.25 * sum(loads) / 256 + 8, (max(loads), sum(loads) / 256)
-    # SigLIP: 16 heads, one 4900-token image: 320 tile items = 1.25 rounds -> the last 8 per XCD are key-split
-    ap = make_plan([4900], [0], 16, 16, False)
-    loads = _loads(ap)
-    assert max(loads) <= 1.35 * sum(loads) / 256, (max(loads), sum(loads) / 256)
+    assert ratio(ap) <= 1.02 and ap.n_comb > 0
+    # one stream of the denoise forward; the causal LLM prefill of the understanding request (4936 tokens, batch 1; items below the split
+    # threshold stay whole); SigLIP (16 heads, one 4900-token image: 320 tile items = 1.25 rounds)
+    assert ratio(make_plan([4098] * 4, [32] * 4, 28, 4, False)) <= 1.02
+    assert ratio(make_plan([4936], [0], 28, 4, True)) <= 1.08
+    assert ratio(make_plan([4900], [0], 16, 16, False)) <= 1.03
 
 
 def test_plan_buffer_too_small_is_reported():
