@@ -81,40 +81,17 @@ __device__ __forceinline__ void a2_glds16s(unsigned voff, const void* sbase_unif
 
 #define ATTN2_DEFER_LOG2 8.0f
 
-// Chunk schedules of one pipeline step (a chunk = one MFMA + its fragment read + a slice of VALU work, closed by sched_barrier).  A step has
-// 16 "slots" per phase (D = 64 folds two slots into one chunk).  The 16 softmax slices of tile t (2 scores each: fma, exp2, row-sum add,
-// bf16 pack = 7 VALU) used to sit one per slot in phase A, beside the S^T(t+1) MFMAs, while phase B carried one v_max3 per slot: phase A
-// was ISSUE-bound (~10 instructions per 32-cycle MFMA), phase B had slack.  P(t) is consumed by the PV MFMAs of phase B in quarters
-// (slot 4f .. 4f+3 reads the bf16 fragment built from slices 4f .. 4f+3), so later slices may run inside phase B:
-//   A_SL[s][slot] / B_SL[s][slot] = number of softmax slices executed in that slot (in order);  A_DMA[s][slot] = 1 + the LDS-DMA piece of
-//   tile t+2 issued in that slot of phase A (0 = none; schedule 0 issues all pieces before the phase).
-// Constraint (static_assert below): before phase-B slot m, at least 4 * (m / 4 + 1) slices are done.
-constexpr int A2_NSCHED = 4;
-#define ATTN2_DEFAULT_SCHED 0
+// Measured and removed in round 3 (profiles/r03_attn_planned_vs_tile.log; the machinery was a table of softmax slices / LDS-DMA pieces per
+// chunk): moving 4-6 of the 16 softmax slices of a tile from phase A (7 VALU per MFMA) into phase B (1 VALU per MFMA), issuing the
+// LDS-DMA pieces of tile t+2 between the first MFMAs of phase A instead of in front of them, and slice PAIRS with their four
+// fma / exp2 / add chains interleaved: all within 1 % of the plain one-slice-per-MFMA schedule (1001 / 988 / 994 / 991 TFLOP/s on one
+// box, 1045 / 1046 on another) -- neither the issue balance of the two phases, nor the DMA issue slots, nor VALU dependency stalls
+// are what this loop waits for.  A fragment prefetch distance of 3 chunks instead of 4 measures the same and frees four registers.
 #ifndef A2_WIN
-#define A2_WIN 3          // fragment prefetch distance in chunks (3 .. 6 measured the same in attention.hip; 3 frees four registers)
+#define A2_WIN 3
 #endif
-constexpr int A_SL[A2_NSCHED][16] = {{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
-                                      {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
-                                      {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
-                                      {0, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1, 1}};
-constexpr int B_SL[A2_NSCHED][16] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-                                      {1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-                                      {1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-                                      {1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
-constexpr int A_DMA[A2_NSCHED][16] = {{0}, {0}, {1, 2, 3, 4}, {1, 2, 3, 4}};
-constexpr bool a2_sched_ok(int s) {
-    int done = 0;
-    for (int m = 0; m < 16; ++m) done += A_SL[s][m];
-    for (int m = 0; m < 16; ++m) {
-        if (done < 4 * (m / 4 + 1)) return false;
-        done += B_SL[s][m];
-    }
-    return done == 16;
-}
-static_assert(a2_sched_ok(0) && a2_sched_ok(1) && a2_sched_ok(2) && a2_sched_ok(3), "softmax slices must be complete before the PV MFMA that reads them");
 
-template <int D, int SCHED>
+template <int D>
 __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, const int* __restrict__ worker_off,
                                                         const AttnItem* __restrict__ item_tab) {
     // (the two tables are separate noalias kernel arguments on purpose: only then does hipcc read them with SCALAR loads -- as members of
@@ -170,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
     unsigned pc_dst[NP];
     bool pc_ctx = false;
     auto dma_piece = [&](int i) { a2_glds16s(i < NLK ? (pc_ctx ? koff_ctx : koff_new) : (pc_ctx ? voff_ctx : voff_new), pc_base[i], pc_dst[i]); };
-    auto dma_prepare = [&](bool defer) -> int {
+    auto dma_next = [&]() -> int {
         if (d_i >= i_end) return 0;
         const unsigned sb = __builtin_amdgcn_readfirstlane(smem_base + d_slot * STAGE + wave * 1024u);
         const bool is_ctx = d_t < d_ntc;
@@ -192,11 +169,9 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
             const char* kt = a2_uniform(kseg + (long)ti * 64 * ldk * 2);
 #pragma unroll
             for (int i = 0; i < NLK; ++i) pc_base[i] = a2_uniform(kt + (long)i * (RS * NW) * ldk * 2);
-            if (!defer) {
 #pragma unroll
-                for (int i = 0; i < NP; ++i) dma_piece(i);
-                mode = 2;
-            }
+            for (int i = 0; i < NP; ++i) dma_piece(i);
+            mode = 2;
         } else {
             // the segment's last tile: rows past its end re-read the last key (masked in the scores); per-lane offsets, issued here
 #pragma unroll
@@ -216,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
         }
         return mode;
     };
-    auto issue_next = [&]() -> bool { return dma_prepare(false) != 0; };
+    auto issue_next = [&]() -> bool { return dma_next() != 0; };
 
     // ---- per-lane constants for fragment reads (attention.hip's layout; here as ONE address per operand) ----
     // K fragment ks of key block kb sits at  koff0 + kb * 32 * KROW + (((2 ks + hi) ^ kswz) << 4)  and  V^T fragment (db, j) at
@@ -329,22 +304,14 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
         // [row max of sn].  LAST: there is no tile t+1 in THIS item (the stream's next tile belongs to the next item and is not waited for here).
         auto step = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int t, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
-            constexpr bool SPREAD = A_DMA[SCHED][0] != 0 && NP <= 16;      // LDS-DMA pieces inside phase A (not in a LAST step: no phase-A MFMAs)
             if (!LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t+1 have landed
             asm volatile("s_barrier" ::: "memory");          // ... everyone's; and everyone is done with tile t-1
-            const int dmode = dma_prepare(SPREAD && !LAST);        // 0 nothing left, 1 pieces deferred into phase A, 2 issued
-            const bool issued = dmode == 1;
-            if (LAST) newer = dmode != 0;
+            const bool issued = issue_next();                 // tile t+2 of the stream (it may belong to the next item)
+            if (LAST) newer = issued;
             const unsigned sbv = vb0 + cs * STAGE;
             cs = next_slot(cs);
             const unsigned sbk = kb0 + cs * STAGE;
-            if (!live) {
-                if (SPREAD && !LAST && issued) {
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) dma_piece(i);
-                }
-                return;
-            }
+            if (!live) return;
             constexpr int WIN = A2_WIN;
             constexpr int NMA = NK, NMB = NV;
             constexpr int SLOTS = 16 / NMA;                 // schedule slots per chunk (1 at D = 128, 2 at D = 64)
@@ -367,7 +334,6 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
                 return __builtin_bit_cast(bf16x8_t, v4);
             };
             bf16x8_t vf[NV];
-            int done = 0;                                   // softmax slices executed so far (compile-time after unrolling)
             // ---------------- phase A ----------------
             __builtin_amdgcn_sched_barrier(0);
             if (!LAST) {
@@ -386,23 +352,14 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
                     if (m + WIN < NK) kf[m + WIN] = kfrag(sbk, kidx(m + WIN));
                     else if (m + WIN - NK < WIN) vf[m + WIN - NK] = vfrag(sbv, vidx(m + WIN - NK));
 #pragma unroll
-                    for (int u = 0; u < SLOTS; ++u) {
-                        const int slot = m * SLOTS + u;
-#pragma unroll
-                        for (int c = 0; c < A_SL[SCHED][slot]; ++c) softmax_slice(done++);
-                        if (SPREAD && A_DMA[SCHED][slot] != 0 && A_DMA[SCHED][slot] <= NP) {
-                            if (issued) dma_piece(A_DMA[SCHED][slot] - 1);
-                        }
-                    }
+                    for (int u = 0; u < SLOTS; ++u) softmax_slice(m * SLOTS + u);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < WIN; ++j) vf[j] = vfrag(sbv, vidx(j));
 #pragma unroll
-                for (int slot = 0; slot < 16; ++slot)
-#pragma unroll
-                    for (int c = 0; c < A_SL[SCHED][slot]; ++c) softmax_slice(done++);
+                for (int slot = 0; slot < 16; ++slot) softmax_slice(slot);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!LAST) mask_tile(sn, t + 1);
@@ -422,8 +379,6 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
                         mx = fmaxf(fmaxf(mx, sn[kb][r]), sn[kb][r + 1]);
                         asm volatile("" : "+v"(mx));
                     }
-#pragma unroll
-                    for (int c = 0; c < B_SL[SCHED][slot]; ++c) softmax_slice(done++);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -506,13 +461,16 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
 }
 
 // Merge the partial slots of every key-split item: out = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s, M = max_s m_s.
-// One workgroup per split item, one thread per query-row slot (32 * wave + row).
+// One workgroup per (split item, 32-row block): thread = (row, eighth of the head dim), so the 8 threads of a row read 8 consecutive
+// D/8-float pieces of each slot's O row (whole 128-byte lines) and write D/8 consecutive bf16.
 template <int D>
 __global__ __launch_bounds__(256) void attn2_combine_kernel(const AttnComb* __restrict__ comb, const float* __restrict__ part,
                                                             bf16_t* __restrict__ out, long ldo) {
     constexpr int PSLOT = 256 * (D + 2);
-    const AttnComb c = comb[blockIdx.x];
-    const int r = threadIdx.x, wave = r >> 5, qi = r & 31;
+    constexpr int W = D / 8;                     // floats per thread
+    const AttnComb c = comb[blockIdx.x >> 3];
+    const int wave = blockIdx.x & 7, qi = threadIdx.x >> 3, part8 = threadIdx.x & 7;
+    const int r = 32 * wave + qi;
     const bool hpw = c.flags & ATTN2_HPW;
     const bool ok = hpw ? (wave < ((c.flags >> 8) & 255) && qi < c.nrows) : r < c.nrows;
     if (!ok) return;
@@ -520,24 +478,29 @@ __global__ __launch_bounds__(256) void attn2_combine_kernel(const AttnComb* __re
     float M = -INFINITY;
     for (int s = 0; s < c.nslots; ++s) M = fmaxf(M, base[(long)s * PSLOT + 256 * D + r]);
     float den = 0.f;
+    float a[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) a[i] = 0.f;
     for (int s = 0; s < c.nslots; ++s) {
-        const float m = base[(long)s * PSLOT + 256 * D + r];
-        den += (m == -INFINITY ? 0.f : exp2f(m - M)) * base[(long)s * PSLOT + 256 * D + 256 + r];
+        const float* ps = base + (long)s * PSLOT;
+        const float m = ps[256 * D + r];
+        const float w = m == -INFINITY ? 0.f : exp2f(m - M);
+        den += w * ps[256 * D + 256 + r];
+        const f32x4_t* src = (const f32x4_t*)(ps + (long)r * D + part8 * W);
+#pragma unroll
+        for (int i = 0; i < W / 4; ++i) {
+            const f32x4_t v = src[i];
+            a[4 * i] += v[0] * w; a[4 * i + 1] += v[1] * w; a[4 * i + 2] += v[2] * w; a[4 * i + 3] += v[3] * w;
+        }
     }
     const float inv = 1.0f / den;
     const long row = hpw ? c.q_row0 + qi : c.q_row0 + r;
     const int h = hpw ? c.h + wave : c.h;
-    bf16_t* op = out + row * ldo + (long)h * D;
-    for (int d = 0; d < D; d += 4) {
-        f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < c.nslots; ++s) {
-            const float m = base[(long)s * PSLOT + 256 * D + r];
-            const float w = m == -INFINITY ? 0.f : exp2f(m - M);
-            const f32x4_t v = *(const f32x4_t*)(base + (long)s * PSLOT + (long)r * D + d);
-            a = a + v * w;
-        }
-        u32x2_t v = {pack2bf(a[0] * inv, a[1] * inv), pack2bf(a[2] * inv, a[3] * inv)};
-        *(u32x2_t*)(op + d) = v;
+    bf16_t* op = out + row * ldo + (long)h * D + part8 * W;
+#pragma unroll
+    for (int i = 0; i < W / 4; ++i) {
+        u32x2_t v = {pack2bf(a[4 * i] * inv, a[4 * i + 1] * inv), pack2bf(a[4 * i + 2] * inv, a[4 * i + 3] * inv)};
+        *(u32x2_t*)(op + 4 * i) = v;
     }
 }
 
@@ -721,32 +684,21 @@ extern "C" int bagel_attn_planned_bf16(const void* q, int64_t ldq, const void* k
     p.part = (float*)partials;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const dim3 grid(n_workers), block(512);
-    static int sched = -1;          // chunk schedule (see A_SL / B_SL): BAGEL_ATTN_SCHED overrides the default, for same-box A/B runs
-    if (sched < 0) {
-        const char* e = getenv("BAGEL_ATTN_SCHED");
-        const int v = e ? atoi(e) : ATTN2_DEFAULT_SCHED;
-        sched = (v >= 0 && v < A2_NSCHED) ? v : ATTN2_DEFAULT_SCHED;
+    if (head_dim == 128) {
+        constexpr int smem = 3 * (64 * 256 + 128 * 128);
+        if (int rc = bagel_enable_lds((const void*)attn2_kernel<128>, smem, "attn2_kernel<128>")) return rc;
+        hipLaunchKernelGGL((attn2_kernel<128>), grid, block, smem, stream, p, worker_off, items);
+    } else if (head_dim == 64) {
+        constexpr int smem = 3 * (64 * 128 + 64 * 128);
+        hipLaunchKernelGGL((attn2_kernel<64>), grid, block, smem, stream, p, worker_off, items);
+    } else {
+        return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_planned: head_dim %d not in {64,128} (pad the head)", head_dim);
     }
-#define A2_GO(DV, SV)                                                                                                              \
-    do {                                                                                                                           \
-        constexpr int smem = 3 * (64 * (DV) * 2 + (DV) * 128);                                                                      \
-        if (int rc = bagel_enable_lds((const void*)attn2_kernel<DV, SV>, smem, "attn2_kernel")) return rc;                          \
-        hipLaunchKernelGGL((attn2_kernel<DV, SV>), grid, block, smem, stream, p, worker_off, items);                                \
-    } while (0)
-#define A2_GO_D(DV)                                                                                                                \
-    do {                                                                                                                           \
-        if (sched == 1) A2_GO(DV, 1); else if (sched == 2) A2_GO(DV, 2); else if (sched == 3) A2_GO(DV, 3); else A2_GO(DV, 0);      \
-    } while (0)
-    if (head_dim == 128) A2_GO_D(128);
-    else if (head_dim == 64) A2_GO_D(64);
-    else return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_planned: head_dim %d not in {64,128} (pad the head)", head_dim);
-#undef A2_GO_D
-#undef A2_GO
     if (int rc = bagel_check_launch("attn2_kernel")) return rc;
     if (n_comb > 0) {
         const AttnComb* cb = (const AttnComb*)(plan_dev + off_comb);
-        if (head_dim == 128) hipLaunchKernelGGL((attn2_combine_kernel<128>), dim3(n_comb), dim3(256), 0, stream, cb, (const float*)partials, (bf16_t*)out, (long)ldo);
-        else hipLaunchKernelGGL((attn2_combine_kernel<64>), dim3(n_comb), dim3(256), 0, stream, cb, (const float*)partials, (bf16_t*)out, (long)ldo);
+        if (head_dim == 128) hipLaunchKernelGGL((attn2_combine_kernel<128>), dim3(8 * n_comb), dim3(256), 0, stream, cb, (const float*)partials, (bf16_t*)out, (long)ldo);
+        else hipLaunchKernelGGL((attn2_combine_kernel<64>), dim3(8 * n_comb), dim3(256), 0, stream, cb, (const float*)partials, (bf16_t*)out, (long)ldo);
         return bagel_check_launch("attn2_combine_kernel");
     }
     return BAGEL_OK;
