@@ -52,6 +52,8 @@ def parse():
                     help="t2i = BASELINE configs[2]/[3] (the headline metric); edit = configs[4] image-edit (VAE enc + ViT + 3-forward CFG)")
     ap.add_argument("--no-taylorseer", action="store_true", help="skip the extra enable_taylorseer=True measurement")
     ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
+    ap.add_argument("--no-batched-decode", action="store_true", help="understanding leg: skip the extra 16-request batched decode")
+    ap.add_argument("--no-train-forward", action="store_true", help="skip the extra training-forward (Bagel.forward, losses only) measurement")
     ap.add_argument("--no-int8", action="store_true", help="understanding leg: skip the extra weight_quant='int8' / 'mxfp4' decodes")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra gen_weight_quant='fp8' measurement")
     ap.add_argument("--no-edit", action="store_true", help="skip the extra configs[4] measurement (one image-edit request per GPU)")
@@ -532,13 +534,14 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
 
     UB = args.und_batch
 
-    def prefill():
+    def prefill(nb=None):
+        nb = UB if nb is None else nb
         cache = NaiveCache(L)
-        gi, lens, ropes = model.prepare_vit_images([0] * UB, [0] * UB, [image] * UB, ident, ids)
+        gi, lens, ropes = model.prepare_vit_images([0] * nb, [0] * nb, [image] * nb, ident, ids)
         cache = model.forward_cache_update_vit(cache, **gi)
         torch.cuda.synchronize()
         t_vit = time.perf_counter()
-        gi, lens, ropes = model.prepare_prompts(lens, ropes, ["p"] * UB, tok, ids)
+        gi, lens, ropes = model.prepare_prompts(lens, ropes, ["p"] * nb, tok, ids)
         cache = model.forward_cache_update_text(cache, **gi)
         torch.cuda.synchronize()
         return cache, lens, ropes, t_vit
@@ -584,6 +587,28 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
         w8 = quantised_decode("int8", "row-wise absmax INT8 (W8A16, de-quantised on the VALU), lm_head bf16")
         # the 4-bit counterpart of the reference's NF4 load mode: OCP-MX FP4 weights x FP8 activations on the block-scaled MFMA
         w4 = quantised_decode("mxfp4", "OCP-MX FP4 E2M1 blocks of 32 with E8M0 scales (W4A8 on v_mfma_scale_f32_16x16x128_f8f6f4), lm_head bf16")
+    # SURVEY 8f.4b beside the batch-1 number: 16 requests decoded together (one weight pass serves the batch; the reference decodes
+    # batch 1 only, bagel.py:996) -- 64 new tokens each on their own 4936-token contexts
+    bd = None
+    if UB == 1 and not args.no_batched_decode:
+        try:
+            nb, nn = 16, 64
+            cb, lb, rb, _ = prefill(nb)
+            sb = model.prepare_start_tokens(lb, rb, ids)
+            model.generate_text(past_key_values=cb, max_length=4, do_sample=False, end_token_id=None, **sb)
+            cb, lb, rb, _ = prefill(nb)
+            sb = model.prepare_start_tokens(lb, rb, ids)
+            fence()
+            t4 = time.perf_counter()
+            tb = model.generate_text(past_key_values=cb, max_length=nn, do_sample=False, end_token_id=None, **sb)
+            fence()
+            dtb = time.perf_counter() - t4
+            bd = {"value": nb * nn / dtb, "unit": "tokens/s", "batch": nb, "new_tokens": nn, "decode_ms_per_step": dtb / nn * 1e3,
+                  "context_tokens": int(lb[0]), "outputs_ok": bool(tb.shape == (nn, nb)),
+                  "note": "batched multi-request decode (SURVEY 8f.4b): beside the batch-1 headline, never as it"}
+            del cb
+        except Exception as e:
+            bd = {"error": repr(e)}
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -607,7 +632,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
             "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
             "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer", "cpu_baseline": cpu,
-            "int8_weights": w8, "mxfp4_weights": w4,
+            "int8_weights": w8, "mxfp4_weights": w4, "batched_decode": bd,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_decode_traffic() if (UB == 1 and args.und_image == 980) else None,
                          "kernel": "gemv_kernel (decode step)",
@@ -670,7 +695,7 @@ def understanding_subprocess(args, local):
     env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding"] + (["--no-cpu-baseline"] if args.no_cpu_baseline or int(os.environ.get("WORLD_SIZE", 1)) != 1 else []) + [
            "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image), "--und-batch", str(args.und_batch)] + (
-           ["--no-int8"] if args.no_int8 else [])
+           ["--no-int8"] if args.no_int8 else []) + (["--no-batched-decode"] if args.no_batched_decode else [])
     if args.layers is not None:
         cmd += ["--layers", str(args.layers)]
     try:
@@ -972,6 +997,29 @@ def main():
         except Exception as e:
             import traceback
             edit = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
+    trainf = None
+    if args.workload == "t2i" and not args.no_train_forward and not args.standins and args.layers is None:
+        # SURVEY 8f.2 beside the headline: Bagel.forward (training forward, per-token CE / MSE losses, no backward) on a packed 7B batch of
+        # 2 x [prompt | 980^2 ViT image | answer + CE] + 2 x [prompt | noised 1024^2 latent + MSE] (tools/train_forward_probe.py)
+        try:
+            from tools.train_forward_probe import build_batch
+            tb = build_batch(model, ids)
+            tn = torch.randn(len(tb["packed_vae_token_indexes"]), 64, generator=torch.Generator().manual_seed(1)).to(dev)
+            o_ = model(noise=tn, **tb)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                o_ = model(noise=tn, **tb)
+            fence()
+            dtt = (time.perf_counter() - t1) / 3
+            ntok = tb["sequence_length"]
+            trainf = {"value": world * ntok / dtt, "unit": "tokens/s", "tokens_per_forward": ntok, "ms_per_forward": dtt * 1e3,
+                      "linear_tflops": 13.0506e-3 * ntok / dtt, "outputs_finite": bool(torch.isfinite(o_["ce"]).all() and torch.isfinite(o_["mse"]).all()),
+                      "note": "training FORWARD only (losses; no backward pass exists in this repository): beside the headline, never as it"}
+            del tb, tn, o_
+        except Exception as e:
+            import traceback
+            trainf = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
     und = None
     if not args.no_understanding:
         und = understanding_subprocess(args, local)
@@ -1025,6 +1073,7 @@ def main():
             "edit": edit,
             "taylorseer": ts,
             "fp8_gen_expert": fp8,
+            "training_forward": trainf,
         }
         if args.workload == "t2i":
             # the whole path against the MFMA roof: denoise FLOPs (linear + attention of the 98 forwards, SURVEY.md 8d: 5.904 PFLOP
