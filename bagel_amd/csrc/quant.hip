@@ -318,3 +318,258 @@ extern "C" int bagel_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int6
                        (unsigned char*)q, (long)ldq_bytes, scale, rows, cols);
     return bagel_check_launch("quantize_rows_fp8_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// NF4 -- the 4-bit load mode the reference ships (app.py:114-125: bitsandbytes, quant_type "nf4", blocksize 64, fp32 absmax, no double
+// quantisation, bf16 compute), restated in oracle/nf4.py from the library's published algorithm:
+//   code book NF4_CODE[16], blocks of 64 consecutive weights with an fp32 absmax, x = w * (1 / absmax), code = number of midpoint
+//   thresholds below x, two codes per byte with the EVEN element in the HIGH nibble, w' = NF4_CODE[code] * absmax.
+//   bagel_quantize_nf4     bf16 [N, K] (K % 64 == 0) -> u8 [N, K / 2] + fp32 absmax [N, K / 64]      (bit-exact vs the restatement)
+//   bagel_gemv_nf4_bf16    C[M <= 4.., N] = A (dequant W)^T with the epilogues / fused RMSNorm of bagel_gemv_bf16 ("W4A16")
+// The projection keeps w' in fp32 (code * absmax is not rounded to bf16 before the multiply, which the library's de-quantise-then-matmul
+// path does): a relative 2^-9 per weight with random sign, far below the bf16 rounding of the output it is tested against.
+// A 16-byte lane chunk carries 32 weights = half a block; the code book lives in LDS (16 floats: 64 lanes hit 16 different banks, equal
+// indices broadcast), one ds_read_b32 per weight beside ~2.75 VALU (index extraction, activation unpack, FMA) -- VALU-bound like the INT8
+// option, at a quarter of the bf16 weight bytes.
+// ---------------------------------------------------------------------------------------------------------
+__constant__ float NF4_CODE_DEV[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f, -0.28444138169288635f,
+                                       -0.18477343022823334f, -0.09105003625154495f, 0.0f, 0.07958029955625534f, 0.16093020141124725f,
+                                       0.24611230194568634f, 0.33791524171829224f, 0.44070982933044434f, 0.5626170039176941f,
+                                       0.7229568362236023f, 1.0f};
+__constant__ float NF4_THRESH_DEV[15] = {-0.8480964004993439f, -0.6106329262256622f, -0.4599952697753906f, -0.33967943489551544f,
+                                         -0.23460740596055984f, -0.13791173323988914f, -0.045525018125772476f, 0.03979014977812767f,
+                                         0.1202552504837513f, 0.2035212516784668f, 0.2920137718319893f, 0.3893125355243683f,
+                                         0.5016634166240692f, 0.6427869200706482f, 0.8614784181118011f};
+
+// one thread per 64-weight block
+__global__ __launch_bounds__(256) void quantize_nf4_kernel(const bf16_t* __restrict__ w, long ldw, unsigned char* __restrict__ q, long ldq,
+                                                           float* __restrict__ absmax, int rows, int nblk) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * nblk) return;
+    const int row = (int)(i / nblk), b = (int)(i % nblk);
+    const bf16_t* src = w + (long)row * ldw + (long)b * 64;
+    u32x4_t v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = *(const u32x4_t*)(src + 8 * c);
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo2f(v[c][e])), fabsf(hi2f(v[c][e]))));
+    absmax[i] = amax;
+    const float inv = __fdiv_rn(1.0f, amax);           // inf for an all-zero block: x = NaN below, every comparison false, code 0
+    auto code = [&](float x) {
+        unsigned c = 0;
+#pragma unroll
+        for (int t = 0; t < 15; ++t) c += (x * inv > NF4_THRESH_DEV[t]) ? 1u : 0u;
+        return c;
+    };
+    unsigned char* dst = q + (long)row * ldq + (long)b * 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        unsigned out = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out |= ((code(lo2f(v[c][e])) << 4) | code(hi2f(v[c][e]))) << (8 * e);   // even element -> high nibble
+        *(unsigned*)(dst + 4 * c) = out;
+    }
+}
+
+extern "C" int bagel_quantize_nf4(const void* w, int64_t ldw, void* q, int64_t ldq_bytes, float* absmax, int32_t rows, int32_t cols,
+                                  hipStream_t stream) {
+    BAGEL_REQUIRE(w && q && absmax, "quantize_nf4: null pointer");
+    BAGEL_REQUIRE(cols > 0 && (cols % 64) == 0 && (ldw % 8) == 0 && (ldq_bytes % 4) == 0, "quantize_nf4: cols must be a multiple of the 64-weight block (ldw % 8, ldq % 4)");
+    BAGEL_REQUIRE((((uintptr_t)w) & 15) == 0 && (((uintptr_t)q) & 3) == 0, "quantize_nf4: w must be 16-byte, q 4-byte aligned");
+    if (rows <= 0) return BAGEL_OK;
+    const int nblk = cols / 64;
+    hipLaunchKernelGGL(quantize_nf4_kernel, dim3(ceil_div((long)rows * nblk, 256)), dim3(256), 0, stream, (const bf16_t*)w, (long)ldw,
+                       (unsigned char*)q, (long)ldq_bytes, absmax, rows, nblk);
+    return bagel_check_launch("quantize_nf4_kernel");
+}
+
+struct GemvNf4Params {
+    const bf16_t* A; long lda;
+    const unsigned char* W; long ldw;      // packed codes [N, K / 2]
+    const float* absmax;                   // [N, K / 64]
+    const bf16_t* bias;
+    const bf16_t* R; long ldr;
+    bf16_t* C; long ldc;
+    const bf16_t* norm_w; float eps;
+    int M, N, K, epi;
+};
+
+// Skeleton of gemv_w8_kernel: a wave owns a pair of weight rows (SwiGLU16: a gate row and its up row), the (optionally RMS-normalised)
+// activations are staged once per workgroup in LDS; a 16-byte lane chunk = 32 weights of each row.
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_nf4_kernel(GemvNf4Params p) {
+    constexpr int U = 2;                    // chunk groups (1 KB of codes = 2048 weights per row each) in flight per row
+    extern __shared__ __attribute__((aligned(16))) unsigned char nf4_smem[];
+    bf16_t* xs = (bf16_t*)nf4_smem;         // [MR][K]
+    __shared__ float red[MR][4];
+    __shared__ __attribute__((aligned(64))) float lut[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, nch8 = K >> 3, nch = K >> 5;       // 8-element bf16 chunks (staging), 32-weight chunks (streaming)
+    const int nb = K >> 6;                                // absmax entries per row
+    const int NP = p.N >> 1;
+    const bool swiglu = p.epi == EPI_SWIGLU16;
+    const int ngr = (nch + 63) >> 6;
+    const int pp = blockIdx.x * 4 + wave;
+    const bool live = pp < NP;
+    const int r0 = swiglu ? ((pp >> 4) << 5) + (pp & 15) : 2 * pp;
+    const int r1 = swiglu ? r0 + 16 : r0 + 1;
+    if (tid < 16) lut[tid] = NF4_CODE_DEV[tid];
+
+    u32x4_t wa[U], wb[U];
+    float sa[U], sb[U];
+    auto load_batch = [&](int g) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ch = (g + u) * 64 + lane;
+            const int cc = ch < nch ? ch : 0;
+            wa[u] = ld_stream<u32x4_t>(p.W + (long)r0 * p.ldw + (long)cc * 16);
+            wb[u] = ld_stream<u32x4_t>(p.W + (long)r1 * p.ldw + (long)cc * 16);
+            sa[u] = p.absmax[(long)r0 * nb + (cc >> 1)];
+            sb[u] = p.absmax[(long)r1 * nb + (cc >> 1)];
+        }
+    };
+    if (live) load_batch(0);
+
+    // ---- staging: RMSNorm (optional) and the bf16 activation rows into LDS ----
+    if (p.norm_w) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const bf16_t* ar = p.A + (long)(m < p.M ? m : p.M - 1) * p.lda;
+            float ss = 0.f;
+            for (int c = tid; c < nch8; c += 256) {
+                const u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = lo2f(v[e]), b = hi2f(v[e]);
+                    ss += a * a + b * b;
+                }
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red[m][wave] = ss;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const bf16_t* ar = p.A + (long)(m < p.M ? m : p.M - 1) * p.lda;
+        float inv = 1.f;
+        if (p.norm_w) inv = rsqrtf((red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K + p.eps);
+        for (int c = tid; c < nch8; c += 256) {
+            u32x4_t v = *(const u32x4_t*)(ar + (long)c * 8);
+            if (p.norm_w) {
+                const u32x4_t g = *(const u32x4_t*)(p.norm_w + (long)c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack2bf(bfround(lo2f(v[e]) * inv) * lo2f(g[e]), bfround(hi2f(v[e]) * inv) * hi2f(g[e]));
+            }
+            *(u32x4_t*)(xs + (long)m * K + (long)c * 8) = v;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    float a0[MR], a1[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) a0[m] = a1[m] = 0.f;
+    const char* lutb = (const char*)lut;
+    for (int g = 0; g < ngr; g += U) {
+        if (g != 0) load_batch(g);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ch = (g + u) * 64 + lane;
+            const bool ok = ch < nch;
+            const long xo = (long)(ok ? ch : 0) * 32;
+            float s0[MR], s1[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) s0[m] = s1[m] = 0.f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {                       // dword d of the code chunk = weights 8d .. 8d+7
+                const unsigned ua = wa[u][d], ub = wb[u][d];
+                const unsigned ea = (ua >> 2) & 0x3C3C3C3Cu, oa = (ua << 2) & 0x3C3C3C3Cu;     // 4 * code of the even / odd elements, one per byte
+                const unsigned eb = (ub >> 2) & 0x3C3C3C3Cu, ob = (ub << 2) & 0x3C3C3C3Cu;
+                u32x4_t xq[MR];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) xq[m] = *(const u32x4_t*)(xs + (long)m * K + xo + 8 * d);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {                   // byte b = elements 8d + 2b (high nibble) and 8d + 2b + 1 (low nibble)
+                    const float ca0 = *(const float*)(lutb + ((ea >> (8 * b)) & 0xFFu)), ca1 = *(const float*)(lutb + ((oa >> (8 * b)) & 0xFFu));
+                    const float cb0 = *(const float*)(lutb + ((eb >> (8 * b)) & 0xFFu)), cb1 = *(const float*)(lutb + ((ob >> (8 * b)) & 0xFFu));
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        const float f0 = lo2f(xq[m][b]), f1 = hi2f(xq[m][b]);
+                        s0[m] = fmaf(ca0, f0, s0[m]); s0[m] = fmaf(ca1, f1, s0[m]);
+                        s1[m] = fmaf(cb0, f0, s1[m]); s1[m] = fmaf(cb1, f1, s1[m]);
+                    }
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) { a0[m] = fmaf(sa[u], s0[m], a0[m]); a1[m] = fmaf(sb[u], s1[m], a1[m]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const float t0 = wave_sum(a0[m]), t1 = wave_sum(a1[m]);
+        if (lane == 0 && m < p.M) {
+            if (swiglu) {
+                const float gg = bfround(t0), uu = bfround(t1);
+                p.C[(long)m * p.ldc + pp] = f2bf(bfround(silu_f(gg)) * uu);
+            } else {
+                float o[2] = {t0, t1};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int n = t ? r1 : r0;
+                    if (p.bias) o[t] += bf2f(p.bias[n]);
+                    if (p.epi == EPI_GELU_TANH) o[t] = gelu_tanh_f(bfround(o[t]));
+                    else if (p.epi == EPI_SILU) o[t] = silu_f(bfround(o[t]));
+                    if (p.R) o[t] = bfround(o[t]) + bf2f(p.R[(long)m * p.ldr + n]);
+                }
+                *(unsigned*)(p.C + (long)m * p.ldc + r0) = pack2bf(o[0], o[1]);
+            }
+        }
+    }
+}
+
+template <int MR>
+static int launch_gemv_nf4(const GemvNf4Params& p, hipStream_t stream) {
+    const size_t smem = (size_t)MR * p.K * sizeof(bf16_t);
+    if (smem > 48 * 1024)
+        if (int rc = bagel_enable_lds((const void*)gemv_nf4_kernel<MR>, (int)W8_MAX_LDS, "gemv_nf4_kernel")) return rc;
+    hipLaunchKernelGGL((gemv_nf4_kernel<MR>), dim3(ceil_div(p.N / 2, 4)), dim3(256), smem, stream, p);
+    return bagel_check_launch("gemv_nf4_kernel");
+}
+
+extern "C" int bagel_gemv_nf4_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldw_bytes, const float* absmax, const void* bias,
+                                   const void* R, int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N,
+                                   int32_t K, int32_t epilogue, hipStream_t stream) {
+    BAGEL_REQUIRE(A && Wq && absmax && C, "gemv_nf4: null pointer");
+    BAGEL_REQUIRE(K > 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldw_bytes % 16) == 0, "gemv_nf4: K must be a multiple of the 64-weight block, lda of 8, ldw of 16 bytes");
+    BAGEL_REQUIRE(N > 0 && (N % 2) == 0, "gemv_nf4: N=%d must be even", N);
+    BAGEL_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemv_nf4: unknown epilogue %d", epilogue);
+    BAGEL_REQUIRE(epilogue != EPI_SWIGLU16 || ((N % 32) == 0 && !bias && !R), "gemv_nf4: swiglu needs N%%32==0, no bias/residual");
+    BAGEL_REQUIRE((((uintptr_t)A | (uintptr_t)Wq | (uintptr_t)norm_w) & 15) == 0, "gemv_nf4: A/W/norm_w must be 16-byte aligned");
+    BAGEL_REQUIRE((ldc % 2) == 0 && (ldr % 2) == 0 && (((uintptr_t)C | (uintptr_t)R) & 3) == 0, "gemv_nf4: C/R rows must be 4-byte aligned");
+    BAGEL_REQUIRE((size_t)K * sizeof(bf16_t) <= W8_MAX_LDS, "gemv_nf4: K=%d does not fit the LDS staging buffer", K);
+    if (M <= 0) return BAGEL_OK;
+    int m0 = 0;
+    while (m0 < M) {
+        int mr = (M - m0 >= 4) ? 4 : (M - m0 >= 2 ? 2 : 1);
+        while (mr > 1 && (size_t)mr * K * sizeof(bf16_t) > W8_MAX_LDS) mr >>= 1;
+        GemvNf4Params p;
+        p.A = (const bf16_t*)A + (long)m0 * lda; p.lda = lda;
+        p.W = (const unsigned char*)Wq; p.ldw = ldw_bytes; p.absmax = absmax;
+        p.bias = (const bf16_t*)bias;
+        p.R = R ? (const bf16_t*)R + (long)m0 * ldr : nullptr; p.ldr = ldr;
+        p.C = (bf16_t*)C + (long)m0 * ldc; p.ldc = ldc;
+        p.norm_w = (const bf16_t*)norm_w; p.eps = eps;
+        p.M = mr; p.N = N; p.K = K; p.epi = epilogue;
+        int rc = mr == 4 ? launch_gemv_nf4<4>(p, stream) : (mr == 2 ? launch_gemv_nf4<2>(p, stream) : launch_gemv_nf4<1>(p, stream));
+        if (rc != BAGEL_OK) return rc;
+        m0 += mr;
+    }
+    return BAGEL_OK;
+}

@@ -136,11 +136,14 @@ class DecodeSession:
         # modes keep it): "int8" = row-wise absmax W8A16, de-quantised on the VALU (csrc/quant.hip); "mxfp4" = OCP-MX FP4 blocks of 32
         # with E8M0 scales x FP8 activations on the block-scaled MFMA (csrc/mxfp4.hip), the counterpart of the reference's NF4 mode.
         # The engine caches the quantised copies next to the bf16 ones.
-        if weight_quant not in (None, "int8", "mxfp4"):
-            raise NotImplementedError(f"weight_quant={weight_quant!r}: 'int8' (row-wise absmax, W8A16) and 'mxfp4' (OCP-MX FP4, W4A8) are built")
+        if weight_quant not in (None, "int8", "mxfp4", "nf4"):
+            raise NotImplementedError(f"weight_quant={weight_quant!r}: 'int8' (row-wise absmax, W8A16), 'mxfp4' (OCP-MX FP4, W4A8) and 'nf4' "
+                                      "(bitsandbytes NF4 blocks of 64, W4A16: the reference's own 4-bit mode) are built")
         self.weight_quant = weight_quant
         if weight_quant == "int8" and (eng.H % 16 or eng.I % 16 or (nq * dp) % 16):
             raise NotImplementedError("int8 weights need row lengths that are multiples of 16")
+        if weight_quant == "nf4" and (eng.H % 64 or eng.I % 64 or (nq * dp) % 64):
+            raise NotImplementedError("nf4 weights need row lengths that are multiples of the 64-weight block")
         if weight_quant == "mxfp4":
             if eng.H % 128 or eng.I % 128 or (nq * dp) % 128:
                 raise NotImplementedError("mxfp4 weights need row lengths that are multiples of 128")
@@ -153,10 +156,10 @@ class DecodeSession:
 
     def _quantised_weights(self):
         eng = self.eng
-        attr = "_w8_cache" if self.weight_quant == "int8" else "_w4_cache"
+        attr = {"int8": "_w8_cache", "mxfp4": "_w4_cache", "nf4": "_nf4_cache"}[self.weight_quant]
         cache = getattr(eng, attr, None)
         if cache is None:
-            qz = ops.quantize_rows_i8 if self.weight_quant == "int8" else ops.quantize_rows_mxfp4
+            qz = {"int8": ops.quantize_rows_i8, "mxfp4": ops.quantize_rows_mxfp4, "nf4": ops.quantize_nf4}[self.weight_quant]
             cache = [dict(wqkv=qz(P.wqkv[0]), wo=qz(P.wo[0]), wgu=qz(P.wgu[0]), wd=qz(P.wd[0])) for P in eng.layers]
             setattr(eng, attr, cache)
         return cache
@@ -180,6 +183,8 @@ class DecodeSession:
             if isinstance(w, tuple):        # int8: (u8 weights, fp32 row scales); mxfp4: (E2M1 codes, E8M0 block scales)
                 if self.weight_quant == "mxfp4":
                     return ops.gemv_w4(inp, w[0], w[1], out, norm_w=norm_w, eps=eng.eps, M=B, **kw)
+                if self.weight_quant == "nf4":
+                    return ops.gemv_nf4(inp, w[0], w[1], out, norm_w=norm_w, eps=eng.eps, M=B, **kw)
                 return ops.gemv_w8(inp, w[0], w[1], out, norm_w=norm_w, eps=eng.eps, M=B, **kw)
             if fused:
                 return ops.gemv(inp, w, out, norm_w=norm_w, eps=eng.eps, **kw)

@@ -217,6 +217,35 @@ def gemv_w8(A, Wq, scale, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=N
     return C
 
 
+def quantize_nf4(W):
+    """bf16 [N, K] (K % 64 == 0) -> (u8 [N, K/2] NF4 codes, even element in the high nibble; fp32 absmax [N, K/64]); bagel_quantize_nf4 /
+    oracle/nf4.py: the reference's own 4-bit load mode (app.py:114-125)."""
+    _req(W, BF16, "quantize_nf4.W")
+    N, K = W.shape
+    if K % 64:
+        raise BagelHipError(f"quantize_nf4: K={K} is not a multiple of the 64-weight block")
+    q = torch.empty((N, K // 2), dtype=torch.uint8, device=W.device)
+    a = torch.empty((N, K // 64), dtype=torch.float32, device=W.device)
+    check(lib().bagel_quantize_nf4(_ptr(W), W.stride(0), _ptr(q), q.stride(0), _ptr(a), N, K, _stream()), "bagel_quantize_nf4")
+    return q, a
+
+
+def gemv_nf4(A, Wq, absmax, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0):
+    """``gemv`` on NF4 weights (packed codes + fp32 block absmax), activations bf16; see bagel_gemv_nf4_bf16."""
+    _req(A, BF16, "gemv_nf4.A"); _req(Wq, torch.uint8, "gemv_nf4.Wq"); _req(absmax, torch.float32, "gemv_nf4.absmax"); _req(C, BF16, "gemv_nf4.C")
+    N, K = Wq.shape[0], 2 * Wq.shape[1]
+    if A.shape[-1] != K or absmax.shape != (N, K // 64) or not absmax.is_contiguous():
+        raise BagelHipError("gemv_nf4: shape mismatch")
+    if M is None:
+        M = A.shape[0]
+    if residual is not None:
+        _req(residual, BF16, "gemv_nf4.residual")
+    check(lib().bagel_gemv_nf4_bf16(_ptr(A), _ld(A), _ptr(Wq), Wq.stride(0), _ptr(absmax), _ptr(bias), _ptr(residual),
+                                    _ld(residual) if residual is not None else 0, _ptr(C), _ld(C), _ptr(norm_w), float(eps), M, N, K,
+                                    epilogue, _stream()), "bagel_gemv_nf4_bf16")
+    return C
+
+
 def quantize_rows_mxfp4(W):
     """bf16 [N, K] (K % 128 == 0) -> (u8 [N, K/2] E2M1 codes, two per byte; u8 [N, 16 * ceil(K/512)] E8M0 block scales in device order);
     see bagel_quantize_rows_mxfp4 / oracle/mxfp4.py."""

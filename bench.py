@@ -582,17 +582,19 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
                     "note": f"weight_quant='{mode}' option (changes results): not the headline metric"}
         except Exception as e:
             return {"error": repr(e)}
-    w8 = w4 = None
+    w8 = w4 = wn = None
     if UB == 1 and not args.no_int8:
+        # the reference's OWN 4-bit load mode (app.py:114-125: bitsandbytes NF4, blocks of 64, fp32 absmax, bf16 compute)
+        wn = quantised_decode("nf4", "bitsandbytes NF4 (code book of 16, blocks of 64 with fp32 absmax, no double quantisation), W4A16, lm_head bf16")
         w8 = quantised_decode("int8", "row-wise absmax INT8 (W8A16, de-quantised on the VALU), lm_head bf16")
         # the 4-bit counterpart of the reference's NF4 load mode: OCP-MX FP4 weights x FP8 activations on the block-scaled MFMA
         w4 = quantised_decode("mxfp4", "OCP-MX FP4 E2M1 blocks of 32 with E8M0 scales (W4A8 on v_mfma_scale_f32_16x16x128_f8f6f4), lm_head bf16")
     # SURVEY 8f.4b beside the batch-1 number: 16 requests decoded together (one weight pass serves the batch; the reference decodes
-    # batch 1 only, bagel.py:996) -- 64 new tokens each on their own 4936-token contexts
+    # batch 1 only, bagel.py:996) -- 160 new tokens each on their own 4936-token contexts
     bd = None
     if UB == 1 and not args.no_batched_decode:
         try:
-            nb, nn = 16, 64
+            nb, nn = 16, 160         # (step 0 runs eagerly and the hipGraph capture follows it: amortised over the run)
             cb, lb, rb, _ = prefill(nb)
             sb = model.prepare_start_tokens(lb, rb, ids)
             model.generate_text(past_key_values=cb, max_length=4, do_sample=False, end_token_id=None, **sb)
@@ -632,7 +634,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
             "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
             "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer", "cpu_baseline": cpu,
-            "int8_weights": w8, "mxfp4_weights": w4, "batched_decode": bd,
+            "int8_weights": w8, "mxfp4_weights": w4, "nf4_weights": wn, "batched_decode": bd,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_decode_traffic() if (UB == 1 and args.und_image == 980) else None,
                          "kernel": "gemv_kernel (decode step)",

@@ -179,6 +179,18 @@ int bagel_gemv_w8_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldw, 
                        const void* R, int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M,
                        int32_t N, int32_t K, int32_t epilogue, bagel_stream_t stream);
 
+/* NF4 -- the 4-bit load mode the reference itself ships (app.py:114-125: bitsandbytes quant_type "nf4", blocksize 64, fp32 absmax, no
+ * double quantisation, bf16 compute; restated in oracle/nf4.py from the library's published algorithm).  quantize: per block of 64
+ * consecutive weights absmax[n, k/64] = max |w| (fp32), code = index of the NF4 code-book entry nearest to w * (1 / absmax) (the
+ * library's midpoint decision tree), two codes per byte with the EVEN element in the HIGH nibble; cols % 64 == 0.  gemv: bagel_gemv_bf16
+ * on the de-quantised weights code_book[code] * absmax ("W4A16": activations bf16, fp32 accumulation, same epilogues / fused RMSNorm /
+ * roundings).  An OPTION that changes results (generate_text(weight_quant="nf4")); ldw in bytes % 16 == 0. */
+int bagel_quantize_nf4(const void* w, int64_t ldw, void* q, int64_t ldq_bytes, float* absmax, int32_t rows, int32_t cols,
+                       bagel_stream_t stream);
+int bagel_gemv_nf4_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldw_bytes, const float* absmax, const void* bias,
+                        const void* R, int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N,
+                        int32_t K, int32_t epilogue, bagel_stream_t stream);
+
 /* MXFP4 weight-only projections for the decode path: the 4-bit counterpart of the reference's bitsandbytes NF4 load mode
  * (app.py:114-125) on the chip's own block-scaled MFMA operand -- an OPTION that changes results.  OCP-MX FP4: codes E2M1, two per
  * byte (element 2i in the low nibble of byte i), one E8M0 scale byte per 32 elements along K (2^(b-127), b = max(exp(max|w|) - 2, 0)),

@@ -74,9 +74,21 @@ def mxfp4_decode_weight_ptrs(W):
     return {v.data_ptr() for k, v in W.items() if "language_model.model.layers." in k and any(k.endswith(f".{n}.weight") for n in names)}
 
 
+# NF4 option of the product's text decode (generate_text(weight_quant="nf4"), oracle/nf4.py = the reference's own 4-bit load mode,
+# app.py:114-125): data_ptr()s of the weight tensors whose linear runs on the de-quantised NF4 weight (same seven linears per layer).
+NF4_WEIGHT_PTRS = set()
+
+
 @_explicit_casts
 def linear(x, w, b=None):
     """F.linear under bf16 autocast: inputs cast to the (bf16) weight dtype, bf16 result."""
+    if NF4_WEIGHT_PTRS and w.data_ptr() in NF4_WEIGHT_PTRS:
+        from oracle import nf4 as NF
+        cache = linear.__dict__.setdefault("_nf4", {})
+        key = (w.data_ptr(), w._version)
+        if key not in cache:
+            cache[key] = NF.dequantize_nf4(*NF.quantize_nf4(w), dtype=w.dtype)
+        return F.linear(x.to(w.dtype), cache[key], None if b is None else b.to(w.dtype))
     if MXFP4_WEIGHT_PTRS and w.data_ptr() in MXFP4_WEIGHT_PTRS:
         from oracle import mxfp4 as MX
         x2 = x.to(w.dtype).reshape(-1, x.shape[-1])

@@ -297,6 +297,17 @@ def gemv_w4(A, Wq, Ws, C, *, bias=None, residual=None, epilogue=0, M=None, norm_
     return C
 
 
+def quantize_nf4(W):
+    from oracle import nf4
+    return nf4.quantize_nf4(W)
+
+
+def gemv_nf4(A, Wq, absmax, C, *, bias=None, residual=None, epilogue=0, M=None, norm_w=None, eps=0.0):
+    """The reference's Linear4bit with bf16 compute: the bf16 projection on the de-quantised bf16 weight (oracle/nf4.py)."""
+    from oracle import nf4
+    return gemv(A, nf4.dequantize_nf4(Wq, absmax), C, bias=bias, residual=residual, epilogue=epilogue, M=M, norm_w=norm_w, eps=eps)
+
+
 def decode_advance(next_tok, cur_tok32, tokens_out, pos, kv_len, step, batch, max_steps):
     s_ = int(step[0])
     cur_tok32.copy_(next_tok.to(torch.int32))
@@ -494,7 +505,7 @@ def chw_f32_to_u8(src):
 _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
-          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4",
+          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
           "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8"]
 

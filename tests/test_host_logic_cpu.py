@@ -285,6 +285,36 @@ def test_decode_mxfp4_weights_host_path_matches_oracle(monkeypatch):
     assert first.w8 is not None and len(first.w8) == L
 
 
+def test_decode_nf4_weights_host_path_matches_oracle(monkeypatch):
+    """generate_text(weight_quant='nf4') -- the reference's own 4-bit load mode (app.py:114-125) -- on the host logic: the und expert's
+    fused qkv / o / interleaved gate+up / down are quantised (row-wise blocks of 64: fusing and interleaving rows changes nothing),
+    lm_head stays bf16 -- vs the oracle's decode loop with oracle/nf4.py switched into exactly those linears."""
+    from oracle import bagel_oracle as O
+    mock_ops.install(monkeypatch)
+    cfg = CFGS["tiny_d128"]
+    model = cpu_model(cfg)
+    W, _ = oracle_weights(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    pi, l2, r2 = model.prepare_prompts([0], [0], ["what is in the picture"], tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(new_cache(cfg), **pi)
+    oc = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **pi)
+    si = model.prepare_start_tokens(l2, r2, NEW_TOKEN_IDS_TINY)
+    n = 5
+    O.NF4_WEIGHT_PTRS = O.mxfp4_decode_weight_ptrs(W)          # the same seven linears per layer
+    try:
+        otoks, ologits = O.generate_text(W, cfg, oc, si["packed_key_value_indexes"], si["key_values_lens"], si["packed_start_tokens"],
+                                         si["packed_query_position_ids"], n, return_logits=True)
+    finally:
+        O.NF4_WEIGHT_PTRS = set()
+    with pytest.raises(NotImplementedError):
+        model.generate_text(past_key_values=copy.deepcopy(cache), max_length=1, do_sample=False, end_token_id=None, use_graph=False, weight_quant="fp4", **si)
+    toks = model.generate_text(past_key_values=cache, max_length=n, do_sample=False, end_token_id=None, use_graph=False, weight_quant="nf4", **si)
+    sess = model._last_decode_session
+    assert sess.weight_quant == "nf4" and sess.w8 is not None and len(sess.w8) == L
+    _tokens_match(toks, otoks, ologits, "tiny_d128 nf4")
+
+
 def cpu_model_and_vae(cfg):
     from bagel_amd.factory import build_bagel
     W, VW = oracle_weights(cfg)

@@ -287,3 +287,33 @@ def test_mxfp4_restatement_known_answers():
     x = torch.tensor([[1.0, -2.0, 0.5, 448.0] + [0.0] * 92]).to(torch.bfloat16)
     y = MX.gemv_w4(x, q2, s2)
     assert torch.equal(y, (x.float() @ w2.float().t()).to(torch.bfloat16))
+
+
+def test_nf4_restatement_known_answers():
+    """oracle/nf4.py (the CPU statement of bitsandbytes' NF4, the reference's 4-bit load mode, app.py:114-125) against what the library
+    publishes: the 16-entry code book (QLoRA appendix E: quantiles of N(0,1), exact zero, symmetric ends), the kernel's thresholds =
+    midpoints of adjacent entries with ties going DOWN, blocks of 64 with an fp32 absmax, the EVEN element in the HIGH nibble."""
+    from oracle import nf4
+    c = nf4.NF4_CODE
+    assert c[0] == -1 and c[7] == 0 and c[15] == 1 and (c[1:] > c[:-1]).all() and len(c) == 16
+    assert torch.allclose(nf4.NF4_THRESH.double(), ((c[1:] + c[:-1]) / 2).double(), atol=5e-8)
+    # every code-book value (times an absmax) quantises to itself; packing order
+    w = (c.repeat(4) * 3.0).view(1, 64)
+    p, a = nf4.quantize_nf4(w)
+    assert a.tolist() == [[3.0]] and nf4.codes_of(p)[0, :16].tolist() == list(range(16))
+    assert p[0, :8].tolist() == [0x01, 0x23, 0x45, 0x67, 0x89, 0xAB, 0xCD, 0xEF], "even element in the high nibble"
+    assert torch.equal(nf4.dequantize_nf4(p, a, torch.float32), w)
+    # a value exactly on a threshold goes to the lower code; just above it to the upper
+    t = nf4.NF4_THRESH[9].item()
+    w2 = torch.zeros(1, 64); w2[0, 0] = 1.0; w2[0, 1] = t; w2[0, 2] = float(torch.nextafter(torch.tensor(t), torch.tensor(1.0)))
+    assert nf4.codes_of(nf4.quantize_nf4(w2)[0])[0, :3].tolist() == [15, 9, 10]
+    # an all-zero block: 1 / absmax = inf, x = NaN, every comparison false -> code 0, de-quantised to (-1) * 0
+    p0, a0 = nf4.quantize_nf4(torch.zeros(2, 128))
+    assert (p0 == 0).all() and (a0 == 0).all() and (nf4.dequantize_nf4(p0, a0).float() == 0).all()
+    # blocks are 64 consecutive elements of a row; a bf16 weight matrix costs ~9 % relative error
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(8, 256, generator=g) * 0.05).to(torch.bfloat16)
+    p3, a3 = nf4.quantize_nf4(W)
+    assert p3.shape == (8, 128) and a3.shape == (8, 4) and torch.equal(a3, W.float().view(8, 4, 64).abs().amax(2))
+    e = ((nf4.dequantize_nf4(p3, a3).float() - W.float()).norm() / W.float().norm()).item()
+    assert 0.05 < e < 0.13, e
