@@ -90,6 +90,24 @@ __device__ __forceinline__ void a2_glds16s(unsigned voff, const void* sbase_unif
 #ifndef A2_WIN
 #define A2_WIN 3
 #endif
+#ifndef A2_ABL
+#define A2_ABL 0             // timing-only ablations (WRONG results; tools/ab_build.sh): bit 0 no barrier / vmcnt waits, bit 1 no softmax / row-max VALU,
+#endif                       // bit 2 no LDS fragment reads inside the phases, bit 3 no LDS-DMA after the priming
+#ifndef A2_SLOTS
+#define A2_SLOTS 4          // LDS ring slots (3 = fetch at the top of a step, two tiles ahead; 4 = fetch inside phase B, three tiles ahead)
+#endif
+
+// value of lane ^ 32 combined with the own value, without the LDS round trip of __shfl_xor (ds_bpermute + 6 address VALU + ~100 cycles
+// on the serial tail of every tile): v_permlane32_swap exchanges the upper half of one register with the lower half of the other, so
+// after swapping two copies of x, (r0, r1) = (x[l & 31], x[32 | (l & 31)]) in every lane.
+__device__ __forceinline__ float a2_max_halves(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float a2_sum_halves(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <int D>
 __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, const int* __restrict__ worker_off,
@@ -103,6 +121,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
     constexpr int KT_BYTES = 64 * KROW;
     constexpr int VT_BYTES = D * 128;
     constexpr int STAGE = KT_BYTES + VT_BYTES;
+    constexpr int NS = A2_SLOTS;            // ring slots; the LDS-DMA cursor runs NS - 1 tiles ahead of the compute cursor
     constexpr int NW = 8;
     constexpr int NLK = KT_BYTES / 1024 / NW;   // LDS-DMA pieces per wave for K   (2 @128)
     constexpr int NLV = VT_BYTES / 1024 / NW;   // ... for V^T
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
     const unsigned voff_new = ((unsigned)dv * (unsigned)p.ldvt_new + gchv * 8) * 2u;
 
     // ---- the DMA cursor: (item, tile) of the next 64-key tile to fetch, two tiles ahead of the compute cursor ----
-    int d_i = i_begin, d_t = 0, d_t1 = 0, d_ntc = 0, d_lc = 0, d_ln = 0, d_slot = 0;
+    int d_i = i_begin, d_t = 0, d_t1 = 0, d_ntc = 0, d_lc = 0, d_ln = 0, d_slot = 0, issued = 0;
     const char *d_kc = nullptr, *d_kn = nullptr, *d_vc = nullptr, *d_vn = nullptr;
     auto d_load = [&](int idx) {
         const AttnItem* it = item_tab + idx;
@@ -184,14 +203,15 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
             for (int i = NLK; i < NP; ++i) dma_piece(i);
             mode = 2;
         }
-        d_slot = d_slot == 2 ? 0 : d_slot + 1;
+        d_slot = d_slot == NS - 1 ? 0 : d_slot + 1;
+        ++issued;
         if (++d_t >= d_t1) {
             ++d_i;
             if (d_i < i_end) d_load(d_i);
         }
         return mode;
     };
-    auto issue_next = [&]() -> bool { return dma_next() != 0; };
+    auto issue_next = [&]() -> bool { if ((A2_ABL & 8) && issued >= NS - 1) { if (d_i >= i_end) return false; ++issued; if (++d_t >= d_t1) { ++d_i; if (d_i < i_end) d_load(d_i); } return true; } return dma_next() != 0; };
 
     // ---- per-lane constants for fragment reads (attention.hip's layout; here as ONE address per operand) ----
     // K fragment ks of key block kb sits at  koff0 + kb * 32 * KROW + (((2 ks + hi) ^ kswz) << 4)  and  V^T fragment (db, j) at
@@ -216,10 +236,18 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
 
     // ---- prime the tile stream: the first two tiles of this worker ----
     d_load(d_i);
-    issue_next();
-    bool newer = issue_next();                  // a tile NEWER than the one needed next is in flight
-    if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLK + NLV) : "memory");
-    else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) issue_next();
+    int u = 0;                                  // stream index of the compute cursor's tile (tiles are consumed in the order they are fetched)
+    // counted wait until this wave's pieces of stream tile x have landed: the `issued - (x + 1)` tiles fetched after it may stay in
+    // flight (LDS-DMA returns in order; anything else hipcc issued meanwhile -- the epilogue's stores -- only makes the wait longer)
+    auto wait_for = [&](int x) {
+        const int n = issued - (x + 1);
+        if (n >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NLK + NLV)) : "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLK + NLV) : "memory");
+        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    wait_for(0);
 
     int cs = 0;                                 // ring slot of the compute cursor's tile (the tile stream is consumed in order)
     for (int ci = i_begin; ci < i_end; ++ci) {
@@ -255,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
             for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f, m_use = 0.f;            // m_run in log2 units
 
-        auto next_slot = [&](int s) { return s == 2 ? 0 : s + 1; };
+        auto next_slot = [&](int s) { return s == NS - 1 ? 0 : s + 1; };
 
         auto mask_tile = [&](f32x16_t (&s)[2], int t) {
             const int tt = t0 + t;
@@ -283,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
                 c = fmaxf(fmaxf(c, s[0][r + 1]), s[1][r + 1]);
             }
             a = fmaxf(a, c);
-            return fmaxf(a, __shfl_xor(a, 32, 64)) * p.scale_log2;
+            return a2_max_halves(a) * p.scale_log2;
         };
         auto raise_max = [&](float mx) {
             const bool grow = mx > m_run + ATTN2_DEFER_LOG2;
@@ -304,10 +332,12 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
         // [row max of sn].  LAST: there is no tile t+1 in THIS item (the stream's next tile belongs to the next item and is not waited for here).
         auto step = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int t, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
-            if (!LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t+1 have landed
-            asm volatile("s_barrier" ::: "memory");          // ... everyone's; and everyone is done with tile t-1
-            const bool issued = issue_next();                 // tile t+2 of the stream (it may belong to the next item)
-            if (LAST) newer = issued;
+            if (!(A2_ABL & 1)) {
+            if (!LAST) wait_for(u + 1);                      // this wave's pieces of tile t+1 have landed
+            asm volatile("s_barrier" ::: "memory");          // ... everyone's; and everyone is done with tile t-1, whose slot the NEXT fetch takes
+            }
+            ++u;
+            if (NS == 3 || !live) issue_next();              // 3 slots: fetch tile t+2 here; 4 slots: tile t+3 goes out inside phase B (below)
             const unsigned sbv = vb0 + cs * STAGE;
             cs = next_slot(cs);
             const unsigned sbk = kb0 + cs * STAGE;
@@ -319,6 +349,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
             unsigned pw[16];
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             auto softmax_slice = [&](int pi) {
+                if (A2_ABL & 2) { pw[pi] = 0x3c003c00u; if (pi == 0) asm volatile("" ::"v"(sc[0][0]), "v"(sc[1][0])); return; }
                 const int kb = pi / 8, r = (2 * pi) % 16;
                 const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], p.scale_log2, -m_use));
                 const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r + 1], p.scale_log2, -m_use));
@@ -349,7 +380,8 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
                 for (int m = 0; m < NMA; ++m) {
                     const int kb = m & 1, ks = m >> 1;
                     sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[m], qf[ks], sn[kb], 0, 0, 0);
-                    if (m + WIN < NK) kf[m + WIN] = kfrag(sbk, kidx(m + WIN));
+                    if (A2_ABL & 4) { if (m + WIN < NK) kf[m + WIN] = kf[m % WIN]; else if (m + WIN - NK < WIN) vf[m + WIN - NK] = kf[m % WIN]; }
+                    else if (m + WIN < NK) kf[m + WIN] = kfrag(sbk, kidx(m + WIN));
                     else if (m + WIN - NK < WIN) vf[m + WIN - NK] = vfrag(sbv, vidx(m + WIN - NK));
 #pragma unroll
                     for (int u = 0; u < SLOTS; ++u) softmax_slice(m * SLOTS + u);
@@ -370,11 +402,14 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
             for (int m = 0; m < NMB; ++m) {
                 const int db = m % DB, jj = m / DB;
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[m], pfrag(jj), o[db], 0, 0, 0);
-                if (m + WIN < NV) vf[m + WIN] = vfrag(sbv, vidx(m + WIN));
+                if (m + WIN < NV) vf[m + WIN] = (A2_ABL & 4) ? vf[m % WIN] : vfrag(sbv, vidx(m + WIN));
+                if (NS > 3 && m == NMB / 2) issue_next();   // the slot of tile t-1 is free since this step's barrier; phase B has the issue slack
 #pragma unroll
                 for (int u = 0; u < SPB; ++u) {
                     const int slot = m * SPB + u;
-                    if (!LAST) {
+                    if (!LAST && (A2_ABL & 2)) {       // keep the S^T MFMAs alive (one element per accumulator), drop the rest of the row max
+                        if (slot < 2) { mx = fmaxf(mx, sn[slot][0]); asm volatile("" : "+v"(mx)); }
+                    } else if (!LAST) {
                         const int kb = slot / 8, r = (2 * slot) % 16;
                         mx = fmaxf(fmaxf(mx, sn[kb][r]), sn[kb][r + 1]);
                         asm volatile("" : "+v"(mx));
@@ -383,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
                 __builtin_amdgcn_sched_barrier(0);
             }
             l_run += (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            if (!LAST) mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
+            if (!LAST) mx = a2_max_halves(mx) * p.scale_log2;
             __builtin_amdgcn_sched_barrier(0);
             if (!LAST) raise_max(mx);
         };
@@ -418,14 +453,11 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
         }
         // the next item's first tile must have landed before this wave meets the others at that item's prologue barrier; waiting HERE keeps
         // the epilogue's stores out of the count
-        if (ci + 1 < i_end) {
-            if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLK + NLV) : "memory");
-            else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (ci + 1 < i_end) wait_for(u);
 
         // ---- epilogue: lane owns d = 32*db + 8*u + 4*hi + (0..3) of query row qi ----
         if (live) {
-            const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+            const float l_tot = a2_sum_halves(l_run);
             if (!partial) {
                 const float inv = 1.0f / l_tot;
                 if (row_ok) {
@@ -685,11 +717,12 @@ extern "C" int bagel_attn_planned_bf16(const void* q, int64_t ldq, const void* k
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const dim3 grid(n_workers), block(512);
     if (head_dim == 128) {
-        constexpr int smem = 3 * (64 * 256 + 128 * 128);
+        constexpr int smem = A2_SLOTS * (64 * 256 + 128 * 128);
         if (int rc = bagel_enable_lds((const void*)attn2_kernel<128>, smem, "attn2_kernel<128>")) return rc;
         hipLaunchKernelGGL((attn2_kernel<128>), grid, block, smem, stream, p, worker_off, items);
     } else if (head_dim == 64) {
-        constexpr int smem = 3 * (64 * 128 + 64 * 128);
+        constexpr int smem = A2_SLOTS * (64 * 128 + 64 * 128);
+        if (int rc = bagel_enable_lds((const void*)attn2_kernel<64>, smem, "attn2_kernel<64>")) return rc;
         hipLaunchKernelGGL((attn2_kernel<64>), grid, block, smem, stream, p, worker_off, items);
     } else {
         return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_planned: head_dim %d not in {64,128} (pad the head)", head_dim);
