@@ -23,6 +23,8 @@ def _pack3(w, cin_pad):
 
 
 class VaeEngine:
+    ATTN_ROWS = 2048       # query rows per score block of the mid-block attention
+
     def __init__(self, ae):
         p0 = ae.encoder.conv_in.weight
         ops.require_gpu_f32(p0, "VaeEngine")
@@ -88,11 +90,21 @@ class VaeEngine:
         q, k, v = self.conv(h, m.q, 0), self.conv(h, m.k, 0), self.conv(h, m.v, 0)
         N = H * W
         o = torch.empty((B, N, C), dtype=F32, device=x.device)
+        # fp32 attention like the reference (autoencoder.py:52-60).  The score matrix is produced in blocks of ATTN_ROWS query rows (rows are
+        # independent: the results do not depend on the block size): at 1024^2 the mid block has 16 384 tokens and the whole matrix would be
+        # a 1.07 GB transient; a 2048-row block is 134 MB and is reused by every block.
+        R = min(N, self.ATTN_ROWS)
+        sbuf = torch.empty((R, N), dtype=F32, device=x.device)
         for b in range(B):
-            s = self.gemm_nt(q[b].view(N, C), k[b].view(N, C))
-            ops.softmax_rows_f32(s, s.stride(0), N, N, float(C) ** -0.5)
+            qb, kb = q[b].view(N, C), k[b].view(N, C)
             vt = v[b].view(N, C).t().contiguous()          # layout copy only
-            o[b] = self.gemm_nt(s, vt)
+            for r0 in range(0, N, R):
+                n = min(R, N - r0)
+                s = sbuf[:n]
+                ops.conv_gemm_f32(qb[r0:r0 + n], qb.stride(0), kb, kb.stride(0), None, None, s, N, 1, 1, n, C, 1, n, N, 0)
+                ops.softmax_rows_f32(s, s.stride(0), n, N, float(C) ** -0.5)
+                ob = o[b, r0:r0 + n]
+                ops.conv_gemm_f32(s, s.stride(0), vt, vt.stride(0), None, None, ob, C, 1, 1, n, N, 1, n, C, 0)
         return self.conv(o.view(B, H, W, C), m.proj_out, 0, residual=x)
 
     @staticmethod

@@ -157,6 +157,29 @@ def gemm_profile_hook():
     return records, orig, timed
 
 
+def attn_profile_hook():
+    """The same for ops.attn_planned (the persistent attention kernel + its combine pass): algorithmic FLOPs 4 * Lq * Lkv * nq * D per sample
+    (causal: the visible half of the new segment) over the HIP-event duration of every launch in the timed region."""
+    from bagel_amd import ops
+    records = []
+    orig = ops.attn_planned
+
+    def flops(ap):
+        f = getattr(ap, "_bench_flops", None)
+        if f is None:
+            f = ap._bench_flops = sum(4.0 * lq * (lq * (0.5 if ap.causal else 1.0) + c) * ap.nq * ap.head_dim for lq, c in zip(ap.q_len, ap.ctx_len))
+        return f
+
+    def timed(q, k_new, vt_new, out, aplan, softmax_scale, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(q, k_new, vt_new, out, aplan, softmax_scale, **kw)
+        e1.record()
+        records.append((flops(aplan), e0, e1, len(aplan.q_len)))
+        return r
+    return records, orig, timed
+
+
 def physical_cores():
     """Physical cores of the host (SMT siblings excluded): what a bf16 GEMM-bound CPU run should use as its thread team."""
     try:
@@ -643,7 +666,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
                         f"prompt tokens prefill, greedy decode of {n} tokens, bf16, batch {UB}/GPU"}
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
 
 
 def _source_digest(names):
@@ -678,6 +701,28 @@ def pmc_traffic(kernel):
         return d["kernels"][kernel]["traffic_bytes_per_launch_corrected"]
     except Exception:
         return None
+
+
+def attention_object(arecords, args, R):
+    """Second kernel of the denoise path: the planned persistent attention kernel (csrc/attention2.hip), timed live like the GEMM (HIP
+    events around every launch of the timed region; the big launches = the stream-batched denoise forwards) + the PMC figures of the
+    committed summary while attention2.hip still hashes to the digest they were collected on."""
+    big = [r for r in arecords if r[0] > 1e11]
+    if not big:
+        return None
+    fl = sum(r[0] for r in big)
+    ms = sum(r[1].elapsed_time(r[2]) for r in big)
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    out = {"kernel": "attn2_kernel<128> (+ attn2_combine_kernel<128>)", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+           "frac": ach / PEAK_BF16_TFLOPS, "launches": len(big), "avg_launch_ms": ms / len(big), "samples_per_launch": big[0][3]}
+    d = _pmc_entry("attention", None, ["attention2.hip", "common.h"]) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None
+    k = (d or {}).get("kernels", {}).get("attn2_kernel<128>")
+    if k:
+        out["traffic"] = k.get("traffic_bytes_per_launch_corrected")
+        out["pmc"] = {x: k.get(x) for x in ("mfma_busy_frac", "l2_hit_rate", "wave_cycles_split", "algorithmic_bytes_per_launch")}
+    else:
+        out["traffic"] = None
+    return out
 
 
 def pmc_decode_traffic():
@@ -907,9 +952,12 @@ def main():
     for _ in range(args.warmup):
         one_step()
     records, orig_gemm = [], ops.gemm
+    arecords, orig_attn = [], ops.attn_planned
     if cuda:
         records, orig_gemm, timed_gemm = gemm_profile_hook()
         ops.gemm = timed_gemm
+        arecords, orig_attn, timed_attn = attn_profile_hook()
+        ops.attn_planned = timed_attn
     del bcast[:]
     fence()
     t0 = time.perf_counter()
@@ -918,6 +966,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.gemm = orig_gemm
+    ops.attn_planned = orig_attn
     bcast_timed = list(bcast)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -1063,6 +1112,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                          "traffic": pmc_traffic(names.get(dom, str(dom))) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None, "kernel": names.get(dom, str(dom)), "launches": len(records),
                          "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},
+            "attention": attention_object(arecords, args, R),
             "outputs_finite": bool(finite),
             # the job as the collective library saw it (an all-reduce of ones at start-up) and the conditioning-KV broadcast of the timed
             # steps as rank 0 timed it (HIP events on the launch stream; null at N = 1: there is no exchange)

@@ -324,6 +324,18 @@ def cpu_model_and_vae(cfg):
     return model.to(torch.bfloat16).eval(), vae.eval()
 
 
+def test_vae_mid_block_attention_is_blocked_over_query_rows(golden, monkeypatch):
+    """VaeEngine.attn produces the score matrix in blocks of ATTN_ROWS query rows (1024^2: 16 384 tokens would be a 1.07 GB transient):
+    ragged blocks give the same encode / decode as one block."""
+    from bagel_amd.modeling import vae_engine
+    mock_ops.install(monkeypatch)
+    g = golden("tiny_vae")
+    _, vae = cpu_model_and_vae(TINY)
+    ref = vae.decode(g["z"]).clone()
+    monkeypatch.setattr(vae_engine.VaeEngine, "ATTN_ROWS", 40)          # 16 x 24 = 384 latent tokens -> 10 blocks, the last one ragged
+    assert torch.equal(vae.decode(g["z"]), ref)
+
+
 def test_vae_host_path_matches_reference(golden, monkeypatch):
     """VaeEngine: weight packing (tap-major 3x3, channel padding), NHWC plumbing, conv modes (3x3, strided with the (0,1,0,1) pad,
     upsample-fused), ResnetBlock / AttnBlock residual folding -- encode / decode vs the reference, and the truncating uint8 image."""

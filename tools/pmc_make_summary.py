@@ -55,9 +55,11 @@ def main():
     kernels = {}
     M, H, I = 32768, 3584, 18944
     algo = {"gemm_pq_kernel<0, false>": 2.0 * (M * H + 2 * I * H) + 2.0 * M * I,                      # gate+up: A + W read, act written
-            "gemm_pq_kernel<2, false>": 2.0 * (M * H + 4608 * H) + 2.0 * M * 4608}                    # qkv
+            "gemm_pq_kernel<2, false>": 2.0 * (M * H + 4608 * H) + 2.0 * M * 4608,                    # qkv
+            # the stream-batched denoise launch: Q read + O written (8 x 4098 rows x 28 heads x 128) + K and V^T of every sample once
+            "attn2_kernel<128>": 2.0 * 2 * (8 * 4098) * 3584 + 2.0 * 2 * (8 * 4098 + 4 * 32) * 512}
     for k, c in den.items():
-        if not (k.startswith("gemm_p") or k.startswith("attn_fwd") or k.startswith("rmsnorm") or k.startswith("qknorm")):
+        if not (k.startswith("gemm_p") or k.startswith("attn") or k.startswith("rmsnorm") or k.startswith("qknorm")):
             continue
         e = {"launches_sampled": max((n for _, n in c.values()), default=0)}
         if "FETCH_SIZE" in c:
@@ -124,13 +126,13 @@ def main():
         commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         commit = ""
-    out = {"source": "tools/gpu_pmc.sh (rocprofv3 --kernel-trace --pmc <one group per pass>); raw per-kernel averages in profiles/r02_pmc_denoise_*.txt / "
-                     "profiles/r02_pmc_decode_*.txt",
+    out = {"source": "tools/gpu_pmc.sh (rocprofv3 --kernel-trace --pmc <one group per pass>); raw per-kernel averages in profiles/r03_pmc_denoise_*.txt / "
+                     "profiles/r03_pmc_decode_*.txt",
            "correction": "FETCH_SIZE (KB) doubled for the 16-B/lane streaming patterns (MI355X_MICROARCH.md, HBM section; cross-checked in round 1 against "
                          "TCC_MISS x 128 B and on an in-place kernel); WRITE_SIZE (KB) as reported",
            "commit": commit,
            "source_digest": {"gemm": digest(["gemm.hip", "common.h"]), "decode": digest(["decode.hip", "skinny.hip", "common.h"]),
-                             "attention": digest(["attention.hip", "common.h"])},
+                             "attention": digest(["attention2.hip", "common.h"])},
            "kernels": kernels, "decode_step": decode}
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
