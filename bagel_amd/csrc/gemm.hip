@@ -48,6 +48,11 @@ struct GemmParams {
     // FP8 operands (gemm_pq_kernel<MODE, true>): A / W are e4m3 bytes, sa[physical A row] and sw[n] the fp32 de-quantisation scales
     const float* sa;
     const float* sw;
+    // split launches of the persistent kernel (launch_gemm_pq): this launch covers the tile indices [w_begin, w_begin + w_count) of the
+    // XCD-aware walk; ksplit > 1 cuts every one of them into ksplit work items along K that leave fp32 partial tiles in `part`
+    // (gemm_pq_kernel<4>) for gemm_splitk_reduce_kernel
+    int w_begin, w_count, ksplit;
+    float* part;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -613,7 +618,7 @@ __device__ __forceinline__ i32x8_t cat_frag(const bf16x8_t& lo, const bf16x8_t& 
 
 template <int MODE, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
-    constexpr bool SWIGLU = MODE == 0, HAS_R = MODE == 1, HAS_BIAS = MODE == 2;
+    constexpr bool SWIGLU = MODE == 0, HAS_R = MODE == 1, HAS_BIAS = MODE == 2, PARTIAL = MODE == 4;
     constexpr int BM = 256, BN = 256;
     constexpr int PIECE = 128 * 128;
     constexpr int STAGE = 4 * PIECE;
@@ -627,11 +632,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     const int grp = wave >> 2, wj = wave & 3;
     const bool g1 = grp != 0;
     const int nblk = p.tiles_m * p.tiles_n;
-    const int nk = p.K >> 6;
+    const int nk_all = p.K >> 6;
+    const int nitems = p.w_count * p.ksplit;       // work items of this launch: item j = K part (j % ksplit) of tile w_begin + j / ksplit
     const int stride = gridDim.x;
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)smem);
+    // k-tile range [kt0, kt0 + nkt) of work item j
+    auto item_k = [&](int j, int& kt0, int& nkt) {
+        if (!PARTIAL) { kt0 = 0; nkt = nk_all; return; }
+        const int part = j % p.ksplit;
+        kt0 = (int)((long)nk_all * part / p.ksplit);
+        nkt = (int)((long)nk_all * (part + 1) / p.ksplit) - kt0;
+    };
 
-    auto tile_of = [&](int w, int& tm, int& tn) {
+    auto tile_of = [&](int j, int& tm, int& tn) {
+        const int w = p.w_begin + (PARTIAL ? j / p.ksplit : j);
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = w & 7, loc = w >> 3;
         const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -660,8 +674,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     // DMA sources of tile (tm, tn): piece-local row lr = 8*j + lane/8 (j = wave + 8*i), LDS chunk lane%8, global chunk
     // swizzled; A rows come from the table in ring slot `buf`.  `ln` is an opaque copy of the lane id (keeps hipcc from
     // hoisting this arithmetic out of the tile loop and spilling it across the k-loop).
-    auto make_src = [&](int tm, int tn, int buf, int ln) {
+    auto make_src = [&](int tm, int tn, int buf, int ln, int kt0) {
         const bf16_t* __restrict__ Wg = p.g[group_of(tm)].W;
+        const long kb = (long)kt0 * 128;           // byte offset of the item's first k-tile inside a row
         const int n0 = tn * BN;
         const int* atab = (const int*)(smem + TBL + buf * 2048);
 #pragma unroll
@@ -671,10 +686,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int row = atab[(lr >> 6) * 128 + half * 64 + (lr & 63)];
-                src[half ? 3 : 0][i] = (const char*)(p.A + (long)row * p.lda) + gch16;
+                src[half ? 3 : 0][i] = (const char*)(p.A + (long)row * p.lda) + gch16 + kb;
                 int n = n0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
                 n = n < p.N ? n : p.N - 1;
-                src[half ? 2 : 1][i] = (const char*)(Wg + (long)n * p.ldw) + gch16;
+                src[half ? 2 : 1][i] = (const char*)(Wg + (long)n * p.ldw) + gch16 + kb;
             }
         }
     };
@@ -754,13 +769,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     // ---- first tile: row tables of tiles 0 and 1, then the standard two-k-tile prologue ----
     int w = blockIdx.x, tm, tn;
     tile_of(w, tm, tn);
+    int kt0, nk;
+    item_k(w, kt0, nk);
     int wn = w + stride, tmn = 0, tnn = 0;
     fetch_tables(tm, 0);
-    if (wn < nblk) { tile_of(wn, tmn, tnn); fetch_tables(tmn, 1); }
+    if (wn < nitems) { tile_of(wn, tmn, tnn); fetch_tables(tmn, 1); }
     PP_VMCNT(0);
     PP_LGKM0();
     PP_BARRIER();
-    make_src(tm, tn, 0, lane);
+    make_src(tm, tn, 0, lane, kt0);
     pin_src();
     issue(0, smem_base, 0); issue(1, smem_base, 0); issue(2, smem_base, 0); issue(3, smem_base, 0);
     issue(0, smem_base + STAGE, 128); issue(1, smem_base + STAGE, 128); issue(2, smem_base + STAGE, 128);
@@ -820,23 +837,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
         asm volatile("" : "+s"(ewave));
         const int efr = elane & 15, ensub = (elane >> 4) * 4, egrp = ewave >> 2, ewj = ewave & 3;
         const int* ctab = (const int*)(smem + TBL + slot * 2048 + 1024);
-        const bool has_next = wn < nblk;
+        const bool has_next = wn < nitems;
         const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
         const int w2 = wn + stride;
         int tm2 = 0, tn2 = 0;
+        int kt0n = 0, nkn = nk_all;
+        if (has_next) item_k(wn, kt0n, nkn);
 
         // next tile: tables of the tile after it, then k-tile 0 into stage 0
         auto start_next = [&]() {
             if (has_next) {
-                if (w2 < nblk) { tile_of(w2, tm2, tn2); fetch_tables(tm2, slot2); }
-                make_src(tmn, tnn, slot1, elane);
+                if (w2 < nitems) { tile_of(w2, tm2, tn2); fetch_tables(tm2, slot2); }
+                make_src(tmn, tnn, slot1, elane, kt0n);
                 pin_src();
                 issue(0, smem_base, 0); issue(1, smem_base, 0); issue(2, smem_base, 0); issue(3, smem_base, 0);
             }
         };
 
         // ---- epilogue of the current tile, staged through LDS stage 1 (64 KB); only the stores are predicated ----
-        if constexpr (SWIGLU) {
+        if constexpr (PARTIAL) {
+            // one K part of a tile: the raw fp32 accumulators, fragment by fragment, 16 bytes per lane (whole 1 KB lines per wave);
+            // gemm_splitk_reduce_kernel sums the parts in this layout and applies the epilogue
+            start_next();
+            f32x4_t* dst = (f32x4_t*)p.part + (long)w * (32 * 512) + (ewave * 64 + elane);
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn) dst[(((ma * 4 + i) * 2 + nb) * 2 + jn) * 512] = acc[ma][i][nb][jn];
+        } else if constexpr (SWIGLU) {
             // LDS image: [256 rows][128 bf16], 8-byte chunk c8 of row r stored at c8 ^ (r & 15)
             const int qs = elane & 15;
             const int oc = (n0 >> 1) + qs * 8;
@@ -1015,20 +1047,94 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
         if (!has_next) break;
         // ---- restart: k-tile 1 of the next tile into stage 1 once the staging area is drained ----
         PP_BARRIER();
-        make_src(tmn, tnn, slot1, elane);
+        make_src(tmn, tnn, slot1, elane, kt0n);
         pin_src();
         issue(0, smem_base + STAGE, 128); issue(1, smem_base + STAGE, 128); issue(2, smem_base + STAGE, 128);
         PP_VMCNT(6);                               // k-tile 0 (issued before the epilogue), the tables and every store have retired
         PP_BARRIER();
         if (g1) PP_BARRIER();
-        w = wn; tm = tmn; tn = tnn;
+        w = wn; tm = tmn; tn = tnn; nk = nkn;
         wn = w2; tmn = tm2; tnn = tn2;
         slot = slot1;
     }
 }
 
+// Second half of a K-split: out tile = epilogue(sum over the ksplit parts of a tile), parts in gemm_pq_kernel<4>'s fragment layout
+// (part j of the launch at ((j * 32 + frag) * 512 + thread) float4).  EIGHT workgroups per tile (one per (ma, i) fragment row group: a
+// few dozen leftover tiles must still cover the chip -- with one workgroup per tile this pass was slower than what the split saved),
+// thread t = the GEMM's thread t, so the (row, column) of every accumulator is the kernel's own:  row = (wave/4)*128 + ma*64 + i*16 +
+// lane%16,  column = (wave%4)*64 + nb*32 + jn*16 + (lane/16)*4 + e.  Rounding points as in the one-pass epilogue: bf16(acc + bias), then
+// bf16(that + residual).
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(const GemmParams p) {
+    constexpr bool HAS_R = MODE == 1, HAS_BIAS = MODE == 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int t = blockIdx.x >> 3, mi = blockIdx.x & 7;           // leftover tile, fragment row group ma * 4 + i
+    const int w = p.w_begin + t;
+    int tm, tn;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = w & 7, loc = w >> 3;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int GM = p.gm;
+        const int band = bid / (GM * p.tiles_n);
+        const int band_rows = min(GM, p.tiles_m - band * GM);
+        const int inb = bid - band * GM * p.tiles_n;
+        tm = band * GM + inb % band_rows;
+        tn = inb / band_rows;
+    }
+    const int gi = (p.ngroups > 1 && tm >= p.g[1].tile0) ? 1 : 0;
+    const int Mg = p.g[gi].M;
+    const int m0 = (tm - p.g[gi].tile0) * 256, n0 = tn * 256;
+    const int* __restrict__ crows = p.g[gi].c_rows;
+    const bf16_t* __restrict__ bias = p.g[gi].bias;
+    const int fr = lane & 15, nsub = (lane >> 4) * 4, grp = wave >> 2, wj = wave & 3;
+    const int m = m0 + grp * 128 + (mi >> 2) * 64 + (mi & 3) * 16 + fr;
+    if (m >= Mg) return;
+    const long row = crows ? crows[m] : m;
+    const f32x4_t* src = (const f32x4_t*)p.part + (long)t * p.ksplit * (32 * 512) + tid;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int n = n0 + wj * 64 + nb * 32 + jn * 16 + nsub;
+            if (n >= p.N) continue;
+            const int frag = (mi * 2 + nb) * 2 + jn;
+            f32x4_t a = src[(long)frag * 512];
+            for (int k = 1; k < p.ksplit; ++k) a = a + src[((long)k * 32 + frag) * 512];
+            float o[4] = {a[0], a[1], a[2], a[3]};
+            if constexpr (HAS_BIAS) {
+                const u32x2_t bv = *(const u32x2_t*)(bias + n);
+                o[0] += lo2f(bv[0]); o[1] += hi2f(bv[0]); o[2] += lo2f(bv[1]); o[3] += hi2f(bv[1]);
+            }
+            u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            if constexpr (HAS_R) {
+                const u32x2_t rv = *(const u32x2_t*)(p.R + row * p.ldr + n);
+                v[0] = pack2bf(lo2f(v[0]) + lo2f(rv[0]), hi2f(v[0]) + hi2f(rv[0]));
+                v[1] = pack2bf(lo2f(v[1]) + lo2f(rv[1]), hi2f(v[1]) + hi2f(rv[1]));
+            }
+            *(u32x2_t*)(p.C + row * p.ldc + n) = v;
+        }
+}
+
+// How a tile count that leaves the last round of the persistent kernel nearly empty is scheduled (LLM prefill of the understanding
+// request: M = 4936 -> 20 row tiles; o / down have 280 tiles = 1.09 rounds of 256 CUs, qkv 360 = 1.41): the FULL rounds run as they
+// are, the leftover tiles are cut along K into `ksplit` parts each so that they fill the chip once more with work items 1 / ksplit as
+// long, and a small pass adds the parts up and applies the epilogue.  Returns the split (1 = do not split).
+static int pq_leftover_split(int nblk, int wgs, int nk, size_t ws_bytes, int* n_full_out) {
+    const int n_full = nblk / wgs * wgs, rest = nblk - n_full;
+    *n_full_out = n_full;
+    if (rest == 0 || 2 * rest > wgs + wgs / 4) return 1;                   // nothing left over, or the last round is > 5/8 full anyway
+    if (n_full == 0 && (2 * rest > wgs || nk < 16)) return 1;              // a single round: split only when it fills less than half the chip
+    int s = wgs / rest;                                                    // parts per leftover tile: fill the chip once
+    if (s > nk / 4) s = nk / 4;                                            // a part keeps >= 4 k-tiles (prologue + steady state)
+    while (s > 1 && (size_t)rest * s * (32 * 512 * 16) > ws_bytes) --s;     // 256 KB of fp32 per part
+    return s < 2 ? 1 : s;
+}
+
 template <int MODE, bool FP8 = false>
-static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream) {
+static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream, void* ws = nullptr, size_t ws_bytes = 0) {
     GemmParams p = p0;
     int t = 0;
     for (int g = 0; g < p.ngroups; ++g) {
@@ -1058,6 +1164,26 @@ static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream) {
     constexpr int smem = 2 * 4 * 128 * 128 + 3 * 2048;   // two k-tile stages + the three-deep row-table ring
     if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<MODE, FP8>, smem, "gemm_pq_kernel")) return rc;
     const int nblk = p.tiles_m * p.tiles_n;
+    p.w_begin = 0; p.w_count = nblk; p.ksplit = 1; p.part = nullptr;
+    if constexpr (!FP8 && MODE != 0) {
+        int n_full = 0;
+        const int s = ws ? pq_leftover_split(nblk, wgs, p.K >> 6, ws_bytes, &n_full) : 1;
+        if (s > 1) {
+            // (1) the full rounds, one pass; (2) the leftover tiles as K parts -> fp32 partials; (3) sum + epilogue
+            if (n_full > 0) {
+                p.w_count = n_full;
+                hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8>), dim3(wgs), dim3(512), smem, stream, p);
+                if (int rc = bagel_check_launch("gemm_pq_kernel")) return rc;
+            }
+            if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<4, false>, smem, "gemm_pq_kernel<4>")) return rc;
+            p.w_begin = n_full; p.w_count = nblk - n_full; p.ksplit = s; p.part = (float*)ws;
+            const int items = p.w_count * s;
+            hipLaunchKernelGGL((gemm_pq_kernel<4, false>), dim3(items < wgs ? items : wgs), dim3(512), smem, stream, p);
+            if (int rc = bagel_check_launch("gemm_pq_kernel<4>")) return rc;
+            hipLaunchKernelGGL((gemm_splitk_reduce_kernel<MODE>), dim3(8 * p.w_count), dim3(512), 0, stream, p);
+            return bagel_check_launch("gemm_splitk_reduce_kernel");
+        }
+    }
     hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8>), dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
     return bagel_check_launch("gemm_pq_kernel");
 }
@@ -1086,11 +1212,39 @@ static int launch_gemm(const GemmParams& p0, hipStream_t stream) {
     return bagel_check_launch("gemm_tn_kernel");
 }
 
+static int gemm_bf16_impl(const void* A, int64_t lda,
+                          const void* W0, const void* bias0, const int32_t* a_rows0, const int32_t* c_rows0, int32_t M0,
+                          const void* W1, const void* bias1, const int32_t* a_rows1, const int32_t* c_rows1, int32_t M1,
+                          int64_t ldw, const void* R, int64_t ldr, void* C, int64_t ldc,
+                          int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int bagel_gemm_bf16(const void* A, int64_t lda,
                                const void* W0, const void* bias0, const int32_t* a_rows0, const int32_t* c_rows0, int32_t M0,
                                const void* W1, const void* bias1, const int32_t* a_rows1, const int32_t* c_rows1, int32_t M1,
                                int64_t ldw, const void* R, int64_t ldr, void* C, int64_t ldc,
                                int32_t N, int32_t K, int32_t epilogue, int32_t variant, hipStream_t stream) {
+    return gemm_bf16_impl(A, lda, W0, bias0, a_rows0, c_rows0, M0, W1, bias1, a_rows1, c_rows1, M1, ldw, R, ldr, C, ldc, N, K, epilogue, variant,
+                          nullptr, 0, stream);
+}
+
+// bagel_gemm_bf16 with a caller-owned fp32 workspace (>= 16-byte aligned): variant 4 may then cut the tiles of a nearly empty last round
+// along K (see pq_leftover_split) -- same result up to the fp32 summation order of those tiles.  The workspace is only touched by this call.
+extern "C" int bagel_gemm_bf16_ws(const void* A, int64_t lda,
+                                  const void* W0, const void* bias0, const int32_t* a_rows0, const int32_t* c_rows0, int32_t M0,
+                                  const void* W1, const void* bias1, const int32_t* a_rows1, const int32_t* c_rows1, int32_t M1,
+                                  int64_t ldw, const void* R, int64_t ldr, void* C, int64_t ldc,
+                                  int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* workspace, int64_t workspace_bytes,
+                                  hipStream_t stream) {
+    BAGEL_REQUIRE(!workspace || ((((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= 0), "gemm_ws: the workspace must be 16-byte aligned");
+    return gemm_bf16_impl(A, lda, W0, bias0, a_rows0, c_rows0, M0, W1, bias1, a_rows1, c_rows1, M1, ldw, R, ldr, C, ldc, N, K, epilogue, variant,
+                          workspace, (size_t)workspace_bytes, stream);
+}
+
+static int gemm_bf16_impl(const void* A, int64_t lda,
+                          const void* W0, const void* bias0, const int32_t* a_rows0, const int32_t* c_rows0, int32_t M0,
+                          const void* W1, const void* bias1, const int32_t* a_rows1, const int32_t* c_rows1, int32_t M1,
+                          int64_t ldw, const void* R, int64_t ldr, void* C, int64_t ldc,
+                          int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* ws, size_t ws_bytes, hipStream_t stream) {
     BAGEL_REQUIRE(A && C && W0, "gemm: null pointer");
     BAGEL_REQUIRE(K > 0 && (K % 8) == 0, "gemm: K=%d must be a positive multiple of 8 (pad the operand)", K);
     BAGEL_REQUIRE(N > 0 && (N % 8) == 0, "gemm: N=%d must be a multiple of 8", N);
@@ -1122,9 +1276,9 @@ extern "C" int bagel_gemm_bf16(const void* A, int64_t lda,
             const bool all_bias = p.g[0].bias != nullptr && p.g[1].bias != nullptr;
             if (K < 128 || epilogue == EPI_GELU_TANH || epilogue == EPI_SILU || (has_bias && (R || !all_bias))) return launch_gemm_pp<0>(p, stream);
             if (epilogue == EPI_SWIGLU16) return launch_gemm_pq<0>(p, stream);
-            if (R) return launch_gemm_pq<1>(p, stream);
-            if (has_bias) return launch_gemm_pq<2>(p, stream);
-            return launch_gemm_pq<3>(p, stream);
+            if (R) return launch_gemm_pq<1>(p, stream, ws, ws_bytes);
+            if (has_bias) return launch_gemm_pq<2>(p, stream, ws, ws_bytes);
+            return launch_gemm_pq<3>(p, stream, ws, ws_bytes);
         }
 #ifdef BAGEL_ENABLE_ABLATIONS
         case 13: return launch_gemm_pp<1>(p, stream);   // timing-only ablation (results are garbage): no DMA in the k-loop

@@ -71,7 +71,7 @@ def default_gemm_variant(M, N, K):
 
 
 def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, bias1=None, a_rows1=None, c_rows1=None,
-         M1=0, residual=None, epilogue=EPI_NONE, variant=None):
+         M1=0, residual=None, epilogue=EPI_NONE, variant=None, splitk=True):
     """C = A @ W^T (+bias)(act)(+residual); see bagel_gemm_bf16.  A:[*,K] W:[N,K] C:[*,N or N/2]."""
     _req(A, BF16, "gemm.A"); _req(W0, BF16, "gemm.W0"); _req(C, BF16, "gemm.C")
     N, K = W0.shape
@@ -102,11 +102,26 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
         return gemv(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if variant is None:
         variant = default_gemm_variant(M0 + M1, N, K)
-    check(lib().bagel_gemm_bf16(_ptr(A), _ld(A), _ptr(W0), _ptr(bias0), _ptr(a_rows0), _ptr(c_rows0), M0,
-                                _ptr(W1), _ptr(bias1), _ptr(a_rows1), _ptr(c_rows1), M1, W0.stride(0),
-                                _ptr(residual), _ld(residual) if residual is not None else 0, _ptr(C), _ld(C),
-                                N, K, epilogue, variant, _stream()), "bagel_gemm_bf16")
+    ws = _gemm_workspace(A.device) if (variant == 4 and splitk and GEMM_SPLITK) else None
+    check(lib().bagel_gemm_bf16_ws(_ptr(A), _ld(A), _ptr(W0), _ptr(bias0), _ptr(a_rows0), _ptr(c_rows0), M0,
+                                   _ptr(W1), _ptr(bias1), _ptr(a_rows1), _ptr(c_rows1), M1, W0.stride(0),
+                                   _ptr(residual), _ld(residual) if residual is not None else 0, _ptr(C), _ld(C),
+                                   N, K, epilogue, variant, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "bagel_gemm_bf16_ws")
     return C
+
+
+# K-split of a nearly empty last round of the persistent GEMM (bagel_gemm_bf16_ws): one fp32 workspace per device, 64 MB = 256 partial
+# tiles of 256 x 256 (every leftover tile cut into at most 256 / leftover parts).  BAGEL_GEMM_SPLITK=0 switches it off (same-box A/B).
+GEMM_SPLITK = os.environ.get("BAGEL_GEMM_SPLITK", "1") != "0"
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device):
+    key = torch.device(device).index
+    ws = _GEMM_WS.get(key)
+    if ws is None:
+        ws = _GEMM_WS[key] = torch.empty(256 * 256 * 256, dtype=torch.float32, device=device)
+    return ws
 
 
 GEMV_MAX_ROWS = 8

@@ -43,6 +43,18 @@ int bagel_gemm_bf16(const void* A, int64_t lda,
                     int64_t ldw, const void* R, int64_t ldr, void* C, int64_t ldc,
                     int32_t N, int32_t K, int32_t epilogue, int32_t variant, bagel_stream_t stream);
 
+/* bagel_gemm_bf16 with a caller-owned fp32 workspace (16-byte aligned; touched only during the call): when the tile count leaves the
+ * last round of the persistent kernel (variant 4) nearly empty -- the LLM prefill of an understanding request, M = 4936: o / down have
+ * 280 tiles on 256 CUs -- the leftover tiles are cut along K into parts that fill the chip once more, each part leaves a 256 KB fp32
+ * partial tile in the workspace and a small pass sums them and applies the epilogue (bias or residual, same rounding points).  Same
+ * result as bagel_gemm_bf16 up to the fp32 summation order of those tiles; with workspace == NULL it IS bagel_gemm_bf16. */
+int bagel_gemm_bf16_ws(const void* A, int64_t lda,
+                       const void* W0, const void* bias0, const int32_t* a_rows0, const int32_t* c_rows0, int32_t M0,
+                       const void* W1, const void* bias1, const int32_t* a_rows1, const int32_t* c_rows1, int32_t M1,
+                       int64_t ldw, const void* R, int64_t ldr, void* C, int64_t ldc,
+                       int32_t N, int32_t K, int32_t epilogue, int32_t variant, void* workspace, int64_t workspace_bytes,
+                       bagel_stream_t stream);
+
 /* Qwen2RMSNorm (modeling_qwen2.py:54-59); expert_of_row (nullable) selects w1 for rows flagged 1
  * (input_layernorm_moe_gen etc., qwen2_navit.py:784-787,812-815,1079-1082). */
 int bagel_rmsnorm_bf16(const void* x, int64_t ldx, const void* w0, const void* w1, const int32_t* expert_of_row,

@@ -30,7 +30,7 @@ def _rows(idx, n, M):
 
 
 def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, bias1=None, a_rows1=None, c_rows1=None,
-         M1=0, residual=None, epilogue=0, variant=None):
+         M1=0, residual=None, epilogue=0, variant=None, splitk=True):
     N, K = W0.shape
     if M0 is None:
         M0 = a_rows0.numel() if a_rows0 is not None else A.shape[0]

@@ -158,8 +158,23 @@ def test_gemm_persistent_identical_to_pingpong(wgs):
         env["BAGEL_GEMM_PERSIST_WGS"] = wgs
     else:
         env.pop("BAGEL_GEMM_PERSIST_WGS", None)
+    env["BAGEL_GEMM_SPLITK"] = "0"        # bit identity is a property of the one-pass schedule (the K-split of leftover tiles re-associates)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_persist_check.py")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ALL IDENTICAL" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("wgs", ["8", "24"])
+def test_gemm_leftover_k_split_small_grids(wgs):
+    """The K-split schedule of bagel_gemm_bf16_ws (full rounds, leftover tiles cut along K, reduce + epilogue) on small problems with 8 / 24
+    persistent workgroups, where almost every shape leaves a partial round: every epilogue it serves (bias, residual, plain), two
+    expert groups with gather / scatter row lists, ragged M / N edges -- against fp32.  Own process (the grid size is read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BAGEL_GEMM_PERSIST_WGS=wgs, BAGEL_GEMM_SPLITK="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_persist_check.py"), "--tolerance"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL WITHIN TOLERANCE" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_gemm_gather_rows_dense_out():

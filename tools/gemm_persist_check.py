@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bagel_amd import ops  # noqa: E402
 
 DEV, BF16 = "cuda", torch.bfloat16
+TOLERANCE = "--tolerance" in sys.argv
 
 
 def rnd(*shape, seed, scale=1.0):
@@ -29,6 +30,16 @@ def both(what, call, out_shape, init=None, repeats=3):
         call(C, variant)
         torch.cuda.synchronize()
         outs.append(C)
+    if TOLERANCE:
+        # K-split schedule (bagel_gemm_bf16_ws): the leftover tiles are summed in another order -- one bf16 ulp of the tensor's magnitude against
+        # the one-tile kernel (itself pinned to fp32 in tests/test_ops_gpu.py), identical between repeats
+        ref = outs[0].float()
+        tol = 2 ** -7 * ref.abs().max().item()
+        ok = all((o.float() - ref).abs().max().item() <= tol for o in outs[1:]) and all(torch.equal(outs[1], o) for o in outs[2:])
+        ok = ok and bool(torch.isfinite(outs[1].float()).all())
+        differ = float((outs[1].float() != ref).float().mean())
+        print(f"{'ok ' if ok else 'BAD'} {what}   (elements that differ from the one-pass result: {differ:.3f})", flush=True)
+        return ok
     ok = all(torch.equal(outs[0].view(torch.int16), o.view(torch.int16)) for o in outs[1:]) and bool(torch.isfinite(outs[0].float()).all())
     print(f"{'ok ' if ok else 'BAD'} {what}", flush=True)
     return ok
@@ -119,7 +130,7 @@ def main():
             print(f"  {name:8s} variant 3: {ms[3]:.3f} ms {fl / ms[3] / 1e9:7.1f} TFLOP/s | variant 4 (persistent): {ms[4]:.3f} ms {fl / ms[4] / 1e9:7.1f} TFLOP/s | "
                   f"time ratio {ms[4] / ms[3]:.3f}", flush=True)
         print(f"  layer total: variant 3 {tot[3]:.3f} ms, variant 4 {tot[4]:.3f} ms, ratio {tot[4] / tot[3]:.3f}", flush=True)
-    print("ALL IDENTICAL" if good else "MISMATCH", flush=True)
+    print(("ALL WITHIN TOLERANCE" if TOLERANCE else "ALL IDENTICAL") if good else "MISMATCH", flush=True)
     sys.exit(0 if good else 1)
 
 
