@@ -17,7 +17,7 @@ i=0
   i=$((i+1))
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/pmc_$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_$i -o pmc -- python $ROOT/bench.py --layers 2 --num-timesteps 3 --no-vae --no-understanding --no-cpu-baseline --no-taylorseer --no-edit --no-fp8 --warmup 0 --steps 1 > $ROOT/gpurun_out/pmc_denoise_run_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_$i -o pmc -- python $ROOT/bench.py --layers 2 --num-timesteps 3 --no-vae --no-understanding --no-cpu-baseline --no-taylorseer --no-edit --no-fp8 --no-train-forward --warmup 0 --steps 1 > $ROOT/gpurun_out/pmc_denoise_run_$i.log 2>&1
   DB=$(find /tmp/pmc_$i -name "*.db" | head -1)
   [ -n "$DB" ] && python $ROOT/tools/pmc_summary.py $DB > "$ROOT/gpurun_out/pmc_denoise_$tag.txt" 2>&1
   rm -rf /tmp/pmc_$i
@@ -26,7 +26,7 @@ i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rm -rf /tmp/pmcd_$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmcd_$i -o pmc -- python $ROOT/bench.py --only-understanding --und-new-tokens 24 --no-cpu-baseline --no-int8 > $ROOT/gpurun_out/pmc_decode_run_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmcd_$i -o pmc -- python $ROOT/bench.py --only-understanding --und-new-tokens 24 --no-cpu-baseline --no-int8 --no-batched-decode > $ROOT/gpurun_out/pmc_decode_run_$i.log 2>&1
   DB=$(find /tmp/pmcd_$i -name "*.db" | head -1)
   [ -n "$DB" ] && python $ROOT/tools/pmc_summary.py $DB > "$ROOT/gpurun_out/pmc_decode_$grp.txt" 2>&1
   rm -rf /tmp/pmcd_$i
