@@ -1,0 +1,359 @@
+// Reverse of the block-masked packed attention of the training forward (PackedAttentionMoT.forward_train, qwen2_navit.py:406-497, with
+// the causal / full / noise split mask of data/data_utils.py:72-103) for gfx950, head_dim 64 or 128, GQA.  The reference differentiates
+// flash-attn / flex-attention through autograd; this is the hand-written counterpart of the forward in attention.hip, same conventions:
+// products on v_mfma_f32_32x32x16_bf16 with the TRANSPOSED score tile (rows = keys of the A operand, columns = the lane's query), so a
+// lane owns all scores of one query (or one key) and the bf16 P / dS values go from the accumulator registers straight into the B
+// operand of the next product; the MFMA row -> key assignment of every 16 rows is permuted (quads 1 <-> 2) so that a lane's 8
+// contraction slots are 8 consecutive keys and the other operand is ONE 16-byte LDS read of a transposed tile.
+//
+// Two kernels, both deterministic (no atomics; a row's gradient is produced by exactly one wave):
+//   attn_bwd_dq_kernel   workgroup = one 128-query item x one q head, wave = 32 queries.
+//                        pass 1: S^T = K Q^T over the item's key tiles -> row log-sum-exp (online max / sum); delta = rowsum(dO o).
+//                        pass 2: P^T = exp(scale S^T - lse), dP^T = V dO^T, dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T.
+//   attn_bwd_dkv_kernel  workgroup = one 128-key item x one kv head, wave = 32 keys; loops over the group's q heads and over the 64-query
+//                        tiles of the rows that see these keys:  P = exp(scale Q K^T - lse),  dV^T += dO^T P,  dS = P (dO V^T - delta) scale,
+//                        dK^T += Q^T dS.
+// The contraction over keys (dq) / queries (dkv) reads K^T / Q^T / dO^T from transposed HBM images (bagel_transpose_bf16) -- the same
+// trick as the forward's V^T image: 2 bytes per element per pass is noise next to the 4 + 4 products of the reverse.
+// The mask is evaluated from per-item scalars (sample start, split start / end, causal flag) and one 64-bit noise-key word per key
+// tile: full / noise splits see the clean prefix of their sample and themselves, causal splits additionally only keys <= the query,
+// and keys of a noise split are hidden from every later split.
+//
+// Algorithmic FLOPs per (query, key) pair and head: 2 D (scores for lse) + 6 D (dq pass) + 8 D (dkv pass) = 16 D, against 4 D of the
+// forward and 10 D of a fused flash backward: the price of two atomics-free kernels and of recomputing the row statistics instead of
+// changing the forward kernel's interface.  First correct version: tiles are staged global -> registers -> LDS with two barriers per
+// tile, not yet through the LDS-DMA ring of the forward.
+#include "common.h"
+
+struct AttnBwdParams {
+    const bf16_t* q; long ldq;
+    const bf16_t* k; long ldk;
+    const bf16_t* v; long ldv;
+    const bf16_t* o; long ldo;
+    const bf16_t* d_o; long lddo;
+    const bf16_t* qt; const bf16_t* dot; const bf16_t* kt; long ld_t;
+    bf16_t* dq; long lddq;
+    bf16_t* dk; long lddk;
+    bf16_t* dv; long lddv;
+    const int* q_items; const int* k_items;
+    const unsigned long long* noise_bits;
+    float* lse; float* delta;            // [nq][rows]
+    int rows, nq, nkv;
+    float scale;
+};
+
+#define AB_TP 72                          // element pitch of the transposed 64-column tiles (144 bytes: 16-byte aligned, banks spread)
+
+__device__ __forceinline__ int ab_perm(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+
+// 64 rows x D columns of a row-major operand -> LDS [64][D + 8]; rows at or beyond rows_total read as zero
+template <int D>
+__device__ __forceinline__ void ab_stage_rows(bf16_t* lds, const bf16_t* src, long ld, int col0, int row0, int rows_total, int tid) {
+    constexpr int CH = D / 8, RP = D + 8;
+#pragma unroll
+    for (int it = 0; it < (64 * CH) / 256; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx / CH, c = idx % CH;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (row0 + r < rows_total) v = *(const u32x4_t*)(src + (long)(row0 + r) * ld + col0 + c * 8);
+        *(u32x4_t*)(lds + r * RP + c * 8) = v;
+    }
+}
+
+// D rows x 64 columns of a transposed image -> LDS [D][AB_TP]
+template <int D>
+__device__ __forceinline__ void ab_stage_t(bf16_t* lds, const bf16_t* srct, long ld_t, int drow0, int col0, int tid) {
+#pragma unroll
+    for (int it = 0; it < (D * 8) / 256; ++it) {
+        const int idx = tid + it * 256;
+        const int d = idx >> 3, c = idx & 7;
+        *(u32x4_t*)(lds + d * AB_TP + c * 8) = *(const u32x4_t*)(srct + (long)(drow0 + d) * ld_t + col0 + c * 8);
+    }
+}
+
+__device__ __forceinline__ bf16x8_t ab_pack8(const float* x) {
+    u32x4_t v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = pack2bf(x[2 * e], x[2 * e + 1]);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// fragment of 8 consecutive d-columns of one row of a [rows, heads * D] operand in HBM (zero for an invalid row)
+__device__ __forceinline__ bf16x8_t ab_row_frag(const bf16_t* base, long ld, int row, bool valid, int col) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (valid) v = *(const u32x4_t*)(base + (long)row * ld + col);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// C-layout (rows d = 32 db + (i & 3) + 8 (i >> 2) + 4 h, column = the lane's row of the output) -> out[row][col0 + d], 8-byte stores
+template <int DB>
+__device__ __forceinline__ void ab_store_t(bf16_t* out, long ld, int row, int col0, const f32x16_t* acc, int h) {
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x2_t v;
+            v[0] = pack2bf(acc[db][4 * j], acc[db][4 * j + 1]);
+            v[1] = pack2bf(acc[db][4 * j + 2], acc[db][4 * j + 3]);
+            *(u32x2_t*)(out + (long)row * ld + col0 + 32 * db + 8 * j + 4 * h) = v;
+        }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+    constexpr int KS = D / 16, DB = D / 32, RP = D + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = (bf16_t*)smem;                        // [64][RP]
+    bf16_t* Vs = Ks + 64 * RP;                         // [64][RP]
+    bf16_t* Kts = Vs + 64 * RP;                        // [D][AB_TP]
+    const int* it = p.q_items + (long)blockIdx.x * 8;
+    const int row0 = it[0], nrows = it[1], kstart = it[2], sstart = it[3], send = it[4], causal = it[5], t0 = it[6], t1 = it[7];
+    const int hq = blockIdx.y, hkv = hq / (p.nq / p.nkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5, pm = ab_perm(m);
+    const int qloc = 32 * wave + m;
+    const bool qvalid = qloc < nrows;
+    const bool wave_on = 32 * wave < nrows;
+    const int qrow = row0 + qloc;
+    const float scale = p.scale;
+
+    bf16x8_t qf[KS], dof[KS];
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int col = hq * D + 16 * ks + 8 * h;
+        qf[ks] = ab_row_frag(p.q, p.ldq, qrow, qvalid, col);
+        dof[ks] = ab_row_frag(p.d_o, p.lddo, qrow, qvalid, col);
+        const u32x4_t ov = __builtin_bit_cast(u32x4_t, ab_row_frag(p.o, p.ldo, qrow, qvalid, col));
+        const u32x4_t dv = __builtin_bit_cast(u32x4_t, dof[ks]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) delta += lo2f(ov[e]) * lo2f(dv[e]) + hi2f(ov[e]) * hi2f(dv[e]);
+    }
+    delta += __shfl_xor(delta, 32, 64);                 // the two halves of the wave hold the two halves of every 16 columns
+
+    auto skip = [&](int t) { return p.noise_bits[t] == ~0ull && 64 * t + 64 <= sstart; };     // a tile of hidden (noise) context keys
+    auto allowed = [&](int c, unsigned long long nb, int key_local) {
+        const bool ctx = c < sstart && !((nb >> key_local) & 1ull);
+        const bool own = c >= sstart && c < send && (!causal || c <= qrow);
+        return qvalid && c >= kstart && (ctx || own);
+    };
+
+    // ---------------- pass 1: row log-sum-exp ----------------
+    float mrun = -INFINITY, lrun = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        if (skip(t)) continue;
+        __syncthreads();
+        ab_stage_rows<D>(Ks, p.k, p.ldk, hkv * D, 64 * t, p.rows, tid);
+        __syncthreads();
+        if (!wave_on) continue;
+        const unsigned long long nb = p.noise_bits[t];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Ks + (32 * kb + pm) * RP + 16 * ks + 8 * h), qf[ks], s, 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kl = 32 * kb + 16 * (i >> 3) + 8 * h + (i & 7);
+                s[i] = allowed(64 * t + kl, nb, kl) ? s[i] * scale : -INFINITY;
+                mx = fmaxf(mx, s[i]);
+            }
+            const float mnew = fmaxf(mrun, mx);
+            if (mnew > -INFINITY) {
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum += __expf(s[i] - mnew);
+                lrun = lrun * __expf(mrun - mnew) + sum;
+                mrun = mnew;
+            }
+        }
+    }
+    float lse = 0.f;
+    {
+        const float mo = __shfl_xor(mrun, 32, 64), lo = __shfl_xor(lrun, 32, 64);
+        const float mm = fmaxf(mrun, mo);
+        if (mm > -INFINITY) {
+            const float ll = (mrun > -INFINITY ? lrun * __expf(mrun - mm) : 0.f) + (mo > -INFINITY ? lo * __expf(mo - mm) : 0.f);
+            lse = mm + __logf(ll);
+        }
+    }
+    if (qvalid && h == 0) {
+        p.lse[(long)hq * p.rows + qrow] = lse;
+        p.delta[(long)hq * p.rows + qrow] = delta;
+    }
+
+    // ---------------- pass 2: dQ ----------------
+    f32x16_t dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        if (skip(t)) continue;
+        __syncthreads();
+        ab_stage_rows<D>(Ks, p.k, p.ldk, hkv * D, 64 * t, p.rows, tid);
+        ab_stage_rows<D>(Vs, p.v, p.ldv, hkv * D, 64 * t, p.rows, tid);
+        ab_stage_t<D>(Kts, p.kt, p.ld_t, hkv * D, 64 * t, tid);
+        __syncthreads();
+        if (!wave_on) continue;
+        const unsigned long long nb = p.noise_bits[t];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Ks + (32 * kb + pm) * RP + 16 * ks + 8 * h), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Vs + (32 * kb + pm) * RP + 16 * ks + 8 * h), dof[ks], dp, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kl = 32 * kb + 16 * (i >> 3) + 8 * h + (i & 7);
+                const float pr = allowed(64 * t + kl, nb, kl) ? __expf(s[i] * scale - lse) : 0.f;
+                ds[i] = pr * (dp[i] - delta) * scale;
+            }
+            const bf16x8_t dsf0 = ab_pack8(ds), dsf1 = ab_pack8(ds + 8);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Kts + (32 * db + m) * AB_TP + 32 * kb + 8 * h), dsf0, dq[db], 0, 0, 0);
+                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Kts + (32 * db + m) * AB_TP + 32 * kb + 16 + 8 * h), dsf1, dq[db], 0, 0, 0);
+            }
+        }
+    }
+    if (qvalid) ab_store_t<DB>(p.dq, p.lddq, qrow, hq * D, dq, h);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+    constexpr int KS = D / 16, DB = D / 32, RP = D + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Qs = (bf16_t*)smem;                        // [64][RP]
+    bf16_t* dOs = Qs + 64 * RP;                        // [64][RP]
+    bf16_t* Qts = dOs + 64 * RP;                       // [D][AB_TP]
+    bf16_t* dOts = Qts + D * AB_TP;                    // [D][AB_TP]
+    float* lse_s = (float*)(dOts + D * AB_TP);         // [64]
+    float* delta_s = lse_s + 64;                       // [64]
+    const int* it = p.k_items + (long)blockIdx.x * 8;
+    const int key0 = it[0], nkeys = it[1], qbeg = it[2], qend = it[3], send = it[4], causal = it[5];
+    const int hkv = blockIdx.y, G = p.nq / p.nkv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5, pm = ab_perm(m);
+    const int kloc = 32 * wave + m;
+    const bool kvalid = kloc < nkeys;
+    const bool wave_on = 32 * wave < nkeys;
+    const int krow = key0 + kloc;
+    const float scale = p.scale;
+
+    bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = ab_row_frag(p.k, p.ldk, krow, kvalid, hkv * D + 16 * ks + 8 * h);
+        vf[ks] = ab_row_frag(p.v, p.ldv, krow, kvalid, hkv * D + 16 * ks + 8 * h);
+    }
+    f32x16_t dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+
+    for (int hq = hkv * G; hq < (hkv + 1) * G; ++hq) {
+        for (int q0 = qbeg & ~63; q0 < qend; q0 += 64) {
+            __syncthreads();
+            ab_stage_rows<D>(Qs, p.q, p.ldq, hq * D, q0, p.rows, tid);
+            ab_stage_rows<D>(dOs, p.d_o, p.lddo, hq * D, q0, p.rows, tid);
+            ab_stage_t<D>(Qts, p.qt, p.ld_t, hq * D, q0, tid);
+            ab_stage_t<D>(dOts, p.dot, p.ld_t, hq * D, q0, tid);
+            if (tid < 64) lse_s[tid] = (q0 + tid < p.rows) ? p.lse[(long)hq * p.rows + q0 + tid] : 0.f;
+            else if (tid < 128) delta_s[tid - 64] = (q0 + tid - 64 < p.rows) ? p.delta[(long)hq * p.rows + q0 + tid - 64] : 0.f;
+            __syncthreads();
+            if (!wave_on) continue;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16_t s, dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Qs + (32 * qb + pm) * RP + 16 * ks + 8 * h), kf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(dOs + (32 * qb + pm) * RP + 16 * ks + 8 * h), vf[ks], dp, 0, 0, 0);
+                }
+                float pr[16], ds[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ql = 32 * qb + 16 * (i >> 3) + 8 * h + (i & 7);
+                    const int qrow = q0 + ql;
+                    const bool ok = kvalid && qrow >= qbeg && qrow < qend && (qrow >= send || !causal || krow <= qrow);
+                    pr[i] = ok ? __expf(s[i] * scale - lse_s[ql]) : 0.f;
+                    ds[i] = pr[i] * (dp[i] - delta_s[ql]) * scale;
+                }
+                const bf16x8_t pf0 = ab_pack8(pr), pf1 = ab_pack8(pr + 8), dsf0 = ab_pack8(ds), dsf1 = ab_pack8(ds + 8);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const bf16_t* a0 = dOts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)a0, pf0, dv[db], 0, 0, 0);
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(a0 + 16), pf1, dv[db], 0, 0, 0);
+                    const bf16_t* b0 = Qts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)b0, dsf0, dk[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(b0 + 16), dsf1, dk[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (kvalid) {
+        ab_store_t<DB>(p.dk, p.lddk, krow, hkv * D, dk, h);
+        ab_store_t<DB>(p.dv, p.lddv, krow, hkv * D, dv, h);
+    }
+}
+
+template <int D>
+static int attn_bwd_launch(const AttnBwdParams& p, int n_q_items, int n_k_items, hipStream_t stream) {
+    constexpr int smem_dq = (2 * 64 * (D + 8) + D * AB_TP) * 2;
+    constexpr int smem_dkv = (2 * 64 * (D + 8) + 2 * D * AB_TP) * 2 + 128 * 4;
+    if (int rc = bagel_enable_lds((const void*)attn_bwd_dq_kernel<D>, smem_dq, "attn_bwd_dq_kernel")) return rc;
+    if (int rc = bagel_enable_lds((const void*)attn_bwd_dkv_kernel<D>, smem_dkv, "attn_bwd_dkv_kernel")) return rc;
+    if (n_q_items > 0) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3(n_q_items, p.nq), dim3(256), smem_dq, stream, p);
+        if (int rc = bagel_check_launch("attn_bwd_dq_kernel")) return rc;
+    }
+    if (n_k_items > 0) {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3(n_k_items, p.nkv), dim3(256), smem_dkv, stream, p);
+        if (int rc = bagel_check_launch("attn_bwd_dkv_kernel")) return rc;
+    }
+    return BAGEL_OK;
+}
+
+extern "C" int bagel_attn_bwd_blockmask_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                                             int64_t ldo, const void* d_o, int64_t lddo, const void* qt, const void* dot, const void* kt,
+                                             int64_t ld_t, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                                             const int32_t* q_items, int32_t n_q_items, const int32_t* k_items, int32_t n_k_items,
+                                             const uint64_t* noise_bits, float* lse_delta, int32_t rows, int32_t nq, int32_t nkv,
+                                             int32_t head_dim, float softmax_scale, hipStream_t stream) {
+    BAGEL_REQUIRE(q && k && v && o && d_o && qt && dot && kt && dq && dk && dv && noise_bits && lse_delta, "attn_bwd: null pointer");
+    BAGEL_REQUIRE((n_q_items == 0 || q_items) && (n_k_items == 0 || k_items), "attn_bwd: item tables missing");
+    BAGEL_REQUIRE(nq > 0 && nkv > 0 && nq % nkv == 0, "attn_bwd: nq must be a multiple of nkv");
+    BAGEL_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ld_t % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
+                  "attn_bwd: leading dimensions must be multiples of 8");
+    BAGEL_REQUIRE(ld_t >= ((int64_t)rows + 63) / 64 * 64, "attn_bwd: the transposed images must hold ceil64(rows) columns");
+    for (const void* ptr : {q, k, v, o, d_o, qt, dot, kt})
+        BAGEL_REQUIRE(((uintptr_t)ptr % 16) == 0, "attn_bwd: 16-byte aligned operands expected");
+    for (const void* ptr : {(const void*)dq, (const void*)dk, (const void*)dv})
+        BAGEL_REQUIRE(((uintptr_t)ptr % 8) == 0, "attn_bwd: 8-byte aligned gradient buffers expected");
+    if (rows <= 0) return BAGEL_OK;
+    AttnBwdParams p;
+    p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.ldk = ldk; p.v = (const bf16_t*)v; p.ldv = ldv;
+    p.o = (const bf16_t*)o; p.ldo = ldo; p.d_o = (const bf16_t*)d_o; p.lddo = lddo;
+    p.qt = (const bf16_t*)qt; p.dot = (const bf16_t*)dot; p.kt = (const bf16_t*)kt; p.ld_t = ld_t;
+    p.dq = (bf16_t*)dq; p.lddq = lddq; p.dk = (bf16_t*)dk; p.lddk = lddk; p.dv = (bf16_t*)dv; p.lddv = lddv;
+    p.q_items = q_items; p.k_items = k_items; p.noise_bits = (const unsigned long long*)noise_bits;
+    p.lse = lse_delta; p.delta = lse_delta + (long)nq * rows;
+    p.rows = rows; p.nq = nq; p.nkv = nkv; p.scale = softmax_scale;
+    if (head_dim == 128) return attn_bwd_launch<128>(p, n_q_items, n_k_items, stream);
+    if (head_dim == 64) return attn_bwd_launch<64>(p, n_q_items, n_k_items, stream);
+    return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_bwd: head_dim %d not in {64,128} (pad the head)", head_dim);
+}

@@ -166,7 +166,7 @@ class Bagel(nn.Module):
         ids = self._dev(token_ids, torch.int32)
         ops.copy_rows(table, seq, ids.numel(), self.hidden_size, src_rows=ids, dst_rows=rows)
 
-    def _timestep_embedding(self, t):
+    def _timestep_embedding(self, t, keep=None):
         """time_embedder(t) for one scalar timestep -> (1, H) bf16  (modeling_utils.py:106-110).  The reference
         recomputes this MLP for every latent token although ``timestep.unique()`` is asserted to be a single value
         (bagel.py:800-802); one row is the same bits."""
@@ -178,6 +178,8 @@ class Bagel(nn.Module):
         ops.gemm(sinus, te.mlp[0].weight.data, h, bias0=te.mlp[0].bias.data, M0=1, epilogue=ops.EPI_SILU)
         out = torch.empty_like(h)
         ops.gemm(h, te.mlp[2].weight.data, out, bias0=te.mlp[2].bias.data, M0=1)
+        if keep is not None:
+            keep.append((sinus, h))        # the training backward needs the sinusoid row and the SiLU output
         return out
 
     def _latent_tokens_into(self, seq, latent_f32, vae_rows, vae_pos_ids, t):
@@ -640,14 +642,15 @@ class Bagel(nn.Module):
         return output.split("<|im_end|>")[0].split("<|im_start|>")[1]
 
     # ------------------------------------------------------------------------------------------------
-    # training forward (losses only; no autograd graph)
+    # training step: Bagel.forward (per-token losses) and its backward (train_step.PackedTrainStep)
     # ------------------------------------------------------------------------------------------------
     @staticmethod
     def _rows(index_or_mask):
         t = torch.as_tensor(index_or_mask)
         return torch.nonzero(t, as_tuple=False).flatten() if t.dtype == torch.bool else t.to(torch.long)
 
-    @torch.no_grad()
+    _TRAINABLE_PREFIXES = ("language_model.", "llm2vae.", "vae2llm.", "time_embedder.", "connector.")
+
     @_bf16_weights
     def forward(self, sequence_length, packed_text_ids, packed_text_indexes, sample_lens, packed_position_ids,
                 nested_attention_masks=None, split_lens=None, attn_modes=None, ce_loss_indexes=None, packed_label_ids=None,
@@ -655,11 +658,44 @@ class Bagel(nn.Module):
                 padded_latent=None, patchified_vae_latent_shapes=None, packed_latent_position_ids=None,
                 packed_vae_token_indexes=None, packed_timesteps=None, mse_loss_indexes=None, noise=None):
         """Bagel.forward (bagel.py:101-229): per-token losses ``dict(mse=[n_mse, 64] fp32, ce=[n_ce] fp32)`` of a packed
-        training batch -- the forward half of a training step (no autograd graph).
+        training batch.
 
         Same arguments as the reference plus ``noise`` (the ``randn_like`` draw of :184; drawn on the GPU when omitted).
         The block mask comes as the per-sample additive masks of the non-flex path (decoded back into splits and checked)
-        or as flat ``split_lens`` + ``attn_modes``; it runs as per-split sequences of the varlen attention kernel."""
+        or as flat ``split_lens`` + ``attn_modes``; it runs as per-split sequences of the varlen attention kernel.
+
+        With grad mode on and at least one parameter that requires grad the losses are attached to ONE autograd node
+        (train_step.PackedTrainStep), so the reference's ``loss.backward()`` (train/pretrain_unified_navit.py:683-735) fills
+        ``param.grad`` from the hand-written reverse kernels; otherwise (``torch.no_grad()``, or a frozen model) no tape is kept."""
+        kw = dict(sequence_length=sequence_length, packed_text_ids=packed_text_ids, packed_text_indexes=packed_text_indexes,
+                  sample_lens=sample_lens, packed_position_ids=packed_position_ids, nested_attention_masks=nested_attention_masks,
+                  split_lens=split_lens, attn_modes=attn_modes, ce_loss_indexes=ce_loss_indexes, packed_label_ids=packed_label_ids,
+                  packed_vit_tokens=packed_vit_tokens, packed_vit_token_indexes=packed_vit_token_indexes,
+                  packed_vit_position_ids=packed_vit_position_ids, vit_token_seqlens=vit_token_seqlens, padded_latent=padded_latent,
+                  patchified_vae_latent_shapes=patchified_vae_latent_shapes, packed_latent_position_ids=packed_latent_position_ids,
+                  packed_vae_token_indexes=packed_vae_token_indexes, packed_timesteps=packed_timesteps, mse_loss_indexes=mse_loss_indexes,
+                  noise=noise)
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        if not named:
+            with torch.no_grad():
+                return self._forward_losses(tape=None, **kw)
+        bad = [n for n, _ in named if not n.startswith(self._TRAINABLE_PREFIXES)]
+        if bad:
+            raise NotImplementedError(
+                "the backward is built for the language model, llm2vae / vae2llm, the time embedder and the connector; freeze the rest "
+                f"(pretrain_unified_navit.py --freeze_vit True; the position tables are frozen in the reference too): {bad[:4]}")
+        from .train_step import PackedTrainStep
+        mse, ce = PackedTrainStep.apply(self, kw, *[p for _, p in named])
+        has_mse = bool(self.config.visual_gen) and padded_latent is not None and mse_loss_indexes is not None
+        return dict(mse=mse if has_mse else None, ce=ce if ce_loss_indexes is not None else None)
+
+    def _forward_losses(self, tape, sequence_length, packed_text_ids, packed_text_indexes, sample_lens, packed_position_ids,
+                        nested_attention_masks=None, split_lens=None, attn_modes=None, ce_loss_indexes=None, packed_label_ids=None,
+                        packed_vit_tokens=None, packed_vit_token_indexes=None, packed_vit_position_ids=None, vit_token_seqlens=None,
+                        padded_latent=None, patchified_vae_latent_shapes=None, packed_latent_position_ids=None,
+                        packed_vae_token_indexes=None, packed_timesteps=None, mse_loss_indexes=None, noise=None):
+        """The forward itself; ``tape`` (train_step.TrainTape or None) collects what the backward needs."""
+        F_ = tape.front if tape is not None else None
         dev = self.device
         H = self.hidden_size
         total = int(sequence_length)
@@ -668,6 +704,8 @@ class Bagel(nn.Module):
         seq = torch.zeros((total, H), dtype=BF16, device=dev)
         text_rows = self._rows(packed_text_indexes)
         self._embed_into(seq, packed_text_ids, self._dev(text_rows, torch.int32))
+        if F_ is not None:
+            F_.update(M=total, text_rows=text_rows.cpu(), text_ids=torch.as_tensor(packed_text_ids).cpu().to(torch.long))
         und_rows = text_rows
         if self.config.visual_und and packed_vit_tokens is not None:
             lens = [int(x) for x in torch.as_tensor(vit_token_seqlens).tolist()]
@@ -684,6 +722,8 @@ class Bagel(nn.Module):
             vit_rows = self._rows(packed_vit_token_indexes)
             ops.copy_rows(emb, seq, n, H, dst_rows=self._dev(vit_rows, torch.int32))
             und_rows = torch.cat([text_rows, vit_rows], dim=0)
+            if F_ is not None:
+                F_.update(vit_feats=feats, vit_hmid=hmid, vit_rows=self._dev(vit_rows, torch.int32))
         gen_rows = None
         if self.config.visual_gen and padded_latent is not None:
             p, C = self.latent_patch_size, self.latent_channel
@@ -704,28 +744,131 @@ class Bagel(nn.Module):
             x16 = ops.flow_mix(clean, noise, t_dev)                                       # (1 - t) x0 + t eps, cast for vae2llm
             ops.gemm(x16, self.vae2llm.weight.data, seq, bias0=self.vae2llm.bias.data, c_rows0=vae_rows, M0=x16.shape[0])
             uniq, inv = torch.unique(t, return_inverse=True)
-            temb = torch.cat([self._timestep_embedding(float(u)) for u in uniq], dim=0)   # one time-MLP pass per distinct t
+            keep = [] if F_ is not None else None
+            temb = torch.cat([self._timestep_embedding(float(u), keep) for u in uniq], dim=0)   # one time-MLP pass per distinct t
             ops.flow_add_rows(seq, vae_rows, temb, inv.to(device=dev, dtype=torch.int32), self.latent_pos_embed.pos_embed.data,
                               self._dev(packed_latent_position_ids, torch.long))
+            if F_ is not None:
+                F_.update(x16=x16, vae_rows=vae_rows, temb_inv=inv.cpu(), time_sinus=torch.cat([a for a, _ in keep], 0),
+                          time_h=torch.cat([b for _, b in keep], 0))
         last = self.language_model.forward_train(
             packed_sequence=seq, sample_lens=sample_lens, attention_mask=nested_attention_masks,
             packed_position_ids=packed_position_ids, packed_und_token_indexes=und_rows, packed_gen_token_indexes=gen_rows,
-            split_lens=split_lens, attn_modes=attn_modes)
+            split_lens=split_lens, attn_modes=attn_modes, tape=tape)
+        if F_ is not None:
+            F_["last"] = last
         mse = None
         if gen_rows is not None and mse_loss_indexes is not None:
             mrows = self._rows(mse_loss_indexes)
+            mrows_d = self._dev(mrows, torch.int32)
             preds = torch.empty((mrows.numel(), self.patch_latent_dim), dtype=BF16, device=dev)
-            ops.gemm(last, self.llm2vae.weight.data, preds, bias0=self.llm2vae.bias.data, a_rows0=self._dev(mrows, torch.int32),
-                     M0=mrows.numel())
+            ops.gemm(last, self.llm2vae.weight.data, preds, bias0=self.llm2vae.bias.data, a_rows0=mrows_d, M0=mrows.numel())
             src = torch.nonzero(t > 0, as_tuple=False).flatten()                         # has_mse (:215)
             if src.numel() != mrows.numel():
                 raise ValueError("mse_loss_indexes must address exactly the latent tokens with timestep > 0")
-            mse = ops.mse_rows(preds, noise, clean, src.to(device=dev, dtype=torch.int32))
+            src_d = src.to(device=dev, dtype=torch.int32)
+            mse = ops.mse_rows(preds, noise, clean, src_d)
+            if F_ is not None:
+                F_.update(mse_rows=mrows_d, preds=preds, noise=noise, clean=clean, mse_src=src_d)
         ce = None
         if ce_loss_indexes is not None:
             crows = self._rows(ce_loss_indexes)
+            crows_d = self._dev(crows, torch.int32)
             head = self.language_model.lm_head.weight.data
             logits = torch.empty((crows.numel(), head.shape[0]), dtype=BF16, device=dev)
-            ops.gemm(last, head, logits, a_rows0=self._dev(crows, torch.int32), M0=crows.numel())
-            ce = ops.cross_entropy(logits, self._dev(packed_label_ids, torch.long))
+            ops.gemm(last, head, logits, a_rows0=crows_d, M0=crows.numel())
+            labels = self._dev(packed_label_ids, torch.long)
+            ce = ops.cross_entropy(logits, labels)
+            if F_ is not None:
+                F_.update(ce_rows=crows_d, logits=logits, labels=labels)
         return dict(mse=mse, ce=ce)
+
+    def _backward_losses(self, tape, d_mse, d_ce):
+        """Reverse of ``_forward_losses``: the upstream gradients of the per-token losses -> every parameter gradient
+        (train_step._Grads).  Runs inside PackedTrainStep.backward, i.e. without grad mode."""
+        from . import train_step as TS
+        F_ = tape.front
+        dev, H, M = self.device, self.hidden_size, F_["M"]
+        lm = self.language_model
+        eng = lm.engine(check=False)
+        grads = TS._Grads()
+        last = F_["last"]
+        d_last = torch.zeros((M, H), dtype=BF16, device=dev)
+        if d_ce is not None and "logits" in F_:
+            head = lm.lm_head.weight
+            dlogits = ops.cross_entropy_bwd(F_["logits"], F_["labels"], d_ce.to(device=dev, dtype=torch.float32).contiguous())
+            n = dlogits.shape[0]
+            ops.gemm(dlogits, TS._wt(head.data), d_last, c_rows0=F_["ce_rows"], M0=n, residual=d_last)
+            if head.requires_grad:
+                Xt = ops.transpose(last, rows=F_["ce_rows"], n=n)
+                dW = torch.empty(tuple(head.shape), dtype=BF16, device=dev)
+                grads.add(head, ops.gemm(ops.transpose(dlogits), Xt, dW))
+        if d_mse is not None and "preds" in F_:
+            lin = self.llm2vae
+            dpred = ops.mse_rows_bwd(F_["preds"], F_["noise"], F_["clean"], F_["mse_src"], d_mse.to(device=dev, dtype=torch.float32).contiguous())
+            n = dpred.shape[0]
+            ops.gemm(dpred, TS._wt(lin.weight.data), d_last, c_rows0=F_["mse_rows"], M0=n, residual=d_last)
+            if lin.weight.requires_grad or lin.bias.requires_grad:
+                Xt = ops.transpose(last, rows=F_["mse_rows"], n=n)
+                dW = torch.empty(tuple(lin.weight.shape), dtype=BF16, device=dev)
+                grads.add(lin.weight, ops.gemm(ops.transpose(dpred), Xt, dW))
+                grads.add(lin.bias, ops.colsum(dpred))
+        g = TS.engine_backward_train(eng, tape, d_last, grads)            # d loss / d packed input sequence
+        # ---- text tokens: embedding rows shared by several tokens sum their gradients (bagel.py:148)
+        emb = lm.model.embed_tokens.weight
+        if emb.requires_grad:
+            ids, rows = F_["text_ids"], F_["text_rows"]
+            order = torch.argsort(ids, stable=True)
+            uniq, counts = torch.unique_consecutive(ids[order], return_counts=True)
+            seg = torch.zeros(uniq.numel() + 1, dtype=torch.int32)
+            seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            dE = torch.zeros(tuple(emb.shape), dtype=BF16, device=dev)
+            i32 = lambda x: x.to(device=dev, dtype=torch.int32)  # noqa: E731
+            ops.rows_segment_sum(g, i32(rows[order]), i32(seg), i32(uniq), dE)
+            grads.add(emb, dE)
+        # ---- ViT tokens: connector (fc1 - gelu_tanh - fc2); the tower itself is frozen
+        if "vit_feats" in F_:
+            c = self.connector
+            if any(p.requires_grad for p in c.parameters()):
+                feats, hmid, n = F_["vit_feats"], F_["vit_hmid"], F_["vit_feats"].shape[0]
+                d_emb = torch.empty((n, H), dtype=BF16, device=dev)
+                ops.copy_rows(g, d_emb, n, H, src_rows=F_["vit_rows"])
+                grads.add(c.fc2.weight, TS._wgrad(d_emb, hmid))
+                grads.add(c.fc2.bias, ops.colsum(d_emb))
+                d_h = torch.empty_like(hmid)
+                ops.gemm(d_emb, TS._wt(c.fc2.weight.data), d_h)
+                pre = torch.empty_like(hmid)
+                ops.gemm(feats, c.fc1.weight.data, pre, bias0=c.fc1.bias.data)        # the un-activated fc1 output, recomputed
+                ops.act_bwd(pre, d_h, ops.EPI_GELU_TANH)
+                grads.add(c.fc1.weight, TS._wgrad(pre, feats))
+                grads.add(c.fc1.bias, ops.colsum(pre))
+        # ---- latent tokens: vae2llm + per-image timestep embedding (bagel.py:186-191); the position table is frozen
+        if "x16" in F_:
+            x16, n = F_["x16"], F_["x16"].shape[0]
+            d_lat = torch.empty((n, H), dtype=BF16, device=dev)
+            ops.copy_rows(g, d_lat, n, H, src_rows=F_["vae_rows"])
+            v2l = self.vae2llm
+            if v2l.weight.requires_grad or v2l.bias.requires_grad:
+                grads.add(v2l.weight, TS._wgrad(d_lat, x16))
+                grads.add(v2l.bias, ops.colsum(d_lat))
+            te = self.time_embedder
+            if any(p.requires_grad for p in te.parameters()):
+                inv = F_["temb_inv"]
+                nu = int(inv.max()) + 1
+                order = torch.argsort(inv, stable=True)
+                seg = torch.zeros(nu + 1, dtype=torch.int32)
+                seg[1:] = torch.cumsum(torch.bincount(inv, minlength=nu), 0).to(torch.int32)
+                i32 = lambda x: x.to(device=dev, dtype=torch.int32)  # noqa: E731
+                d_temb = torch.zeros((nu, H), dtype=BF16, device=dev)
+                ops.rows_segment_sum(d_lat, i32(order), i32(seg), i32(torch.arange(nu)), d_temb)
+                sinus, th = F_["time_sinus"], F_["time_h"]
+                grads.add(te.mlp[2].weight, TS._wgrad(d_temb, th))
+                grads.add(te.mlp[2].bias, ops.colsum(d_temb))
+                d_th = torch.empty_like(th)
+                ops.gemm(d_temb, TS._wt(te.mlp[2].weight.data), d_th)
+                pre = torch.empty_like(th)
+                ops.gemm(sinus, te.mlp[0].weight.data, pre, bias0=te.mlp[0].bias.data)
+                ops.act_bwd(pre, d_th, ops.EPI_SILU)
+                grads.add(te.mlp[0].weight, TS._wgrad(pre, sinus))
+                grads.add(te.mlp[0].bias, ops.colsum(pre))
+        return grads

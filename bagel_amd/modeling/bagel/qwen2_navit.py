@@ -564,6 +564,7 @@ class TrainPlan:
 
     def __init__(self, device, sample_lens, sample_splits, position_ids, und_indexes, gen_indexes, inv_freq):
         self.M = int(sum(sample_lens))
+        self.sample_lens, self.sample_splits = list(sample_lens), [(list(l), list(m)) for l, m in sample_splits]   # the backward's items
         i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=device)  # noqa: E731
         q_start, q_end, new_col, clean_rows, cu_clean, clean_col = [], [], [], [], [0], []
         groups = {True: dict(qs=[], qe=[], cs=[], ce=[], ncol=[], ccol=[]), False: dict(qs=[], qe=[], cs=[], ce=[], ncol=[], ccol=[])}
@@ -910,11 +911,12 @@ class MoTEngine:
         return out
 
 
-def _engine_forward_train(self, seq, tp: "TrainPlan"):
+def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
     """Qwen2Model.forward_train (qwen2_navit.py:970-1016) with Qwen2MoTDecoderLayer.forward_train (:713-755) and
     PackedAttentionMoT.forward_train (:406-497): und rows (text + ViT) on the und expert, gen rows (VAE latents) on the gen
     expert, bf16 cast points for BOTH experts' QK-norm (no fp32 path here, unlike forward_inference's gen mode), and the
-    block mask executed as per-split sequences (TrainPlan)."""
+    block mask executed as per-split sequences (TrainPlan).  With a ``tape`` (train_step.TrainTape) every layer writes its residual
+    streams, raw projection, attention output and SwiGLU output into buffers of its own, which the tape keeps for the backward."""
     if not self.mot:
         raise NotImplementedError("forward_train is built for Qwen2MoTDecoderLayer (BAGEL's layer_module)")
     if seq.shape != (tp.M, self.H):
@@ -931,6 +933,9 @@ def _engine_forward_train(self, seq, tp: "TrainPlan"):
     vt_clean = torch.zeros((kw_, _ceil_to(max(tp.vt_clean_cols, 1), 256)), dtype=BF16, device=dev)
     x.copy_(seq)
     q_v, k_v, v_v = qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
+    if tape is not None:
+        tape.tp = tp
+        tape.x.append(x)
     two = tp.n_vae > 0
     expert = tp.expert if two else None
     scale = hd ** -0.5
@@ -942,8 +947,16 @@ def _engine_forward_train(self, seq, tp: "TrainPlan"):
         return dict(W0=w[0], bias0=None if b is None else b[0], M0=M)
 
     for P in self.layers:
+        x_mid, x_out = x, x                                   # in place without a tape
+        if tape is not None:
+            raw, att, act, x_mid, x_out = e(M, qw + 2 * kw_), e(M, qw), e(M, self.I), e(M, self.H), e(M, self.H)
+            tape.qkv_raw.append(raw); tape.att.append(att); tape.act.append(act); tape.x_mid.append(x_mid); tape.x.append(x_out)
         ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if two else None, expert=expert)
-        ops.gemm(h, C=qkv, **groups(P.wqkv, P.bqkv))
+        if tape is not None:
+            ops.gemm(h, C=raw, **groups(P.wqkv, P.bqkv))
+            qkv.copy_(raw)
+        else:
+            ops.gemm(h, C=qkv, **groups(P.wqkv, P.bqkv))
         ops.qknorm_rope(qkv, tp.cos, tp.sin, P.qn[0] if self.use_norm else None, P.kn[0] if self.use_norm else None,
                         P.qn[1] if (self.use_norm and two) else None, P.kn[1] if (self.use_norm and two) else None,
                         expert, nq, nkv, hd, dp, self.eps, gen_mode=False, use_norm=self.use_norm)
@@ -955,10 +968,11 @@ def _engine_forward_train(self, seq, tp: "TrainPlan"):
         for g in tp.groups:
             ops.attn_varlen_ranges(q_v, k_v, vt, att, g["qs"], g["qe"], g["ncol"], g["n"], g["max_lq"], nq, nkv, dp, g["causal"], scale,
                                    k_ctx=k_clean, vt_ctx=vt_clean, ctx_start=g["cs"], ctx_end=g["ce"], vt_ctx_col=g["ccol"])
-        ops.gemm(att, C=x, residual=x, **groups(P.wo))
-        ops.rmsnorm(x, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if two else None, expert=expert)
+        ops.gemm(att, C=x_mid, residual=x, **groups(P.wo))
+        ops.rmsnorm(x_mid, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if two else None, expert=expert)
         ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu))
-        ops.gemm(act, C=x, residual=x, **groups(P.wd))
+        ops.gemm(act, C=x_out, residual=x_mid, **groups(P.wd))
+        x = x_out
     out = torch.empty_like(x)
     m = self.model
     ops.rmsnorm(x, m.norm.weight.data, out, self.eps, w1=m.norm_moe_gen.weight.data if two else None, expert=expert)
@@ -1040,7 +1054,7 @@ class Qwen2ForCausalLM(PackedWeights):
 
     @torch.no_grad()
     def forward_train(self, packed_sequence, sample_lens, attention_mask, packed_position_ids, packed_und_token_indexes=None,
-                      packed_gen_token_indexes=None, split_lens=None, attn_modes=None):
+                      packed_gen_token_indexes=None, split_lens=None, attn_modes=None, tape=None):
         """qwen2_navit.py:1124-1143 (forward only: no autograd graph is built).  ``attention_mask``: the list of per-sample
         additive masks of the non-flex path, or None with flat ``split_lens`` / ``attn_modes`` (the flex path's inputs)."""
         eng = self.engine(check=True)
@@ -1064,7 +1078,7 @@ class Qwen2ForCausalLM(PackedWeights):
         seq = packed_sequence
         if seq.device != eng.device or seq.dtype != BF16:
             seq = seq.to(device=eng.device, dtype=BF16)
-        return eng.forward_train(seq, tp)
+        return eng.forward_train(seq, tp, tape)
 
     def forward(self, *args, **kwargs):
         if self.training:

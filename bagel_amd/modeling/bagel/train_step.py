@@ -1,0 +1,251 @@
+"""The backward half of a training step: ``loss.backward()`` over ``Bagel.forward`` (bagel.py:101-229) without torch autograd inside.
+
+The reference differentiates its eager graph (train/pretrain_unified_navit.py:683-735: bf16 autocast forward, weighted CE / MSE means,
+``loss.backward()``).  Here the whole packed forward is ONE autograd node (``PackedTrainStep``): its forward runs the HIP kernels of the
+training forward and keeps a tape of five activations per decoder layer; its backward chains hand-written reverse kernels
+(csrc/backward.hip, csrc/attention_bwd.hip) and the forward's own GEMM kernel on transposed operand images, and hands the parameter
+gradients back to torch -- so ``loss_dict = model(**data); loss.backward()`` of the reference's loop works unchanged and every
+``param.grad`` (and whatever hooks FSDP / DDP hang on them) sees the same tensors it would see from autograd.
+
+MI355X-first choices:
+  * no activation checkpointing: 288 GB of HBM holds the tape of a 32k-token pack at 7B depth (x_in, raw qkv, attention output, x_mid,
+    SwiGLU output per layer = 68 KB per token per layer, 62 GB at 32 768 tokens x 28 layers); only the un-activated gate/up projection
+    (76 KB per token per layer on its own) is recomputed, by one more launch of the forward's GEMM;
+  * dX = dY W and dW = dY^T X both run on the forward's NT MFMA kernel over transposed bf16 images (bagel_transpose_bf16, an HBM-bound
+    pass that costs a few per cent of the product it feeds), including the MoT routing: each expert's dW contracts over that expert's
+    rows only (the transpose gathers them), each dX launch routes rows to the two transposed weights exactly like the forward;
+  * the block mask (causal / full / noise splits) is differentiated by two deterministic kernels over per-split work items -- no
+    atomics, so the same batch gives the same gradients bit for bit on every run.
+
+Scope: gradients of every parameter of the language model (both experts, embeddings, norms, lm_head), llm2vae / vae2llm / the time
+embedder and the ViT connector; the SigLIP tower and the VAE are frozen (``--freeze_vit True --freeze_vae True`` of
+pretrain_unified_navit.py:382-393) -- a ViT parameter that requires grad raises instead of silently staying without a gradient."""
+import numpy as np
+import torch
+
+from ... import ops
+
+BF16 = torch.bfloat16
+
+
+def _ceil_to(x, m):
+    return -(-x // m) * m
+
+
+class AttnBackwardPlan:
+    """Work items of bagel_attn_bwd_blockmask_bf16 for one packed batch (include/bagel_hip.h): 128-row query items and 128-key items
+    per split, with the sample / split bounds that define the mask of data/data_utils.py:72-103, and the noise-key bitmap."""
+
+    ROWS = 128
+
+    def __init__(self, device, sample_lens, sample_splits):
+        M = int(sum(sample_lens))
+        q_items, k_items = [], []
+        noise = np.zeros(_ceil_to(max(M, 1), 64), dtype=bool)
+        row = 0
+        for n, (lens, modes) in zip(sample_lens, sample_splits):
+            a0, a1, s0 = row, row + n, row
+            for L, mode in zip(lens, modes):
+                s1 = s0 + L
+                causal = int(mode == "causal")
+                if mode == "noise":
+                    noise[s0:s1] = True
+                for r0 in range(s0, s1, self.ROWS):
+                    nr = min(self.ROWS, s1 - r0)
+                    k_end = r0 + nr if causal else s1                       # a causal chunk sees nothing beyond its last row
+                    q_items.append((r0, nr, a0, s0, s1, causal, a0 // 64, -(-k_end // 64)))
+                    # who sees these keys: the own split (from the chunk's first row when causal), and -- unless the split is
+                    # noise -- every later row of the sample
+                    k_items.append((r0, nr, r0 if causal else s0, s1 if mode == "noise" else a1, s1, causal, 0, 0))
+                s0 = s1
+            row = a1
+        self.M = M
+        self.q_items = torch.tensor(q_items, dtype=torch.int32, device=device).reshape(-1, 8)
+        self.k_items = torch.tensor(k_items, dtype=torch.int32, device=device).reshape(-1, 8)
+        words = np.packbits(noise.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1).astype(np.int64)
+        self.noise_bits = torch.from_numpy(words.copy()).to(device)
+
+
+class TrainTape:
+    """What the forward leaves behind for the backward (all device tensors stay resident; nothing is recomputed but h = rmsnorm(x),
+    the rotated q / k and the un-activated gate / up projection)."""
+
+    def __init__(self):
+        self.tp = None          # TrainPlan
+        self.x = []             # L + 1 residual streams: x[l] = input of layer l, x[L] = input of the final norm
+        self.x_mid = []         # residual stream after the attention block
+        self.qkv_raw = []       # fused projection before QK-norm / RoPE
+        self.att = []           # attention output (o_proj input)
+        self.act = []           # SwiGLU output (down_proj input)
+        self.front = {}         # embedding / ViT / latent front end and the loss heads (Bagel._forward_losses)
+
+
+def _wt(W):
+    """[N, K] -> its transposed image [K, N] (row stride ceil64(N)): the weight operand of dX = dY W on the NT kernel."""
+    return ops.transpose(W)[:, :W.shape[0]]
+
+
+def _wgrad(dY, X, rows=None, n=None):
+    """dW [N, K] = sum over the listed rows of dY[r]^T X[r]  (all rows when rows is None)."""
+    dYt, Xt = ops.transpose(dY, rows=rows, n=n), ops.transpose(X, rows=rows, n=n)
+    dW = torch.empty((dY.shape[1], X.shape[1]), dtype=BF16, device=dY.device)
+    return ops.gemm(dYt, Xt, dW)
+
+
+def _unpad_rows(w, nheads, hd, dp):
+    if dp == hd:
+        return w
+    return w.view(nheads, dp, *w.shape[1:])[:, :hd].reshape(nheads * hd, *w.shape[1:])
+
+
+def _unpad_cols(w, nheads, hd, dp):
+    if dp == hd:
+        return w
+    return w.view(w.shape[0], nheads, dp)[:, :, :hd].reshape(w.shape[0], nheads * hd)
+
+
+def _deinterleave_gate_up(w):
+    I2, H = w.shape
+    v = w.view(I2 // 32, 2, 16, H)
+    return v[:, 0].reshape(I2 // 2, H), v[:, 1].reshape(I2 // 2, H)
+
+
+class _Grads:
+    """parameter -> gradient, summed when a parameter collects more than one contribution (tied embeddings)."""
+
+    def __init__(self):
+        self.by_id = {}
+
+    def add(self, param, g):
+        if param is None or g is None or not param.requires_grad:
+            return
+        g = g.reshape(param.shape)
+        if g.dtype != param.dtype:
+            g = g.to(param.dtype)
+        k = id(param)
+        self.by_id[k] = g.contiguous() if k not in self.by_id else self.by_id[k] + g
+
+    def get(self, param):
+        return self.by_id.get(id(param))
+
+
+def engine_backward_train(eng, tape, g, grads):
+    """Reverse of MoTEngine.forward_train: ``g`` [M, H] bf16 = d loss / d (final-norm output), overwritten on the way; returns
+    d loss / d (packed input sequence) [M, H] bf16 and adds every decoder-layer / final-norm parameter gradient to ``grads``."""
+    tp = tape.tp
+    dev = eng.device
+    nq, nkv, dp, hd = eng.nq, eng.nkv, eng.dp, eng.hd
+    qw, kw_ = nq * dp, nkv * dp
+    M, H, I = tp.M, eng.H, eng.I
+    two = tp.n_vae > 0
+    expert = tp.expert if two else None
+    scale = hd ** -0.5
+    e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
+    sel = [(tp.text_idx, tp.n_text), (tp.vae_idx, tp.n_vae)] if two else [(None, M)]
+    sufs = ("", "_moe_gen")
+
+    def groups(w, b=None):
+        if two:
+            return dict(W0=w[0], bias0=None if b is None else b[0], a_rows0=tp.text_idx, c_rows0=tp.text_idx, M0=tp.n_text,
+                        W1=w[1], bias1=None if b is None else b[1], a_rows1=tp.vae_idx, c_rows1=tp.vae_idx, M1=tp.n_vae)
+        return dict(W0=w[0], bias0=None if b is None else b[0], M0=M)
+
+    def wgrads(dY, X):
+        return [_wgrad(dY, X, rows, n) for rows, n in sel]
+
+    def wts(ws):
+        return [_wt(w) for w in ws[:len(sel)]]
+
+    bplan = AttnBackwardPlan(dev, tp.sample_lens, tp.sample_splits)
+    m = eng.model
+    # final norm (qwen2_navit.py:1011-1015)
+    gx = e(M, H)
+    dw0, dw1 = ops.rmsnorm_bwd(tape.x[-1], g, m.norm.weight.data, gx, eng.eps, w1=m.norm_moe_gen.weight.data if two else None, expert=expert,
+                               accumulate=False)
+    grads.add(m.norm.weight, dw0)
+    if two:
+        grads.add(m.norm_moe_gen.weight, dw1)
+    g = gx
+    h, d_h = e(M, H), e(M, H)
+    for li in range(len(eng.layers) - 1, -1, -1):
+        P, Lm = eng.layers[li], m.layers[li]
+        x_in, x_mid, act, att, qkv_raw = tape.x[li], tape.x_mid[li], tape.act[li], tape.att[li], tape.qkv_raw[li]
+        # ---- MLP block: x_out = x_mid + down(swiglu(gate_up(rmsnorm(x_mid))))   (qwen2_navit.py:744-753)
+        d_act = e(M, I)
+        ops.gemm(g, C=d_act, **groups(wts(P.wd)))
+        dWd = wgrads(g, act)
+        ops.rmsnorm(x_mid, P.ln_post[0], h, eng.eps, w1=P.ln_post[1] if two else None, expert=expert)
+        gu = e(M, 2 * I)
+        ops.gemm(h, C=gu, **groups(P.wgu))                       # the un-activated projection, recomputed
+        ops.swiglu_bwd(gu, d_act)
+        del d_act
+        dWgu = wgrads(gu, h)
+        ops.gemm(gu, C=d_h, **groups(wts(P.wgu)))
+        del gu
+        dpost = ops.rmsnorm_bwd(x_mid, d_h, P.ln_post[0], g, eng.eps, w1=P.ln_post[1] if two else None, expert=expert)
+        # ---- attention block: x_mid = x_in + o(attn(rope(qknorm(qkv(rmsnorm(x_in))))))   (qwen2_navit.py:406-497, 713-743)
+        d_att = e(M, qw)
+        ops.gemm(g, C=d_att, **groups(wts(P.wo)))
+        dWo = wgrads(g, att)
+        qkv = qkv_raw.clone()
+        ops.qknorm_rope(qkv, tp.cos, tp.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
+                        P.qn[1] if (eng.use_norm and two) else None, P.kn[1] if (eng.use_norm and two) else None,
+                        expert, nq, nkv, hd, dp, eng.eps, gen_mode=False, use_norm=eng.use_norm)
+        dqkv = e(M, qw + 2 * kw_)
+        ops.attn_bwd_blockmask(qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:], att, d_att, dqkv[:, :qw], dqkv[:, qw:qw + kw_],
+                               dqkv[:, qw + kw_:], bplan.q_items, bplan.k_items, bplan.noise_bits, nq, nkv, dp, scale)
+        del qkv, d_att
+        dqn = ops.qknorm_rope_bwd(dqkv, qkv_raw, tp.cos, tp.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
+                                  P.qn[1] if (eng.use_norm and two) else None, P.kn[1] if (eng.use_norm and two) else None,
+                                  expert, nq, nkv, hd, dp, eng.eps, eng.use_norm)
+        ops.rmsnorm(x_in, P.ln_in[0], h, eng.eps, w1=P.ln_in[1] if two else None, expert=expert)
+        dWqkv = wgrads(dqkv, h)
+        dbqkv = [ops.colsum(dqkv, rows, n) for rows, n in sel]
+        ops.gemm(dqkv, C=d_h, **groups(wts(P.wqkv)))
+        del dqkv
+        din = ops.rmsnorm_bwd(x_in, d_h, P.ln_in[0], g, eng.eps, w1=P.ln_in[1] if two else None, expert=expert)
+        # ---- unpack the MI355X layouts into the reference's parameter shapes
+        a = Lm.self_attn
+        for ei in range(len(sel)):
+            s = sufs[ei]
+            wq, wk, wv = dWqkv[ei][:qw], dWqkv[ei][qw:qw + kw_], dWqkv[ei][qw + kw_:]
+            bq, bk, bv = dbqkv[ei][:qw], dbqkv[ei][qw:qw + kw_], dbqkv[ei][qw + kw_:]
+            for name, w_, b_, nh in (("q_proj", wq, bq, nq), ("k_proj", wk, bk, nkv), ("v_proj", wv, bv, nkv)):
+                lin = getattr(a, name + s)
+                grads.add(lin.weight, _unpad_rows(w_, nh, hd, dp))
+                grads.add(lin.bias, _unpad_rows(b_, nh, hd, dp))
+            grads.add(getattr(a, "o_proj" + s).weight, _unpad_cols(dWo[ei], nq, hd, dp))
+            if eng.use_norm:
+                grads.add(getattr(a, "q_norm" + s).weight, dqn[2 * ei])
+                grads.add(getattr(a, "k_norm" + s).weight, dqn[2 * ei + 1])
+            grads.add(getattr(Lm, "input_layernorm" + s).weight, din[ei])
+            grads.add(getattr(Lm, "post_attention_layernorm" + s).weight, dpost[ei])
+            mlp = getattr(Lm, "mlp" + s)
+            dg, du = _deinterleave_gate_up(dWgu[ei])
+            grads.add(mlp.gate_proj.weight, dg)
+            grads.add(mlp.up_proj.weight, du)
+            grads.add(mlp.down_proj.weight, dWd[ei])
+    return g
+
+
+class PackedTrainStep(torch.autograd.Function):
+    """``Bagel.forward`` as one autograd node: forward = the HIP training forward with a tape, backward = the hand-chained reverse."""
+
+    @staticmethod
+    def forward(ctx, model, kwargs, *params):
+        tape = TrainTape()
+        out = model._forward_losses(tape=tape, **kwargs)
+        ctx.model, ctx.tape, ctx.params = model, tape, params
+        ctx.has = (out["mse"] is not None, out["ce"] is not None)
+        dev = model.device
+        empty = lambda: torch.zeros((0,), dtype=torch.float32, device=dev)  # noqa: E731
+        return (out["mse"] if ctx.has[0] else empty()), (out["ce"] if ctx.has[1] else empty())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_mse, d_ce):
+        if ctx.tape is None:
+            raise RuntimeError("the tape of this training step was already consumed (backward runs once per forward)")
+        grads = ctx.model._backward_losses(ctx.tape, d_mse if ctx.has[0] else None, d_ce if ctx.has[1] else None)
+        ctx.tape = None
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)

@@ -473,6 +473,141 @@ def cross_entropy(logits, labels):
     return out
 
 
+# ---- training backward (the reverse kernels of backward.hip / attention_bwd.hip; chained by modeling/bagel/train_step.py) ----
+def _colsum_ws(rows, cols, device):
+    return torch.empty((-(-max(int(rows), 1) // 64) * int(cols),), dtype=torch.float32, device=device)
+
+
+def transpose(src, dst=None, rows=None, n=None):
+    """dst[c, j] = src[rows[j] if rows is not None else j, c] for j < n; dst[:, n:] = 0.  src [*, C] bf16 -> dst [C, ceil64(n)]."""
+    _req(src, BF16, "transpose.src")
+    if rows is not None:
+        _req(rows, torch.int32, "transpose.rows")
+    if n is None:
+        n = rows.numel() if rows is not None else src.shape[0]
+    C = src.shape[1]
+    npad = -(-max(n, 1) // 64) * 64
+    if dst is None:
+        dst = torch.empty((C, npad), dtype=BF16, device=src.device)
+    _req(dst, BF16, "transpose.dst")
+    if dst.shape[0] < C or dst.shape[1] < npad:
+        raise BagelHipError(f"transpose: dst {tuple(dst.shape)} too small for [{C}, {npad}]")
+    check(lib().bagel_transpose_bf16(_ptr(src), _ld(src), _ptr(rows), n, C, _ptr(dst), _ld(dst), npad, _stream()), "bagel_transpose_bf16")
+    return dst[:C, :npad]
+
+
+def rmsnorm_bwd(x, dy, w0, g, eps, w1=None, expert=None, accumulate=True):
+    """g = bf16((g if accumulate else 0) + d rmsnorm / dx); -> (dw0, dw1) bf16 [cols] (dw1 None without a second expert)."""
+    _req(x, BF16, "rmsnorm_bwd.x"); _req(dy, BF16, "rmsnorm_bwd.dy"); _req(g, BF16, "rmsnorm_bwd.g"); _req(w0, BF16, "rmsnorm_bwd.w0")
+    rows, cols = x.shape
+    dw0 = torch.empty((cols,), dtype=BF16, device=x.device)
+    dw1 = torch.empty_like(dw0) if w1 is not None else None
+    ws = _colsum_ws(rows, 2 * cols, x.device)
+    check(lib().bagel_rmsnorm_bwd_bf16(_ptr(x), _ld(x), _ptr(dy), _ld(dy), _ptr(w0), _ptr(w1), _ptr(expert if w1 is not None else None),
+                                       _ptr(g), _ld(g), int(bool(accumulate)), _ptr(dw0), _ptr(dw1), _ptr(ws), rows, cols, float(eps),
+                                       _stream()), "bagel_rmsnorm_bwd_bf16")
+    return dw0, dw1
+
+
+def qknorm_rope_bwd(dqkv, qkv_raw, cos, sin, q_w0, k_w0, q_w1, k_w1, expert, nq, nkv, head_dim, head_dim_padded, eps, use_norm):
+    """In place: gradient of the rotated [q | k | v] rows -> gradient of the raw projection; -> (dqw0, dkw0, dqw1, dkw1)."""
+    _req(dqkv, BF16, "qknorm_rope_bwd.dqkv"); _req(qkv_raw, BF16, "qknorm_rope_bwd.qkv_raw")
+    dev = dqkv.device
+    two = use_norm and q_w1 is not None
+    mk = lambda on: torch.empty((head_dim,), dtype=BF16, device=dev) if on else None  # noqa: E731
+    dq0, dk0, dq1, dk1 = mk(use_norm), mk(use_norm), mk(two), mk(two)
+    ws = _colsum_ws(dqkv.shape[0], 4 * head_dim, dev)
+    check(lib().bagel_qknorm_rope_bwd_bf16(_ptr(dqkv), _ld(dqkv), _ptr(qkv_raw), _ld(qkv_raw), _ptr(cos), _ptr(sin), _ptr(q_w0), _ptr(k_w0),
+                                           _ptr(q_w1 if two else None), _ptr(k_w1 if two else None), _ptr(expert if two else None),
+                                           _ptr(dq0), _ptr(dk0), _ptr(dq1), _ptr(dk1), _ptr(ws), dqkv.shape[0], nq, nkv, head_dim,
+                                           head_dim_padded, float(eps), int(use_norm), _stream()), "bagel_qknorm_rope_bwd_bf16")
+    return dq0, dk0, dq1, dk1
+
+
+def swiglu_bwd(gu, d_act):
+    """gu [rows, 2 I] (interleaved [16 gate | 16 up]) <- its gradient given d_act [rows, I]."""
+    _req(gu, BF16, "swiglu_bwd.gu"); _req(d_act, BF16, "swiglu_bwd.d_act")
+    if gu.shape[1] != 2 * d_act.shape[1] or gu.shape[0] != d_act.shape[0]:
+        raise BagelHipError("swiglu_bwd: gu must be [rows, 2 * I] for d_act [rows, I]")
+    check(lib().bagel_swiglu_bwd_bf16(_ptr(gu), _ld(gu), _ptr(d_act), _ld(d_act), gu.shape[0], d_act.shape[1], _stream()), "bagel_swiglu_bwd_bf16")
+    return gu
+
+
+def act_bwd(pre, d_out, kind):
+    """pre <- d_out * act'(pre) for the GELU-tanh / SiLU epilogues (kind = EPI_GELU_TANH / EPI_SILU)."""
+    _req(pre, BF16, "act_bwd.pre"); _req(d_out, BF16, "act_bwd.d_out")
+    if pre.shape != d_out.shape or kind not in (EPI_GELU_TANH, EPI_SILU):
+        raise BagelHipError("act_bwd: same-shape operands and kind in (EPI_GELU_TANH, EPI_SILU) expected")
+    check(lib().bagel_act_bwd_bf16(_ptr(pre), _ld(pre), _ptr(d_out), _ld(d_out), pre.shape[0], pre.shape[1], kind, _stream()), "bagel_act_bwd_bf16")
+    return pre
+
+
+def cross_entropy_bwd(logits, labels, d_loss):
+    """logits <- (softmax(logits) - onehot(labels)) * d_loss[:, None], in place."""
+    _req(logits, BF16, "cross_entropy_bwd.logits"); _req(labels, torch.int64, "cross_entropy_bwd.labels")
+    _req(d_loss, torch.float32, "cross_entropy_bwd.d_loss")
+    if d_loss.numel() != logits.shape[0] or not d_loss.is_contiguous():
+        raise BagelHipError("cross_entropy_bwd: d_loss must be a contiguous [rows] vector")
+    check(lib().bagel_cross_entropy_bwd_bf16(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(d_loss), logits.shape[0], logits.shape[1],
+                                             _stream()), "bagel_cross_entropy_bwd_bf16")
+    return logits
+
+
+def mse_rows_bwd(pred, noise, clean, src_rows, d_loss):
+    """-> bf16 [n, cols]: 2 (pred - (noise - clean)[src_rows]) d_loss."""
+    _req(pred, BF16, "mse_rows_bwd.pred"); _req(noise, torch.float32, "mse_rows_bwd.noise"); _req(clean, torch.float32, "mse_rows_bwd.clean")
+    _req(src_rows, torch.int32, "mse_rows_bwd.src_rows"); _req(d_loss, torch.float32, "mse_rows_bwd.d_loss")
+    n, cols = src_rows.numel(), noise.shape[1]
+    if tuple(d_loss.shape) != (n, cols) or not d_loss.is_contiguous():
+        raise BagelHipError("mse_rows_bwd: d_loss must be contiguous [n, cols]")
+    out = torch.empty((n, cols), dtype=BF16, device=pred.device)
+    check(lib().bagel_mse_rows_bwd_bf16(_ptr(pred), pred.stride(0), _ptr(noise), _ptr(clean), _ptr(src_rows), _ptr(d_loss), _ptr(out),
+                                        out.stride(0), n, cols, _stream()), "bagel_mse_rows_bwd_bf16")
+    return out
+
+
+def rows_segment_sum(src, order, seg_off, dst_rows, dst):
+    """dst[dst_rows[s]] = sum(src[order[seg_off[s]:seg_off[s + 1]]]) (fp32 sums, bf16 result)."""
+    _req(src, BF16, "rows_segment_sum.src"); _req(dst, BF16, "rows_segment_sum.dst")
+    for t, nm in ((order, "order"), (seg_off, "seg_off"), (dst_rows, "dst_rows")):
+        _req(t, torch.int32, "rows_segment_sum." + nm)
+    check(lib().bagel_rows_segment_sum_bf16(_ptr(src), _ld(src), _ptr(order), _ptr(seg_off), _ptr(dst_rows), _ptr(dst), _ld(dst),
+                                            dst_rows.numel(), src.shape[1], _stream()), "bagel_rows_segment_sum_bf16")
+    return dst
+
+
+def colsum(src, rows=None, n=None):
+    """-> bf16 [cols]: sum over the listed rows (all rows when rows is None)."""
+    _req(src, BF16, "colsum.src")
+    if rows is not None:
+        _req(rows, torch.int32, "colsum.rows")
+    if n is None:
+        n = rows.numel() if rows is not None else src.shape[0]
+    out = torch.empty((src.shape[1],), dtype=BF16, device=src.device)
+    ws = _colsum_ws(n, src.shape[1], src.device)
+    check(lib().bagel_colsum_bf16(_ptr(src), _ld(src), _ptr(rows), n, src.shape[1], _ptr(ws), _ptr(out), _stream()), "bagel_colsum_bf16")
+    return out
+
+
+def attn_bwd_blockmask(q, k, v, o, d_o, dq, dk, dv, q_items, k_items, noise_bits, nq, nkv, head_dim, softmax_scale):
+    """Reverse of the block-masked packed attention (bagel_attn_bwd_blockmask_bf16); q / k / v / o / d_o / dq / dk / dv are
+    [rows, heads * head_dim] views (any row stride); head_dim = the padded width (64 or 128)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _req(t, BF16, "attn_bwd." + nm)
+    _req(q_items, torch.int32, "attn_bwd.q_items"); _req(k_items, torch.int32, "attn_bwd.k_items"); _req(noise_bits, torch.int64, "attn_bwd.noise_bits")
+    rows = q.shape[0]
+    qt, dot, kt = transpose(q), transpose(d_o), transpose(k)
+    if noise_bits.numel() * 64 < qt.shape[1]:
+        raise BagelHipError("attn_bwd: noise_bits must cover ceil64(rows) keys")
+    ws = torch.empty((2, nq, rows), dtype=torch.float32, device=q.device)
+    check(lib().bagel_attn_bwd_blockmask_bf16(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
+                                              _ptr(d_o), d_o.stride(0), _ptr(qt), _ptr(dot), _ptr(kt), qt.stride(0), _ptr(dq), dq.stride(0),
+                                              _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), _ptr(q_items), q_items.shape[0], _ptr(k_items),
+                                              k_items.shape[0], _ptr(noise_bits), _ptr(ws), rows, nq, nkv, head_dim, float(softmax_scale),
+                                              _stream()), "bagel_attn_bwd_blockmask_bf16")
+    return dq, dk, dv
+
+
 def _ptr_array(tensors, n):
     arr = (ctypes.c_void_p * max(n, 1))()
     for i in range(n):

@@ -322,6 +322,65 @@ int bagel_u8_to_chw_f32(const void* in, int64_t in_stride, float* out, int32_t H
 int bagel_chw_f32_to_u8(const float* in, int64_t chan_stride, int64_t row_stride, void* out, int64_t out_stride,
                         int32_t H, int32_t W, int32_t C, bagel_stream_t stream);
 
+/* ---- training backward (loss.backward() of train/pretrain_unified_navit.py:683-735 over Bagel.forward, bagel.py:101-229; the
+ *      reference gets it from torch autograd, these are the hand-written reverse kernels the product chains) ---------------------- */
+/* dst[c][j] = src[src_rows ? src_rows[j] : j][c] for j < rows, 0 for rows <= j < rows_padded: the K-contiguous operand images of
+ * the weight-gradient and input-gradient GEMMs (dW = dY^T X and dX = dY W are NT products of transposed images on bagel_gemm_bf16;
+ * src_rows = one MoT expert's row list).  cols % 8 == 0, ld_dst >= rows_padded. */
+int bagel_transpose_bf16(const void* src, int64_t ld_src, const int32_t* src_rows, int32_t rows, int32_t cols, void* dst,
+                         int64_t ld_dst, int32_t rows_padded, bagel_stream_t stream);
+/* Reverse of bagel_rmsnorm_bf16 (Qwen2RMSNorm, modeling_qwen2.py:54-59): with xh = x * rsqrt(mean(x^2) + eps), w = the row's expert
+ * weight:  dx = rsqrt(..) * (dy w - xh * mean(dy w xh));  g = bf16((accumulate ? g : 0) + bf16(dx));  dw_e[c] = sum over the rows of
+ * expert e of dy * bf16(xh).  fp32 arithmetic; dw0 / dw1 bf16 [cols] (dw1 NULL without a second expert); partial_ws fp32, at least
+ * BAGEL_COLSUM_WS_FLOATS(rows, 2 * cols) floats. */
+#define BAGEL_COLSUM_WS_FLOATS(rows, cols) ((((int64_t)(rows) + 63) / 64) * (int64_t)(cols))   /* one partial row per 64 input rows */
+int bagel_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* w0, const void* w1,
+                           const int32_t* expert_of_row, void* g, int64_t ldg, int32_t accumulate, void* dw0, void* dw1,
+                           float* partial_ws, int32_t rows, int32_t cols, float eps, bagel_stream_t stream);
+/* Reverse of bagel_qknorm_rope_bf16 in its training form (gen_mode 0; PackedAttentionMoT.forward_train, qwen2_navit.py:430-455): in
+ * place on the gradient of the rotated [q | k | v] rows -> gradient of the raw projection (v columns untouched); qkv_raw = the
+ * projection output the forward normalised.  dqw / dkw: bf16 [head_dim] per expert (NULL when use_norm == 0 or no second expert);
+ * partial_ws fp32, at least BAGEL_COLSUM_WS_FLOATS(rows, 4 * head_dim) floats. */
+int bagel_qknorm_rope_bwd_bf16(void* dqkv, int64_t ld, const void* qkv_raw, int64_t ld_raw, const void* cos_tab, const void* sin_tab,
+                               const void* q_w0, const void* k_w0, const void* q_w1, const void* k_w1, const int32_t* expert_of_row,
+                               void* dqw0, void* dkw0, void* dqw1, void* dkw1, float* partial_ws, int32_t rows, int32_t nq,
+                               int32_t nkv, int32_t head_dim, int32_t head_dim_padded, float eps, int32_t use_norm,
+                               bagel_stream_t stream);
+/* Reverse of the SwiGLU16 epilogue (Qwen2MLP, modeling_qwen2.py:201): gu = the un-activated gate/up projection in the interleaved
+ * [16 gate | 16 up] column layout, overwritten with its gradient: d_up = d_act * bf16(silu(g)), d_gate = d_act * u * silu'(g). */
+int bagel_swiglu_bwd_bf16(void* gu, int64_t ld, const void* d_act, int64_t ld_d, int64_t rows, int32_t inter, bagel_stream_t stream);
+/* Reverse of the GELU-tanh (kind 1) / SiLU (kind 2) epilogues: pre = the un-activated projection, overwritten with d_out * act'(pre). */
+int bagel_act_bwd_bf16(void* pre, int64_t ld, const void* d_out, int64_t ld_d, int64_t rows, int32_t cols, int32_t kind,
+                       bagel_stream_t stream);
+/* Reverse of bagel_cross_entropy_bf16: logits <- bf16((softmax(logits) - onehot(label)) * d_loss[row]) (zero row for an ignored label). */
+int bagel_cross_entropy_bwd_bf16(void* logits, int64_t ld, const int64_t* labels, const float* d_loss, int32_t rows, int32_t cols,
+                                 bagel_stream_t stream);
+/* Reverse of bagel_mse_rows_f32: d_pred[i][c] = bf16(2 (pred - (noise - clean)[src_rows[i]]) d_loss[i][c]). */
+int bagel_mse_rows_bwd_bf16(const void* pred, int64_t ld_pred, const float* noise, const float* clean, const int32_t* src_rows,
+                            const float* d_loss, void* d_pred, int64_t ld_d, int64_t n_rows, int32_t cols, bagel_stream_t stream);
+/* dst[dst_rows[s]] = bf16(sum_{i in [seg_off[s], seg_off[s+1])} src[order[i]]) in fp32, deterministic: the gradient of an embedding
+ * gather (nn.Embedding rows that several tokens share, bagel.py:148; the per-image timestep embedding, bagel.py:188). */
+int bagel_rows_segment_sum_bf16(const void* src, int64_t ld_src, const int32_t* order, const int32_t* seg_off, const int32_t* dst_rows,
+                                void* dst, int64_t ld_dst, int32_t n_seg, int32_t cols, bagel_stream_t stream);
+/* out[c] = bf16(sum_j src[rows ? rows[j] : j][c]) (bias gradients); partial_ws fp32, BAGEL_COLSUM_WS_FLOATS(n_rows, cols) floats. */
+int bagel_colsum_bf16(const void* src, int64_t ld, const int32_t* rows, int32_t n_rows, int32_t cols, float* partial_ws, void* out,
+                      bagel_stream_t stream);
+/* Reverse of the block-masked packed attention of forward_train (the causal / full / noise split mask of data/data_utils.py:72-103
+ * that bagel_attn_varlen_ranges_bf16 runs as per-split sequences): dq, dk, dv from q, k, v (rotated, [rows, heads * D]), the forward
+ * output o and its gradient d_o; qt / dot / kt = bagel_transpose_bf16 images of q / d_o / k ([heads * D, ld_t]).
+ * Two deterministic kernels, no atomics: (1) per 128-query item and q head: row log-sum-exp and delta = rowsum(d_o * o), then
+ * dQ = scale * sum_keys dS K;  (2) per 128-key item and kv head, over the group's q heads: dV = P^T dO, dK = scale * dS^T Q.
+ * q_items [n_q_items][8] = {row0, nrows, sample_start, split_start, split_end, causal, first 64-key tile, end tile};
+ * k_items [n_k_items][8] = {key0, nkeys, first visible query row, end visible query row, split_end, causal, 0, 0};
+ * noise_bits[t] bit j = key 64 t + j belongs to a noise split (hidden from every later split);
+ * lse_delta: fp32 workspace [2][nq][rows].  D = 64 or 128. */
+int bagel_attn_bwd_blockmask_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                                  int64_t ldo, const void* d_o, int64_t lddo, const void* qt, const void* dot, const void* kt,
+                                  int64_t ld_t, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                                  const int32_t* q_items, int32_t n_q_items, const int32_t* k_items, int32_t n_k_items,
+                                  const uint64_t* noise_bits, float* lse_delta, int32_t rows, int32_t nq, int32_t nkv,
+                                  int32_t head_dim, float softmax_scale, bagel_stream_t stream);
+
 /* ---- VAE (fp32, NHWC) ------------------------------------------------------------------------------------- */
 /* Implicit-GEMM convolution / plain GEMM on the exact-fp32 MFMA.  mode 0: out[M,Cout] = in[M,Cin] w[Cout,Cin]^T
  * (1x1 conv, attention products; M = B*Hout*Wout); 1: 3x3 stride 1 pad 1; 2: 3x3 stride 2 with the (0,1,0,1) pad of

@@ -31,9 +31,16 @@ def _explicit_casts(fn):
 
     @functools.wraps(fn)
     def wrapped(*a, **k):
-        with torch.no_grad(), torch.autocast("cpu", enabled=False):
+        with torch.set_grad_enabled(GRAD_ENABLED), torch.autocast("cpu", enabled=False):
             return fn(*a, **k)
     return wrapped
+
+
+# Gradient oracle of the training step (oracle/make_golden_train_grads.py, tests/test_train_backward_*.py): with GRAD_ENABLED the
+# restatement keeps torch's autograd graph, so ``loss.backward()`` on its losses yields the gradients the reference's own
+# ``loss.backward()`` (train/pretrain_unified_navit.py:690-735) produces -- the explicit casts are differentiable ``.to()`` calls at
+# the places autocast puts them.  Off everywhere else (the forward oracle never builds a graph).
+GRAD_ENABLED = False
 
 _spec = importlib.util.spec_from_file_location(
     "_oracle_flash_attn", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_shims", "flash_attn", "__init__.py"))
@@ -696,6 +703,39 @@ def bagel_forward_train(W, cfg, batch, noise, timestep_shift=1.0):
         logits = linear(out[b["ce_loss_indexes"]], W["language_model.lm_head.weight"])
         ce = F.cross_entropy(logits.float(), b["packed_label_ids"], reduction="none")
     return dict(mse=mse, ce=ce)
+
+
+def training_step_loss(out, ce_loss_weights=None, ce_weight=1.0, mse_weight=1.0):
+    """The scalar loss of one rank's micro-step, train/pretrain_unified_navit.py:705-727 (world size 1): the CE mean (weighted by
+    ``ce_loss_weights`` under ``ce_loss_reweighting``) times ce_weight plus the per-token mean-over-channels MSE, averaged over the
+    MSE tokens, times mse_weight."""
+    loss = 0
+    if out.get("ce") is not None:
+        ce = out["ce"]
+        ce = (ce * ce_loss_weights).sum() / ce_loss_weights.sum() if ce_loss_weights is not None else ce.sum() / ce.shape[0]
+        loss = loss + ce * ce_weight
+    if out.get("mse") is not None:
+        loss = loss + out["mse"].mean(dim=-1).sum() / out["mse"].shape[0] * mse_weight
+    return loss
+
+
+def training_step_grads(W, cfg, batch, noise, ce_loss_weights=None, names=None, ce_weight=1.0, mse_weight=1.0):
+    """``loss.backward()`` of the reference's training step (pretrain_unified_navit.py:683-735) through torch's autograd over the
+    restated forward: -> (loss float, {state-dict key: gradient}, losses).  ``names`` = the keys to differentiate (default: every
+    floating-point entry of ``W``).  Bit-exact against the unmodified reference's own backward on the host that runs both
+    (oracle/make_golden_train_grads.py, tests/test_reference_crosscheck.py)."""
+    global GRAD_ENABLED
+    if names is None:
+        names = {k for k, v in W.items() if v.is_floating_point() and "pos_embed" not in k and "inv_freq" not in k}
+    Wg = {k: (v.detach().clone().requires_grad_(True) if k in names else v) for k, v in W.items()}
+    GRAD_ENABLED = True
+    try:
+        out = bagel_forward_train(Wg, cfg, batch, noise, timestep_shift=cfg["bagel"]["timestep_shift"])
+        loss = training_step_loss(out, ce_loss_weights, ce_weight, mse_weight)
+        loss.backward()
+    finally:
+        GRAD_ENABLED = False
+    return float(loss.detach()), {k: Wg[k].grad for k in names if Wg[k].grad is not None}, {k: (None if v is None else v.detach()) for k, v in out.items()}
 
 
 # ----------------------------------------------------------------------------------------------

@@ -412,6 +412,172 @@ def cross_entropy(logits, labels):
     return F.cross_entropy(logits.float(), labels.long(), reduction="none")
 
 
+# ---- training backward: stand-ins with the contracts of include/bagel_hip.h ("training backward" section) ----
+def transpose(src, dst=None, rows=None, n=None):
+    if n is None:
+        n = rows.numel() if rows is not None else src.shape[0]
+    C = src.shape[1]
+    npad = -(-max(n, 1) // 64) * 64
+    if dst is None:
+        dst = torch.empty((C, npad), dtype=BF16)
+    idx = rows.long()[:n] if rows is not None else torch.arange(n)
+    dst[:C, :npad] = 0
+    dst[:C, :n] = src[idx].t()
+    return dst[:C, :npad]
+
+
+def _by_expert(w0, w1, expert, M):
+    if w1 is None or expert is None:
+        return w0.float()[None].expand(M, -1), torch.zeros(M, dtype=torch.bool)
+    ex = expert.bool()
+    return torch.where(ex[:, None], w1.float()[None], w0.float()[None]), ex
+
+
+def _rms_bwd(x, dy, w, eps):
+    """-> (dx fp32, dy * bf16(xh) fp32) for y = w * bf16(x * rsqrt(mean(x^2) + eps))."""
+    xf = x.double()
+    r = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    xh = xf * r
+    dxh = dy.double() * w.double()
+    dx = r * (dxh - xh * (dxh * xh).mean(-1, keepdim=True))
+    return dx.float(), (dy.double() * _bf(xh.float()).double()).float()
+
+
+def rmsnorm_bwd(x, dy, w0, g, eps, w1=None, expert=None, accumulate=True):
+    M = x.shape[0]
+    w, ex = _by_expert(w0, w1, expert, M)
+    dx, dwrow = _rms_bwd(x, dy, w, eps)
+    base = g.float() if accumulate else torch.zeros_like(dx)
+    g.copy_(_bf(base + _bf(dx).float()))
+    dw0 = _bf(dwrow[~ex].double().sum(0).float())
+    dw1 = _bf(dwrow[ex].double().sum(0).float()) if w1 is not None else None
+    return dw0, dw1
+
+
+def qknorm_rope_bwd(dqkv, qkv_raw, cos, sin, q_w0, k_w0, q_w1, k_w1, expert, nq, nkv, head_dim, head_dim_padded, eps, use_norm):
+    M, hd, dp = dqkv.shape[0], head_dim, head_dim_padded
+    half = hd // 2
+    heads = dqkv[:, :(nq + nkv) * dp].view(M, nq + nkv, dp)
+    raw = qkv_raw[:, :(nq + nkv) * dp].view(M, nq + nkv, dp)[:, :, :hd]
+    dy = heads[:, :, :hd].float()
+    c, s_ = cos.float()[:, None, :], sin.float()[:, None, :]
+    d1, d2 = dy[..., :half], dy[..., half:]
+    dn = torch.cat([d1 * c + d2 * s_, d2 * c - d1 * s_], -1)            # gradient of the normalised heads
+    outs = (None, None, None, None)
+    if use_norm:
+        wq, ex = _by_expert(q_w0, q_w1, expert, M)
+        wk, _ = _by_expert(k_w0, k_w1, expert, M)
+        w = torch.cat([wq[:, None, :].expand(M, nq, hd), wk[:, None, :].expand(M, nkv, hd)], 1)
+        dx, dwrow = _rms_bwd(raw, _bf(dn), w, eps)
+        dn = dx
+        def red(rows, lo, hi):
+            return _bf(dwrow[rows][:, lo:hi].double().sum((0, 1)).float())
+        two = q_w1 is not None
+        outs = (red(~ex, 0, nq), red(~ex, nq, nq + nkv), red(ex, 0, nq) if two else None, red(ex, nq, nq + nkv) if two else None)
+    heads[:, :, :hd] = _bf(dn)
+    return outs
+
+
+def swiglu_bwd(gu, d_act):
+    M, I = d_act.shape
+    v = gu.view(M, I // 16, 2, 16)
+    g, u = v[:, :, 0].float(), v[:, :, 1].float()
+    d = d_act.view(M, I // 16, 16).float()
+    sg = torch.sigmoid(g)
+    du = d * _bf(g * sg).float()
+    dg = d * u * (sg * (1 + g * (1 - sg)))
+    v[:, :, 0] = _bf(dg)
+    v[:, :, 1] = _bf(du)
+    return gu
+
+
+def act_bwd(pre, d_out, kind):
+    x = pre.float().requires_grad_(True)
+    with torch.enable_grad():
+        y = F.gelu(x, approximate="tanh") if kind == 1 else F.silu(x)
+        (gx,) = torch.autograd.grad(y, x, d_out.float())
+    pre.copy_(_bf(gx))
+    return pre
+
+
+def cross_entropy_bwd(logits, labels, d_loss):
+    p = torch.softmax(logits.float(), -1)
+    lab = labels.long()
+    ok = (lab >= 0) & (lab < logits.shape[1])
+    p[torch.arange(p.shape[0])[ok], lab[ok]] -= 1.0
+    p[~ok] = 0
+    logits.copy_(_bf(p * d_loss.float()[:, None]))
+    return logits
+
+
+def mse_rows_bwd(pred, noise, clean, src_rows, d_loss):
+    i = src_rows.long()
+    return _bf(2.0 * (pred.float() - (noise[i].float() - clean[i].float())) * d_loss.float())
+
+
+def rows_segment_sum(src, order, seg_off, dst_rows, dst):
+    off, o = seg_off.tolist(), order.long()
+    for s_, r in enumerate(dst_rows.tolist()):
+        dst[r] = _bf(src[o[off[s_]:off[s_ + 1]]].double().sum(0).float())
+    return dst
+
+
+def colsum(src, rows=None, n=None):
+    if n is None:
+        n = rows.numel() if rows is not None else src.shape[0]
+    idx = rows.long()[:n] if rows is not None else torch.arange(n)
+    return _bf(src[idx].double().sum(0).float())
+
+
+def attn_bwd_blockmask(q, k, v, o, d_o, dq, dk, dv, q_items, k_items, noise_bits, nq, nkv, head_dim, softmax_scale):
+    """An interpreter of the two kernels' work items (include/bagel_hip.h): what the items describe is what is computed, so the host
+    code that builds them is checked against the oracle's autograd by the CPU suite."""
+    M, D, grp = q.shape[0], head_dim, nq // nkv
+    bits = noise_bits.tolist()
+    noise = torch.tensor([(bits[c // 64] >> (c % 64)) & 1 for c in range(M)], dtype=torch.bool)
+    lse = torch.zeros((nq, M), dtype=torch.float64)
+    delta = torch.zeros((nq, M), dtype=torch.float64)
+    seen_q, seen_k = torch.zeros(M, dtype=torch.int32), torch.zeros(M, dtype=torch.int32)
+    for row0, nrows, kstart, sstart, send, causal, t0, t1 in q_items.tolist():
+        rows = torch.arange(row0, row0 + nrows)
+        seen_q[rows] += 1
+        keys = torch.arange(64 * t0, min(64 * t1, M))
+        c, r = keys[None, :], rows[:, None]
+        allow = (c >= kstart) & (((c < sstart) & ~noise[keys][None, :]) | ((c >= sstart) & (c < send) & ((c <= r) | (causal == 0))))
+        for h in range(nq):
+            g = h // grp
+            qh = q[rows, h * D:(h + 1) * D].double()
+            kh, vh = k[keys, g * D:(g + 1) * D].double(), v[keys, g * D:(g + 1) * D].double()
+            doh = d_o[rows, h * D:(h + 1) * D].double()
+            s_ = (qh @ kh.t()) * softmax_scale
+            s_ = s_.masked_fill(~allow, float("-inf"))
+            L = torch.logsumexp(s_, -1)
+            dl = (doh * o[rows, h * D:(h + 1) * D].double()).sum(-1)
+            lse[h, rows], delta[h, rows] = L, dl
+            p = torch.exp(s_ - L[:, None])
+            ds = _bf((p * (doh @ vh.t() - dl[:, None]) * softmax_scale).float()).double()
+            dq[rows, h * D:(h + 1) * D] = _bf((ds @ kh).float())
+    for key0, nkeys, qbeg, qend, send, causal, _, _ in k_items.tolist():
+        keys = torch.arange(key0, key0 + nkeys)
+        seen_k[keys] += 1
+        rows = torch.arange(qbeg, qend)
+        c, r = keys[None, :], rows[:, None]
+        allow = (r >= send) | (c <= r) | (causal == 0)
+        for g in range(nkv):
+            kh, vh = k[keys, g * D:(g + 1) * D].double(), v[keys, g * D:(g + 1) * D].double()
+            dkh, dvh = torch.zeros_like(kh), torch.zeros_like(vh)
+            for h in range(g * grp, (g + 1) * grp):
+                qh, doh = q[rows, h * D:(h + 1) * D].double(), d_o[rows, h * D:(h + 1) * D].double()
+                p = torch.exp((qh @ kh.t()) * softmax_scale - lse[h, rows][:, None]).masked_fill(~allow, 0.0)
+                ds = _bf((p * (doh @ vh.t() - delta[h, rows][:, None]) * softmax_scale).float()).double()
+                dvh += _bf(p.float()).double().t() @ doh
+                dkh += ds.t() @ qh
+            dk[keys, g * D:(g + 1) * D] = _bf(dkh.float())
+            dv[keys, g * D:(g + 1) * D] = _bf(dvh.float())
+    assert bool((seen_q == 1).all()) and bool((seen_k == 1).all()), "attention backward items must cover every row exactly once"
+    return dq, dk, dv
+
+
 def require_gpu_bf16(t, what=""):
     return None
 
@@ -507,7 +673,8 @@ _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
           "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
           "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
-          "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8"]
+          "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
+          "act_bwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]
 
 
 def install(monkeypatch):

@@ -261,3 +261,31 @@ def test_reference_batch_driver_drives_the_product():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "reference_gen_images_dropin.py")], capture_output=True,
                        text=True, cwd=root, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("cfg", [TINY, TINY_D128], ids=lambda c: c["name"])
+def test_oracle_autograd_bit_exact_vs_the_reference_backward(cfg):
+    """The pin behind the training-backward parity tests: ``loss.backward()`` of the UNMODIFIED reference (bf16 autocast forward, the
+    loss of train/pretrain_unified_navit.py:705-727) vs torch autograd over the oracle's restatement, on the scenario_train batch and on
+    two random packs -- every parameter gradient (111 tensors, ViT included) bit for bit on this host."""
+    import random
+    from oracle import make_golden as G
+    from oracle import make_golden_train_grads as GG
+    from tests.util_models import pack_training_batch
+    model, _, W, _ = G.build(cfg)
+    fx = torch.load(f"{G.GOLD}/{cfg['name']}_train.pt", weights_only=False)
+    w_ce = torch.rand(fx["ce"].shape[0], generator=torch.Generator().manual_seed(5)) + 0.5
+    loss, grads = GG.check_pair(cfg, model, W, fx["batch"], fx["noise"], w_ce)
+    assert len(grads) == 111 and loss > 0
+    if cfg is TINY:
+        committed = torch.load(f"{G.GOLD}/tiny_train_grads.pt", weights_only=False)
+        assert torch.equal(committed["ce_loss_weights"], w_ce)
+    for seed in (0, 1):
+        rng = random.Random(4000 + seed)
+        samples = [[("text", 3, True), ("vit", 28, 42), ("vae", 16 * rng.randint(1, 3), 16 * rng.randint(1, 3), False), ("text", rng.randint(1, 6), True)],
+                   [("text", rng.randint(1, 5), False), ("vae", 32, 48, True), ("text", 2, True), ("vae", 16 * rng.randint(1, 4), 32, True)]]
+        batch, _, _, _ = pack_training_batch(cfg, samples, seed)
+        torch.manual_seed(47)                      # the reference draws its noise with randn_like under this seed (check_pair)
+        noise = torch.randn(batch["packed_vae_token_indexes"].numel(), cfg["bagel"]["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"])
+        w = torch.rand(batch["ce_loss_indexes"].numel(), generator=torch.Generator().manual_seed(seed)) + 0.5
+        GG.check_pair(cfg, model, W, batch, noise, w)

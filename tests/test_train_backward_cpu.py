@@ -1,0 +1,185 @@
+"""CPU: the HOST logic of the training backward (bagel_amd/modeling/bagel/train_step.py, Bagel._backward_losses: the tape, the reverse
+chain, MoT routing of dX / dW, the attention-backward work items, the unpacking of the MI355X weight layouts into the reference's
+parameter shapes) on the torch stand-ins of the launch wrappers (tests/mock_ops.py) against the oracle's autograd -- which is pinned
+bit for bit to the unmodified reference's own ``loss.backward()`` (oracle/make_golden_train_grads.py, tests/test_reference_crosscheck.py).
+The kernels themselves are checked on the MI355X by tests/test_train_backward_gpu.py."""
+import random
+
+import pytest
+import torch
+
+from oracle import bagel_oracle as O
+from oracle.configs import TINY, TINY_D128
+from tests import mock_ops
+from tests.util_models import oracle_weights, pack_training_batch
+
+CFGS = {"tiny": TINY, "tiny_d128": TINY_D128}
+FROZEN = ("vit_model.", "vit_pos_embed.", "latent_pos_embed.")
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def cpu_model(cfg):
+    from bagel_amd.factory import build_bagel
+    W, _ = oracle_weights(cfg)
+    model, _ = build_bagel(cfg, device="cpu", with_vae=False)
+    model.load_state_dict(W, strict=True)
+    return model.to(torch.bfloat16).eval()
+
+
+def trainable(model):
+    names = []
+    for n, p in model.named_parameters():
+        if not n.startswith(FROZEN):
+            p.requires_grad_(True)
+            names.append(n)
+    return names
+
+
+def product_step(model, batch, noise, w_ce, **extra):
+    for p in model.parameters():
+        p.grad = None
+    out = model(noise=noise, **batch, **extra)
+    loss = O.training_step_loss(out, w_ce)
+    loss.backward()
+    return float(loss.detach()), {n: p.grad for n, p in model.named_parameters() if p.grad is not None}, out
+
+
+def compare(grads, ref, names, tol, what):
+    worst = ("", 0.0)
+    for n in names:
+        assert n in ref, n
+        rn = float(ref[n].float().norm())
+        if rn == 0.0:
+            assert n not in grads or float(grads[n].float().norm()) == 0.0, (what, n)
+            continue
+        assert n in grads, (what, n, "no gradient")
+        assert grads[n].shape == ref[n].shape and grads[n].dtype == ref[n].dtype, (what, n)
+        d = rel(grads[n], ref[n])
+        if d > worst[1]:
+            worst = (n, d)
+        assert d < tol, (what, n, d)
+    return worst
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_training_step_gradients_match_the_reference_batch(golden, monkeypatch, name):
+    """The hand-packed batch of oracle/make_golden.scenario_train (und sample + gen sample with causal / full / noise splits): every
+    trainable parameter's gradient vs the oracle's autograd; for 'tiny' also vs the committed reference gradients."""
+    mock_ops.install(monkeypatch)
+    cfg = CFGS[name]
+    g = golden(f"{name}_train")
+    batch, noise = g["batch"], g["noise"]
+    gen = torch.Generator().manual_seed(5)
+    w_ce = torch.rand(g["ce"].shape[0], generator=gen) + 0.5
+    W, _ = oracle_weights(cfg)
+    model = cpu_model(cfg)
+    names = trainable(model)
+    rloss, rgrads, rout = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
+    loss, grads, out = product_step(model, batch, noise, w_ce)
+    assert abs(loss - rloss) < 2e-2 * abs(rloss)
+    assert out["mse"].requires_grad and out["ce"].requires_grad
+    worst = compare(grads, rgrads, names, 6e-2, name)
+    print(f"[{name}] {len(names)} gradients, worst rel-L2 {worst[1]:.2e} at {worst[0]}")
+    if name == "tiny":
+        fx = golden("tiny_train_grads")
+        assert torch.equal(fx["ce_loss_weights"], w_ce)
+        compare(grads, fx["grads"], names, 6e-2, "fixture")
+    # the flat split API gives the same gradients bit for bit (same plan, same launches)
+    b2 = {k: v for k, v in batch.items() if k != "nested_attention_masks"}
+    _, grads2, _ = product_step(model, b2, noise, w_ce, split_lens=g["split_lens"], attn_modes=g["attn_modes"])
+    for n in names:
+        if n in grads:
+            assert torch.equal(grads[n], grads2[n]), n
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_training_step_gradients_on_random_batches(monkeypatch, seed):
+    """Differential fuzz: random packs (1-3 samples, 1-5 splits, prompts / ViT images / clean and noised VAE images, CE / MSE anywhere;
+    chunks longer than one 128-row work item included) -- gradients vs the oracle's autograd."""
+    mock_ops.install(monkeypatch)
+    rng = random.Random(3000 + seed)
+    cfg = TINY if seed % 2 == 0 else TINY_D128
+    samples = []
+    for _ in range(rng.randint(1, 3)):
+        sp = []
+        for _ in range(rng.randint(1, 5)):
+            kind = rng.choice(["text", "text", "vit", "vae", "vae"])
+            if kind == "text":
+                sp.append(("text", rng.randint(1, 7), rng.random() < 0.5))
+            elif kind == "vit":
+                sp.append(("vit", 14 * rng.randint(1, 4), 14 * rng.randint(1, 4)))
+            else:
+                sp.append(("vae", 16 * rng.randint(1, 4), 16 * rng.randint(1, 4), rng.random() < 0.6))
+        samples.append(sp)
+    samples[0] = [("text", 3, True), ("vit", 28, 42)] + samples[0]
+    samples[-1].append(("vae", 32 * (1 + seed % 2), 48 * (1 + seed % 3), True))
+    batch, noise, split_lens, attn_modes = pack_training_batch(cfg, samples, seed)
+    W, _ = oracle_weights(cfg)
+    model = cpu_model(cfg)
+    names = trainable(model)
+    n_ce = batch["ce_loss_indexes"].numel() if batch.get("ce_loss_indexes") is not None else 0
+    w_ce = torch.rand(n_ce, generator=torch.Generator().manual_seed(seed)) + 0.5 if n_ce else None
+    rloss, rgrads, _ = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
+    loss, grads, _ = product_step(model, batch, noise, w_ce)
+    assert abs(loss - rloss) < 2e-2 * abs(rloss)
+    compare(grads, rgrads, names, 8e-2, (seed, samples))
+
+
+def test_frozen_and_no_grad_paths(golden, monkeypatch):
+    """No tape without grad mode or without a trainable parameter; a ViT parameter that requires grad is refused; only the parameters
+    that require grad receive one."""
+    mock_ops.install(monkeypatch)
+    g = golden("tiny_train")
+    model = cpu_model(TINY)
+    out = model(noise=g["noise"], **g["batch"])
+    assert not out["mse"].requires_grad and not out["ce"].requires_grad
+    names = trainable(model)
+    with torch.no_grad():
+        out = model(noise=g["noise"], **g["batch"])
+    assert not out["mse"].requires_grad
+    for n, p in model.named_parameters():
+        p.requires_grad_(n.endswith("mlp_moe_gen.down_proj.weight") or n == "llm2vae.bias")
+    out = model(noise=g["noise"], **g["batch"])
+    (out["mse"].mean() + out["ce"].mean()).backward()
+    got = sorted(n for n, p in model.named_parameters() if p.grad is not None)
+    assert got == sorted(n for n in names if n.endswith("mlp_moe_gen.down_proj.weight") or n == "llm2vae.bias")
+    next(p for n, p in model.named_parameters() if n.startswith("vit_model.")).requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        model(noise=g["noise"], **g["batch"])
+
+
+def test_attention_backward_items_cover_the_block_mask():
+    """AttnBackwardPlan vs the mask of data_utils.py:72-103 rebuilt densely: the union of what the query items and the key items allow
+    is exactly the mask, every row is in one query item and one key item."""
+    from bagel_amd.modeling.bagel.train_step import AttnBackwardPlan
+    rng = random.Random(7)
+    for _ in range(20):
+        sample_lens, splits = [], []
+        for _ in range(rng.randint(1, 3)):
+            lens = [rng.choice([1, 3, 17, 64, 130, 257]) for _ in range(rng.randint(1, 5))]
+            modes = [rng.choice(["causal", "full", "noise"]) for _ in lens]
+            sample_lens.append(sum(lens)); splits.append((lens, modes))
+        bp = AttnBackwardPlan("cpu", sample_lens, splits)
+        M = sum(sample_lens)
+        dense = torch.zeros((M, M), dtype=torch.bool)
+        r = 0
+        for n, (lens, modes) in zip(sample_lens, splits):
+            dense[r:r + n, r:r + n] = torch.isfinite(O.attention_mask_per_sample(lens, modes))
+            r += n
+        bits = bp.noise_bits.tolist()
+        noise = torch.tensor([(bits[c // 64] >> (c % 64)) & 1 for c in range(M)], dtype=torch.bool)
+        fromq, fromk = torch.zeros_like(dense), torch.zeros_like(dense)
+        for row0, nrows, kstart, sstart, send, causal, t0, t1 in bp.q_items.tolist():
+            rows, keys = torch.arange(row0, row0 + nrows)[:, None], torch.arange(64 * t0, min(64 * t1, M))[None, :]
+            allow = (keys >= kstart) & (((keys < sstart) & ~noise[keys[0]][None]) | ((keys >= sstart) & (keys < send) & ((keys <= rows) | (causal == 0))))
+            assert not fromq[row0:row0 + nrows].any()
+            fromq[row0:row0 + nrows, 64 * t0:min(64 * t1, M)] = allow
+        for key0, nkeys, qbeg, qend, send, causal, _, _ in bp.k_items.tolist():
+            rows, keys = torch.arange(qbeg, qend)[:, None], torch.arange(key0, key0 + nkeys)[None, :]
+            assert not fromk[:, key0:key0 + nkeys].any()
+            fromk[qbeg:qend, key0:key0 + nkeys] = (rows >= send) | (keys <= rows) | (causal == 0)
+        assert torch.equal(fromq, dense) and torch.equal(fromk, dense), (sample_lens, splits)
