@@ -69,6 +69,8 @@ struct AttnParams {
     int batch, nqt;          // samples, 256-row query tiles per sample (from max_lq)
     int qsplit;              // interleaved query-tile sets per (sample, KV head) pair: 8 / gcd(pairs, 8), see the kernel
     float scale_log2;
+    float* lse; long ld_lse; // optional: lse[h * ld_lse + row] = log2 of the row's softmax denominator in the scaled base-2 domain
+                             // (P = exp2(scale_log2 * s - lse)), what the training backward needs from the forward (attention_bwd.hip)
 };
 
 // 16 bytes per lane HBM -> LDS (destination = wave-uniform LDS byte address + lane*16).  Issued from inline asm on
@@ -452,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int qb = 0; qb < NQB; ++qb) {
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = 1.0f / l_tot;
+        if (p.lse && hi == 0 && qrow[qb] < Lq) p.lse[(long)h * p.ld_lse + q0 + qrow[qb]] = m_use[qb] + log2f(l_tot);
         if (qrow[qb] < Lq) {
             bf16_t* op = p.out + (long)(q0 + qrow[qb]) * p.ldo + (long)h * D + 4 * hi;
 #pragma unroll
@@ -470,7 +473,8 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
                        int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
                        int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* cu_q, const int32_t* q_end, const int32_t* cu_ctx,
                        const int32_t* ctx_end, const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t max_lq,
-                       int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale, hipStream_t stream);
+                       int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale, hipStream_t stream,
+                       float* lse = nullptr, int64_t ld_lse = 0);
 
 extern "C" int bagel_attn_varlen_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
                                       int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
@@ -497,11 +501,27 @@ extern "C" int bagel_attn_varlen_ranges_bf16(const void* q, int64_t ldq, const v
                        ctx_end, vt_new_col, vt_ctx_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale, stream);
 }
 
+// bagel_attn_varlen_ranges_bf16 that also leaves the row statistics the training backward needs: lse[h * ld_lse + row] = log2 of the
+// softmax denominator of (row, q head h) in the scaled base-2 domain, fp32 (every query row must belong to exactly one range).
+extern "C" int bagel_attn_varlen_ranges_lse_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
+                                                 int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
+                                                 int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* q_start,
+                                                 const int32_t* q_end, const int32_t* ctx_start, const int32_t* ctx_end,
+                                                 const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch,
+                                                 int32_t max_lq, int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal,
+                                                 float softmax_scale, float* lse, int64_t ld_lse, hipStream_t stream) {
+    BAGEL_REQUIRE(q_end && (!ctx_start || ctx_end), "attn_ranges: end arrays missing");
+    BAGEL_REQUIRE(lse && ld_lse > 0, "attn_ranges_lse: lse buffer missing");
+    return attn_launch(q, ldq, k_new, ldk_new, vt_new, ldvt_new, k_ctx, ldk_ctx, vt_ctx, ldvt_ctx, out, ldo, q_start, q_end, ctx_start,
+                       ctx_end, vt_new_col, vt_ctx_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale, stream, lse, ld_lse);
+}
+
 static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new,
                        int64_t ldvt_new, const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx,
                        int64_t ldvt_ctx, void* out, int64_t ldo, const int32_t* cu_q, const int32_t* q_end, const int32_t* cu_ctx,
                        const int32_t* ctx_end, const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t max_lq,
-                       int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale, hipStream_t stream) {
+                       int32_t nq, int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale, hipStream_t stream,
+                       float* lse, int64_t ld_lse) {
     BAGEL_REQUIRE(q && k_new && vt_new && out && cu_q && vt_new_col, "attn: null pointer");
     BAGEL_REQUIRE(!cu_ctx || (k_ctx && vt_ctx && vt_ctx_col), "attn: context segment incomplete");
     BAGEL_REQUIRE(nq > 0 && nkv > 0 && nq % nkv == 0, "attn: bad head counts %d/%d", nq, nkv);
@@ -520,6 +540,7 @@ static int attn_launch(const void* q, int64_t ldq, const void* k_new, int64_t ld
     p.nq = nq; p.nkv = nkv; p.causal = causal;
     p.batch = batch; p.nqt = ceil_div(max_lq, 256);
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    p.lse = lse; p.ld_lse = ld_lse;
     const int npairs = batch * nkv;
     int gcd8 = 8;
     while (npairs % gcd8) gcd8 >>= 1;

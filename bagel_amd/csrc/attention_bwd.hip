@@ -21,9 +21,11 @@
 //
 // Algorithmic FLOPs per (query, key) pair and head: 2 D (scores for lse) + 6 D (dq pass) + 8 D (dkv pass) = 16 D, against 4 D of the
 // forward and 10 D of a fused flash backward: the price of two atomics-free kernels and of recomputing the row statistics instead of
-// changing the forward kernel's interface.  First correct version: tiles are staged global -> registers -> LDS with two barriers per
-// tile, not yet through the LDS-DMA ring of the forward.
+// changing the forward kernel's interface.  Tiles are staged global -> registers -> LDS with the loads of tile t + 1 issued before the
+// products of tile t (two barriers per tile; not yet the LDS-DMA ring of the forward); tiles that every row of the item sees completely
+// take a mask-free path; exponentials in base 2 with scale * log2(e) folded into one multiply (the lse workspace holds log2 values).
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnBwdParams {
     const bf16_t* q; long ldq;
@@ -38,36 +40,62 @@ struct AttnBwdParams {
     const int* q_items; const int* k_items;
     const unsigned long long* noise_bits;
     float* lse; float* delta;            // [nq][rows]
-    int rows, nq, nkv;
+    int rows, nq, nkv, have_lse;
     float scale;
 };
 
+// Timing-only ablations (tools/ab_attn_bwd.sh builds one library per bit set; results are wrong by construction, never in the product
+// build): 1 no lse pass, 2 no exp / mask arithmetic, 4 tile loads only once, 8 no barriers, 16 no LDS stores, 32 no dQ / dK / dV products,
+// 64 no score products.
+#ifndef AB_ABL
+#define AB_ABL 0
+#endif
 #define AB_TP 72                          // element pitch of the transposed 64-column tiles (144 bytes: 16-byte aligned, banks spread)
 
 __device__ __forceinline__ int ab_perm(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
-// 64 rows x D columns of a row-major operand -> LDS [64][D + 8]; rows at or beyond rows_total read as zero
+// 64 rows x D columns of a row-major operand: global -> registers (rows at or beyond rows_total repeat the last row: finite values that
+// the mask turns into exact zeros -- no branch around the load), registers -> LDS [64][D + 8].
+// The two halves are separate so that the loads of tile t + 1 are in flight while tile t is being multiplied.
 template <int D>
-__device__ __forceinline__ void ab_stage_rows(bf16_t* lds, const bf16_t* src, long ld, int col0, int row0, int rows_total, int tid) {
-    constexpr int CH = D / 8, RP = D + 8;
+struct AbRows { u32x4_t r[(64 * (D / 8)) / 256]; };
+template <int D>
+__device__ __forceinline__ void ab_load_rows(AbRows<D>& x, const bf16_t* src, long ld, int col0, int row0, int rows_total, int tid) {
+    constexpr int CH = D / 8;
 #pragma unroll
     for (int it = 0; it < (64 * CH) / 256; ++it) {
         const int idx = tid + it * 256;
         const int r = idx / CH, c = idx % CH;
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if (row0 + r < rows_total) v = *(const u32x4_t*)(src + (long)(row0 + r) * ld + col0 + c * 8);
-        *(u32x4_t*)(lds + r * RP + c * 8) = v;
+        x.r[it] = *(const u32x4_t*)(src + (long)min(row0 + r, rows_total - 1) * ld + col0 + c * 8);
+    }
+}
+template <int D>
+__device__ __forceinline__ void ab_store_rows(bf16_t* lds, const AbRows<D>& x, int tid) {
+    constexpr int CH = D / 8, RP = D + 8;
+#pragma unroll
+    for (int it = 0; it < (64 * CH) / 256; ++it) {
+        const int idx = tid + it * 256;
+        *(u32x4_t*)(lds + (idx / CH) * RP + (idx % CH) * 8) = x.r[it];
     }
 }
 
-// D rows x 64 columns of a transposed image -> LDS [D][AB_TP]
+// D rows x 64 columns of a transposed image -> registers -> LDS [D][AB_TP]
 template <int D>
-__device__ __forceinline__ void ab_stage_t(bf16_t* lds, const bf16_t* srct, long ld_t, int drow0, int col0, int tid) {
+struct AbT { u32x4_t r[(D * 8) / 256]; };
+template <int D>
+__device__ __forceinline__ void ab_load_t(AbT<D>& x, const bf16_t* srct, long ld_t, int drow0, int col0, int tid) {
 #pragma unroll
     for (int it = 0; it < (D * 8) / 256; ++it) {
         const int idx = tid + it * 256;
-        const int d = idx >> 3, c = idx & 7;
-        *(u32x4_t*)(lds + d * AB_TP + c * 8) = *(const u32x4_t*)(srct + (long)(drow0 + d) * ld_t + col0 + c * 8);
+        x.r[it] = *(const u32x4_t*)(srct + (long)(drow0 + (idx >> 3)) * ld_t + col0 + (idx & 7) * 8);
+    }
+}
+template <int D>
+__device__ __forceinline__ void ab_store_t(bf16_t* lds, const AbT<D>& x, int tid) {
+#pragma unroll
+    for (int it = 0; it < (D * 8) / 256; ++it) {
+        const int idx = tid + it * 256;
+        *(u32x4_t*)(lds + (idx >> 3) * AB_TP + (idx & 7) * 8) = x.r[it];
     }
 }
 
@@ -87,7 +115,7 @@ __device__ __forceinline__ bf16x8_t ab_row_frag(const bf16_t* base, long ld, int
 
 // C-layout (rows d = 32 db + (i & 3) + 8 (i >> 2) + 4 h, column = the lane's row of the output) -> out[row][col0 + d], 8-byte stores
 template <int DB>
-__device__ __forceinline__ void ab_store_t(bf16_t* out, long ld, int row, int col0, const f32x16_t* acc, int h) {
+__device__ __forceinline__ void ab_store_acc(bf16_t* out, long ld, int row, int col0, const f32x16_t* acc, int h) {
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -115,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     const bool qvalid = qloc < nrows;
     const bool wave_on = 32 * wave < nrows;
     const int qrow = row0 + qloc;
-    const float scale = p.scale;
+    const float c2 = p.scale * 1.4426950408889634f;    // scores go through exp2: scale * log2(e) folded into one multiply
 
     bf16x8_t qf[KS], dof[KS];
     float delta = 0.f;
@@ -131,58 +159,85 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     }
     delta += __shfl_xor(delta, 32, 64);                 // the two halves of the wave hold the two halves of every 16 columns
 
-    auto skip = [&](int t) { return p.noise_bits[t] == ~0ull && 64 * t + 64 <= sstart; };     // a tile of hidden (noise) context keys
-    auto allowed = [&](int c, unsigned long long nb, int key_local) {
-        const bool ctx = c < sstart && !((nb >> key_local) & 1ull);
-        const bool own = c >= sstart && c < send && (!causal || c <= qrow);
-        return qvalid && c >= kstart && (ctx || own);
+    // a tile of hidden (noise) context keys is skipped; a tile that every query of the item sees completely needs no mask
+    auto skip = [&](int t) { return p.noise_bits[t] == ~0ull && 64 * t + 64 <= sstart; };
+    auto next_tile = [&](int t) { ++t; while (t < t1 && skip(t)) ++t; return t; };
+    auto plain = [&](int t, unsigned long long nb) {
+        const int c0 = 64 * t, c1 = c0 + 64;
+        const bool in_ctx = c0 >= kstart && c1 <= sstart && nb == 0ull;
+        const bool in_own = c0 >= sstart && c1 <= send && (!causal || c1 - 1 <= row0);
+        return (in_ctx || in_own) && nrows == 128;
     };
+    // branch-free mask of the lane's 16 scores of key block kb (bit i <-> accumulator register i <-> key 32 kb + 16 (i >> 3) + 8 h + (i & 7))
+    auto mask16 = [&](int t, unsigned long long nb, int kb) {
+        const unsigned w = (unsigned)(nb >> (32 * kb)) >> (8 * h);          // noise bits of the lane's keys at positions 16 a + e
+        unsigned ok = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = 64 * t + 32 * kb + 16 * (i >> 3) + 8 * h + (i & 7);
+            const unsigned nbit = (w >> (16 * (i >> 3) + (i & 7))) & 1u;
+            const unsigned ctx = (unsigned)(c < sstart) & (nbit ^ 1u);
+            const unsigned own = (unsigned)(c >= sstart) & (unsigned)(c < send) & ((unsigned)(causal == 0) | (unsigned)(c <= qrow));
+            ok |= ((unsigned)(c >= kstart) & (ctx | own)) << i;
+        }
+        return qvalid ? ok : 0u;
+    };
+    const int tfirst = next_tile(t0 - 1);
 
-    // ---------------- pass 1: row log-sum-exp ----------------
+    // ---------------- pass 1: row log-sum-exp (base 2) ----------------
     float mrun = -INFINITY, lrun = 0.f;
-    for (int t = t0; t < t1; ++t) {
-        if (skip(t)) continue;
-        __syncthreads();
-        ab_stage_rows<D>(Ks, p.k, p.ldk, hkv * D, 64 * t, p.rows, tid);
-        __syncthreads();
-        if (!wave_on) continue;
-        const unsigned long long nb = p.noise_bits[t];
+    if (!(AB_ABL & 1) && !p.have_lse) {
+        AbRows<D> rk;
+        if (tfirst < t1) ab_load_rows<D>(rk, p.k, p.ldk, hkv * D, 64 * tfirst, p.rows, tid);
+        for (int t = tfirst; t < t1;) {
+            if (!(AB_ABL & 8)) __syncthreads();
+            if (!(AB_ABL & 16)) ab_store_rows<D>(Ks, rk, tid);
+            if (!(AB_ABL & 8)) __syncthreads();
+            const int tn = next_tile(t);
+            if (tn < t1 && !(AB_ABL & 4)) ab_load_rows<D>(rk, p.k, p.ldk, hkv * D, 64 * tn, p.rows, tid);
+            if (wave_on) {
+                const unsigned long long nb = p.noise_bits[t];
+                const bool pl = plain(t, nb);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x16_t s;
+                for (int kb = 0; kb < 2; ++kb) {
+                    f32x16_t s;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+                    for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Ks + (32 * kb + pm) * RP + 16 * ks + 8 * h), qf[ks], s, 0, 0, 0);
-            float mx = -INFINITY;
+                    for (int ks = 0; ks < KS; ++ks)
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Ks + (32 * kb + pm) * RP + 16 * ks + 8 * h), qf[ks], s, 0, 0, 0);
+                    const unsigned ok = pl ? 0xffffu : mask16(t, nb, kb);
+                    float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kl = 32 * kb + 16 * (i >> 3) + 8 * h + (i & 7);
-                s[i] = allowed(64 * t + kl, nb, kl) ? s[i] * scale : -INFINITY;
-                mx = fmaxf(mx, s[i]);
+                    for (int i = 0; i < 16; ++i) {
+                        s[i] = ((ok >> i) & 1u) ? s[i] * c2 : -INFINITY;
+                        mx = fmaxf(mx, s[i]);
+                    }
+                    const float mnew = fmaxf(mrun, mx);
+                    if (mnew > -INFINITY) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(s[i] - mnew);
+                        lrun = lrun * __builtin_amdgcn_exp2f(mrun - mnew) + sum;
+                        mrun = mnew;
+                    }
+                }
             }
-            const float mnew = fmaxf(mrun, mx);
-            if (mnew > -INFINITY) {
-                float sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sum += __expf(s[i] - mnew);
-                lrun = lrun * __expf(mrun - mnew) + sum;
-                mrun = mnew;
-            }
+            t = tn;
         }
     }
-    float lse = 0.f;
+    float lse2 = 0.f;                                   // log2 of the softmax denominator, in the scaled base-2 domain
     {
         const float mo = __shfl_xor(mrun, 32, 64), lo = __shfl_xor(lrun, 32, 64);
         const float mm = fmaxf(mrun, mo);
         if (mm > -INFINITY) {
-            const float ll = (mrun > -INFINITY ? lrun * __expf(mrun - mm) : 0.f) + (mo > -INFINITY ? lo * __expf(mo - mm) : 0.f);
-            lse = mm + __logf(ll);
+            const float ll = (mrun > -INFINITY ? lrun * exp2f(mrun - mm) : 0.f) + (mo > -INFINITY ? lo * exp2f(mo - mm) : 0.f);
+            lse2 = mm + log2f(ll);
         }
     }
+    if (p.have_lse) lse2 = qvalid ? p.lse[(long)hq * p.rows + qrow] : 0.f;      // left by the forward (bagel_attn_varlen_ranges_lse_bf16)
     if (qvalid && h == 0) {
-        p.lse[(long)hq * p.rows + qrow] = lse;
+        if (!p.have_lse) p.lse[(long)hq * p.rows + qrow] = lse2;
         p.delta[(long)hq * p.rows + qrow] = delta;
     }
 
@@ -192,41 +247,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
-    for (int t = t0; t < t1; ++t) {
-        if (skip(t)) continue;
-        __syncthreads();
-        ab_stage_rows<D>(Ks, p.k, p.ldk, hkv * D, 64 * t, p.rows, tid);
-        ab_stage_rows<D>(Vs, p.v, p.ldv, hkv * D, 64 * t, p.rows, tid);
-        ab_stage_t<D>(Kts, p.kt, p.ld_t, hkv * D, 64 * t, tid);
-        __syncthreads();
-        if (!wave_on) continue;
-        const unsigned long long nb = p.noise_bits[t];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x16_t s, dp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Ks + (32 * kb + pm) * RP + 16 * ks + 8 * h), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Vs + (32 * kb + pm) * RP + 16 * ks + 8 * h), dof[ks], dp, 0, 0, 0);
+    {
+        AbRows<D> rk, rv;
+        AbT<D> rt;
+        auto load = [&](int t) {
+            ab_load_rows<D>(rk, p.k, p.ldk, hkv * D, 64 * t, p.rows, tid);
+            ab_load_rows<D>(rv, p.v, p.ldv, hkv * D, 64 * t, p.rows, tid);
+            ab_load_t<D>(rt, p.kt, p.ld_t, hkv * D, 64 * t, tid);
+        };
+        if (tfirst < t1) load(tfirst);
+        for (int t = tfirst; t < t1;) {
+            if (!(AB_ABL & 8)) __syncthreads();
+            if (!(AB_ABL & 16)) {
+                ab_store_rows<D>(Ks, rk, tid);
+                ab_store_rows<D>(Vs, rv, tid);
+                ab_store_t<D>(Kts, rt, tid);
             }
-            float ds[16];
+            if (!(AB_ABL & 8)) __syncthreads();
+            const int tn = next_tile(t);
+            if (tn < t1 && !(AB_ABL & 4)) load(tn);
+            if (wave_on) {
+                const unsigned long long nb = p.noise_bits[t];
+                const bool pl = plain(t, nb);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kl = 32 * kb + 16 * (i >> 3) + 8 * h + (i & 7);
-                const float pr = allowed(64 * t + kl, nb, kl) ? __expf(s[i] * scale - lse) : 0.f;
-                ds[i] = pr * (dp[i] - delta) * scale;
-            }
-            const bf16x8_t dsf0 = ab_pack8(ds), dsf1 = ab_pack8(ds + 8);
+                for (int kb = 0; kb < 2; ++kb) {
+                    f32x16_t s, dp;
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Kts + (32 * db + m) * AB_TP + 32 * kb + 8 * h), dsf0, dq[db], 0, 0, 0);
-                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Kts + (32 * db + m) * AB_TP + 32 * kb + 16 + 8 * h), dsf1, dq[db], 0, 0, 0);
+                    for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (AB_ABL & 64) { s[ks] = delta * (float)t; dp[ks] = lse2; continue; }
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Ks + (32 * kb + pm) * RP + 16 * ks + 8 * h), qf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Vs + (32 * kb + pm) * RP + 16 * ks + 8 * h), dof[ks], dp, 0, 0, 0);
+                    }
+                    const unsigned ok = pl ? 0xffffu : mask16(t, nb, kb);
+                    float ds[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (AB_ABL & 2) { ds[i] = s[i] + dp[i]; continue; }
+                        const float e = __builtin_amdgcn_exp2f(s[i] * c2 - lse2);
+                        const float pr = ((ok >> i) & 1u) ? e : 0.f;
+                        ds[i] = pr * (dp[i] - delta) * p.scale;
+                    }
+                    const bf16x8_t dsf0 = ab_pack8(ds), dsf1 = ab_pack8(ds + 8);
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        if (AB_ABL & 32) { dq[db][0] += ds[db] + ds[db + 8]; continue; }
+                        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Kts + (32 * db + m) * AB_TP + 32 * kb + 8 * h), dsf0, dq[db], 0, 0, 0);
+                        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Kts + (32 * db + m) * AB_TP + 32 * kb + 16 + 8 * h), dsf1, dq[db], 0, 0, 0);
+                    }
+                }
             }
+            t = tn;
         }
     }
-    if (qvalid) ab_store_t<DB>(p.dq, p.lddq, qrow, hq * D, dq, h);
+    if (qvalid) ab_store_acc<DB>(p.dq, p.lddq, qrow, hq * D, dq, h);
 }
 
 template <int D>
@@ -248,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     const bool kvalid = kloc < nkeys;
     const bool wave_on = 32 * wave < nkeys;
     const int krow = key0 + kloc;
-    const float scale = p.scale;
+    const float c2 = p.scale * 1.4426950408889634f;
 
     bf16x8_t kf[KS], vf[KS];
 #pragma unroll
@@ -262,52 +337,89 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
 
-    for (int hq = hkv * G; hq < (hkv + 1) * G; ++hq) {
-        for (int q0 = qbeg & ~63; q0 < qend; q0 += 64) {
-            __syncthreads();
-            ab_stage_rows<D>(Qs, p.q, p.ldq, hq * D, q0, p.rows, tid);
-            ab_stage_rows<D>(dOs, p.d_o, p.lddo, hq * D, q0, p.rows, tid);
-            ab_stage_t<D>(Qts, p.qt, p.ld_t, hq * D, q0, tid);
-            ab_stage_t<D>(dOts, p.dot, p.ld_t, hq * D, q0, tid);
-            if (tid < 64) lse_s[tid] = (q0 + tid < p.rows) ? p.lse[(long)hq * p.rows + q0 + tid] : 0.f;
-            else if (tid < 128) delta_s[tid - 64] = (q0 + tid - 64 < p.rows) ? p.delta[(long)hq * p.rows + q0 + tid - 64] : 0.f;
-            __syncthreads();
-            if (!wave_on) continue;
+    // the (q head, 64-query tile) pairs of this item as one flat sequence, so that the loads of the next pair fly under the current products
+    const int q00 = qbeg & ~63;
+    const int ntile = qend > q00 ? (qend - q00 + 63) >> 6 : 0;
+    const int nstep = ntile * G;
+    AbRows<D> rq, rdo;
+    AbT<D> rqt, rdot;
+    float rstat = 0.f;
+    auto load = [&](int step) {
+        const int hq = hkv * G + step / ntile, q0 = q00 + 64 * (step % ntile);
+        ab_load_rows<D>(rq, p.q, p.ldq, hq * D, q0, p.rows, tid);
+        ab_load_rows<D>(rdo, p.d_o, p.lddo, hq * D, q0, p.rows, tid);
+        ab_load_t<D>(rqt, p.qt, p.ld_t, hq * D, q0, tid);
+        ab_load_t<D>(rdot, p.dot, p.ld_t, hq * D, q0, tid);
+        if (tid < 128) {
+            const int r = q0 + (tid & 63);
+            const float* src = tid < 64 ? p.lse : p.delta;
+            rstat = r < p.rows ? src[(long)hq * p.rows + r] : 0.f;
+        }
+    };
+    if (nstep > 0) load(0);
+    for (int step = 0; step < nstep; ++step) {
+        const int q0 = q00 + 64 * (step % ntile);
+        if (!(AB_ABL & 8)) __syncthreads();
+        if (!(AB_ABL & 16)) {
+            ab_store_rows<D>(Qs, rq, tid);
+            ab_store_rows<D>(dOs, rdo, tid);
+            ab_store_t<D>(Qts, rqt, tid);
+            ab_store_t<D>(dOts, rdot, tid);
+            if (tid < 128) lse_s[tid] = rstat;          // lse_s and delta_s are adjacent: [0, 64) lse, [64, 128) delta
+        }
+        if (!(AB_ABL & 8)) __syncthreads();
+        if (step + 1 < nstep && !(AB_ABL & 4)) load(step + 1);
+        if (!wave_on) continue;
+        // every query of the tile sees every key of the item: rows of later splits, or of the own full / noise split
+        const bool pl = nkeys == 128 && q0 >= qbeg && q0 + 64 <= qend && (q0 >= send || !causal);
+#pragma nounroll                                          // one 32-query block at a time: both unrolled would not fit the register file
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16_t s, dp;
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                f32x16_t s, dp;
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            for (int ks = 0; ks < KS; ++ks) {
+                if (AB_ABL & 64) { s[ks] = (float)step; dp[ks] = (float)q0; continue; }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Qs + (32 * qb + pm) * RP + 16 * ks + 8 * h), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(dOs + (32 * qb + pm) * RP + 16 * ks + 8 * h), vf[ks], dp, 0, 0, 0);
+            }
+            float pr[16], ds[16], lv[16], dl[16];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Qs + (32 * qb + pm) * RP + 16 * ks + 8 * h), kf[ks], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(dOs + (32 * qb + pm) * RP + 16 * ks + 8 * h), vf[ks], dp, 0, 0, 0);
+            for (int a = 0; a < 2; ++a)                      // the lane's 16 queries are two runs of 8: four 16-byte LDS reads each
+#pragma unroll
+                for (int e4 = 0; e4 < 2; ++e4) {
+                    const f32x4_t x = *(const f32x4_t*)(lse_s + 32 * qb + 16 * a + 8 * h + 4 * e4);
+                    const f32x4_t y = *(const f32x4_t*)(delta_s + 32 * qb + 16 * a + 8 * h + 4 * e4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { lv[8 * a + 4 * e4 + e] = x[e]; dl[8 * a + 4 * e4 + e] = y[e]; }
                 }
-                float pr[16], ds[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int ql = 32 * qb + 16 * (i >> 3) + 8 * h + (i & 7);
-                    const int qrow = q0 + ql;
-                    const bool ok = kvalid && qrow >= qbeg && qrow < qend && (qrow >= send || !causal || krow <= qrow);
-                    pr[i] = ok ? __expf(s[i] * scale - lse_s[ql]) : 0.f;
-                    ds[i] = pr[i] * (dp[i] - delta_s[ql]) * scale;
-                }
-                const bf16x8_t pf0 = ab_pack8(pr), pf1 = ab_pack8(pr + 8), dsf0 = ab_pack8(ds), dsf1 = ab_pack8(ds + 8);
+            for (int i = 0; i < 16; ++i) {
+                const int ql = 32 * qb + 16 * (i >> 3) + 8 * h + (i & 7);
+                const int qrow = q0 + ql;
+                const unsigned ok = (unsigned)pl | ((unsigned)kvalid & (unsigned)(qrow >= qbeg) & (unsigned)(qrow < qend) &
+                                                   ((unsigned)(qrow >= send) | (unsigned)(causal == 0) | (unsigned)(krow <= qrow)));
+                if (AB_ABL & 2) { pr[i] = s[i]; ds[i] = dp[i]; continue; }
+                const float e = __builtin_amdgcn_exp2f(s[i] * c2 - lv[i]);
+                pr[i] = ok ? e : 0.f;
+                ds[i] = pr[i] * (dp[i] - dl[i]) * p.scale;
+            }
+            const bf16x8_t pf0 = ab_pack8(pr), pf1 = ab_pack8(pr + 8), dsf0 = ab_pack8(ds), dsf1 = ab_pack8(ds + 8);
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const bf16_t* a0 = dOts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)a0, pf0, dv[db], 0, 0, 0);
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(a0 + 16), pf1, dv[db], 0, 0, 0);
-                    const bf16_t* b0 = Qts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)b0, dsf0, dk[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(b0 + 16), dsf1, dk[db], 0, 0, 0);
-                }
+            for (int db = 0; db < DB; ++db) {
+                if (AB_ABL & 32) { dv[db][0] += pr[db] + pr[db + 8]; dk[db][0] += ds[db] + ds[db + 8]; continue; }
+                const bf16_t* a0 = dOts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)a0, pf0, dv[db], 0, 0, 0);
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(a0 + 16), pf1, dv[db], 0, 0, 0);
+                const bf16_t* b0 = Qts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)b0, dsf0, dk[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(b0 + 16), dsf1, dk[db], 0, 0, 0);
             }
         }
     }
     if (kvalid) {
-        ab_store_t<DB>(p.dk, p.lddk, krow, hkv * D, dk, h);
-        ab_store_t<DB>(p.dv, p.lddv, krow, hkv * D, dv, h);
+        ab_store_acc<DB>(p.dk, p.lddk, krow, hkv * D, dk, h);
+        ab_store_acc<DB>(p.dv, p.lddv, krow, hkv * D, dv, h);
     }
 }
 
@@ -317,6 +429,9 @@ static int attn_bwd_launch(const AttnBwdParams& p, int n_q_items, int n_k_items,
     constexpr int smem_dkv = (2 * 64 * (D + 8) + 2 * D * AB_TP) * 2 + 128 * 4;
     if (int rc = bagel_enable_lds((const void*)attn_bwd_dq_kernel<D>, smem_dq, "attn_bwd_dq_kernel")) return rc;
     if (int rc = bagel_enable_lds((const void*)attn_bwd_dkv_kernel<D>, smem_dkv, "attn_bwd_dkv_kernel")) return rc;
+#if AB_ABL || defined(BAGEL_ENABLE_ABLATIONS)
+    if (const char* only = getenv("BAGEL_ABWD_ONLY")) { if (only[1] == 'q') n_k_items = 0; else n_q_items = 0; }    // "dq" | "dkv"
+#endif
     if (n_q_items > 0) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3(n_q_items, p.nq), dim3(256), smem_dq, stream, p);
         if (int rc = bagel_check_launch("attn_bwd_dq_kernel")) return rc;
@@ -332,8 +447,8 @@ extern "C" int bagel_attn_bwd_blockmask_bf16(const void* q, int64_t ldq, const v
                                              int64_t ldo, const void* d_o, int64_t lddo, const void* qt, const void* dot, const void* kt,
                                              int64_t ld_t, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
                                              const int32_t* q_items, int32_t n_q_items, const int32_t* k_items, int32_t n_k_items,
-                                             const uint64_t* noise_bits, float* lse_delta, int32_t rows, int32_t nq, int32_t nkv,
-                                             int32_t head_dim, float softmax_scale, hipStream_t stream) {
+                                             const uint64_t* noise_bits, float* lse_delta, int32_t lse_from_forward, int32_t rows, int32_t nq,
+                                             int32_t nkv, int32_t head_dim, float softmax_scale, hipStream_t stream) {
     BAGEL_REQUIRE(q && k && v && o && d_o && qt && dot && kt && dq && dk && dv && noise_bits && lse_delta, "attn_bwd: null pointer");
     BAGEL_REQUIRE((n_q_items == 0 || q_items) && (n_k_items == 0 || k_items), "attn_bwd: item tables missing");
     BAGEL_REQUIRE(nq > 0 && nkv > 0 && nq % nkv == 0, "attn_bwd: nq must be a multiple of nkv");
@@ -352,7 +467,7 @@ extern "C" int bagel_attn_bwd_blockmask_bf16(const void* q, int64_t ldq, const v
     p.dq = (bf16_t*)dq; p.lddq = lddq; p.dk = (bf16_t*)dk; p.lddk = lddk; p.dv = (bf16_t*)dv; p.lddv = lddv;
     p.q_items = q_items; p.k_items = k_items; p.noise_bits = (const unsigned long long*)noise_bits;
     p.lse = lse_delta; p.delta = lse_delta + (long)nq * rows;
-    p.rows = rows; p.nq = nq; p.nkv = nkv; p.scale = softmax_scale;
+    p.rows = rows; p.nq = nq; p.nkv = nkv; p.have_lse = lse_from_forward; p.scale = softmax_scale;
     if (head_dim == 128) return attn_bwd_launch<128>(p, n_q_items, n_k_items, stream);
     if (head_dim == 64) return attn_bwd_launch<64>(p, n_q_items, n_k_items, stream);
     return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_bwd: head_dim %d not in {64,128} (pad the head)", head_dim);

@@ -950,7 +950,8 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
         x_mid, x_out = x, x                                   # in place without a tape
         if tape is not None:
             raw, att, act, x_mid, x_out = e(M, qw + 2 * kw_), e(M, qw), e(M, self.I), e(M, self.H), e(M, self.H)
-            tape.qkv_raw.append(raw); tape.att.append(att); tape.act.append(act); tape.x_mid.append(x_mid); tape.x.append(x_out)
+            lse = torch.empty((nq, M), dtype=torch.float32, device=dev)
+            tape.qkv_raw.append(raw); tape.att.append(att); tape.act.append(act); tape.x_mid.append(x_mid); tape.x.append(x_out); tape.lse.append(lse)
         ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if two else None, expert=expert)
         if tape is not None:
             ops.gemm(h, C=raw, **groups(P.wqkv, P.bqkv))
@@ -967,7 +968,8 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
             ops.v_transpose(v_clean, vt_clean, tp.cu_clean, tp.clean_col, tp.n_samples, tp.max_clean, nkv, dp)
         for g in tp.groups:
             ops.attn_varlen_ranges(q_v, k_v, vt, att, g["qs"], g["qe"], g["ncol"], g["n"], g["max_lq"], nq, nkv, dp, g["causal"], scale,
-                                   k_ctx=k_clean, vt_ctx=vt_clean, ctx_start=g["cs"], ctx_end=g["ce"], vt_ctx_col=g["ccol"])
+                                   k_ctx=k_clean, vt_ctx=vt_clean, ctx_start=g["cs"], ctx_end=g["ce"], vt_ctx_col=g["ccol"],
+                                   lse=lse if tape is not None else None)
         ops.gemm(att, C=x_mid, residual=x, **groups(P.wo))
         ops.rmsnorm(x_mid, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if two else None, expert=expert)
         ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu))

@@ -77,6 +77,7 @@ class TrainTape:
         self.qkv_raw = []       # fused projection before QK-norm / RoPE
         self.att = []           # attention output (o_proj input)
         self.act = []           # SwiGLU output (down_proj input)
+        self.lse = []           # log2 softmax denominators of the attention rows, fp32 [nq, M] (112 bytes per token and layer)
         self.front = {}         # embedding / ViT / latent front end and the loss heads (Bagel._forward_losses)
 
 
@@ -193,7 +194,7 @@ def engine_backward_train(eng, tape, g, grads):
                         expert, nq, nkv, hd, dp, eng.eps, gen_mode=False, use_norm=eng.use_norm)
         dqkv = e(M, qw + 2 * kw_)
         ops.attn_bwd_blockmask(qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:], att, d_att, dqkv[:, :qw], dqkv[:, qw:qw + kw_],
-                               dqkv[:, qw + kw_:], bplan.q_items, bplan.k_items, bplan.noise_bits, nq, nkv, dp, scale)
+                               dqkv[:, qw + kw_:], bplan.q_items, bplan.k_items, bplan.noise_bits, nq, nkv, dp, scale, lse=tape.lse[li])
         del qkv, d_att
         dqn = ops.qknorm_rope_bwd(dqkv, qkv_raw, tp.cos, tp.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
                                   P.qn[1] if (eng.use_norm and two) else None, P.kn[1] if (eng.use_norm and two) else None,

@@ -418,13 +418,25 @@ def chw_f32_to_u8(src):
 
 
 def attn_varlen_ranges(q, k_new, vt_new, out, q_start, q_end, vt_new_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale,
-                       k_ctx=None, vt_ctx=None, ctx_start=None, ctx_end=None, vt_ctx_col=None):
-    """attn_varlen with explicit [start, end) row ranges per sequence (ranges may skip rows; context ranges may overlap)."""
+                       k_ctx=None, vt_ctx=None, ctx_start=None, ctx_end=None, vt_ctx_col=None, lse=None):
+    """attn_varlen with explicit [start, end) row ranges per sequence (ranges may skip rows; context ranges may overlap).
+    ``lse`` (fp32 [nq, rows]) additionally receives log2 of every row's softmax denominator -- the statistics the training backward
+    reads instead of recomputing them (every query row must then belong to exactly one range)."""
     for t, n in ((q, "q"), (k_new, "k_new"), (vt_new, "vt_new"), (out, "out")):
         _req(t, BF16, "attn_ranges." + n)
     for t in (q_start, q_end, vt_new_col, ctx_start, ctx_end, vt_ctx_col):
         if t is not None:
             _req(t, torch.int32, "attn_ranges.index")
+    if lse is not None:
+        _req(lse, torch.float32, "attn_ranges.lse")
+        if lse.dim() != 2 or lse.shape[0] != nq or lse.shape[1] < q.shape[0]:
+            raise BagelHipError("attn_ranges: lse must be fp32 [nq, rows]")
+        check(lib().bagel_attn_varlen_ranges_lse_bf16(
+            _ptr(q), q.stride(0), _ptr(k_new), k_new.stride(0), _ptr(vt_new), vt_new.stride(0),
+            _ptr(k_ctx), k_ctx.stride(0) if k_ctx is not None else 0, _ptr(vt_ctx), vt_ctx.stride(0) if vt_ctx is not None else 0,
+            _ptr(out), out.stride(0), _ptr(q_start), _ptr(q_end), _ptr(ctx_start), _ptr(ctx_end), _ptr(vt_new_col), _ptr(vt_ctx_col),
+            batch, max_lq, nq, nkv, head_dim, int(causal), float(softmax_scale), _ptr(lse), lse.stride(0), _stream()), "bagel_attn_varlen_ranges_lse_bf16")
+        return out
     check(lib().bagel_attn_varlen_ranges_bf16(
         _ptr(q), q.stride(0), _ptr(k_new), k_new.stride(0), _ptr(vt_new), vt_new.stride(0),
         _ptr(k_ctx), k_ctx.stride(0) if k_ctx is not None else 0, _ptr(vt_ctx), vt_ctx.stride(0) if vt_ctx is not None else 0,
@@ -589,9 +601,10 @@ def colsum(src, rows=None, n=None):
     return out
 
 
-def attn_bwd_blockmask(q, k, v, o, d_o, dq, dk, dv, q_items, k_items, noise_bits, nq, nkv, head_dim, softmax_scale):
+def attn_bwd_blockmask(q, k, v, o, d_o, dq, dk, dv, q_items, k_items, noise_bits, nq, nkv, head_dim, softmax_scale, lse=None):
     """Reverse of the block-masked packed attention (bagel_attn_bwd_blockmask_bf16); q / k / v / o / d_o / dq / dk / dv are
-    [rows, heads * head_dim] views (any row stride); head_dim = the padded width (64 or 128)."""
+    [rows, heads * head_dim] views (any row stride); head_dim = the padded width (64 or 128).  ``lse`` = the forward's row statistics
+    (attn_varlen_ranges(..., lse=)): contiguous fp32 [nq, rows]; without it the first kernel recomputes them."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _req(t, BF16, "attn_bwd." + nm)
     _req(q_items, torch.int32, "attn_bwd.q_items"); _req(k_items, torch.int32, "attn_bwd.k_items"); _req(noise_bits, torch.int64, "attn_bwd.noise_bits")
@@ -600,10 +613,15 @@ def attn_bwd_blockmask(q, k, v, o, d_o, dq, dk, dv, q_items, k_items, noise_bits
     if noise_bits.numel() * 64 < qt.shape[1]:
         raise BagelHipError("attn_bwd: noise_bits must cover ceil64(rows) keys")
     ws = torch.empty((2, nq, rows), dtype=torch.float32, device=q.device)
+    if lse is not None:
+        _req(lse, torch.float32, "attn_bwd.lse")
+        if tuple(lse.shape) != (nq, rows):
+            raise BagelHipError("attn_bwd: lse must be fp32 [nq, rows]")
+        ws[0].copy_(lse)
     check(lib().bagel_attn_bwd_blockmask_bf16(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
                                               _ptr(d_o), d_o.stride(0), _ptr(qt), _ptr(dot), _ptr(kt), qt.stride(0), _ptr(dq), dq.stride(0),
                                               _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), _ptr(q_items), q_items.shape[0], _ptr(k_items),
-                                              k_items.shape[0], _ptr(noise_bits), _ptr(ws), rows, nq, nkv, head_dim, float(softmax_scale),
+                                              k_items.shape[0], _ptr(noise_bits), _ptr(ws), int(lse is not None), rows, nq, nkv, head_dim, float(softmax_scale),
                                               _stream()), "bagel_attn_bwd_blockmask_bf16")
     return dq, dk, dv
 

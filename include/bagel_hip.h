@@ -324,6 +324,15 @@ int bagel_chw_f32_to_u8(const float* in, int64_t chan_stride, int64_t row_stride
 
 /* ---- training backward (loss.backward() of train/pretrain_unified_navit.py:683-735 over Bagel.forward, bagel.py:101-229; the
  *      reference gets it from torch autograd, these are the hand-written reverse kernels the product chains) ---------------------- */
+/* bagel_attn_varlen_ranges_bf16 that also leaves the row statistics the attention reverse needs: lse[h * ld_lse + row] = log2 of the
+ * softmax denominator of (row, q head h) in the scaled base-2 domain (P = exp2(scale * log2(e) * s - lse)), fp32.  Every query row must
+ * belong to exactly one range (the split decomposition of forward_train does that). */
+int bagel_attn_varlen_ranges_lse_bf16(const void* q, int64_t ldq, const void* k_new, int64_t ldk_new, const void* vt_new, int64_t ldvt_new,
+                                      const void* k_ctx, int64_t ldk_ctx, const void* vt_ctx, int64_t ldvt_ctx, void* out, int64_t ldo,
+                                      const int32_t* q_start, const int32_t* q_end, const int32_t* ctx_start, const int32_t* ctx_end,
+                                      const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t max_lq, int32_t nq,
+                                      int32_t nkv, int32_t head_dim, int32_t causal, float softmax_scale, float* lse, int64_t ld_lse,
+                                      bagel_stream_t stream);
 /* dst[c][j] = src[src_rows ? src_rows[j] : j][c] for j < rows, 0 for rows <= j < rows_padded: the K-contiguous operand images of
  * the weight-gradient and input-gradient GEMMs (dW = dY^T X and dX = dY W are NT products of transposed images on bagel_gemm_bf16;
  * src_rows = one MoT expert's row list).  cols % 8 == 0, ld_dst >= rows_padded. */
@@ -373,13 +382,14 @@ int bagel_colsum_bf16(const void* src, int64_t ld, const int32_t* rows, int32_t 
  * q_items [n_q_items][8] = {row0, nrows, sample_start, split_start, split_end, causal, first 64-key tile, end tile};
  * k_items [n_k_items][8] = {key0, nkeys, first visible query row, end visible query row, split_end, causal, 0, 0};
  * noise_bits[t] bit j = key 64 t + j belongs to a noise split (hidden from every later split);
- * lse_delta: fp32 workspace [2][nq][rows].  D = 64 or 128. */
+ * lse_delta: fp32 workspace [2][nq][rows]; with lse_from_forward != 0 its first half already holds the rows' log2 softmax denominators
+ * written by bagel_attn_varlen_ranges_lse_bf16 and the first kernel skips its statistics pass.  D = 64 or 128. */
 int bagel_attn_bwd_blockmask_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                                   int64_t ldo, const void* d_o, int64_t lddo, const void* qt, const void* dot, const void* kt,
                                   int64_t ld_t, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
                                   const int32_t* q_items, int32_t n_q_items, const int32_t* k_items, int32_t n_k_items,
-                                  const uint64_t* noise_bits, float* lse_delta, int32_t rows, int32_t nq, int32_t nkv,
-                                  int32_t head_dim, float softmax_scale, bagel_stream_t stream);
+                                  const uint64_t* noise_bits, float* lse_delta, int32_t lse_from_forward, int32_t rows, int32_t nq,
+                                  int32_t nkv, int32_t head_dim, float softmax_scale, bagel_stream_t stream);
 
 /* ---- VAE (fp32, NHWC) ------------------------------------------------------------------------------------- */
 /* Implicit-GEMM convolution / plain GEMM on the exact-fp32 MFMA.  mode 0: out[M,Cout] = in[M,Cin] w[Cout,Cin]^T

@@ -351,7 +351,7 @@ def taylor_eval(factors, n, x, out):
 
 
 def attn_varlen_ranges(q, k_new, vt_new, out, q_start, q_end, vt_new_col, batch, max_lq, nq, nkv, head_dim, causal, softmax_scale,
-                       k_ctx=None, vt_ctx=None, ctx_start=None, ctx_end=None, vt_ctx_col=None):
+                       k_ctx=None, vt_ctx=None, ctx_start=None, ctx_end=None, vt_ctx_col=None, lse=None):
     D, grp = head_dim, nq // nkv
     qs, qe, ncol = q_start.tolist(), q_end.tolist(), vt_new_col.tolist()
     cs = ctx_start.tolist() if ctx_start is not None else None
@@ -375,6 +375,8 @@ def attn_varlen_ranges(q, k_new, vt_new, out, q_start, q_end, vt_new_col, batch,
                 Lk = C + Lq
                 s = s.masked_fill(~torch.ones(Lq, Lk).tril(diagonal=Lk - Lq).bool(), float("-inf"))
             out[q0:q0 + Lq, h * D:(h + 1) * D] = _bf((torch.softmax(s, -1).double() @ v).float())
+            if lse is not None:                              # log2 of the softmax denominator in the scaled base-2 domain
+                lse[h, q0:q0 + Lq] = torch.logsumexp(s.double(), -1).float() * 1.4426950408889634
     return out
 
 
@@ -529,13 +531,13 @@ def colsum(src, rows=None, n=None):
     return _bf(src[idx].double().sum(0).float())
 
 
-def attn_bwd_blockmask(q, k, v, o, d_o, dq, dk, dv, q_items, k_items, noise_bits, nq, nkv, head_dim, softmax_scale):
+def attn_bwd_blockmask(q, k, v, o, d_o, dq, dk, dv, q_items, k_items, noise_bits, nq, nkv, head_dim, softmax_scale, lse=None):
     """An interpreter of the two kernels' work items (include/bagel_hip.h): what the items describe is what is computed, so the host
     code that builds them is checked against the oracle's autograd by the CPU suite."""
     M, D, grp = q.shape[0], head_dim, nq // nkv
     bits = noise_bits.tolist()
     noise = torch.tensor([(bits[c // 64] >> (c % 64)) & 1 for c in range(M)], dtype=torch.bool)
-    lse = torch.zeros((nq, M), dtype=torch.float64)
+    lse_in, lse = lse, torch.zeros((nq, M), dtype=torch.float64)
     delta = torch.zeros((nq, M), dtype=torch.float64)
     seen_q, seen_k = torch.zeros(M, dtype=torch.int32), torch.zeros(M, dtype=torch.int32)
     for row0, nrows, kstart, sstart, send, causal, t0, t1 in q_items.tolist():
@@ -551,7 +553,7 @@ def attn_bwd_blockmask(q, k, v, o, d_o, dq, dk, dv, q_items, k_items, noise_bits
             doh = d_o[rows, h * D:(h + 1) * D].double()
             s_ = (qh @ kh.t()) * softmax_scale
             s_ = s_.masked_fill(~allow, float("-inf"))
-            L = torch.logsumexp(s_, -1)
+            L = torch.logsumexp(s_, -1) if lse_in is None else lse_in[h, rows].double() / 1.4426950408889634
             dl = (doh * o[rows, h * D:(h + 1) * D].double()).sum(-1)
             lse[h, rows], delta[h, rows] = L, dl
             p = torch.exp(s_ - L[:, None])

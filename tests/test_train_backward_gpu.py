@@ -204,6 +204,19 @@ def test_attention_backward_block_mask(case, nq, nkv, D):
     for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
         assert torch.isfinite(got.float()).all(), (case, name)
         assert rel(got, want) < 1e-2, (case, name, rel(got, want))
+    # the same with the row statistics handed over by the forward (log2 of the softmax denominators) instead of the first kernel's own pass
+    lse, r0 = torch.empty(nq, Mr), 0
+    for (lens, modes), n in zip(samples, sample_lens):
+        mask = O.attention_mask_per_sample(lens, modes)
+        qs = q[r0:r0 + n].float().view(n, nq, D).transpose(0, 1)
+        ks = k[r0:r0 + n].float().view(n, nkv, D).repeat_interleave(G, dim=1).transpose(0, 1)
+        lse[:, r0:r0 + n] = torch.logsumexp(qs @ ks.transpose(1, 2) * scale + mask[None], dim=-1) * 1.4426950408889634
+        r0 += n
+    dq2, dk2, dv2 = (torch.full(t.shape, float("nan"), dtype=BF16, device=DEV) for t in (q, k, v))
+    o.attn_bwd_blockmask(q.to(DEV), k.to(DEV), v.to(DEV), out.detach().to(BF16).to(DEV), do.to(DEV), dq2, dk2, dv2, bp.q_items, bp.k_items, bp.noise_bits,
+                         nq, nkv, D, scale, lse=lse.to(DEV))
+    for name, got, want in (("dq", dq2, qf.grad), ("dk", dk2, kf.grad), ("dv", dv2, vf.grad)):
+        assert rel(got, want) < 1e-2, (case, name, "lse from the forward", rel(got, want))
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -46,22 +46,28 @@ def test_block_mask_attention_as_split_sequences(nq, nkv, D):
     o.copy_rows(vd, v_clean, tp.n_clean, kw_, src_rows=tp.clean_rows)
     o.v_transpose(v_clean, vt_clean, tp.cu_clean, tp.clean_col, tp.n_samples, tp.max_clean, nkv, D)
     out = torch.full((M, nq * D), float("nan"), dtype=BF16, device=DEV)
+    lse = torch.full((nq, M), float("nan"), dtype=torch.float32, device=DEV)
     scale = D ** -0.5
     for g in tp.groups:
         o.attn_varlen_ranges(qd, kd, vt, out, g["qs"], g["qe"], g["ncol"], g["n"], g["max_lq"], nq, nkv, D, g["causal"], scale,
-                             k_ctx=k_clean, vt_ctx=vt_clean, ctx_start=g["cs"], ctx_end=g["ce"], vt_ctx_col=g["ccol"])
+                             k_ctx=k_clean, vt_ctx=vt_clean, ctx_start=g["cs"], ctx_end=g["ce"], vt_ctx_col=g["ccol"], lse=lse)
     # reference: masked attention per sample, fp32 softmax, GQA by head repeat
-    ref, r0 = [], 0
+    ref, ref_lse, r0 = [], [], 0
     G = nq // nkv
     for (lens, modes), n in zip(samples, sample_lens):
         mask = O.attention_mask_per_sample(lens, modes)
         qs = q[r0:r0 + n].float().view(n, nq, D).transpose(0, 1)
         ks = k[r0:r0 + n].float().view(n, nkv, D).repeat_interleave(G, dim=1).transpose(0, 1)
         vs = v[r0:r0 + n].float().view(n, nkv, D).repeat_interleave(G, dim=1).transpose(0, 1)
-        p = torch.softmax(qs @ ks.transpose(1, 2) * scale + mask[None], dim=-1)
+        sc = qs @ ks.transpose(1, 2) * scale + mask[None]
+        p = torch.softmax(sc, dim=-1)
         ref.append((p @ vs).transpose(0, 1).reshape(n, nq * D))
+        ref_lse.append(torch.logsumexp(sc, dim=-1) * 1.4426950408889634)
         r0 += n
     close(out, torch.cat(ref).to(BF16), ulps=2, what="block-mask attention")
+    # the row statistics for the training backward: log2 of the softmax denominator (P is summed after its bf16 rounding: 2^-8 relative)
+    d = (lse.cpu() - torch.cat(ref_lse, dim=1)).abs().max().item()
+    assert d < 2e-2, f"lse: max |d| {d}"
 
 
 def test_training_glue_kernels():
