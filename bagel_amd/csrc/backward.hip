@@ -113,28 +113,21 @@ extern "C" int bagel_colsum_bf16(const void* src, int64_t ld, const int32_t* row
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Qwen2RMSNorm reverse (modeling_qwen2.py:54-59: y = w * bf16(x * rsqrt(mean(x^2) + eps))).
-// One workgroup = 64 rows, 16 per wave; a lane owns the 8-column chunks lane, lane + 64, ... (NV of them).  The per-expert weight
-// gradients stay in registers over the wave's rows and meet in LDS once per workgroup.
+// Qwen2RMSNorm reverse (modeling_qwen2.py:54-59: y = w * bf16(x * rsqrt(mean(x^2) + eps))), two passes, both deterministic:
+//   rows     one wave per row (8 rows per wave, 64 per workgroup of 8 waves): rsqrt and the dot product, dx, g += dx; the row's rsqrt
+//            goes to a small fp32 side buffer.  No weight-gradient state in registers, so several waves per SIMD hide the latencies.
+//   columns  dw_e[c] = sum over the rows of expert e of dy * bf16(x * rsqrt): a thread owns 8 columns and walks 64 rows (no cross-thread
+//            reduction), 64-row partial sums, then the shared column pass.  Re-reads x and dy (6 instead of 4 passes over [rows, cols]).
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int NV>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
-                                                          const bf16_t* __restrict__ w0, const bf16_t* __restrict__ w1,
-                                                          const int* __restrict__ expert, bf16_t* __restrict__ g, long ldg, int accumulate,
-                                                          float* __restrict__ partial, int rows, int cols, float eps) {
-    extern __shared__ float red[];                           // [2][cols]
+__global__ __launch_bounds__(512) void rmsnorm_bwd_rows_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
+                                                               const bf16_t* __restrict__ w0, const bf16_t* __restrict__ w1,
+                                                               const int* __restrict__ expert, bf16_t* __restrict__ g, long ldg, int accumulate,
+                                                               float* __restrict__ rinv_out, int rows, int cols, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = cols >> 3;
-    float dw[2][NV][8];
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dw[e][v][i] = 0.f;
-    for (int c = threadIdx.x; c < 2 * cols; c += 256) red[c] = 0.f;
-    const int r0 = blockIdx.x * 64 + wave * 16;
-    for (int r = r0; r < min(r0 + 16, rows); ++r) {
+    const int r0 = blockIdx.x * 64 + wave * 8;
+    for (int r = r0; r < min(r0 + 8, rows); ++r) {
         const int ex = (expert && w1) ? expert[r] : 0;
         const bf16_t* wr = ex ? w1 : w0;
         float xv[NV][8], dv[NV][8];
@@ -157,6 +150,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         }
         ss = wave_sum(ss);
         const float rinv = rsqrtf(ss / (float)cols + eps);
+        if (lane == 0) rinv_out[r] = rinv;
         float dot = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
@@ -167,7 +161,6 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         for (int v = 0; v < NV; ++v) {
             const int c = lane + 64 * v;
             if (c >= nch) continue;
-            const u32x4_t b = *(const u32x4_t*)(dy + (long)r * lddy + c * 8);
             u32x4_t gin = {0u, 0u, 0u, 0u};
             if (accumulate) gin = *(const u32x4_t*)(g + (long)r * ldg + c * 8);
             u32x4_t o;
@@ -175,26 +168,37 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
             for (int e = 0; e < 4; ++e) {
                 const float dx0 = rinv * (dv[v][2 * e] - xv[v][2 * e] * dot), dx1 = rinv * (dv[v][2 * e + 1] - xv[v][2 * e + 1] * dot);
                 o[e] = pack2bf(lo2f(gin[e]) + bfround(dx0), hi2f(gin[e]) + bfround(dx1));
-                const float d0 = lo2f(b[e]) * bfround(xv[v][2 * e]), d1 = hi2f(b[e]) * bfround(xv[v][2 * e + 1]);
-                if (ex) { dw[1][v][2 * e] += d0; dw[1][v][2 * e + 1] += d1; }
-                else    { dw[0][v][2 * e] += d0; dw[0][v][2 * e + 1] += d1; }
             }
             *(u32x4_t*)(g + (long)r * ldg + c * 8) = o;
         }
     }
-    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_bwd_cols_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
+                                                               const int* __restrict__ expert, const float* __restrict__ rinv,
+                                                               float* __restrict__ partial, int rows, int cols) {
+    const int ch = blockIdx.y * 256 + threadIdx.x;
+    if (ch * 8 >= cols) return;
+    const int r0 = blockIdx.x * 64, r1 = min(r0 + 64, rows);
+    float acc[2][8];
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int c = lane + 64 * v;
-            if (c < nch)
+        for (int i = 0; i < 8; ++i) acc[e][i] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const int ex = expert ? expert[r] : 0;
+        const float ri = rinv[r];
+        const u32x4_t a = *(const u32x4_t*)(x + (long)r * ldx + ch * 8), b = *(const u32x4_t*)(dy + (long)r * lddy + ch * 8);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) atomicAdd(&red[e * cols + c * 8 + i], dw[e][v][i]);
+        for (int e = 0; e < 4; ++e) {
+            const float d0 = lo2f(b[e]) * bfround(lo2f(a[e]) * ri), d1 = hi2f(b[e]) * bfround(hi2f(a[e]) * ri);
+            if (ex) { acc[1][2 * e] += d0; acc[1][2 * e + 1] += d1; }
+            else    { acc[0][2 * e] += d0; acc[0][2 * e + 1] += d1; }
         }
-    __syncthreads();
-    float* p = partial + (long)blockIdx.x * 2 * cols;
-    for (int c = threadIdx.x; c < 2 * cols; c += 256) p[c] = red[c];
+    }
+    float* p = partial + (long)blockIdx.x * 2 * cols + ch * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { p[i] = acc[0][i]; p[cols + i] = acc[1][i]; }
 }
 
 extern "C" int bagel_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* w0, const void* w1,
@@ -206,19 +210,21 @@ extern "C" int bagel_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* dy
     BAGEL_REQUIRE((w1 == nullptr) == (dw1 == nullptr), "rmsnorm_bwd: w1 and dw1 go together");
     const int nblk = max(ceil_div(rows, 64), 0);
     if (nblk > 0) {
+        float* rinv = partial_ws + (long)nblk * 2 * cols;            // the rows' rsqrt values, behind the partial sums
         const int nv = ceil_div(cols / 8, 64);
-        const size_t lds = (size_t)2 * cols * sizeof(float);
-#define BAGEL_RMSBWD(NV)                                                                                                              \
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<NV>, dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (long)ldx, (const bf16_t*)dy,  \
-                           (long)lddy, (const bf16_t*)w0, (const bf16_t*)w1, expert_of_row, (bf16_t*)g, (long)ldg, (int)accumulate,  \
-                           partial_ws, rows, cols, eps)
+#define BAGEL_RMSBWD(NV)                                                                                                                 \
+        hipLaunchKernelGGL(rmsnorm_bwd_rows_kernel<NV>, dim3(nblk), dim3(512), 0, stream, (const bf16_t*)x, (long)ldx, (const bf16_t*)dy,  \
+                           (long)lddy, (const bf16_t*)w0, (const bf16_t*)w1, expert_of_row, (bf16_t*)g, (long)ldg, (int)accumulate, rinv,   \
+                           rows, cols, eps)
         if (nv <= 1) BAGEL_RMSBWD(1);
         else if (nv <= 2) BAGEL_RMSBWD(2);
         else if (nv <= 4) BAGEL_RMSBWD(4);
         else BAGEL_RMSBWD(8);
 #undef BAGEL_RMSBWD
-        const int rc = bagel_check_launch("rmsnorm_bwd_kernel");
-        if (rc) return rc;
+        if (int rc = bagel_check_launch("rmsnorm_bwd_rows_kernel")) return rc;
+        hipLaunchKernelGGL(rmsnorm_bwd_cols_kernel, dim3(nblk, ceil_div(cols / 8, 256)), dim3(256), 0, stream, (const bf16_t*)x, (long)ldx,
+                           (const bf16_t*)dy, (long)lddy, w1 ? expert_of_row : nullptr, rinv, partial_ws, rows, cols);
+        if (int rc = bagel_check_launch("rmsnorm_bwd_cols_kernel")) return rc;
     }
     return colsum_finish(partial_ws, nblk, 2 * cols, cols, (bf16_t*)dw0, (bf16_t*)dw1, nullptr, nullptr, stream);
 }
@@ -226,8 +232,15 @@ extern "C" int bagel_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* dy
 // ------------------------------------------------------------------------------------------------------------------------------
 // QK-norm + RoPE reverse (training form of PackedAttentionMoT.forward_train, qwen2_navit.py:430-455: both experts in the bf16
 // pipeline).  Forward per head:  n = w * bf16(x * rsqrt(mean(x^2) + eps));  y1 = n1 c - n2 s,  y2 = n2 c + n1 s.
-// One wave per row, lane i < head_dim / 2 owns the pair (i, i + head_dim / 2) of every head.
 // ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sum16(float v) {          // sum over the 16 lanes of a head group
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// A wave works on 4 heads at a time: 16 lanes per head, lane `sub` owns the elements 4 sub .. 4 sub + 3 of BOTH halves of the head (the
+// rotation pairs element i with i + head_dim / 2), 8-byte loads and stores.
 __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(bf16_t* __restrict__ dqkv, long ld, const bf16_t* __restrict__ raw, long ld_raw,
                                                               const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t,
                                                               const bf16_t* __restrict__ qw0, const bf16_t* __restrict__ kw0,
@@ -237,36 +250,66 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(bf16_t* __restrict
     __shared__ float red[4 * 128];                           // [expert][q | k][hd]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = hd >> 1;
-    const bool on = lane < half;
-    float dw[2][2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};      // [expert][q | k][half of the head]
+    const int sub = lane & 15, grp = lane >> 4;
+    const bool on = 4 * sub < half;
+    float dw[2][2][8];                                       // [expert][q | k][4 of the first half, 4 of the second]
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dw[e][k][i] = 0.f;
     for (int c = threadIdx.x; c < 4 * hd; c += 256) red[c] = 0.f;
     const int r0 = blockIdx.x * 64 + wave * 16;
+    auto ld4 = [&](const bf16_t* p_, float* out) {
+        const u32x2_t v = *(const u32x2_t*)p_;
+        out[0] = lo2f(v[0]); out[1] = hi2f(v[0]); out[2] = lo2f(v[1]); out[3] = hi2f(v[1]);
+    };
     for (int r = r0; r < min(r0 + 16, rows); ++r) {
         const int ex = (expert && qw1) ? expert[r] : 0;
-        float c = 0.f, s = 0.f;
-        if (on) { c = bf2f(cos_t[(long)r * half + lane]); s = bf2f(sin_t[(long)r * half + lane]); }
-        for (int h = 0; h < nq + nkv; ++h) {
+        float c[4] = {0.f, 0.f, 0.f, 0.f}, s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (on) { ld4(cos_t + (long)r * half + 4 * sub, c); ld4(sin_t + (long)r * half + 4 * sub, s); }
+        for (int h0 = 0; h0 < nq + nkv; h0 += 4) {
+            const int h = h0 + grp;
+            const bool live = on && h < nq + nkv;
             const int isk = h >= nq;
-            bf16_t* d = dqkv + (long)r * ld + (long)h * dp;
-            float d1 = 0.f, d2 = 0.f;
-            if (on) { d1 = bf2f(d[lane]); d2 = bf2f(d[half + lane]); }
-            float n1 = d1 * c + d2 * s, n2 = d2 * c - d1 * s;                         // gradient of the normalised head
+            bf16_t* d = dqkv + (long)r * ld + (long)h * dp + 4 * sub;
+            float d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f}, n1[4], n2[4];
+            if (live) { ld4(d, d1); ld4(d + half, d2); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { n1[i] = d1[i] * c[i] + d2[i] * s[i]; n2[i] = d2[i] * c[i] - d1[i] * s[i]; }     // gradient of the normalised head
             if (use_norm) {
-                const bf16_t* xr = raw + (long)r * ld_raw + (long)h * dp;
-                const bf16_t* w = isk ? (ex ? kw1 : kw0) : (ex ? qw1 : qw0);
-                float x1 = 0.f, x2 = 0.f, w1_ = 0.f, w2_ = 0.f;
-                if (on) { x1 = bf2f(xr[lane]); x2 = bf2f(xr[half + lane]); w1_ = bf2f(w[lane]); w2_ = bf2f(w[half + lane]); }
-                const float rinv = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)hd + eps);
-                x1 *= rinv; x2 *= rinv;
-                n1 = bfround(n1); n2 = bfround(n2);                                   // the bf16 tensor between the two reverse ops
-                const float a1 = n1 * w1_, a2 = n2 * w2_;
-                const float dot = wave_sum(a1 * x1 + a2 * x2) / (float)hd;
-                dw[ex][isk][0] += n1 * bfround(x1);
-                dw[ex][isk][1] += n2 * bfround(x2);
-                n1 = rinv * (a1 - x1 * dot);
-                n2 = rinv * (a2 - x2 * dot);
+                const bf16_t* xr = raw + (long)r * ld_raw + (long)h * dp + 4 * sub;
+                const bf16_t* w = (isk ? (ex ? kw1 : kw0) : (ex ? qw1 : qw0)) + 4 * sub;
+                float x1[4] = {0.f, 0.f, 0.f, 0.f}, x2[4] = {0.f, 0.f, 0.f, 0.f}, w1_[4] = {0.f, 0.f, 0.f, 0.f}, w2_[4] = {0.f, 0.f, 0.f, 0.f};
+                if (live) { ld4(xr, x1); ld4(xr + half, x2); ld4(w, w1_); ld4(w + half, w2_); }
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ss += x1[i] * x1[i] + x2[i] * x2[i];
+                const float rinv = rsqrtf(sum16(ss) / (float)hd + eps);
+                float dot = 0.f, a1[4], a2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x1[i] *= rinv; x2[i] *= rinv;
+                    n1[i] = bfround(n1[i]); n2[i] = bfround(n2[i]);              // the bf16 tensor between the two reverse ops
+                    a1[i] = n1[i] * w1_[i]; a2[i] = n2[i] * w2_[i];
+                    dot += a1[i] * x1[i] + a2[i] * x2[i];
+                }
+                dot = sum16(dot) / (float)hd;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float g1 = n1[i] * bfround(x1[i]), g2 = n2[i] * bfround(x2[i]);
+                    if (ex) { if (isk) { dw[1][1][i] += g1; dw[1][1][4 + i] += g2; } else { dw[1][0][i] += g1; dw[1][0][4 + i] += g2; } }
+                    else    { if (isk) { dw[0][1][i] += g1; dw[0][1][4 + i] += g2; } else { dw[0][0][i] += g1; dw[0][0][4 + i] += g2; } }
+                    n1[i] = rinv * (a1[i] - x1[i] * dot);
+                    n2[i] = rinv * (a2[i] - x2[i] * dot);
+                }
             }
-            if (on) { d[lane] = f2bf(n1); d[half + lane] = f2bf(n2); }
+            if (live) {
+                u32x2_t o1 = {pack2bf(n1[0], n1[1]), pack2bf(n1[2], n1[3])}, o2 = {pack2bf(n2[0], n2[1]), pack2bf(n2[2], n2[3])};
+                *(u32x2_t*)d = o1;
+                *(u32x2_t*)(d + half) = o2;
+            }
         }
     }
     __syncthreads();
@@ -274,10 +317,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(bf16_t* __restrict
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                atomicAdd(&red[(e * 2 + k) * hd + lane], dw[e][k][0]);
-                atomicAdd(&red[(e * 2 + k) * hd + half + lane], dw[e][k][1]);
-            }
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    atomicAdd(&red[(e * 2 + k) * hd + 4 * sub + i], dw[e][k][i]);
+                    atomicAdd(&red[(e * 2 + k) * hd + half + 4 * sub + i], dw[e][k][4 + i]);
+                }
     }
     __syncthreads();
     float* p = partial + (long)blockIdx.x * 4 * hd;
@@ -290,7 +335,8 @@ extern "C" int bagel_qknorm_rope_bwd_bf16(void* dqkv, int64_t ld, const void* qk
                                           int32_t nkv, int32_t head_dim, int32_t head_dim_padded, float eps, int32_t use_norm,
                                           hipStream_t stream) {
     BAGEL_REQUIRE(dqkv && cos_tab && sin_tab && partial_ws, "qknorm_rope_bwd: null pointer");
-    BAGEL_REQUIRE(head_dim % 2 == 0 && head_dim <= 128 && head_dim_padded >= head_dim, "qknorm_rope_bwd: head_dim must be even, at most 128");
+    BAGEL_REQUIRE(head_dim % 8 == 0 && head_dim <= 128 && head_dim_padded >= head_dim && head_dim_padded % 4 == 0 && ld % 4 == 0 && ld_raw % 4 == 0,
+                  "qknorm_rope_bwd: head_dim must be a multiple of 8, at most 128");
     BAGEL_REQUIRE(!use_norm || (qkv_raw && q_w0 && k_w0 && dqw0 && dkw0), "qknorm_rope_bwd: use_norm needs the raw projection, the weights and dqw0 / dkw0");
     BAGEL_REQUIRE((q_w1 == nullptr) == (k_w1 == nullptr) && (!use_norm || ((q_w1 == nullptr) == (dqw1 == nullptr) && (k_w1 == nullptr) == (dkw1 == nullptr))),
                   "qknorm_rope_bwd: the second expert's weights and gradient outputs go together");

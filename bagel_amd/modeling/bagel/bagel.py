@@ -855,12 +855,10 @@ class Bagel(nn.Module):
             if any(p.requires_grad for p in te.parameters()):
                 inv = F_["temb_inv"]
                 nu = int(inv.max()) + 1
-                order = torch.argsort(inv, stable=True)
-                seg = torch.zeros(nu + 1, dtype=torch.int32)
-                seg[1:] = torch.cumsum(torch.bincount(inv, minlength=nu), 0).to(torch.int32)
-                i32 = lambda x: x.to(device=dev, dtype=torch.int32)  # noqa: E731
-                d_temb = torch.zeros((nu, H), dtype=BF16, device=dev)
-                ops.rows_segment_sum(d_lat, i32(order), i32(seg), i32(torch.arange(nu)), d_temb)
+                # one row per distinct timestep = the column sum over that image's latent tokens (thousands of rows: the two-stage
+                # column reduction, not the per-id gather reverse that sums a segment serially)
+                d_temb = torch.stack([ops.colsum(d_lat, torch.nonzero(inv == u, as_tuple=False).flatten().to(device=dev, dtype=torch.int32))
+                                      for u in range(nu)], dim=0)
                 sinus, th = F_["time_sinus"], F_["time_h"]
                 grads.add(te.mlp[2].weight, TS._wgrad(d_temb, th))
                 grads.add(te.mlp[2].bias, ops.colsum(d_temb))

@@ -486,8 +486,8 @@ def cross_entropy(logits, labels):
 
 
 # ---- training backward (the reverse kernels of backward.hip / attention_bwd.hip; chained by modeling/bagel/train_step.py) ----
-def _colsum_ws(rows, cols, device):
-    return torch.empty((-(-max(int(rows), 1) // 64) * int(cols),), dtype=torch.float32, device=device)
+def _colsum_ws(rows, cols, device, extra=0):
+    return torch.empty((-(-max(int(rows), 1) // 64) * int(cols) + int(extra),), dtype=torch.float32, device=device)
 
 
 def transpose(src, dst=None, rows=None, n=None):
@@ -514,7 +514,7 @@ def rmsnorm_bwd(x, dy, w0, g, eps, w1=None, expert=None, accumulate=True):
     rows, cols = x.shape
     dw0 = torch.empty((cols,), dtype=BF16, device=x.device)
     dw1 = torch.empty_like(dw0) if w1 is not None else None
-    ws = _colsum_ws(rows, 2 * cols, x.device)
+    ws = _colsum_ws(rows, 2 * cols, x.device, extra=rows)
     check(lib().bagel_rmsnorm_bwd_bf16(_ptr(x), _ld(x), _ptr(dy), _ld(dy), _ptr(w0), _ptr(w1), _ptr(expert if w1 is not None else None),
                                        _ptr(g), _ld(g), int(bool(accumulate)), _ptr(dw0), _ptr(dw1), _ptr(ws), rows, cols, float(eps),
                                        _stream()), "bagel_rmsnorm_bwd_bf16")

@@ -341,7 +341,7 @@ int bagel_transpose_bf16(const void* src, int64_t ld_src, const int32_t* src_row
 /* Reverse of bagel_rmsnorm_bf16 (Qwen2RMSNorm, modeling_qwen2.py:54-59): with xh = x * rsqrt(mean(x^2) + eps), w = the row's expert
  * weight:  dx = rsqrt(..) * (dy w - xh * mean(dy w xh));  g = bf16((accumulate ? g : 0) + bf16(dx));  dw_e[c] = sum over the rows of
  * expert e of dy * bf16(xh).  fp32 arithmetic; dw0 / dw1 bf16 [cols] (dw1 NULL without a second expert); partial_ws fp32, at least
- * BAGEL_COLSUM_WS_FLOATS(rows, 2 * cols) floats. */
+ * BAGEL_COLSUM_WS_FLOATS(rows, 2 * cols) + rows floats (the rows' rsqrt values are kept behind the partial sums). */
 #define BAGEL_COLSUM_WS_FLOATS(rows, cols) ((((int64_t)(rows) + 63) / 64) * (int64_t)(cols))   /* one partial row per 64 input rows */
 int bagel_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* w0, const void* w1,
                            const int32_t* expert_of_row, void* g, int64_t ldg, int32_t accumulate, void* dw0, void* dw1,
