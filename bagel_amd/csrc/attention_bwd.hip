@@ -21,8 +21,10 @@
 //
 // Algorithmic FLOPs per (query, key) pair and head: 2 D (scores for lse) + 6 D (dq pass) + 8 D (dkv pass) = 16 D, against 4 D of the
 // forward and 10 D of a fused flash backward: the price of two atomics-free kernels and of recomputing the row statistics instead of
-// changing the forward kernel's interface.  Tiles are staged global -> registers -> LDS with the loads of tile t + 1 issued before the
-// products of tile t (two barriers per tile; not yet the LDS-DMA ring of the forward); tiles that every row of the item sees completely
+// changing the forward kernel's interface (the training forward hands the statistics over: lse_from_forward).  Tiles are staged
+// global -> registers -> LDS (two barriers per tile; not yet the LDS-DMA ring of the forward): in the dkv kernel (one wave per SIMD,
+// its accumulators fill the register file) with the loads of step t + 1 issued before the products of step t, in the dq kernel with
+// two workgroups per CU covering each other's latencies; tiles that every row of the item sees completely
 // take a mask-free path; exponentials in base 2 with scale * log2(e) folded into one multiply (the lse workspace holds log2 values).
 #include "common.h"
 #include <stdlib.h>
@@ -127,8 +129,11 @@ __device__ __forceinline__ void ab_store_acc(bf16_t* out, long ld, int row, int 
         }
 }
 
+// Two waves per SIMD (two workgroups per CU: 223 registers, 2 x 52 KB of LDS): one workgroup's exponentials and tile staging run under the
+// other's products -- measured 4.28 -> 2.86 ms at the probe's shapes against the one-wave form with a register prefetch of the next tile
+// (profiles/r03_attn_bwd_ablations.log), so this kernel stages each tile global -> registers -> LDS right where it needs it.
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams p) {
     constexpr int KS = D / 16, DB = D / 32, RP = D + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = (bf16_t*)smem;                        // [64][RP]
@@ -188,13 +193,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     float mrun = -INFINITY, lrun = 0.f;
     if (!(AB_ABL & 1) && !p.have_lse) {
         AbRows<D> rk;
-        if (tfirst < t1) ab_load_rows<D>(rk, p.k, p.ldk, hkv * D, 64 * tfirst, p.rows, tid);
         for (int t = tfirst; t < t1;) {
+            if (!(AB_ABL & 4) || t == tfirst) ab_load_rows<D>(rk, p.k, p.ldk, hkv * D, 64 * t, p.rows, tid);
             if (!(AB_ABL & 8)) __syncthreads();
             if (!(AB_ABL & 16)) ab_store_rows<D>(Ks, rk, tid);
             if (!(AB_ABL & 8)) __syncthreads();
             const int tn = next_tile(t);
-            if (tn < t1 && !(AB_ABL & 4)) ab_load_rows<D>(rk, p.k, p.ldk, hkv * D, 64 * tn, p.rows, tid);
             if (wave_on) {
                 const unsigned long long nb = p.noise_bits[t];
                 const bool pl = plain(t, nb);
@@ -255,8 +259,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
             ab_load_rows<D>(rv, p.v, p.ldv, hkv * D, 64 * t, p.rows, tid);
             ab_load_t<D>(rt, p.kt, p.ld_t, hkv * D, 64 * t, tid);
         };
-        if (tfirst < t1) load(tfirst);
         for (int t = tfirst; t < t1;) {
+            if (!(AB_ABL & 4) || t == tfirst) load(t);
             if (!(AB_ABL & 8)) __syncthreads();
             if (!(AB_ABL & 16)) {
                 ab_store_rows<D>(Ks, rk, tid);
@@ -265,7 +269,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
             }
             if (!(AB_ABL & 8)) __syncthreads();
             const int tn = next_tile(t);
-            if (tn < t1 && !(AB_ABL & 4)) load(tn);
             if (wave_on) {
                 const unsigned long long nb = p.noise_bits[t];
                 const bool pl = plain(t, nb);

@@ -30,7 +30,8 @@ def main():
     q, k, v, o, do = rn(M, nq * D), rn(M, nkv * D), rn(M, nkv * D), rn(M, nq * D), rn(M, nq * D)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     bp = AttnBackwardPlan(DEV, lens, samples)
-    fn = lambda: ops.attn_bwd_blockmask(q, k, v, o, do, dq, dk, dv, bp.q_items, bp.k_items, bp.noise_bits, nq, nkv, D, D ** -0.5)  # noqa: E731
+    lse = torch.full((nq, M), 8.0, dtype=torch.float32, device=DEV) if os.environ.get("PROBE_LSE") else None     # timing only: any finite value
+    fn = lambda: ops.attn_bwd_blockmask(q, k, v, o, do, dq, dk, dv, bp.q_items, bp.k_items, bp.noise_bits, nq, nkv, D, D ** -0.5, lse=lse)  # noqa: E731
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
