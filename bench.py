@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-understanding", action="store_true", help="skip the configs[1] leg (ViT prefill + text decode)")
     ap.add_argument("--no-batched-decode", action="store_true", help="understanding leg: skip the extra 16-request batched decode")
     ap.add_argument("--no-train-forward", action="store_true", help="skip the extra training-forward (Bagel.forward, losses only) measurement")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step leg (forward with tape + backward) inside training_forward")
     ap.add_argument("--no-int8", action="store_true", help="understanding leg: skip the extra weight_quant='int8' / 'mxfp4' decodes")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra gen_weight_quant='fp8' measurement")
     ap.add_argument("--no-edit", action="store_true", help="skip the extra configs[4] measurement (one image-edit request per GPU)")
@@ -1066,7 +1067,48 @@ def main():
             ntok = tb["sequence_length"]
             trainf = {"value": world * ntok / dtt, "unit": "tokens/s", "tokens_per_forward": ntok, "ms_per_forward": dtt * 1e3,
                       "linear_tflops": 13.0506e-3 * ntok / dtt, "outputs_finite": bool(torch.isfinite(o_["ce"]).all() and torch.isfinite(o_["mse"]).all()),
-                      "note": "training FORWARD only (losses; no backward pass exists in this repository): beside the headline, never as it"}
+                      "note": "training FORWARD only (losses, no tape): beside the headline, never as it"}
+            if not args.no_train_step:
+                # the whole step of train/pretrain_unified_navit.py:683-735 minus the optimizer: forward with a tape + loss.backward() through
+                # the hand-written reverse (bagel_amd/modeling/bagel/train_step.py), every language-model / connector / head parameter trainable,
+                # SigLIP frozen (--freeze_vit True); gradients of 14.2 G parameters are produced and dropped
+                frozen = ("vit_model.", "vit_pos_embed.", "latent_pos_embed.")
+                try:
+                    n_train = 0
+                    for n_, p_ in model.named_parameters():
+                        p_.requires_grad_(not n_.startswith(frozen))
+                        n_train += p_.numel() if p_.requires_grad else 0
+
+                    def one_train_step():
+                        for p_ in model.parameters():
+                            p_.grad = None
+                        fence(); a0 = time.perf_counter()
+                        with torch.enable_grad():
+                            oo = model(noise=tn, **tb)
+                            loss = oo["ce"].mean() + oo["mse"].mean()
+                        fence(); a1 = time.perf_counter()
+                        loss.backward()
+                        fence(); a2 = time.perf_counter()
+                        return float(loss.detach()), a1 - a0, a2 - a1
+                    one_train_step()
+                    rs = [one_train_step() for _ in range(2)]
+                    tf_, tb_ = sum(r[1] for r in rs) / 2, sum(r[2] for r in rs) / 2
+                    gn = sum(float(p_.grad.float().norm()) ** 2 for p_ in model.parameters() if p_.grad is not None) ** 0.5
+                    lin = 13.0506e-3 * ntok                                   # TFLOP of the decoder's linears in one forward
+                    trainf["training_step"] = {
+                        "value": world * ntok / (tf_ + tb_), "unit": "tokens/s", "ms_forward_with_tape": tf_ * 1e3, "ms_backward": tb_ * 1e3,
+                        "trainable_params": n_train, "loss": rs[-1][0], "grad_norm": gn, "finite": bool(gn == gn and gn < float("inf")),
+                        "linear_tflops_whole_step": 3 * lin / (tf_ + tb_), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                        "note": "forward with tape + backward, no optimizer step (the optimizer is torch's, out of scope); 3 x the forward's linear "
+                                "FLOPs over the step time (the gate/up recompute and the attention reverse are not counted as useful work)"}
+                except Exception as e:
+                    import traceback
+                    trainf["training_step"] = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
+                finally:
+                    for p_ in model.parameters():
+                        p_.requires_grad_(False)
+                        p_.grad = None
+                    torch.cuda.empty_cache()
             del tb, tn, o_
         except Exception as e:
             import traceback

@@ -196,6 +196,24 @@ def test_training_forward_matches_reference(golden, name):
         assert torch.equal(O.attention_mask_per_sample(lens, modes), m)
 
 
+def test_training_backward_matches_reference(golden):
+    """``loss.backward()`` of the unmodified reference (train/pretrain_unified_navit.py:683-735) vs torch autograd over the oracle's
+    restated forward: every parameter gradient of the tiny model (111 tensors, ViT included) -- bit for bit on the fixture host, within
+    the cross-host bf16 spread elsewhere (gradients pass through ~4 bf16 roundings per layer, twice: 3e-2)."""
+    cfg = CFGS["tiny"]
+    g, fx = golden("tiny_train"), golden("tiny_train_grads")
+    W, _ = oracle_weights(cfg)
+    loss, grads, _ = O.training_step_grads(W, cfg, g["batch"], g["noise"], fx["ce_loss_weights"], names=set(fx["grads"]))
+    assert abs(loss - fx["loss"]) <= 1e-2 * abs(fx["loss"])
+    assert set(grads) == set(fx["grads"]) and len(grads) == 111
+    for k, ref in fx["grads"].items():
+        if float(ref.float().norm()) == 0.0:
+            assert float(grads[k].float().norm()) == 0.0, k
+        else:
+            same(grads[k], ref, 3e-2, f"grad {k}")
+    assert not O.GRAD_ENABLED, "the gradient oracle must leave the forward oracle graph-free"
+
+
 @pytest.mark.parametrize("name", ["tiny_dense", "tiny_moe"])
 def test_dense_and_moe_layer_kinds_match_reference(golden, name):
     """Decoder_layer_dict alternates (qwen2_navit.py:936-940): Qwen2DecoderLayer and Qwen2MoEDecoderLayer, bit-exact."""
