@@ -382,6 +382,33 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(bf16_t* __restrict__ gu
     *(u32x4_t*)(gp + 16) = ou;
 }
 
+// The SwiGLU16 epilogue as a kernel of its own: act = bf16(bf16(silu(g)) * u) from the STORED bf16 gate/up projection -- bit-identical to
+// the fused epilogue of bagel_gemm_bf16 (which rounds the accumulators to bf16 before the activation).  The training forward uses it when
+// the tape keeps the un-activated projection (288 GB: 76 KB per token and layer) instead of recomputing it in the backward.
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, long ld, bf16_t* __restrict__ act, long ld_a, long rows, int inter) {
+    const int nch = inter >> 3;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * nch) return;
+    const long r = i / nch;
+    const int a0 = (int)(i - r * nch) * 8;
+    const bf16_t* gp = gu + r * ld + (a0 >> 4) * 32 + (a0 & 15);
+    const u32x4_t gv = *(const u32x4_t*)gp, uv = *(const u32x4_t*)(gp + 16);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        o[e] = pack2bf(bfround(silu_f(lo2f(gv[e]))) * lo2f(uv[e]), bfround(silu_f(hi2f(gv[e]))) * hi2f(uv[e]));
+    *(u32x4_t*)(act + r * ld_a + a0) = o;
+}
+
+extern "C" int bagel_swiglu_fwd_bf16(const void* gu, int64_t ld, void* act, int64_t ld_act, int64_t rows, int32_t inter, hipStream_t stream) {
+    BAGEL_REQUIRE(gu && act, "swiglu_fwd: null pointer");
+    BAGEL_REQUIRE(inter % 16 == 0 && ld % 8 == 0 && ld_act % 8 == 0, "swiglu_fwd: the intermediate size must be a multiple of 16");
+    if (rows <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ceil_div(rows * (inter / 8), 256)), dim3(256), 0, stream, (const bf16_t*)gu, (long)ld, (bf16_t*)act,
+                       (long)ld_act, (long)rows, inter);
+    return bagel_check_launch("swiglu_fwd_kernel");
+}
+
 extern "C" int bagel_swiglu_bwd_bf16(void* gu, int64_t ld, const void* d_act, int64_t ld_d, int64_t rows, int32_t inter, hipStream_t stream) {
     BAGEL_REQUIRE(gu && d_act, "swiglu_bwd: null pointer");
     BAGEL_REQUIRE(inter % 16 == 0 && ld % 8 == 0 && ld_d % 8 == 0, "swiglu_bwd: the intermediate size must be a multiple of 16");

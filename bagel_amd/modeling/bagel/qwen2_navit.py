@@ -652,7 +652,7 @@ def interleave_gate_up(gate, up):
 
 
 class _PackedLayer:
-    __slots__ = ("wqkv", "bqkv", "wo", "wgu", "wd", "qn", "kn", "ln_in", "ln_post")
+    __slots__ = ("wqkv", "bqkv", "wo", "wgu", "wd", "qn", "kn", "ln_in", "ln_post", "wt")    # wt: transposed images for the training backward
 
 
 class MoTEngine:
@@ -688,6 +688,7 @@ class MoTEngine:
         a = L.self_attn
         P = _PackedLayer()
         P.wqkv, P.bqkv, P.wo, P.wgu, P.wd, P.qn, P.kn, P.ln_in, P.ln_post = [], [], [], [], [], [], [], [], []
+        P.wt = {}
         attn_sufs = ("", "_moe_gen") if self.mot else ("",)
         for s in attn_sufs:
             q, k, v, o = (getattr(a, n + s) for n in ("q_proj", "k_proj", "v_proj", "o_proj"))
@@ -931,11 +932,15 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
     k_clean = torch.zeros((_ceil_to(tp.n_clean + 64, 64), kw_), dtype=BF16, device=dev)
     v_clean = torch.zeros_like(k_clean)
     vt_clean = torch.zeros((kw_, _ceil_to(max(tp.vt_clean_cols, 1), 256)), dtype=BF16, device=dev)
-    x.copy_(seq)
-    q_v, k_v, v_v = qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
     if tape is not None:
         tape.tp = tp
+        tape.decide_gate_up(dev, len(self.layers), M, self.I)
+        tape.begin(self, (M, tape.keep_gate_up))
+        tb = lambda name, li, *shape, dtype=BF16: tape.buf(name, li, *shape, dtype=dtype, device=dev)  # noqa: E731
+        x = tb("x", 0, M, self.H)
         tape.x.append(x)
+    x.copy_(seq)
+    q_v, k_v, v_v = qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
     two = tp.n_vae > 0
     expert = tp.expert if two else None
     scale = hd ** -0.5
@@ -949,8 +954,10 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
     for P in self.layers:
         x_mid, x_out = x, x                                   # in place without a tape
         if tape is not None:
-            raw, att, act, x_mid, x_out = e(M, qw + 2 * kw_), e(M, qw), e(M, self.I), e(M, self.H), e(M, self.H)
-            lse = torch.empty((nq, M), dtype=torch.float32, device=dev)
+            li = len(tape.x_mid)
+            raw, att, act, x_mid, x_out = (tb("raw", li, M, qw + 2 * kw_), tb("att", li, M, qw), tb("act", li, M, self.I), tb("x_mid", li, M, self.H),
+                                           tb("x", li + 1, M, self.H))
+            lse = tb("lse", li, nq, M, dtype=torch.float32)
             tape.qkv_raw.append(raw); tape.att.append(att); tape.act.append(act); tape.x_mid.append(x_mid); tape.x.append(x_out); tape.lse.append(lse)
         ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if two else None, expert=expert)
         if tape is not None:
@@ -972,7 +979,13 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
                                    lse=lse if tape is not None else None)
         ops.gemm(att, C=x_mid, residual=x, **groups(P.wo))
         ops.rmsnorm(x_mid, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if two else None, expert=expert)
-        ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu))
+        if tape is not None and tape.keep_gate_up:
+            gu = tb("gu", len(tape.gu), M, 2 * self.I)        # the tape keeps the un-activated projection: no recompute in the backward
+            tape.gu.append(gu)
+            ops.gemm(h, C=gu, **groups(P.wgu))
+            ops.swiglu_fwd(gu, act)                           # same bits as the fused epilogue
+        else:
+            ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu))
         ops.gemm(act, C=x_out, residual=x_mid, **groups(P.wd))
         x = x_out
     out = torch.empty_like(x)

@@ -20,12 +20,23 @@ MI355X-first choices:
 Scope: gradients of every parameter of the language model (both experts, embeddings, norms, lm_head), llm2vae / vae2llm / the time
 embedder and the ViT connector; the SigLIP tower and the VAE are frozen (``--freeze_vit True --freeze_vae True`` of
 pretrain_unified_navit.py:382-393) -- a ViT parameter that requires grad raises instead of silently staying without a gradient."""
+import os
+
 import numpy as np
 import torch
 
 from ... import ops
 
 BF16 = torch.bfloat16
+
+# Two memory-for-time switches of the backward, both sized for 288 GB of HBM:
+#   KEEP_GATE_UP  the tape keeps the un-activated gate/up projection (76 KB per token and layer) and the forward applies SwiGLU as a
+#                 kernel of its own, instead of recomputing the largest GEMM of the layer in the backward (3.8 of 31 ms per layer at
+#                 18 k tokens).  "auto": when the projections of all layers fit a third of the memory that is free when the tape starts.
+#   CACHE_WT      the transposed weight images (the B operands of dX = dY W) stay with the packed layer until the parameters change
+#                 (the engine is re-packed then): +2 bytes per parameter, -2 ms per layer for every micro-step after the first.
+KEEP_GATE_UP = {"0": False, "1": True}.get(os.environ.get("BAGEL_TRAIN_KEEP_GATE_UP", ""), "auto")
+CACHE_WT = os.environ.get("BAGEL_TRAIN_CACHE_WT", "1") != "0"
 
 
 def _ceil_to(x, m):
@@ -78,7 +89,46 @@ class TrainTape:
         self.att = []           # attention output (o_proj input)
         self.act = []           # SwiGLU output (down_proj input)
         self.lse = []           # log2 softmax denominators of the attention rows, fp32 [nq, M] (112 bytes per token and layer)
+        self.gu = []            # un-activated gate/up projection, only with keep_gate_up (else recomputed in the backward)
+        self.keep_gate_up = False
         self.front = {}         # embedding / ViT / latent front end and the loss heads (Bagel._forward_losses)
+        self._store, self._pool, self._key = {}, None, None
+
+    # The tape's buffers are RESIDENT: a step takes the buffer set of its shape from the engine's pool and hands it back when its backward
+    # has run, so step after step reuses the same 35-75 GB instead of sending 150+ multi-GB requests through the allocator (a fresh
+    # hipMalloc of 1.4 GB is milliseconds).  A forward that starts while another tape is still alive simply gets a set of its own.
+    def begin(self, eng, key):
+        self._pool = eng.__dict__.setdefault("_tape_pool", {})
+        self._key = key
+        sets = self._pool.get(key)
+        self._store = sets.pop() if sets else {}
+
+    def buf(self, name, li, *shape, dtype=BF16, device=None):
+        t = self._store.get((name, li))
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = self._store[(name, li)] = torch.empty(shape, dtype=dtype, device=device)
+        return t
+
+    def release(self):
+        if self._pool is not None and self._store:
+            sets = self._pool.setdefault(self._key, [])
+            if len(sets) < 2:
+                sets.append(self._store)
+        self._store, self._pool = {}, None
+
+
+def _decide_gate_up(self, device, n_layers, M, inter):
+    if KEEP_GATE_UP != "auto":
+        self.keep_gate_up = bool(KEEP_GATE_UP)
+    elif torch.device(device).type != "cuda":
+        self.keep_gate_up = False
+    else:
+        free, _ = torch.cuda.mem_get_info(device)
+        free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # what torch's allocator can hand out again
+        self.keep_gate_up = n_layers * M * 2 * inter * 2 <= free // 3
+
+
+TrainTape.decide_gate_up = _decide_gate_up
 
 
 def _wt(W):
@@ -154,8 +204,13 @@ def engine_backward_train(eng, tape, g, grads):
     def wgrads(dY, X):
         return [_wgrad(dY, X, rows, n) for rows, n in sel]
 
-    def wts(ws):
-        return [_wt(w) for w in ws[:len(sel)]]
+    def wts(P, name):
+        ws = getattr(P, name)[:len(sel)]
+        if not CACHE_WT:
+            return [_wt(w) for w in ws]
+        if name not in P.wt or len(P.wt[name]) < len(ws):
+            P.wt[name] = [_wt(w) for w in ws]
+        return P.wt[name]
 
     bplan = AttnBackwardPlan(dev, tp.sample_lens, tp.sample_splits)
     m = eng.model
@@ -173,20 +228,23 @@ def engine_backward_train(eng, tape, g, grads):
         x_in, x_mid, act, att, qkv_raw = tape.x[li], tape.x_mid[li], tape.act[li], tape.att[li], tape.qkv_raw[li]
         # ---- MLP block: x_out = x_mid + down(swiglu(gate_up(rmsnorm(x_mid))))   (qwen2_navit.py:744-753)
         d_act = e(M, I)
-        ops.gemm(g, C=d_act, **groups(wts(P.wd)))
+        ops.gemm(g, C=d_act, **groups(wts(P, "wd")))
         dWd = wgrads(g, act)
         ops.rmsnorm(x_mid, P.ln_post[0], h, eng.eps, w1=P.ln_post[1] if two else None, expert=expert)
-        gu = e(M, 2 * I)
-        ops.gemm(h, C=gu, **groups(P.wgu))                       # the un-activated projection, recomputed
+        if tape.gu:
+            gu, tape.gu[li] = tape.gu[li], None                  # kept by the forward; consumed (overwritten with its gradient) here
+        else:
+            gu = e(M, 2 * I)
+            ops.gemm(h, C=gu, **groups(P.wgu))                   # the un-activated projection, recomputed
         ops.swiglu_bwd(gu, d_act)
         del d_act
         dWgu = wgrads(gu, h)
-        ops.gemm(gu, C=d_h, **groups(wts(P.wgu)))
+        ops.gemm(gu, C=d_h, **groups(wts(P, "wgu")))
         del gu
         dpost = ops.rmsnorm_bwd(x_mid, d_h, P.ln_post[0], g, eng.eps, w1=P.ln_post[1] if two else None, expert=expert)
         # ---- attention block: x_mid = x_in + o(attn(rope(qknorm(qkv(rmsnorm(x_in))))))   (qwen2_navit.py:406-497, 713-743)
         d_att = e(M, qw)
-        ops.gemm(g, C=d_att, **groups(wts(P.wo)))
+        ops.gemm(g, C=d_att, **groups(wts(P, "wo")))
         dWo = wgrads(g, att)
         qkv = qkv_raw.clone()
         ops.qknorm_rope(qkv, tp.cos, tp.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
@@ -202,7 +260,7 @@ def engine_backward_train(eng, tape, g, grads):
         ops.rmsnorm(x_in, P.ln_in[0], h, eng.eps, w1=P.ln_in[1] if two else None, expert=expert)
         dWqkv = wgrads(dqkv, h)
         dbqkv = [ops.colsum(dqkv, rows, n) for rows, n in sel]
-        ops.gemm(dqkv, C=d_h, **groups(wts(P.wqkv)))
+        ops.gemm(dqkv, C=d_h, **groups(wts(P, "wqkv")))
         del dqkv
         din = ops.rmsnorm_bwd(x_in, d_h, P.ln_in[0], g, eng.eps, w1=P.ln_in[1] if two else None, expert=expert)
         # ---- unpack the MI355X layouts into the reference's parameter shapes
@@ -248,5 +306,6 @@ class PackedTrainStep(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("the tape of this training step was already consumed (backward runs once per forward)")
         grads = ctx.model._backward_losses(ctx.tape, d_mse if ctx.has[0] else None, d_ce if ctx.has[1] else None)
+        ctx.tape.release()
         ctx.tape = None
         return (None, None) + tuple(grads.get(p) for p in ctx.params)

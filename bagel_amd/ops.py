@@ -545,6 +545,15 @@ def swiglu_bwd(gu, d_act):
     return gu
 
 
+def swiglu_fwd(gu, act):
+    """act [rows, I] = SwiGLU of the stored un-activated projection gu [rows, 2 I] (bit-identical to the EPI_SWIGLU16 epilogue)."""
+    _req(gu, BF16, "swiglu_fwd.gu"); _req(act, BF16, "swiglu_fwd.act")
+    if gu.shape[1] != 2 * act.shape[1] or gu.shape[0] != act.shape[0]:
+        raise BagelHipError("swiglu_fwd: gu must be [rows, 2 * I] for act [rows, I]")
+    check(lib().bagel_swiglu_fwd_bf16(_ptr(gu), _ld(gu), _ptr(act), _ld(act), gu.shape[0], act.shape[1], _stream()), "bagel_swiglu_fwd_bf16")
+    return act
+
+
 def act_bwd(pre, d_out, kind):
     """pre <- d_out * act'(pre) for the GELU-tanh / SiLU epilogues (kind = EPI_GELU_TANH / EPI_SILU)."""
     _req(pre, BF16, "act_bwd.pre"); _req(d_out, BF16, "act_bwd.d_out")

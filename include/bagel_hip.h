@@ -358,6 +358,9 @@ int bagel_qknorm_rope_bwd_bf16(void* dqkv, int64_t ld, const void* qkv_raw, int6
 /* Reverse of the SwiGLU16 epilogue (Qwen2MLP, modeling_qwen2.py:201): gu = the un-activated gate/up projection in the interleaved
  * [16 gate | 16 up] column layout, overwritten with its gradient: d_up = d_act * bf16(silu(g)), d_gate = d_act * u * silu'(g). */
 int bagel_swiglu_bwd_bf16(void* gu, int64_t ld, const void* d_act, int64_t ld_d, int64_t rows, int32_t inter, bagel_stream_t stream);
+/* The SwiGLU16 epilogue as a kernel of its own, act = bf16(bf16(silu(g)) * u) from the stored bf16 projection: bit-identical to the fused
+ * epilogue; used when the training tape keeps the un-activated gate/up projection instead of recomputing it in the backward. */
+int bagel_swiglu_fwd_bf16(const void* gu, int64_t ld, void* act, int64_t ld_act, int64_t rows, int32_t inter, bagel_stream_t stream);
 /* Reverse of the GELU-tanh (kind 1) / SiLU (kind 2) epilogues: pre = the un-activated projection, overwritten with d_out * act'(pre). */
 int bagel_act_bwd_bf16(void* pre, int64_t ld, const void* d_out, int64_t ld_d, int64_t rows, int32_t cols, int32_t kind,
                        bagel_stream_t stream);

@@ -493,6 +493,13 @@ def swiglu_bwd(gu, d_act):
     return gu
 
 
+def swiglu_fwd(gu, act):
+    M, I = act.shape
+    v = gu.view(M, I // 16, 2, 16)
+    act.copy_(_bf(_bf(F.silu(v[:, :, 0].float())).float() * v[:, :, 1].float()).reshape(M, I))
+    return act
+
+
 def act_bwd(pre, d_out, kind):
     x = pre.float().requires_grad_(True)
     with torch.enable_grad():
@@ -676,7 +683,7 @@ _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "
           "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
           "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
-          "act_bwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]
+          "act_bwd", "swiglu_fwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]
 
 
 def install(monkeypatch):

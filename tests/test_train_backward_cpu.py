@@ -129,6 +129,43 @@ def test_training_step_gradients_on_random_batches(monkeypatch, seed):
     compare(grads, rgrads, names, 8e-2, (seed, samples))
 
 
+def test_tape_options_do_not_change_the_gradients(golden, monkeypatch):
+    """KEEP_GATE_UP (the tape keeps the un-activated gate/up projection instead of recomputing it) and CACHE_WT (transposed weight images
+    kept with the packed layer across micro-steps): same gradients bit for bit in every combination, also on the second micro-step (cached
+    images) and after a parameter update (the images must be rebuilt with the re-packed engine)."""
+    from bagel_amd.modeling.bagel import train_step as TS
+    mock_ops.install(monkeypatch)
+    g = golden("tiny_train")
+    w_ce = torch.rand(g["ce"].shape[0], generator=torch.Generator().manual_seed(5)) + 0.5
+    model = cpu_model(TINY)
+    names = trainable(model)
+    ref = None
+    for keep, cache in ((False, False), (True, False), (False, True), (True, True)):
+        monkeypatch.setattr(TS, "KEEP_GATE_UP", keep)
+        monkeypatch.setattr(TS, "CACHE_WT", cache)
+        for _ in range(2):
+            _, grads, _ = product_step(model, g["batch"], g["noise"], w_ce)
+            if ref is None:
+                ref = grads
+            for n in names:
+                if n in ref:
+                    assert torch.equal(grads[n], ref[n]), (keep, cache, n)
+    # an optimizer-like in-place update: the engine re-packs, the cached images follow
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.requires_grad:
+                p.mul_(1.01)
+    _, g1, _ = product_step(model, g["batch"], g["noise"], w_ce)
+    monkeypatch.setattr(TS, "CACHE_WT", False)
+    _, g2, _ = product_step(model, g["batch"], g["noise"], w_ce)
+    changed = 0
+    for n in names:
+        if n in g1:
+            assert torch.equal(g1[n], g2[n]), n
+            changed += int(not torch.equal(g1[n], ref[n]))
+    assert changed > len(names) // 2
+
+
 def test_frozen_and_no_grad_paths(golden, monkeypatch):
     """No tape without grad mode or without a trainable parameter; a ViT parameter that requires grad is refused; only the parameters
     that require grad receive one."""

@@ -120,6 +120,19 @@ def test_elementwise_reverse_kernels():
     assert rel(got, M.mse_rows_bwd(pred, noise, clean, src, dl)) < 4e-3
 
 
+def test_swiglu_kernel_equals_the_fused_epilogue():
+    """gemm (plain) + swiglu_fwd == gemm with the SwiGLU16 epilogue, bit for bit (the tape's KEEP_GATE_UP path)."""
+    o = ops()
+    Mr, K, I = 300, 512, 1024
+    A, W = rnd(Mr, K, seed=1), rnd(2 * I, K, seed=2, scale=K ** -0.5)
+    fused = torch.empty(Mr, I, dtype=BF16, device=DEV)
+    o.gemm(A.to(DEV), W.to(DEV), fused, epilogue=o.EPI_SWIGLU16)
+    gu = torch.empty(Mr, 2 * I, dtype=BF16, device=DEV)
+    o.gemm(A.to(DEV), W.to(DEV), gu)
+    act = o.swiglu_fwd(gu, torch.empty_like(fused))
+    assert torch.equal(act.view(torch.int16), fused.view(torch.int16))
+
+
 def test_segment_sum_and_colsum():
     o = ops()
     src = rnd(500, 256, seed=1)
@@ -260,9 +273,12 @@ def _compare(grads, ref, names, tol, what):
     return worst
 
 
+@pytest.mark.parametrize("keep_gate_up", [False, True], ids=["recompute_gate_up", "keep_gate_up"])
 @pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
-def test_training_step_gradients_match_the_oracle(golden, name):
+def test_training_step_gradients_match_the_oracle(golden, monkeypatch, name, keep_gate_up):
+    from bagel_amd.modeling.bagel import train_step as TS
     from oracle import bagel_oracle as O
+    monkeypatch.setattr(TS, "KEEP_GATE_UP", keep_gate_up)
     from oracle.configs import TINY, TINY_D128
     from tests.util_models import oracle_weights, product_model
     cfg = {"tiny": TINY, "tiny_d128": TINY_D128}[name]
