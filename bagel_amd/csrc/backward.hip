@@ -6,6 +6,7 @@
 //   bagel_transpose_bf16          dst[c][j] = src[rows[j]][c]: 64 x 64 tiles through LDS, 16-byte loads and stores on both sides
 //   bagel_rmsnorm_bwd_bf16        Qwen2RMSNorm reverse + residual-gradient add, per-expert weight gradients (64-row partial sums,
 //                                 then a column pass: deterministic, no atomics in HBM)
+//   bagel_layernorm_bwd_bf16      nn.LayerNorm reverse (SigLIP), same two passes, weight and bias gradients
 //   bagel_qknorm_rope_bwd_bf16    inverse rotation + per-head RMSNorm reverse on the [q | k | v] gradient rows, q_norm / k_norm gradients
 //   bagel_swiglu_bwd_bf16         SiLU-gate reverse in the interleaved [16 gate | 16 up] layout of the fused gate/up GEMM
 //   bagel_act_bwd_bf16            GELU-tanh / SiLU reverse (connector, time embedder)
@@ -227,6 +228,120 @@ extern "C" int bagel_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* dy
         if (int rc = bagel_check_launch("rmsnorm_bwd_cols_kernel")) return rc;
     }
     return colsum_finish(partial_ws, nblk, 2 * cols, cols, (bf16_t*)dw0, (bf16_t*)dw1, nullptr, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// nn.LayerNorm reverse (SigLIP, siglip_navit.py:266-269,342: y = bf16((x - mean) * rsqrt(var + eps) * w + b), fp32 statistics), the
+// same two deterministic passes as the RMSNorm reverse: rows -> dx (+ residual gradient), mean and rsqrt to a side buffer;
+// columns -> dw[c] = sum dy * xh, db[c] = sum dy (partial layout [block][dw | db]).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(512) void layernorm_bwd_rows_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
+                                                                 const bf16_t* __restrict__ w, bf16_t* __restrict__ g, long ldg, int accumulate,
+                                                                 float* __restrict__ stats, int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = cols >> 3;
+    const int r0 = blockIdx.x * 64 + wave * 8;
+    for (int r = r0; r < min(r0 + 8, rows); ++r) {
+        float xv[NV][8], dv[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = lane + 64 * v;
+            u32x4_t a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u}, ww = {0u, 0u, 0u, 0u};
+            if (c < nch) {
+                a = *(const u32x4_t*)(x + (long)r * ldx + c * 8);
+                b = *(const u32x4_t*)(dy + (long)r * lddy + c * 8);
+                ww = *(const u32x4_t*)(w + c * 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[v][2 * e] = lo2f(a[e]); xv[v][2 * e + 1] = hi2f(a[e]);
+                dv[v][2 * e] = lo2f(b[e]) * lo2f(ww[e]); dv[v][2 * e + 1] = hi2f(b[e]) * hi2f(ww[e]);      // dy * w
+                s += xv[v][2 * e] + xv[v][2 * e + 1];
+            }
+        }
+        const float mean = wave_sum(s) / (float)cols;
+        float ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bool on = lane + 64 * v < nch;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { xv[v][i] = on ? xv[v][i] - mean : 0.f; ss += xv[v][i] * xv[v][i]; }
+        }
+        const float rinv = rsqrtf(wave_sum(ss) / (float)cols + eps);
+        if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rinv; }
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { xv[v][i] *= rinv; d1 += dv[v][i]; d2 += dv[v][i] * xv[v][i]; }
+        d1 = wave_sum(d1) / (float)cols;
+        d2 = wave_sum(d2) / (float)cols;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = lane + 64 * v;
+            if (c >= nch) continue;
+            u32x4_t gin = {0u, 0u, 0u, 0u};
+            if (accumulate) gin = *(const u32x4_t*)(g + (long)r * ldg + c * 8);
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dx0 = rinv * (dv[v][2 * e] - d1 - xv[v][2 * e] * d2), dx1 = rinv * (dv[v][2 * e + 1] - d1 - xv[v][2 * e + 1] * d2);
+                o[e] = pack2bf(lo2f(gin[e]) + bfround(dx0), hi2f(gin[e]) + bfround(dx1));
+            }
+            *(u32x4_t*)(g + (long)r * ldg + c * 8) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
+                                                                 const float* __restrict__ stats, float* __restrict__ partial, int rows, int cols) {
+    const int ch = blockIdx.y * 256 + threadIdx.x;
+    if (ch * 8 >= cols) return;
+    const int r0 = blockIdx.x * 64, r1 = min(r0 + 64, rows);
+    float dw[8], db[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dw[i] = 0.f; db[i] = 0.f; }
+    for (int r = r0; r < r1; ++r) {
+        const float mean = stats[2 * r], ri = stats[2 * r + 1];
+        const u32x4_t a = *(const u32x4_t*)(x + (long)r * ldx + ch * 8), b = *(const u32x4_t*)(dy + (long)r * lddy + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y0 = lo2f(b[e]), y1 = hi2f(b[e]);
+            dw[2 * e] += y0 * ((lo2f(a[e]) - mean) * ri); dw[2 * e + 1] += y1 * ((hi2f(a[e]) - mean) * ri);
+            db[2 * e] += y0; db[2 * e + 1] += y1;
+        }
+    }
+    float* p = partial + (long)blockIdx.x * 2 * cols + ch * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { p[i] = dw[i]; p[cols + i] = db[i]; }
+}
+
+extern "C" int bagel_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* w, void* g, int64_t ldg,
+                                        int32_t accumulate, void* dw, void* db, float* partial_ws, int32_t rows, int32_t cols, float eps,
+                                        hipStream_t stream) {
+    BAGEL_REQUIRE(x && dy && w && g && dw && db && partial_ws, "layernorm_bwd: null pointer");
+    BAGEL_REQUIRE(cols % 8 == 0 && cols > 0 && cols <= 4096, "layernorm_bwd: cols must be a multiple of 8, at most 4096");
+    BAGEL_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && ldg % 8 == 0, "layernorm_bwd: leading dimensions must be multiples of 8");
+    const int nblk = max(ceil_div(rows, 64), 0);
+    if (nblk > 0) {
+        float* stats = partial_ws + (long)nblk * 2 * cols;           // (mean, rsqrt) per row, behind the partial sums
+        const int nv = ceil_div(cols / 8, 64);
+#define BAGEL_LNBWD(NV)                                                                                                                    \
+        hipLaunchKernelGGL(layernorm_bwd_rows_kernel<NV>, dim3(nblk), dim3(512), 0, stream, (const bf16_t*)x, (long)ldx, (const bf16_t*)dy,  \
+                           (long)lddy, (const bf16_t*)w, (bf16_t*)g, (long)ldg, (int)accumulate, stats, rows, cols, eps)
+        if (nv <= 1) BAGEL_LNBWD(1);
+        else if (nv <= 2) BAGEL_LNBWD(2);
+        else if (nv <= 4) BAGEL_LNBWD(4);
+        else BAGEL_LNBWD(8);
+#undef BAGEL_LNBWD
+        if (int rc = bagel_check_launch("layernorm_bwd_rows_kernel")) return rc;
+        hipLaunchKernelGGL(layernorm_bwd_cols_kernel, dim3(nblk, ceil_div(cols / 8, 256)), dim3(256), 0, stream, (const bf16_t*)x, (long)ldx,
+                           (const bf16_t*)dy, (long)lddy, stats, partial_ws, rows, cols);
+        if (int rc = bagel_check_launch("layernorm_bwd_cols_kernel")) return rc;
+    }
+    return colsum_finish(partial_ws, nblk, 2 * cols, cols, (bf16_t*)dw, (bf16_t*)db, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

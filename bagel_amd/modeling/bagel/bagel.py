@@ -649,7 +649,7 @@ class Bagel(nn.Module):
         t = torch.as_tensor(index_or_mask)
         return torch.nonzero(t, as_tuple=False).flatten() if t.dtype == torch.bool else t.to(torch.long)
 
-    _TRAINABLE_PREFIXES = ("language_model.", "llm2vae.", "vae2llm.", "time_embedder.", "connector.")
+    _TRAINABLE_PREFIXES = ("language_model.", "llm2vae.", "vae2llm.", "time_embedder.", "connector.", "vit_model.")
 
     @_bf16_weights
     def forward(self, sequence_length, packed_text_ids, packed_text_indexes, sample_lens, packed_position_ids,
@@ -682,8 +682,8 @@ class Bagel(nn.Module):
         bad = [n for n, _ in named if not n.startswith(self._TRAINABLE_PREFIXES)]
         if bad:
             raise NotImplementedError(
-                "the backward is built for the language model, llm2vae / vae2llm, the time embedder and the connector; freeze the rest "
-                f"(pretrain_unified_navit.py --freeze_vit True; the position tables are frozen in the reference too): {bad[:4]}")
+                "the backward is built for the language model, llm2vae / vae2llm, the time embedder, the connector and the SigLIP tower; "
+                f"freeze the rest (the sin-cos position tables are frozen in the reference too): {bad[:4]}")
         from .train_step import PackedTrainStep
         mse, ce = PackedTrainStep.apply(self, kw, *[p for _, p in named])
         has_mse = bool(self.config.visual_gen) and padded_latent is not None and mse_loss_indexes is not None
@@ -710,8 +710,9 @@ class Bagel(nn.Module):
         if self.config.visual_und and packed_vit_tokens is not None:
             lens = [int(x) for x in torch.as_tensor(vit_token_seqlens).tolist()]
             cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+            vit_tape = {} if (F_ is not None and any(p.requires_grad for p in self.vit_model.parameters())) else None
             feats = self.vit_model(packed_pixel_values=packed_vit_tokens, packed_flattened_position_ids=packed_vit_position_ids,
-                                   cu_seqlens=cu, max_seqlen=max(lens))
+                                   cu_seqlens=cu, max_seqlen=max(lens), **({"tape": vit_tape} if vit_tape is not None else {}))
             c = self.connector
             n = feats.shape[0]
             hmid = torch.empty((n, H), dtype=BF16, device=dev)
@@ -723,7 +724,7 @@ class Bagel(nn.Module):
             ops.copy_rows(emb, seq, n, H, dst_rows=self._dev(vit_rows, torch.int32))
             und_rows = torch.cat([text_rows, vit_rows], dim=0)
             if F_ is not None:
-                F_.update(vit_feats=feats, vit_hmid=hmid, vit_rows=self._dev(vit_rows, torch.int32))
+                F_.update(vit_feats=feats, vit_hmid=hmid, vit_rows=self._dev(vit_rows, torch.int32), vit_tape=vit_tape)
         gen_rows = None
         if self.config.visual_gen and padded_latent is not None:
             p, C = self.latent_patch_size, self.latent_channel
@@ -826,10 +827,11 @@ class Bagel(nn.Module):
             i32 = lambda x: x.to(device=dev, dtype=torch.int32)  # noqa: E731
             ops.rows_segment_sum(g, i32(rows[order]), i32(seg), i32(uniq), dE)
             grads.add(emb, dE)
-        # ---- ViT tokens: connector (fc1 - gelu_tanh - fc2); the tower itself is frozen
+        # ---- ViT tokens: connector (fc1 - gelu_tanh - fc2), then the SigLIP tower when it is trainable
         if "vit_feats" in F_:
             c = self.connector
-            if any(p.requires_grad for p in c.parameters()):
+            vit_tape = F_.get("vit_tape")
+            if vit_tape is not None or any(p.requires_grad for p in c.parameters()):
                 feats, hmid, n = F_["vit_feats"], F_["vit_hmid"], F_["vit_feats"].shape[0]
                 d_emb = torch.empty((n, H), dtype=BF16, device=dev)
                 ops.copy_rows(g, d_emb, n, H, src_rows=F_["vit_rows"])
@@ -842,6 +844,10 @@ class Bagel(nn.Module):
                 ops.act_bwd(pre, d_h, ops.EPI_GELU_TANH)
                 grads.add(c.fc1.weight, TS._wgrad(pre, feats))
                 grads.add(c.fc1.bias, ops.colsum(pre))
+                if vit_tape is not None:
+                    d_feats = torch.empty_like(feats)
+                    ops.gemm(pre, TS._wt(c.fc1.weight.data), d_feats)
+                    TS.siglip_backward(self.vit_model, vit_tape, d_feats, grads)
         # ---- latent tokens: vae2llm + per-image timestep embedding (bagel.py:186-191); the position table is frozen
         if "x16" in F_:
             x16, n = F_["x16"], F_["x16"].shape[0]

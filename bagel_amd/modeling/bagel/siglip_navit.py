@@ -173,7 +173,9 @@ class SiglipVisionModel(PackedWeights):
         return self._packed
 
     @torch.no_grad()
-    def forward(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
+    def forward(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen, tape=None):
+        """``tape`` (a dict, training only): every layer writes its residual streams, projection, attention output, row statistics and MLP
+        activation into buffers of its own, kept for train_step.siglip_backward (the tower's backward; learned-position variant only)."""
         self._check_packed()
         P = self._packed or self._pack()
         cfg = self.config
@@ -195,6 +197,12 @@ class SiglipVisionModel(PackedWeights):
         x, h, qkv, att, mid = e(n, D), e(n, D), e(n, 3 * nh * dp), e(n, nh * dp), e(n, I)
         vt = torch.zeros((nh * dp, _ceil_to(c, 256)), dtype=BF16, device=dev)
         a16 = ops.f32_to_bf16(pix, cols_padded=P["kpad"])
+        if tape is not None:
+            if P["rope"] is not None:
+                raise NotImplementedError("the SigLIP backward is built for the learned position table (BAGEL's so400m config), not the 2-D RoPE variant")
+            tape.update(a16=a16, pos=pos.cpu(), lens=[int(l) for l in lens], x=[], x_mid=[], qkv=[], att=[], mid=[], lse=[], n=n)
+            x = e(n, D)
+            tape["x"].append(x)
         ops.gemm(a16, P["wpatch"], x, bias0=P["bpatch"])
         if P["rope"] is None:
             ops.add_table_rows(x, self.vision_model.embeddings.position_embedding.weight.data, pos)
@@ -202,25 +210,35 @@ class SiglipVisionModel(PackedWeights):
         scale = P["hd"] ** -0.5
         from .qwen2_navit import ATTN_PLANNED
         aplan = None
-        if ATTN_PLANNED:           # the persistent kernel's work list: one per image batch, shared by the 26 layers
+        if ATTN_PLANNED and tape is None:   # the persistent kernel's work list: one per image batch, shared by the 26 layers
             starts, at = [], 0
             for l in lens:
                 starts.append(at); at += int(l)
             aplan = ops.AttnPlan(starts, [int(l) for l in lens], cols, nh, nh, dp, False, dev)
         for L in P["layers"]:
+            x_mid, x_out, lse = x, x, None
+            if tape is not None:
+                qkv, att, mid, x_mid, x_out = e(n, 3 * nh * dp), e(n, nh * dp), e(n, I), e(n, D), e(n, D)
+                lse = torch.empty((nh, n), dtype=torch.float32, device=dev)
+                tape["qkv"].append(qkv); tape["att"].append(att); tape["mid"].append(mid); tape["x_mid"].append(x_mid); tape["x"].append(x_out)
+                tape["lse"].append(lse)
             ops.layernorm(x, L["ln1"][0], L["ln1"][1], h, eps)
             ops.gemm(h, L["wqkv"], qkv, bias0=L["bqkv"])
             if P["rope"] is not None:
                 ops.rope2d(qkv, P["rope"], pos, 2 * nh, P["hd"], dp)       # q heads then k heads
             ops.v_transpose(qkv[:, 2 * qw:], vt, cu, vcol, B, int(max_seqlen), nh, dp)
-            if aplan is not None:
+            if lse is not None:         # the tile kernel leaves the row statistics the attention reverse reads
+                ops.attn_varlen_ranges(qkv[:, :qw], qkv[:, qw:2 * qw], vt, att, cu[:-1].contiguous(), cu[1:].contiguous(), vcol, B, int(max_seqlen), nh, nh, dp,
+                                       False, scale, lse=lse)
+            elif aplan is not None:
                 ops.attn_planned(qkv[:, :qw], qkv[:, qw:2 * qw], vt, att, aplan, scale)
             else:
                 ops.attn_varlen(qkv[:, :qw], qkv[:, qw:2 * qw], vt, att, cu, vcol, B, int(max_seqlen), nh, nh, dp, False, scale)
-            ops.gemm(att, L["wo"], x, bias0=L["bo"], residual=x)
-            ops.layernorm(x, L["ln2"][0], L["ln2"][1], h, eps)
+            ops.gemm(att, L["wo"], x_mid, bias0=L["bo"], residual=x)
+            ops.layernorm(x_mid, L["ln2"][0], L["ln2"][1], h, eps)
             ops.gemm(h, L["fc1"][0], mid, bias0=L["fc1"][1], epilogue=ops.EPI_GELU_TANH)
-            ops.gemm(mid, L["fc2"][0], x, bias0=L["fc2"][1], residual=x)
+            ops.gemm(mid, L["fc2"][0], x_out, bias0=L["fc2"][1], residual=x_mid)
+            x = x_out
         out = torch.empty_like(x)
         pl = self.vision_model.post_layernorm
         ops.layernorm(x, pl.weight.data, pl.bias.data, out, eps)

@@ -18,8 +18,9 @@ MI355X-first choices:
     atomics, so the same batch gives the same gradients bit for bit on every run.
 
 Scope: gradients of every parameter of the language model (both experts, embeddings, norms, lm_head), llm2vae / vae2llm / the time
-embedder and the ViT connector; the SigLIP tower and the VAE are frozen (``--freeze_vit True --freeze_vae True`` of
-pretrain_unified_navit.py:382-393) -- a ViT parameter that requires grad raises instead of silently staying without a gradient."""
+embedder, the ViT connector and the SigLIP tower (learned-position variant); the VAE is frozen as in the reference (``--freeze_vae True``,
+pretrain_unified_navit.py:390-393) and the sin-cos position tables are frozen parameters there too -- a parameter outside that set that
+requires grad raises instead of silently staying without a gradient."""
 import os
 
 import numpy as np
@@ -284,6 +285,78 @@ def engine_backward_train(eng, tape, g, grads):
             grads.add(mlp.gate_proj.weight, dg)
             grads.add(mlp.up_proj.weight, du)
             grads.add(mlp.down_proj.weight, dWd[ei])
+    return g
+
+
+def siglip_backward(vit, tape, g, grads):
+    """Reverse of SiglipVisionModel.forward (siglip_navit.py:145-402: patch embedding + learned positions, pre-LN encoder layers with
+    full attention inside every image, GELU-tanh MLP, post-LayerNorm): ``g`` [n, D] bf16 = d loss / d (tower output), overwritten;
+    every tower parameter's gradient goes to ``grads``.  Same building blocks as the decoder's reverse (one "full" split per image for
+    the attention items, dX / dW on the forward GEMM over transposed images), dense: no expert routing."""
+    P = vit._packed
+    cfg, vm = vit.config, vit.vision_model
+    dev = g.device
+    D, I, nh, dp, hd = cfg.hidden_size, cfg.intermediate_size, P["nh"], P["dp"], P["hd"]
+    qw, n, eps = nh * dp, tape["n"], cfg.layer_norm_eps
+    e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
+    bplan = AttnBackwardPlan(dev, tape["lens"], [([l], ["full"]) for l in tape["lens"]])
+    pl = vm.post_layernorm
+    gx = e(n, D)
+    dw, db = ops.layernorm_bwd(tape["x"][-1], g, pl.weight.data, gx, eps, accumulate=False)
+    grads.add(pl.weight, dw); grads.add(pl.bias, db)
+    g = gx
+    h, d_h = e(n, D), e(n, D)
+    for li in range(len(P["layers"]) - 1, -1, -1):
+        L, Lm = P["layers"][li], vm.encoder.layers[li]
+        x_in, x_mid, qkv, att, mid = tape["x"][li], tape["x_mid"][li], tape["qkv"][li], tape["att"][li], tape["mid"][li]
+        # MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
+        grads.add(Lm.mlp.fc2.weight, _wgrad(g, mid)); grads.add(Lm.mlp.fc2.bias, ops.colsum(g))
+        d_mid = e(n, I)
+        ops.gemm(g, _wt(L["fc2"][0]), d_mid)
+        ops.layernorm(x_mid, L["ln2"][0], L["ln2"][1], h, eps)
+        pre = e(n, I)
+        ops.gemm(h, L["fc1"][0], pre, bias0=L["fc1"][1])                  # the un-activated fc1 output, recomputed
+        ops.act_bwd(pre, d_mid, ops.EPI_GELU_TANH)
+        del d_mid
+        grads.add(Lm.mlp.fc1.weight, _wgrad(pre, h)); grads.add(Lm.mlp.fc1.bias, ops.colsum(pre))
+        ops.gemm(pre, _wt(L["fc1"][0]), d_h)
+        del pre
+        dw, db = ops.layernorm_bwd(x_mid, d_h, L["ln2"][0], g, eps)
+        grads.add(Lm.layer_norm2.weight, dw); grads.add(Lm.layer_norm2.bias, db)
+        # attention: x_mid = x_in + out_proj(attn(qkv(ln1(x_in))))
+        a = Lm.self_attn
+        grads.add(a.out_proj.weight, _unpad_cols(_wgrad(g, att), nh, hd, dp)); grads.add(a.out_proj.bias, ops.colsum(g))
+        d_att = e(n, qw)
+        ops.gemm(g, _wt(L["wo"]), d_att)
+        dqkv = e(n, 3 * qw)
+        ops.attn_bwd_blockmask(qkv[:, :qw], qkv[:, qw:2 * qw], qkv[:, 2 * qw:], att, d_att, dqkv[:, :qw], dqkv[:, qw:2 * qw], dqkv[:, 2 * qw:],
+                               bplan.q_items, bplan.k_items, bplan.noise_bits, nh, nh, dp, hd ** -0.5, lse=tape["lse"][li])
+        del d_att
+        ops.layernorm(x_in, L["ln1"][0], L["ln1"][1], h, eps)
+        dW, dB = _wgrad(dqkv, h), ops.colsum(dqkv)
+        for j, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            lin = getattr(a, name)
+            grads.add(lin.weight, _unpad_rows(dW[j * qw:(j + 1) * qw], nh, hd, dp))
+            grads.add(lin.bias, _unpad_rows(dB[j * qw:(j + 1) * qw], nh, hd, dp))
+        ops.gemm(dqkv, _wt(L["wqkv"]), d_h)
+        del dqkv
+        dw, db = ops.layernorm_bwd(x_in, d_h, L["ln1"][0], g, eps)
+        grads.add(Lm.layer_norm1.weight, dw); grads.add(Lm.layer_norm1.bias, db)
+    # front: x0 = patch_embedding(pixels) + position_embedding[pos]
+    emb = vm.embeddings
+    grads.add(emb.patch_embedding.weight, _wgrad(g, tape["a16"])[:, :P["kin"]])
+    grads.add(emb.patch_embedding.bias, ops.colsum(g))
+    pe = emb.position_embedding.weight
+    if pe.requires_grad:
+        pos = tape["pos"]
+        order = torch.argsort(pos, stable=True)
+        uniq, counts = torch.unique_consecutive(pos[order], return_counts=True)
+        seg = torch.zeros(uniq.numel() + 1, dtype=torch.int32)
+        seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        i32 = lambda t: t.to(device=dev, dtype=torch.int32)  # noqa: E731
+        dE = torch.zeros(tuple(pe.shape), dtype=BF16, device=dev)
+        ops.rows_segment_sum(g, i32(order), i32(seg), i32(uniq), dE)
+        grads.add(pe, dE)
     return g
 
 

@@ -521,6 +521,18 @@ def rmsnorm_bwd(x, dy, w0, g, eps, w1=None, expert=None, accumulate=True):
     return dw0, dw1
 
 
+def layernorm_bwd(x, dy, w, g, eps, accumulate=True):
+    """g = bf16((g if accumulate else 0) + d layernorm / dx); -> (dw, db) bf16 [cols]."""
+    _req(x, BF16, "layernorm_bwd.x"); _req(dy, BF16, "layernorm_bwd.dy"); _req(g, BF16, "layernorm_bwd.g"); _req(w, BF16, "layernorm_bwd.w")
+    rows, cols = x.shape
+    dw = torch.empty((cols,), dtype=BF16, device=x.device)
+    db = torch.empty_like(dw)
+    ws = _colsum_ws(rows, 2 * cols, x.device, extra=2 * rows)
+    check(lib().bagel_layernorm_bwd_bf16(_ptr(x), _ld(x), _ptr(dy), _ld(dy), _ptr(w), _ptr(g), _ld(g), int(bool(accumulate)), _ptr(dw), _ptr(db),
+                                         _ptr(ws), rows, cols, float(eps), _stream()), "bagel_layernorm_bwd_bf16")
+    return dw, db
+
+
 def qknorm_rope_bwd(dqkv, qkv_raw, cos, sin, q_w0, k_w0, q_w1, k_w1, expert, nq, nkv, head_dim, head_dim_padded, eps, use_norm):
     """In place: gradient of the rotated [q | k | v] rows -> gradient of the raw projection; -> (dqw0, dkw0, dqw1, dkw1)."""
     _req(dqkv, BF16, "qknorm_rope_bwd.dqkv"); _req(qkv_raw, BF16, "qknorm_rope_bwd.qkv_raw")

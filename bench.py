@@ -1071,8 +1071,8 @@ def main():
             if not args.no_train_step:
                 # the whole step of train/pretrain_unified_navit.py:683-735 minus the optimizer: forward with a tape + loss.backward() through
                 # the hand-written reverse (bagel_amd/modeling/bagel/train_step.py), every language-model / connector / head parameter trainable,
-                # SigLIP frozen (--freeze_vit True); gradients of 14.2 G parameters are produced and dropped
-                frozen = ("vit_model.", "vit_pos_embed.", "latent_pos_embed.")
+                # SigLIP tower included; gradients of 14.6 G parameters are produced and dropped
+                frozen = ("vit_pos_embed.", "latent_pos_embed.")
                 try:
                     n_train = 0
                     for n_, p_ in model.named_parameters():

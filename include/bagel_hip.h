@@ -346,6 +346,11 @@ int bagel_transpose_bf16(const void* src, int64_t ld_src, const int32_t* src_row
 int bagel_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* w0, const void* w1,
                            const int32_t* expert_of_row, void* g, int64_t ldg, int32_t accumulate, void* dw0, void* dw1,
                            float* partial_ws, int32_t rows, int32_t cols, float eps, bagel_stream_t stream);
+/* Reverse of bagel_layernorm_bf16 (nn.LayerNorm of the SigLIP tower, siglip_navit.py:266-269,342): g = bf16((accumulate ? g : 0) +
+ * bf16(dx)), dw[c] = sum dy * xh, db[c] = sum dy (bf16 [cols]); partial_ws fp32, BAGEL_COLSUM_WS_FLOATS(rows, 2 * cols) + 2 * rows floats. */
+int bagel_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* w, void* g, int64_t ldg,
+                             int32_t accumulate, void* dw, void* db, float* partial_ws, int32_t rows, int32_t cols, float eps,
+                             bagel_stream_t stream);
 /* Reverse of bagel_qknorm_rope_bf16 in its training form (gen_mode 0; PackedAttentionMoT.forward_train, qwen2_navit.py:430-455): in
  * place on the gradient of the rotated [q | k | v] rows -> gradient of the raw projection (v columns untouched); qkv_raw = the
  * projection output the forward normalised.  dqw / dkw: bf16 [head_dim] per expert (NULL when use_norm == 0 or no second expert);

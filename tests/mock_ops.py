@@ -456,6 +456,18 @@ def rmsnorm_bwd(x, dy, w0, g, eps, w1=None, expert=None, accumulate=True):
     return dw0, dw1
 
 
+def layernorm_bwd(x, dy, w, g, eps, accumulate=True):
+    xf = x.double()
+    mean = xf.mean(-1, keepdim=True)
+    r = torch.rsqrt(((xf - mean) ** 2).mean(-1, keepdim=True) + eps)
+    xh = (xf - mean) * r
+    dxh = dy.double() * w.double()
+    dx = (r * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))).float()
+    base = g.float() if accumulate else torch.zeros_like(dx)
+    g.copy_(_bf(base + _bf(dx).float()))
+    return _bf((dy.double() * xh).sum(0).float()), _bf(dy.double().sum(0).float())
+
+
 def qknorm_rope_bwd(dqkv, qkv_raw, cos, sin, q_w0, k_w0, q_w1, k_w1, expert, nq, nkv, head_dim, head_dim_padded, eps, use_norm):
     M, hd, dp = dqkv.shape[0], head_dim, head_dim_padded
     half = hd // 2
@@ -682,7 +694,7 @@ _NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
           "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
           "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
-          "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
+          "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "layernorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
           "act_bwd", "swiglu_fwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]
 
 

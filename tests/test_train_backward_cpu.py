@@ -14,7 +14,7 @@ from tests import mock_ops
 from tests.util_models import oracle_weights, pack_training_batch
 
 CFGS = {"tiny": TINY, "tiny_d128": TINY_D128}
-FROZEN = ("vit_model.", "vit_pos_embed.", "latent_pos_embed.")
+FROZEN = ("vit_pos_embed.", "latent_pos_embed.")
 
 
 def rel(a, b):
@@ -53,6 +53,12 @@ def compare(grads, ref, names, tol, what):
     for n in names:
         assert n in ref, n
         rn = float(ref[n].float().norm())
+        if n.startswith("vit_model.") and n.endswith("k_proj.bias"):
+            # softmax is invariant to a constant added to every key of a row: the exact gradient of SigLIP's key bias is ZERO, what both
+            # sides hold is rounding noise -- check that it is noise (against the query bias of the same layer), not that the noises agree
+            qn = float(ref[n.replace("k_proj", "q_proj")].float().norm())
+            assert rn <= 0.1 * qn and (n not in grads or float(grads[n].float().norm()) <= 0.1 * qn), (what, n)
+            continue
         if rn == 0.0:
             assert n not in grads or float(grads[n].float().norm()) == 0.0, (what, n)
             continue
@@ -184,7 +190,7 @@ def test_frozen_and_no_grad_paths(golden, monkeypatch):
     (out["mse"].mean() + out["ce"].mean()).backward()
     got = sorted(n for n, p in model.named_parameters() if p.grad is not None)
     assert got == sorted(n for n in names if n.endswith("mlp_moe_gen.down_proj.weight") or n == "llm2vae.bias")
-    next(p for n, p in model.named_parameters() if n.startswith("vit_model.")).requires_grad_(True)
+    model.latent_pos_embed.pos_embed.requires_grad_(True)          # frozen in the reference (a fixed sin-cos table): refused, not ignored
     with pytest.raises(NotImplementedError):
         model(noise=g["noise"], **g["batch"])
 

@@ -2,7 +2,7 @@
 """Time one training step -- Bagel.forward with a tape + loss.backward() through the hand-written reverse (bagel_amd/modeling/bagel/
 train_step.py) -- at BAGEL-7B-MoT shapes and full depth on one MI355X: the packed batch of tools/train_forward_probe.py (two understanding
 samples [prompt | 980^2 ViT image | answer with CE] + two generation samples [prompt | noised 1024^2 latent image with MSE], 18.3k tokens),
-random-init bf16 weights, every language-model / connector / head parameter trainable (ViT frozen).  No optimizer step (out of scope:
+random-init bf16 weights, every language-model / connector / head parameter trainable (SigLIP tower frozen; PROBE_VIT=1 trains it too).  No optimizer step (out of scope:
 the optimizer is torch's).  Prints one JSON line."""
 import json
 import os
@@ -24,7 +24,7 @@ def main():
     model, _ = build_bagel(cfg, device=dev, with_vae=False)
     init_random_(model, seed=0)
     model.llm2vae.weight.data.normal_(0, 3584 ** -0.5)
-    frozen = ("vit_model.", "vit_pos_embed.", "latent_pos_embed.")
+    frozen = ("vit_pos_embed.", "latent_pos_embed.") if os.environ.get("PROBE_VIT") else ("vit_model.", "vit_pos_embed.", "latent_pos_embed.")
     n_train = 0
     for n, p in model.named_parameters():
         p.requires_grad_(not n.startswith(frozen))
