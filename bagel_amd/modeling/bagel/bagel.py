@@ -435,8 +435,17 @@ class Bagel(nn.Module):
         mode = ops.RENORM_MODES[cfg_renorm_type]
         multi = None
         if self.cfg_batched and plan_t is not None:
-            multi = self._stream_batch(st, [plan, plan_t] + ([plan_i] if plan_i is not None else []),
-                                       [past_key_values, cfg_text_past_key_values] + ([cfg_img_past_key_values] if plan_i is not None else []))
+            # the batched forward reads ONE concatenated context: a second resident copy of every stream's K / V rows for the duration of
+            # this call (the image-edit request: 3 streams x ~9 k tokens x 28 layers x 2 KB = 1.6 GB per sample).  If that does not fit,
+            # the step falls back to the sequential forwards (same results, no copy) instead of failing the request.
+            try:
+                multi = self._stream_batch(st, [plan, plan_t] + ([plan_i] if plan_i is not None else []),
+                                           [past_key_values, cfg_text_past_key_values] + ([cfg_img_past_key_values] if plan_i is not None else []))
+            except torch.cuda.OutOfMemoryError:
+                import warnings
+                warnings.warn("bagel_amd: no memory for the stream-batched CFG context copy; running the conditional and CFG forwards one after the other")
+                torch.cuda.empty_cache()
+                multi = None
         for i, t in enumerate(timesteps):
             use_cfg = bool(t > cfg_interval[0] and t <= cfg_interval[1])   # fp32 tensor vs python float, as bagel.py:701
             s_t = cfg_text_scale if use_cfg else 1.0

@@ -934,7 +934,7 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
     vt_clean = torch.zeros((kw_, _ceil_to(max(tp.vt_clean_cols, 1), 256)), dtype=BF16, device=dev)
     if tape is not None:
         tape.tp = tp
-        tape.decide_gate_up(dev, len(self.layers), M, self.I)
+        tape.decide_gate_up(self, M)
         tape.begin(self, (M, tape.keep_gate_up))
         tb = lambda name, li, *shape, dtype=BF16: tape.buf(name, li, *shape, dtype=dtype, device=dev)  # noqa: E731
         x = tb("x", 0, M, self.H)

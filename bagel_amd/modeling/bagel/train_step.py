@@ -118,15 +118,25 @@ class TrainTape:
         self._store, self._pool = {}, None
 
 
-def _decide_gate_up(self, device, n_layers, M, inter):
+def _decide_gate_up(self, eng, M):
+    """KEEP_GATE_UP = "auto": decided once per (engine, row count), on the first step, when neither the gradients nor the transposed
+    weight images exist yet: the kept projections + the rest of the tape + three more copies of the decoder's weights (gradients, the
+    weight images, slack for the backward's transients) have to fit 80 % of what is free."""
     if KEEP_GATE_UP != "auto":
         self.keep_gate_up = bool(KEEP_GATE_UP)
-    elif torch.device(device).type != "cuda":
-        self.keep_gate_up = False
-    else:
-        free, _ = torch.cuda.mem_get_info(device)
-        free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # what torch's allocator can hand out again
-        self.keep_gate_up = n_layers * M * 2 * inter * 2 <= free // 3
+        return
+    memo = eng.__dict__.setdefault("_keep_gate_up", {})
+    if M not in memo:
+        if torch.device(eng.device).type != "cuda":
+            memo[M] = False
+        else:
+            L = len(eng.layers)
+            free, _ = torch.cuda.mem_get_info(eng.device)
+            free += torch.cuda.memory_reserved(eng.device) - torch.cuda.memory_allocated(eng.device)   # what torch's allocator can hand out again
+            wbytes = sum(w.numel() * 2 for P in eng.layers for ws in (P.wqkv, P.wo, P.wgu, P.wd) for w in ws)
+            base = L * M * 2 * (3 * eng.H + (eng.nq + 2 * eng.nkv) * eng.dp + eng.nq * eng.dp + eng.I)
+            memo[M] = L * M * 2 * eng.I * 2 + base + 3 * wbytes <= 0.8 * free
+    self.keep_gate_up = memo[M]
 
 
 TrainTape.decide_gate_up = _decide_gate_up

@@ -29,7 +29,8 @@ def main():
     for n, p in model.named_parameters():
         p.requires_grad_(not n.startswith(frozen))
         n_train += p.numel() if p.requires_grad else 0
-    batch = build_batch(model, NEW_TOKEN_IDS_QWEN25)
+    scale = int(os.environ.get("PROBE_SCALE", "1"))          # 2: 36.5 k tokens, the reference's max_num_tokens class (pretrain_unified_navit.py)
+    batch = build_batch(model, NEW_TOKEN_IDS_QWEN25, n_und=2 * scale, n_gen=2 * scale)
     noise = torch.randn(len(batch["packed_vae_token_indexes"]), 64, generator=torch.Generator().manual_seed(1)).to(dev)
 
     def step():
