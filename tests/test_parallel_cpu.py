@@ -222,3 +222,65 @@ def test_bench_one_step_on_two_gloo_ranks():
     one = run(1, 1, 0)
     assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and one["broadcast"] is None and one["collective_backend"] is None
     assert one["latents_checksum"] == two["latents_checksum"], "rank 0 of the 2-rank job must reproduce the 1-rank job's samples"
+
+
+def _ddp_worker(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from tests import mock_ops
+    mock_ops.install_permanently()
+    from oracle.configs import TINY
+    from oracle import bagel_oracle as O
+    from tests.util_models import oracle_weights, pack_training_batch
+    from bagel_amd.factory import build_bagel
+    W, _ = oracle_weights(TINY)
+    model, _ = build_bagel(TINY, device="cpu", with_vae=False)
+    model.load_state_dict(W, strict=True)
+    model = model.to(torch.bfloat16).eval()
+    for n, p in model.named_parameters():
+        p.requires_grad_(not n.startswith(("vit_pos_embed.", "latent_pos_embed.")))
+
+    def batch_of(r):
+        samples = [[("text", 3, True), ("vit", 28, 42), ("text", 2 + r, True)], [("text", 2, False), ("vae", 32, 32 + 16 * r, True)]]
+        return pack_training_batch(TINY, samples, 100 + r)
+    local = {}
+    for r in range(ws):                                    # every rank's gradients, computed here without any exchange
+        b, noise, _, _ = batch_of(r)
+        for p in model.parameters():
+            p.grad = None
+        O.training_step_loss(model(noise=noise, **b)).backward()
+        local[r] = {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():
+        p.grad = None
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    b, noise, _, _ = batch_of(rank)
+    O.training_step_loss(ddp(noise=noise, **b)).backward()  # this rank's batch; DDP all-reduces what the packed autograd node returns
+    worst, n_grads = 0.0, 0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        want = sum(local[r][n] for r in range(ws)) / ws
+        if float(want.norm()) == 0.0:
+            continue
+        worst = max(worst, float((p.grad.float() - want).norm() / want.norm()))
+        n_grads += 1
+    q.put((rank, worst, n_grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_step_under_ddp_gloo_world2():
+    """Training shards by batch and its exchange step is the gradient all-reduce: the packed forward is ONE autograd node that hands
+    ordinary gradient tensors to torch, so torch's DistributedDataParallel (RCCL on the GPUs, gloo here) averages them like autograd's --
+    two ranks with different packs end with the mean of the two ranks' gradients (to one bf16 rounding of the averaged tensors)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in ps:
+        p.join(60)
+    for rank, worst, n_grads in res:
+        assert n_grads >= 100 and worst < 1e-2, (rank, worst, n_grads)
