@@ -42,7 +42,7 @@ struct AttnBwdParams {
     const int* q_items; const int* k_items;
     const unsigned long long* noise_bits;
     float* lse; float* delta;            // [nq][rows]
-    int rows, nq, nkv, have_lse;
+    int rows, nq, nkv, have_lse, n_q_items, n_k_items;
     float scale;
 };
 
@@ -53,6 +53,40 @@ struct AttnBwdParams {
 #define AB_ABL 0
 #endif
 #define AB_TP 72                          // element pitch of the transposed 64-column tiles (144 bytes: 16-byte aligned, banks spread)
+
+// XCD-aware work mapping (workgroups are dealt to the 8 XCDs round-robin by their linear id): every kv head's work lands on the same
+// XCD(s), so the K / V / K^T (Q / dO / Q^T / dO^T) tiles that the items and q heads of one kv head re-read stay in that XCD's 4 MB L2
+// instead of being streamed through all eight.  nkv < 8: 8 / nkv XCDs per kv head share its items; nkv >= 8: kv heads g, g + 8, ... share
+// XCD g.  `per` = the units of one kv head in one item (its q heads for the dq kernel, 1 for the dkv kernel).
+// Returns false for the padding workgroups of the rounded-up grid.
+__device__ __forceinline__ bool ab_map(int n_items, int nkv, int per, int& item, int& hkv, int& sub) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (nkv < 8 && 8 % nkv == 0) {
+        const int xpg = 8 / nkv;                           // XCDs per kv head
+        hkv = xcd / xpg;
+        const int j = slot * xpg + (xcd % xpg);
+        item = j / per; sub = j % per;
+        return item < n_items;
+    }
+    if (nkv < 8) {                                         // 3, 5, 6, 7 kv heads: no even split of the XCDs -- plain round-robin
+        const int u = blockIdx.x;
+        hkv = u % nkv;
+        item = (u / nkv) / per; sub = (u / nkv) % per;
+        return item < n_items;
+    }
+    const int hpx = (nkv + 7) / 8;                         // kv heads per XCD
+    const int j = slot;
+    const int hl = j % hpx;                                // which of this XCD's kv heads
+    hkv = xcd + 8 * hl;
+    const int r = j / hpx;
+    item = r / per; sub = r % per;
+    return item < n_items && hkv < nkv;
+}
+__host__ static inline int ab_grid(int n_items, int nkv, int per) {
+    if (nkv < 8 && 8 % nkv == 0) { const int xpg = 8 / nkv; return 8 * ((n_items * per + xpg - 1) / xpg); }
+    if (nkv < 8) return (n_items * per * nkv + 7) / 8 * 8;
+    return 8 * (n_items * per * ((nkv + 7) / 8));
+}
 
 __device__ __forceinline__ int ab_perm(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
@@ -139,9 +173,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
     bf16_t* Ks = (bf16_t*)smem;                        // [64][RP]
     bf16_t* Vs = Ks + 64 * RP;                         // [64][RP]
     bf16_t* Kts = Vs + 64 * RP;                        // [D][AB_TP]
-    const int* it = p.q_items + (long)blockIdx.x * 8;
+    int item_, hkv, sub_;
+    if (!ab_map(p.n_q_items, p.nkv, p.nq / p.nkv, item_, hkv, sub_)) return;
+    const int* it = p.q_items + (long)item_ * 8;
     const int row0 = it[0], nrows = it[1], kstart = it[2], sstart = it[3], send = it[4], causal = it[5], t0 = it[6], t1 = it[7];
-    const int hq = blockIdx.y, hkv = hq / (p.nq / p.nkv);
+    const int hq = hkv * (p.nq / p.nkv) + sub_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, h = lane >> 5, pm = ab_perm(m);
     const int qloc = 32 * wave + m;
@@ -317,9 +353,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     bf16_t* dOts = Qts + D * AB_TP;                    // [D][AB_TP]
     float* lse_s = (float*)(dOts + D * AB_TP);         // [64]
     float* delta_s = lse_s + 64;                       // [64]
-    const int* it = p.k_items + (long)blockIdx.x * 8;
+    int item_, hkv, sub_;
+    if (!ab_map(p.n_k_items, p.nkv, 1, item_, hkv, sub_)) return;
+    const int* it = p.k_items + (long)item_ * 8;
     const int key0 = it[0], nkeys = it[1], qbeg = it[2], qend = it[3], send = it[4], causal = it[5];
-    const int hkv = blockIdx.y, G = p.nq / p.nkv;
+    const int G = p.nq / p.nkv;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, h = lane >> 5, pm = ab_perm(m);
     const int kloc = 32 * wave + m;
@@ -436,11 +474,11 @@ static int attn_bwd_launch(const AttnBwdParams& p, int n_q_items, int n_k_items,
     if (const char* only = getenv("BAGEL_ABWD_ONLY")) { if (only[1] == 'q') n_k_items = 0; else n_q_items = 0; }    // "dq" | "dkv"
 #endif
     if (n_q_items > 0) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3(n_q_items, p.nq), dim3(256), smem_dq, stream, p);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3(ab_grid(n_q_items, p.nkv, p.nq / p.nkv)), dim3(256), smem_dq, stream, p);
         if (int rc = bagel_check_launch("attn_bwd_dq_kernel")) return rc;
     }
     if (n_k_items > 0) {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3(n_k_items, p.nkv), dim3(256), smem_dkv, stream, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3(ab_grid(n_k_items, p.nkv, 1)), dim3(256), smem_dkv, stream, p);
         if (int rc = bagel_check_launch("attn_bwd_dkv_kernel")) return rc;
     }
     return BAGEL_OK;
@@ -471,6 +509,7 @@ extern "C" int bagel_attn_bwd_blockmask_bf16(const void* q, int64_t ldq, const v
     p.q_items = q_items; p.k_items = k_items; p.noise_bits = (const unsigned long long*)noise_bits;
     p.lse = lse_delta; p.delta = lse_delta + (long)nq * rows;
     p.rows = rows; p.nq = nq; p.nkv = nkv; p.have_lse = lse_from_forward; p.scale = softmax_scale;
+    p.n_q_items = n_q_items; p.n_k_items = n_k_items;
     if (head_dim == 128) return attn_bwd_launch<128>(p, n_q_items, n_k_items, stream);
     if (head_dim == 64) return attn_bwd_launch<64>(p, n_q_items, n_k_items, stream);
     return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_bwd: head_dim %d not in {64,128} (pad the head)", head_dim);
