@@ -135,6 +135,33 @@ def test_training_step_gradients_on_random_batches(monkeypatch, seed):
     compare(grads, rgrads, names, 8e-2, (seed, samples))
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_text_only_pack_takes_the_single_expert_path(monkeypatch, name):
+    """A pack without images (two samples of causal text splits, CE on some): no gen rows, so the engines run without expert routing and
+    only the und expert, the embeddings, the norms and lm_head receive gradients -- vs the oracle's primitives under autograd."""
+    from tests.util_models import text_only_training_grads
+    mock_ops.install(monkeypatch)
+    cfg = CFGS[name]
+    batch, _, split_lens, attn_modes = pack_training_batch(cfg, [[("text", 5, True), ("text", 3, False), ("text", 4, True)], [("text", 6, True)]], 3)
+    w_ce = torch.rand(batch["ce_loss_indexes"].numel(), generator=torch.Generator().manual_seed(2)) + 0.5
+    W, _ = oracle_weights(cfg)
+    rloss, rgrads = text_only_training_grads(W, cfg, batch, w_ce)
+    model = cpu_model(cfg)
+    trainable(model)
+    for p in model.parameters():
+        p.grad = None
+    out = model(**batch)
+    assert out["mse"] is None and out["ce"].requires_grad
+    loss = O.training_step_loss(out, w_ce)
+    loss.backward()
+    assert abs(float(loss.detach()) - rloss) < 2e-2 * abs(rloss)
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(rgrads), sorted(set(grads) ^ set(rgrads))[:6]
+    for n, r in rgrads.items():
+        if float(r.float().norm()) > 0:
+            assert rel(grads[n], r) < 6e-2, (n, rel(grads[n], r))
+
+
 def test_tape_options_do_not_change_the_gradients(golden, monkeypatch):
     """KEEP_GATE_UP (the tape keeps the un-activated gate/up projection instead of recomputing it) and CACHE_WT (transposed weight images
     kept with the packed layer across micro-steps): same gradients bit for bit in every combination, also on the second micro-step (cached

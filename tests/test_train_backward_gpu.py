@@ -325,6 +325,40 @@ def test_training_step_gradients_match_the_oracle(golden, monkeypatch, name, kee
             p.grad = None
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+def test_text_only_pack_takes_the_single_expert_path(name):
+    """No image in the pack: no gen rows, the engines run without expert routing (one row group per GEMM, plain norms) and only the und
+    expert, the embeddings, the norms and lm_head receive gradients -- vs the oracle's primitives under autograd."""
+    from oracle import bagel_oracle as O
+    from oracle.configs import TINY, TINY_D128
+    from tests.util_models import oracle_weights, pack_training_batch, product_model, text_only_training_grads
+    cfg = {"tiny": TINY, "tiny_d128": TINY_D128}[name]
+    batch, _, _, _ = pack_training_batch(cfg, [[("text", 5, True), ("text", 3, False), ("text", 4, True)], [("text", 150, True)]], 3)
+    w_ce = torch.rand(batch["ce_loss_indexes"].numel(), generator=torch.Generator().manual_seed(2)) + 0.5
+    W, _ = oracle_weights(cfg)
+    rloss, rgrads = text_only_training_grads(W, cfg, batch, w_ce)
+    model, _ = product_model(cfg)
+    try:
+        _trainable(model)
+        for p in model.parameters():
+            p.grad = None
+        out = model(**batch)
+        assert out["mse"] is None
+        loss = O.training_step_loss(out, w_ce.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss.detach()) - rloss) < 2e-2 * abs(rloss)
+        grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        assert set(grads) == set(rgrads), sorted(set(grads) ^ set(rgrads))[:6]
+        for n, r in rgrads.items():
+            if float(r.float().norm()) > 0:
+                assert rel(grads[n], r) < 6e-2, (n, rel(grads[n], r))
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(False)
+            p.grad = None
+
+
 def test_training_step_gradients_at_7b_width():
     """Hidden 3584, 28 / 4 heads of 128, intermediate 18 944, 2 MoT layers: an understanding sample (prompt + 28 x 42 ViT image + answer
     with CE loss) and a generation sample (prompt + clean 64 x 64 image + two noised images, one of them 320 x 256 = 320 latent tokens,

@@ -140,3 +140,27 @@ def pack_training_batch(cfg, samples, seed):
             batch["mse_loss_indexes"] = torch.tensor(mse_idx)
         noise = torch.randn(len(vae_idx), cfg["bagel"]["latent_patch_size"] ** 2 * cfg["vae"]["z_channels"], generator=g)
     return batch, noise, all_splits, all_modes
+
+
+def text_only_training_grads(W, cfg, batch, ce_loss_weights=None):
+    """Gradient oracle of a TEXT-ONLY pack (no ViT image, no latent: the single-expert path of the engines): the oracle's primitives --
+    embed_tokens, llm_forward_train with an empty gen row list, lm_head, cross-entropy -- under torch autograd.  (bagel_forward_train
+    restates the reference's Bagel.forward, which indexes every modality unconditionally, bagel.py:150-226.)
+    -> (loss, {state-dict key: gradient})."""
+    import torch.nn.functional as F
+    names = [k for k in W if k.startswith("language_model.") and "moe_gen" not in k and "inv_freq" not in k]
+    Wg = {k: (v.detach().clone().requires_grad_(True) if k in names else v) for k, v in W.items()}
+    O.GRAD_ENABLED = True
+    try:
+        te = O.embed_tokens(Wg, batch["packed_text_ids"])
+        seq = te.new_zeros((batch["sequence_length"], cfg["llm"]["hidden_size"]))
+        seq[batch["packed_text_indexes"]] = te
+        out = O.llm_forward_train(Wg, cfg["llm"], seq, batch["sample_lens"], batch["nested_attention_masks"], batch["packed_position_ids"],
+                                  batch["packed_text_indexes"], torch.zeros(0, dtype=torch.long))
+        logits = O.linear(out[batch["ce_loss_indexes"]], Wg["language_model.lm_head.weight"])
+        ce = F.cross_entropy(logits.float(), batch["packed_label_ids"], reduction="none")
+        loss = O.training_step_loss(dict(ce=ce, mse=None), ce_loss_weights)
+        loss.backward()
+    finally:
+        O.GRAD_ENABLED = False
+    return float(loss.detach()), {k: Wg[k].grad for k in names if Wg[k].grad is not None}
