@@ -13,6 +13,10 @@ supported size -- zero q/k lanes leave every score unchanged, zero v lanes produ
 softmax scale still taken from the ORIGINAL head_dim.  Keys and queries of a sample may differ in number (cached LLM forwards pass
 the merged [context | new] keys): the queries are then the LAST ``Lq`` positions of the sample's key range, which is exactly the
 bottom-right alignment, so the call maps onto the kernel's two-segment form with context = the first ``Lk - Lq`` keys.
+Training: when grad mode is on and q / k / v require grad, the SELF-attention form (same query and key ranges: SigLIP's call,
+siglip_navit.py:232-241, the one flash-attn call the reference's training step makes) is an autograd node whose backward is the
+hand-written reverse of csrc/attention_bwd.hip (row statistics from ``bagel_attn_varlen_ranges_lse_bf16``, one "full" or "causal"
+split per sample); the cached two-segment form is inference-only and refuses inputs that require grad.
 Fails loudly (RuntimeError with ``bagel_hip_last_error()``) -- there is no fallback."""
 import ctypes
 import os
@@ -29,6 +33,14 @@ _L.bagel_v_transpose_bf16.restype = ctypes.c_int
 _L.bagel_attn_varlen_ranges_bf16.argtypes = [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P,
                                              _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]
 _L.bagel_attn_varlen_ranges_bf16.restype = ctypes.c_int
+_L.bagel_attn_varlen_ranges_lse_bf16.argtypes = [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P,
+                                                 _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _I64, _P]
+_L.bagel_attn_varlen_ranges_lse_bf16.restype = ctypes.c_int
+_L.bagel_transpose_bf16.argtypes = [_P, _I64, _P, _I32, _I32, _P, _I64, _I32, _P]
+_L.bagel_transpose_bf16.restype = ctypes.c_int
+_L.bagel_attn_bwd_blockmask_bf16.argtypes = [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64,
+                                             _P, _I32, _P, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P]
+_L.bagel_attn_bwd_blockmask_bf16.restype = ctypes.c_int
 
 
 def _check(rc):
@@ -38,6 +50,79 @@ def _check(rc):
 
 def _i32(t):
     return t.to(torch.int32).contiguous()
+
+
+def _transpose(x):
+    """[rows, C] bf16 -> [C, ceil64(rows)] (zero padded): the K-contiguous operand images of the attention reverse."""
+    rows, C = x.shape
+    npad = (max(rows, 1) + 63) // 64 * 64
+    out = torch.empty((C, npad), dtype=x.dtype, device=x.device)
+    _check(_L.bagel_transpose_bf16(x.data_ptr(), x.stride(0), None, rows, C, out.data_ptr(), npad, npad, torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+class _SelfAttnVarlen(torch.autograd.Function):
+    """flash_attn_varlen_func for cu_seqlens_q == cu_seqlens_k with a backward: forward = the tile kernel + row statistics, backward =
+    bagel_attn_bwd_blockmask_bf16 over 128-row work items, one split per sample ("causal" or "full")."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu, max_len, scale, causal):
+        Tq, Hq, D0 = q.shape
+        Hk = k.shape[1]
+        D = 64 if D0 <= 64 else 128
+        if D != D0:
+            pad = lambda t: torch.nn.functional.pad(t, (0, D - D0))  # noqa: E731
+            q, k, v = pad(q), pad(k), pad(v)
+        q2, k2, v2 = q.reshape(Tq, Hq * D).contiguous(), k.reshape(Tq, Hk * D).contiguous(), v.reshape(Tq, Hk * D).contiguous()
+        dev, s = q.device, torch.cuda.current_stream().cuda_stream
+        B = cu.numel() - 1
+        lens = cu[1:] - cu[:-1]
+        blk = (lens + 63) // 64 * 64
+        col = torch.zeros(B, dtype=torch.int32, device=dev)
+        col[1:] = torch.cumsum(blk[:-1], 0)
+        cols = int(blk.sum()) + 64
+        vt = torch.zeros((Hk * D, cols), dtype=q.dtype, device=dev)
+        _check(_L.bagel_v_transpose_bf16(v2.data_ptr(), Hk * D, vt.data_ptr(), cols, cu.data_ptr(), col.data_ptr(), B, int(max_len), Hk, D, s))
+        out = torch.empty_like(q2)
+        lse = torch.empty((Hq, Tq), dtype=torch.float32, device=dev)
+        q_start, q_end = cu[:-1].contiguous(), cu[1:].contiguous()
+        _check(_L.bagel_attn_varlen_ranges_lse_bf16(q2.data_ptr(), Hq * D, k2.data_ptr(), Hk * D, vt.data_ptr(), cols, None, Hk * D, None, 0,
+                                                    out.data_ptr(), Hq * D, q_start.data_ptr(), q_end.data_ptr(), None, None, col.data_ptr(), None,
+                                                    B, int(max_len), Hq, Hk, D, int(bool(causal)), scale, lse.data_ptr(), Tq, s))
+        ctx.save_for_backward(q2, k2, v2, out, lse)
+        ctx.meta = (Tq, Hq, Hk, D0, D, scale, bool(causal), [int(x) for x in cu.tolist()])
+        o3 = out.view(Tq, Hq, D)
+        return o3[..., :D0].contiguous() if D != D0 else o3.clone()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        q2, k2, v2, out, lse = ctx.saved_tensors
+        Tq, Hq, Hk, D0, D, scale, causal, cu = ctx.meta
+        dev, s = q2.device, torch.cuda.current_stream().cuda_stream
+        do = d_out.to(torch.bfloat16)
+        if D != D0:
+            do = torch.nn.functional.pad(do, (0, D - D0))
+        do2 = do.reshape(Tq, Hq * D).contiguous()
+        q_items, k_items = [], []
+        for a0, a1 in zip(cu[:-1], cu[1:]):
+            for r0 in range(a0, a1, 128):
+                nr = min(128, a1 - r0)
+                q_items.append((r0, nr, a0, a0, a1, int(causal), a0 // 64, -(-((r0 + nr) if causal else a1) // 64)))
+                k_items.append((r0, nr, r0 if causal else a0, a1, a1, int(causal), 0, 0))
+        qi = torch.tensor(q_items, dtype=torch.int32, device=dev).reshape(-1, 8)
+        ki = torch.tensor(k_items, dtype=torch.int32, device=dev).reshape(-1, 8)
+        noise = torch.zeros(((Tq + 63) // 64,), dtype=torch.int64, device=dev)
+        qt, dot, kt = _transpose(q2), _transpose(do2), _transpose(k2)
+        ws = torch.empty((2, Hq, Tq), dtype=torch.float32, device=dev)
+        ws[0].copy_(lse)
+        dq, dk, dv = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
+        _check(_L.bagel_attn_bwd_blockmask_bf16(q2.data_ptr(), Hq * D, k2.data_ptr(), Hk * D, v2.data_ptr(), Hk * D, out.data_ptr(), Hq * D,
+                                                do2.data_ptr(), Hq * D, qt.data_ptr(), dot.data_ptr(), kt.data_ptr(), qt.stride(0),
+                                                dq.data_ptr(), Hq * D, dk.data_ptr(), Hk * D, dv.data_ptr(), Hk * D, qi.data_ptr(), qi.shape[0],
+                                                ki.data_ptr(), ki.shape[0], noise.data_ptr(), ws.data_ptr(), 1, Tq, Hq, Hk, D, scale, s))
+        cut = lambda t, H: t.view(Tq, H, D)[..., :D0].contiguous()  # noqa: E731
+        return cut(dq, Hq), cut(dk, Hk), cut(dv, Hk), None, None, None, None
 
 
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0, softmax_scale=None,
@@ -53,6 +138,11 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
     D = 64 if D0 <= 64 else 128
     if D0 > 128:
         raise NotImplementedError(f"flash_attn stand-in: head_dim {D0} > 128")
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        if Tq != Tk or not torch.equal(cu_seqlens_q.to(torch.int64).cpu(), cu_seqlens_k.to(torch.int64).cpu()):
+            raise NotImplementedError("flash_attn stand-in: the backward is built for self-attention (cu_seqlens_q == cu_seqlens_k); the cached "
+                                      "two-segment form is inference-only")
+        return _SelfAttnVarlen.apply(q, k, v, _i32(cu_seqlens_q), int(max_seqlen_q), scale, bool(causal))
     if D != D0:
         pad = lambda t: torch.nn.functional.pad(t, (0, D - D0))  # noqa: E731
         q, k, v = pad(q), pad(k), pad(v)

@@ -57,3 +57,34 @@ def test_flash_attn_stub_fails_loudly(stub):
         stub.flash_attn_varlen_func(q, k, v, cq, ck, 8, 8)                       # host tensors: no CPU fallback
     with pytest.raises(RuntimeError):
         stub.flash_attn_varlen_func(q.to(DEV), k.to(DEV)[:4], v.to(DEV)[:4], cq.to(DEV), torch.tensor([0, 4], dtype=torch.int32, device=DEV), 8, 4)
+
+
+@pytest.mark.parametrize("lens,nq,nkv,D,causal", [([300, 64, 130], 16, 16, 72, False), ([257, 70], 4, 2, 64, True), ([140], 28, 4, 128, False)],
+                         ids=["siglip_heads_72", "causal_d64_gqa", "gqa_d128"])
+def test_flash_attn_stub_backward_for_self_attention(stub, lens, nq, nkv, D, causal):
+    """The stub under autograd, as the stock reference's SigLIP uses it in training (siglip_navit.py:232-241): gradients of q / k / v vs
+    torch autograd of the flash-attn definition (the oracle's shim, fp32 softmax)."""
+    from oracle import bagel_oracle as O
+    q, k, v, cq, ck = _case(lens, lens, nq, nkv, D, seed=len(lens) * 5 + D)
+    do = rnd(sum(lens), nq, D, seed=99)
+    qf, kf, vf = (t.clone().requires_grad_(True) for t in (q, k, v))
+    O.GRAD_ENABLED = True
+    try:
+        with torch.enable_grad():
+            ref = O.attn_varlen(qf, kf, vf, cq, ck, max(lens), max(lens), causal=causal)
+        ref.backward(do)
+    finally:
+        O.GRAD_ENABLED = False
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    got = stub.flash_attn_varlen_func(qd, kd, vd, cq.to(DEV), ck.to(DEV), max(lens), max(lens), causal=causal)
+    assert got.requires_grad and got.shape == q.shape
+    close(got, ref, ulps=2, rel_l2=6e-3, what="forward under autograd")
+    got.backward(do.to(DEV))
+    for name, a, b in (("dq", qd.grad, qf.grad), ("dk", kd.grad, kf.grad), ("dv", vd.grad, vf.grad)):
+        assert a.shape == b.shape and a.dtype == BF16
+        rel = ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+        assert rel < 1.5e-2, (name, rel)
+    # the cached two-segment form stays inference-only
+    q2, k2, v2, cq2, ck2 = _case([5], [45], 4, 2, 64, seed=3)
+    with pytest.raises(NotImplementedError):
+        stub.flash_attn_varlen_func(q2.to(DEV).requires_grad_(True), k2.to(DEV), v2.to(DEV), cq2.to(DEV), ck2.to(DEV), 5, 45, causal=True)
