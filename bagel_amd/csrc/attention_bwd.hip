@@ -9,9 +9,9 @@
 // Two kernels, both deterministic (no atomics; a row's gradient is produced by exactly one wave):
 //   attn_bwd_dq_kernel   workgroup = one 128-query item x one q head, wave = 32 queries.
 //                        pass 1: S^T = K Q^T over the item's key tiles -> row log-sum-exp (online max / sum); delta = rowsum(dO o).
-//                        pass 2: P^T = exp(scale S^T - lse), dP^T = V dO^T, dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T.
+//                        pass 2: P^T = exp(scale S^T - lse), dP^T = V dO^T, dS^T = P^T (dP^T - delta), dQ^T += K^T dS^T (x scale at the store).
 //   attn_bwd_dkv_kernel  workgroup = one 128-key item x one kv head, wave = 32 keys; loops over the group's q heads and over the 64-query
-//                        tiles of the rows that see these keys:  P = exp(scale Q K^T - lse),  dV^T += dO^T P,  dS = P (dO V^T - delta) scale,
+//                        tiles of the rows that see these keys:  P = exp(scale Q K^T - lse),  dV^T += dO^T P,  dS = P (dO V^T - delta),
 //                        dK^T += Q^T dS.
 // The contraction over keys (dq) / queries (dkv) reads K^T / Q^T / dO^T from transposed HBM images (bagel_transpose_bf16) -- the same
 // trick as the forward's V^T image: 2 bytes per element per pass is noise next to the 4 + 4 products of the reverse.
@@ -151,14 +151,14 @@ __device__ __forceinline__ bf16x8_t ab_row_frag(const bf16_t* base, long ld, int
 
 // C-layout (rows d = 32 db + (i & 3) + 8 (i >> 2) + 4 h, column = the lane's row of the output) -> out[row][col0 + d], 8-byte stores
 template <int DB>
-__device__ __forceinline__ void ab_store_acc(bf16_t* out, long ld, int row, int col0, const f32x16_t* acc, int h) {
+__device__ __forceinline__ void ab_store_acc(bf16_t* out, long ld, int row, int col0, const f32x16_t* acc, int h, float f = 1.0f) {
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             u32x2_t v;
-            v[0] = pack2bf(acc[db][4 * j], acc[db][4 * j + 1]);
-            v[1] = pack2bf(acc[db][4 * j + 2], acc[db][4 * j + 3]);
+            v[0] = pack2bf(acc[db][4 * j] * f, acc[db][4 * j + 1] * f);
+            v[1] = pack2bf(acc[db][4 * j + 2] * f, acc[db][4 * j + 3] * f);
             *(u32x2_t*)(out + (long)row * ld + col0 + 32 * db + 8 * j + 4 * h) = v;
         }
 }
@@ -319,14 +319,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
                         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Ks + (32 * kb + pm) * RP + 16 * ks + 8 * h), qf[ks], s, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Vs + (32 * kb + pm) * RP + 16 * ks + 8 * h), dof[ks], dp, 0, 0, 0);
                     }
-                    const unsigned ok = pl ? 0xffffu : mask16(t, nb, kb);
-                    float ds[16];
+                    float ds[16];                            // dS / scale: the softmax scale multiplies the dQ accumulators once, at the store
+                    if (pl) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        if (AB_ABL & 2) { ds[i] = s[i] + dp[i]; continue; }
-                        const float e = __builtin_amdgcn_exp2f(s[i] * c2 - lse2);
-                        const float pr = ((ok >> i) & 1u) ? e : 0.f;
-                        ds[i] = pr * (dp[i] - delta) * p.scale;
+                        for (int i = 0; i < 16; ++i) {
+                            if (AB_ABL & 2) { ds[i] = s[i] + dp[i]; continue; }
+                            ds[i] = __builtin_amdgcn_exp2f(s[i] * c2 - lse2) * (dp[i] - delta);
+                        }
+                    } else {
+                        const unsigned ok = mask16(t, nb, kb);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            if (AB_ABL & 2) { ds[i] = s[i] + dp[i]; continue; }
+                            const float e = __builtin_amdgcn_exp2f(s[i] * c2 - lse2);
+                            ds[i] = (((ok >> i) & 1u) ? e : 0.f) * (dp[i] - delta);
+                        }
                     }
                     const bf16x8_t dsf0 = ab_pack8(ds), dsf1 = ab_pack8(ds + 8);
 #pragma unroll
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
             t = tn;
         }
     }
-    if (qvalid) ab_store_acc<DB>(p.dq, p.lddq, qrow, hq * D, dq, h);
+    if (qvalid) ab_store_acc<DB>(p.dq, p.lddq, qrow, hq * D, dq, h, p.scale);
 }
 
 template <int D>
@@ -434,16 +441,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { lv[8 * a + 4 * e4 + e] = x[e]; dl[8 * a + 4 * e4 + e] = y[e]; }
                 }
+            if (pl) {                                        // dS / scale: the softmax scale multiplies the dK accumulators once, at the store
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int ql = 32 * qb + 16 * (i >> 3) + 8 * h + (i & 7);
-                const int qrow = q0 + ql;
-                const unsigned ok = (unsigned)pl | ((unsigned)kvalid & (unsigned)(qrow >= qbeg) & (unsigned)(qrow < qend) &
-                                                   ((unsigned)(qrow >= send) | (unsigned)(causal == 0) | (unsigned)(krow <= qrow)));
-                if (AB_ABL & 2) { pr[i] = s[i]; ds[i] = dp[i]; continue; }
-                const float e = __builtin_amdgcn_exp2f(s[i] * c2 - lv[i]);
-                pr[i] = ok ? e : 0.f;
-                ds[i] = pr[i] * (dp[i] - dl[i]) * p.scale;
+                for (int i = 0; i < 16; ++i) {
+                    if (AB_ABL & 2) { pr[i] = s[i]; ds[i] = dp[i]; continue; }
+                    pr[i] = __builtin_amdgcn_exp2f(s[i] * c2 - lv[i]);
+                    ds[i] = pr[i] * (dp[i] - dl[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ql = 32 * qb + 16 * (i >> 3) + 8 * h + (i & 7);
+                    const int qrow = q0 + ql;
+                    const unsigned ok = (unsigned)kvalid & (unsigned)(qrow >= qbeg) & (unsigned)(qrow < qend) &
+                                        ((unsigned)(qrow >= send) | (unsigned)(causal == 0) | (unsigned)(krow <= qrow));
+                    if (AB_ABL & 2) { pr[i] = s[i]; ds[i] = dp[i]; continue; }
+                    const float e = __builtin_amdgcn_exp2f(s[i] * c2 - lv[i]);
+                    pr[i] = ok ? e : 0.f;
+                    ds[i] = pr[i] * (dp[i] - dl[i]);
+                }
             }
             const bf16x8_t pf0 = ab_pack8(pr), pf1 = ab_pack8(pr + 8), dsf0 = ab_pack8(ds), dsf1 = ab_pack8(ds + 8);
 #pragma unroll
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
         }
     }
     if (kvalid) {
-        ab_store_acc<DB>(p.dk, p.lddk, krow, hkv * D, dk, h);
+        ab_store_acc<DB>(p.dk, p.lddk, krow, hkv * D, dk, h, p.scale);
         ab_store_acc<DB>(p.dv, p.lddv, krow, hkv * D, dv, h);
     }
 }

@@ -175,7 +175,7 @@ class SiglipVisionModel(PackedWeights):
     @torch.no_grad()
     def forward(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen, tape=None):
         """``tape`` (a dict, training only): every layer writes its residual streams, projection, attention output, row statistics and MLP
-        activation into buffers of its own, kept for train_step.siglip_backward (the tower's backward; learned-position variant only)."""
+        activation into buffers of its own, kept for train_step.siglip_backward (the tower's backward; the learned position table of BAGEL's so400m config and the 2-D RoPE variant)."""
         self._check_packed()
         P = self._packed or self._pack()
         cfg = self.config
@@ -198,8 +198,6 @@ class SiglipVisionModel(PackedWeights):
         vt = torch.zeros((nh * dp, _ceil_to(c, 256)), dtype=BF16, device=dev)
         a16 = ops.f32_to_bf16(pix, cols_padded=P["kpad"])
         if tape is not None:
-            if P["rope"] is not None:
-                raise NotImplementedError("the SigLIP backward is built for the learned position table (BAGEL's so400m config), not the 2-D RoPE variant")
             tape.update(a16=a16, pos=pos.cpu(), lens=[int(l) for l in lens], x=[], x_mid=[], qkv=[], att=[], mid=[], lse=[], n=n)
             x = e(n, D)
             tape["x"].append(x)

@@ -18,7 +18,7 @@ MI355X-first choices:
     atomics, so the same batch gives the same gradients bit for bit on every run.
 
 Scope: gradients of every parameter of the language model (both experts, embeddings, norms, lm_head), llm2vae / vae2llm / the time
-embedder, the ViT connector and the SigLIP tower (learned-position variant); the VAE is frozen as in the reference (``--freeze_vae True``,
+embedder, the ViT connector and the SigLIP tower (learned positions or 2-D RoPE); the VAE is frozen as in the reference (``--freeze_vae True``,
 pretrain_unified_navit.py:390-393) and the sin-cos position tables are frozen parameters there too -- a parameter outside that set that
 requires grad raises instead of silently staying without a gradient."""
 import os
@@ -310,6 +310,11 @@ def siglip_backward(vit, tape, g, grads):
     qw, n, eps = nh * dp, tape["n"], cfg.layer_norm_eps
     e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
     bplan = AttnBackwardPlan(dev, tape["lens"], [([l], ["full"]) for l in tape["lens"]])
+    rope_inv, pos_dev = None, None
+    if P["rope"] is not None:            # 2-D RoPE variant (siglip_navit.py:102-142,224-230): the reverse of a rotation is the rotation by -angle
+        ch, sh, cw, sw = P["rope"]
+        rope_inv = (ch, (-sh.float()).to(BF16), cw, (-sw.float()).to(BF16))
+        pos_dev = tape["pos"].to(device=dev, dtype=torch.long).contiguous()
     pl = vm.post_layernorm
     gx = e(n, D)
     dw, db = ops.layernorm_bwd(tape["x"][-1], g, pl.weight.data, gx, eps, accumulate=False)
@@ -342,6 +347,8 @@ def siglip_backward(vit, tape, g, grads):
         ops.attn_bwd_blockmask(qkv[:, :qw], qkv[:, qw:2 * qw], qkv[:, 2 * qw:], att, d_att, dqkv[:, :qw], dqkv[:, qw:2 * qw], dqkv[:, 2 * qw:],
                                bplan.q_items, bplan.k_items, bplan.noise_bits, nh, nh, dp, hd ** -0.5, lse=tape["lse"][li])
         del d_att
+        if rope_inv is not None:
+            ops.rope2d(dqkv, rope_inv, pos_dev, 2 * nh, hd, dp)            # gradients of the rotated q / k heads -> of the projection's
         ops.layernorm(x_in, L["ln1"][0], L["ln1"][1], h, eps)
         dW, dB = _wgrad(dqkv, h), ops.colsum(dqkv)
         for j, name in enumerate(("q_proj", "k_proj", "v_proj")):
@@ -352,12 +359,12 @@ def siglip_backward(vit, tape, g, grads):
         del dqkv
         dw, db = ops.layernorm_bwd(x_in, d_h, L["ln1"][0], g, eps)
         grads.add(Lm.layer_norm1.weight, dw); grads.add(Lm.layer_norm1.bias, db)
-    # front: x0 = patch_embedding(pixels) + position_embedding[pos]
+    # front: x0 = patch_embedding(pixels) + position_embedding[pos]  (no position table in the RoPE variant)
     emb = vm.embeddings
     grads.add(emb.patch_embedding.weight, _wgrad(g, tape["a16"])[:, :P["kin"]])
     grads.add(emb.patch_embedding.bias, ops.colsum(g))
-    pe = emb.position_embedding.weight
-    if pe.requires_grad:
+    pe = getattr(getattr(emb, "position_embedding", None), "weight", None)
+    if pe is not None and pe.requires_grad and P["rope"] is None:
         pos = tape["pos"]
         order = torch.argsort(pos, stable=True)
         uniq, counts = torch.unique_consecutive(pos[order], return_counts=True)

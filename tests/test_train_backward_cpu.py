@@ -9,11 +9,11 @@ import pytest
 import torch
 
 from oracle import bagel_oracle as O
-from oracle.configs import TINY, TINY_D128
+from oracle.configs import TINY, TINY_D128, TINY_ROPE
 from tests import mock_ops
 from tests.util_models import oracle_weights, pack_training_batch
 
-CFGS = {"tiny": TINY, "tiny_d128": TINY_D128}
+CFGS = {"tiny": TINY, "tiny_d128": TINY_D128, "tiny_rope": TINY_ROPE}
 FROZEN = ("vit_pos_embed.", "latent_pos_embed.")
 
 
@@ -48,12 +48,12 @@ def product_step(model, batch, noise, w_ce, **extra):
     return float(loss.detach()), {n: p.grad for n, p in model.named_parameters() if p.grad is not None}, out
 
 
-def compare(grads, ref, names, tol, what):
+def compare(grads, ref, names, tol, what, key_bias_is_zero=True):
     worst = ("", 0.0)
     for n in names:
         assert n in ref, n
         rn = float(ref[n].float().norm())
-        if n.startswith("vit_model.") and n.endswith("k_proj.bias"):
+        if key_bias_is_zero and n.startswith("vit_model.") and n.endswith("k_proj.bias"):
             # softmax is invariant to a constant added to every key of a row: the exact gradient of SigLIP's key bias is ZERO, what both
             # sides hold is rounding noise -- check that it is noise (against the query bias of the same layer), not that the noises agree
             qn = float(ref[n.replace("k_proj", "q_proj")].float().norm())
@@ -160,6 +160,25 @@ def test_text_only_pack_takes_the_single_expert_path(monkeypatch, name):
     for n, r in rgrads.items():
         if float(r.float().norm()) > 0:
             assert rel(grads[n], r) < 6e-2, (n, rel(grads[n], r))
+
+
+def test_siglip_2d_rope_variant_backward(monkeypatch):
+    """The SigLIP tower with 2-D RoPE instead of the learned position table (config.rope, siglip_navit.py:102-142,224-230): the reverse of
+    the rotation is the rotation by the negated angle on the q / k gradient heads -- every gradient vs the oracle's autograd."""
+    mock_ops.install(monkeypatch)
+    cfg = TINY_ROPE
+    samples = [[("text", 3, True), ("vit", 28, 42), ("text", 4, True)], [("text", 2, False), ("vit", 42, 14), ("vae", 32, 48, True)]]
+    batch, noise, _, _ = pack_training_batch(cfg, samples, 21)
+    w_ce = torch.rand(batch["ce_loss_indexes"].numel(), generator=torch.Generator().manual_seed(4)) + 0.5
+    W, _ = oracle_weights(cfg)
+    model = cpu_model(cfg)
+    names = trainable(model)
+    assert not any("position_embedding" in n for n in names)
+    rloss, rgrads, _ = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
+    loss, grads, _ = product_step(model, batch, noise, w_ce)
+    assert abs(loss - rloss) < 2e-2 * abs(rloss)
+    worst = compare(grads, rgrads, names, 6e-2, "tiny_rope", key_bias_is_zero=False)      # a rotated key bias is a real gradient
+    assert worst[1] > 0
 
 
 def test_tape_options_do_not_change_the_gradients(golden, monkeypatch):

@@ -271,11 +271,11 @@ def _step(model, batch, noise, w_ce):
     return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
 
 
-def _compare(grads, ref, names, tol, what):
+def _compare(grads, ref, names, tol, what, key_bias_is_zero=True):
     worst = ("", 0.0)
     for n in names:
         rn = float(ref[n].float().norm())
-        if n.startswith("vit_model.") and n.endswith("k_proj.bias"):
+        if key_bias_is_zero and n.startswith("vit_model.") and n.endswith("k_proj.bias"):
             # the exact gradient of SigLIP's key bias is zero (softmax is invariant to a constant added to every key of a row): both sides
             # hold rounding noise -- it has to BE noise next to the query bias of the same layer
             qn = float(ref[n.replace("k_proj", "q_proj")].float().norm())
@@ -353,6 +353,29 @@ def test_text_only_pack_takes_the_single_expert_path(name):
         for n, r in rgrads.items():
             if float(r.float().norm()) > 0:
                 assert rel(grads[n], r) < 6e-2, (n, rel(grads[n], r))
+    finally:
+        for p in model.parameters():
+            p.requires_grad_(False)
+            p.grad = None
+
+
+def test_siglip_2d_rope_variant_backward():
+    """The tower with 2-D RoPE (config.rope) instead of the learned position table: the rotation's reverse on the q / k gradient heads."""
+    from oracle import bagel_oracle as O
+    from oracle.configs import TINY_ROPE
+    from tests.util_models import oracle_weights, pack_training_batch, product_model
+    cfg = TINY_ROPE
+    samples = [[("text", 3, True), ("vit", 28, 42), ("text", 4, True)], [("text", 2, False), ("vit", 42, 14), ("vae", 32, 48, True)]]
+    batch, noise, _, _ = pack_training_batch(cfg, samples, 21)
+    w_ce = torch.rand(batch["ce_loss_indexes"].numel(), generator=torch.Generator().manual_seed(4)) + 0.5
+    W, _ = oracle_weights(cfg)
+    model, _ = product_model(cfg)
+    try:
+        names = _trainable(model)
+        rloss, rgrads, _ = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
+        loss, grads = _step(model, batch, noise, w_ce)
+        assert abs(loss - rloss) < 2e-2 * abs(rloss)
+        _compare(grads, rgrads, names, 6e-2, "tiny_rope", key_bias_is_zero=False)
     finally:
         for p in model.parameters():
             p.requires_grad_(False)
