@@ -272,3 +272,23 @@ def test_attention_backward_items_cover_the_block_mask():
             assert not fromk[:, key0:key0 + nkeys].any()
             fromk[qbeg:qend, key0:key0 + nkeys] = (rows >= send) | (keys <= rows) | (causal == 0)
         assert torch.equal(fromq, dense) and torch.equal(fromk, dense), (sample_lens, splits)
+
+
+def test_a_few_optimizer_steps_reduce_the_loss(golden, monkeypatch):
+    """The reference's loop shape -- forward, loss, backward, torch optimizer step -- on the stand-ins: every step re-packs the engines'
+    weight copies from the updated parameters (modeling/packed.py) and the loss of the same batch goes down."""
+    mock_ops.install(monkeypatch)
+    g = golden("tiny_train")
+    model = cpu_model(TINY)
+    trainable(model)
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=2e-2)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        out = model(noise=g["noise"], **g["batch"])
+        loss = O.training_step_loss(out)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(b < a for a, b in zip(losses, losses[1:])), losses
+    assert losses[-1] < 0.97 * losses[0], losses
