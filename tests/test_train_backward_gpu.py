@@ -11,8 +11,12 @@
 (d) determinism: the same batch twice gives bit-identical gradients (no atomics anywhere in the reverse).
 
 Tolerances (rel-L2 per tensor): kernels 4e-3 (one bf16 rounding of an fp32 result; 1e-2 where two bf16 roundings chain); attention
-reverse 1e-2 (P and dS are rounded to bf16 before their products, as flash-attn's backward does); parameter gradients 6e-2 on the tiny
-models (the same bound as the CPU stand-in run of tests/test_train_backward_cpu.py, measured there 1.6e-2) and 8e-2 at 7B width."""
+reverse 1e-2 (P and dS are rounded to bf16 before their products, as flash-attn's backward does); parameter gradients 4e-2 on the fixed
+batches.  That bound is set against the REFERENCE'S OWN noise: tools/train_grad_noise_floor.py re-runs the oracle's autograd with
+fp32-accumulating linears (same bf16 operands and rounding points, another summation order -- what another CPU backend or a GPU does) and
+the reference's gradients move by up to 1.9e-2 at 7B width, 8.7e-3 on tiny_d128, 2.1e-3 on tiny (profiles/r03_train_grad_noise_floor.log);
+the product adds flash-attn's bf16 P / dS and its own rounding points on top: measured 2.8e-2 (tiny), 1.7e-2 (tiny_d128), 2.4e-2 (7B width),
+2.9e-2 (SigLIP width).  Frozen rule: <= max(4e-2, 2 x floor); 6e-2 for the text-only / RoPE-variant packs, 8e-2 in the CPU fuzz."""
 import pytest
 import torch
 
@@ -311,10 +315,10 @@ def test_training_step_gradients_match_the_oracle(golden, monkeypatch, name, kee
         rloss, rgrads, _ = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
         loss, grads = _step(model, batch, noise, w_ce)
         assert abs(loss - rloss) < 2e-2 * abs(rloss)
-        worst = _compare(grads, rgrads, names, 6e-2, name)
+        worst = _compare(grads, rgrads, names, 4e-2, name)
         print(f"[{name}] {len(names)} gradients, worst rel-L2 {worst[1]:.2e} at {worst[0]}")
         if name == "tiny":
-            _compare(grads, golden("tiny_train_grads")["grads"], names, 6e-2, "reference fixture")
+            _compare(grads, golden("tiny_train_grads")["grads"], names, 4e-2, "reference fixture")
         loss2, grads2 = _step(model, batch, noise, w_ce)               # (d) no atomics: bit-identical on a second run
         assert loss2 == loss
         for n in grads:
@@ -407,7 +411,7 @@ def test_training_step_gradients_at_7b_width():
     rloss, rgrads, _ = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
     loss, grads = _step(model, batch, noise, w_ce)
     assert abs(loss - rloss) < 2e-2 * abs(rloss)
-    worst = _compare(grads, rgrads, names, 8e-2, "wide7b")
+    worst = _compare(grads, rgrads, names, 4e-2, "wide7b")
     print(f"[wide7b] {len(names)} gradients, worst rel-L2 {worst[1]:.2e} at {worst[0]}")
 
 
@@ -436,5 +440,5 @@ def test_training_step_gradients_at_siglip_width():
     rloss, rgrads, _ = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
     loss, grads = _step(model, batch, noise, w_ce)
     assert abs(loss - rloss) < 2e-2 * abs(rloss)
-    worst = _compare(grads, rgrads, names, 8e-2, "wide7b_und")
+    worst = _compare(grads, rgrads, names, 4.5e-2, "wide7b_und")
     print(f"[wide7b_und] {len(names)} gradients, worst rel-L2 {worst[1]:.2e} at {worst[0]}")
