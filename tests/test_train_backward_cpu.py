@@ -88,12 +88,12 @@ def test_training_step_gradients_match_the_reference_batch(golden, monkeypatch, 
     loss, grads, out = product_step(model, batch, noise, w_ce)
     assert abs(loss - rloss) < 2e-2 * abs(rloss)
     assert out["mse"].requires_grad and out["ce"].requires_grad
-    worst = compare(grads, rgrads, names, 6e-2, name)
+    worst = compare(grads, rgrads, names, 4e-2, name)
     print(f"[{name}] {len(names)} gradients, worst rel-L2 {worst[1]:.2e} at {worst[0]}")
     if name == "tiny":
         fx = golden("tiny_train_grads")
         assert torch.equal(fx["ce_loss_weights"], w_ce)
-        compare(grads, fx["grads"], names, 6e-2, "fixture")
+        compare(grads, fx["grads"], names, 4e-2, "fixture")
     # the flat split API gives the same gradients bit for bit (same plan, same launches)
     b2 = {k: v for k, v in batch.items() if k != "nested_attention_masks"}
     _, grads2, _ = product_step(model, b2, noise, w_ce, split_lens=g["split_lens"], attn_modes=g["attn_modes"])
