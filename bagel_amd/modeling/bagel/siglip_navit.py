@@ -198,7 +198,7 @@ class SiglipVisionModel(PackedWeights):
         vt = torch.zeros((nh * dp, _ceil_to(c, 256)), dtype=BF16, device=dev)
         a16 = ops.f32_to_bf16(pix, cols_padded=P["kpad"])
         if tape is not None:
-            tape.update(a16=a16, pos=pos.cpu(), lens=[int(l) for l in lens], x=[], x_mid=[], qkv=[], att=[], mid=[], lse=[], n=n)
+            tape.update(a16=a16, pos=packed_flattened_position_ids.detach().to(device="cpu", dtype=torch.long), lens=[int(l) for l in lens], x=[], x_mid=[], qkv=[], att=[], mid=[], lse=[], n=n)
             x = e(n, D)
             tape["x"].append(x)
         ops.gemm(a16, P["wpatch"], x, bias0=P["bpatch"])
