@@ -1050,13 +1050,17 @@ def main():
             import traceback
             edit = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
     trainf = None
-    if args.workload == "t2i" and not args.no_train_forward and not args.standins and args.layers is None:
+    if args.workload == "t2i" and not args.no_train_forward and (args.layers is None or args.standins):
         # SURVEY 8f.2 beside the headline: Bagel.forward (training forward, per-token CE / MSE losses, no backward) on a packed 7B batch of
         # 2 x [prompt | 980^2 ViT image | answer + CE] + 2 x [prompt | noised 1024^2 latent + MSE] (tools/train_forward_probe.py)
         try:
-            from tools.train_forward_probe import build_batch
-            tb = build_batch(model, ids)
-            tn = torch.randn(len(tb["packed_vae_token_indexes"]), 64, generator=torch.Generator().manual_seed(1)).to(dev)
+            if args.standins:        # the tiny model on the CPU stand-ins: a hand-packed two-sample batch (test-only mode, host logic of the legs)
+                from tests.util_models import pack_training_batch
+                tb, tn, _, _ = pack_training_batch(cfg, [[("text", 3, True), ("vit", 28, 42), ("text", 4, True)], [("text", 2, False), ("vae", 32, 48, True)]], 7)
+            else:
+                from tools.train_forward_probe import build_batch
+                tb = build_batch(model, ids)
+                tn = torch.randn(len(tb["packed_vae_token_indexes"]), 64, generator=torch.Generator().manual_seed(1)).to(dev)
             o_ = model(noise=tn, **tb)
             fence()
             t1 = time.perf_counter()
@@ -1098,7 +1102,7 @@ def main():
                     trainf["training_step"] = {
                         "value": world * ntok / (tf_ + tb_), "unit": "tokens/s", "ms_forward_with_tape": tf_ * 1e3, "ms_backward": tb_ * 1e3,
                         "trainable_params": n_train, "loss": rs[-1][0], "grad_norm": gn, "finite": bool(gn == gn and gn < float("inf")),
-                        "linear_tflops_whole_step": 3 * lin / (tf_ + tb_), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                        "linear_tflops_whole_step": 3 * lin / (tf_ + tb_), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30 if cuda else None,
                         "note": "forward with tape + backward, no optimizer step (the optimizer is torch's, out of scope); 3 x the forward's linear "
                                 "FLOPs over the step time (the gate/up recompute and the attention reverse are not counted as useful work)"}
                 except Exception as e:
@@ -1108,7 +1112,8 @@ def main():
                     for p_ in model.parameters():
                         p_.requires_grad_(False)
                         p_.grad = None
-                    torch.cuda.empty_cache()
+                    if cuda:
+                        torch.cuda.empty_cache()
             del tb, tn, o_
         except Exception as e:
             import traceback

@@ -219,6 +219,10 @@ def test_bench_one_step_on_two_gloo_ranks():
     # 2 layers x (K, V) x 2 samples x 8 prompt rows x (2 KV heads x 64 padded lanes) bf16 + the int64 header (count, L, nkv, hd, dp, 2 lens)
     assert b["calls"] == 2 and b["bytes_per_call"] == 2 * 2 * 16 * 128 * 2 + 8 * (1 + 4 + 2) and b["ms_per_call"] > 0
     assert two["cpu_baseline"] is None and two["understanding"] is None
+    tr = two["training_forward"]                        # the training legs run on every rank (fence inside): forward, then forward with tape + backward
+    assert tr["outputs_finite"] is True and tr["value"] > 0
+    ts = tr["training_step"]
+    assert "error" not in ts and ts["finite"] is True and ts["grad_norm"] > 0 and ts["trainable_params"] > 0 and ts["ms_backward"] > 0
     one = run(1, 1, 0)
     assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and one["broadcast"] is None and one["collective_backend"] is None
     assert one["latents_checksum"] == two["latents_checksum"], "rank 0 of the 2-rank job must reproduce the 1-rank job's samples"
