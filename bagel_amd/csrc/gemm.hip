@@ -594,6 +594,27 @@ static int launch_gemm_pp(const GemmParams& p0, hipStream_t stream) {
 //     instructions may be in flight) covers k-tile 0 and every store, whatever order loads and stores retire in.
 // Tile order: work item w keeps its XCD (gridDim.x is a multiple of 8), same band walk as variant 3.
 // =========================================================================================================
+// SGPR-base form of the LDS-DMA: address = wave-uniform 64-bit base + the lane's unsigned 32-bit byte offset.  One address VGPR per
+// instruction instead of a register pair (the k advance moves to the scalar unit).  BAGEL_PQ_SADDR=1 builds gemm_pq_kernel on it;
+// contract of that build: every operand row the launch touches lies within 4 GiB of the operand's base pointer.
+#ifndef BAGEL_PQ_SADDR
+#define BAGEL_PQ_SADDR 0
+#endif
+#ifndef BAGEL_PQ_ABL
+#define BAGEL_PQ_ABL 0                 /* timing-only ablations of the SwiGLU epilogue (tools/ab_build.sh): 1 no exp/rcp, 2 no global stores */
+#endif
+__device__ __forceinline__ const char* pq_uniform(const char* ptr) {          // makes wave-uniformity provable to hipcc (an "s" operand)
+    const unsigned long v = (unsigned long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16_saddr(unsigned voff, const void* sbase_uniform, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase_uniform), "s"(lds_dst_uniform)
+                 : "memory");
+}
 __device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_dst_uniform) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -670,7 +691,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
         if (lst) glds4_asm(lst + m, smem_base + off);
         else *(int*)(smem + off + lane * 4) = m;
     };
+#if BAGEL_PQ_SADDR
+    unsigned src[4][2];      // [piece][i]: byte offset from the operand's base (A: pieces 0 / 3, W: pieces 1 / 2)
+    const char* baseA = nullptr;   // wave-uniform bases of the current tile (operand base + the item's first k-tile)
+    const char* baseW = nullptr;
+#else
     const char* src[4][2];   // [piece][i]
+#endif
     // DMA sources of tile (tm, tn): piece-local row lr = 8*j + lane/8 (j = wave + 8*i), LDS chunk lane%8, global chunk
     // swizzled; A rows come from the table in ring slot `buf`.  `ln` is an opaque copy of the lane id (keeps hipcc from
     // hoisting this arithmetic out of the tile loop and spilling it across the k-loop).
@@ -679,6 +706,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
         const long kb = (long)kt0 * 128;           // byte offset of the item's first k-tile inside a row
         const int n0 = tn * BN;
         const int* atab = (const int*)(smem + TBL + buf * 2048);
+#if BAGEL_PQ_SADDR
+        baseA = pq_uniform((const char*)p.A + kb);
+        baseW = pq_uniform((const char*)Wg + kb);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int lr = (wave + 8 * i) * 8 + (ln >> 3);
@@ -686,10 +717,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int row = atab[(lr >> 6) * 128 + half * 64 + (lr & 63)];
-                src[half ? 3 : 0][i] = (const char*)(p.A + (long)row * p.lda) + gch16 + kb;
                 int n = n0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
                 n = n < p.N ? n : p.N - 1;
+#if BAGEL_PQ_SADDR
+                src[half ? 3 : 0][i] = (unsigned)row * (unsigned)(p.lda * 2) + gch16;
+                src[half ? 2 : 1][i] = (unsigned)n * (unsigned)(p.ldw * 2) + gch16;
+#else
+                src[half ? 3 : 0][i] = (const char*)(p.A + (long)row * p.lda) + gch16 + kb;
                 src[half ? 2 : 1][i] = (const char*)(Wg + (long)n * p.ldw) + gch16 + kb;
+#endif
             }
         }
     };
@@ -700,11 +736,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
             for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(src[pc][i]));
     };
     auto issue = [&](int piece, unsigned stage_base, long koff) {
+#if BAGEL_PQ_SADDR
+        const char* sb = ((piece == 0 || piece == 3) ? baseA : baseW) + koff;
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = wave + 8 * i;
             const unsigned d = (piece == 0 ? OFF_A0 : piece == 1 ? OFF_B0 : piece == 2 ? OFF_B1 : OFF_A1) + j * 1024;
+#if BAGEL_PQ_SADDR
+            glds16_saddr(src[piece][i], sb, stage_base + d);
+#else
             glds16_asm(src[piece][i] + koff, stage_base + d);
+#endif
         }
     };
 
@@ -916,7 +959,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
                         for (int e = 0; e < 4; ++e) {
                             const float g = bfround(FP8 ? acc[ma][i][nb][0][e] * (sa_r[ma][i] * sw_c[nb][0][e]) : acc[ma][i][nb][0][e]);
                             const float u = bfround(FP8 ? acc[ma][i][nb][1][e] * (sa_r[ma][i] * sw_c[nb][1][e]) : acc[ma][i][nb][1][e]);
+#if BAGEL_PQ_ABL & 1                 /* timing-only ablation (wrong results): no exp / rcp */
+                            o[e] = g * u;
+#else
                             o[e] = bfround(silu_f(g)) * u;
+#endif
                         }
                         u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                         *(u32x2_t*)(rowp + (((c >> 2) ^ efr) << 3)) = v;
@@ -932,7 +979,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
                 for (int it = 0; it < 8; ++it) {
                     u32x4_t v = *(const u32x4_t*)(rd + it * 8192);
                     if (x & 1) { v = (u32x4_t){v[2], v[3], v[0], v[1]}; }
+#if BAGEL_PQ_ABL & 2                 /* timing-only ablation (wrong results): no global stores; the staged tile is kept live */
+                    asm volatile("" ::"v"(v));
+#else
                     if (col_ok && m0 + it * 32 + rb < Mg) *(u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc) = v;
+#endif
                 }
             }
             PP_LGKM0();

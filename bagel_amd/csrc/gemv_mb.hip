@@ -1,0 +1,295 @@
+// Batched-decode projection: C[M <= 16, N] = norm(A)[M,K] W[N,K]^T (+bias)(act)(SwiGLU16)(+R) as a pure WEIGHT STREAM through the MFMA.
+//
+// Replaces, for 2..16 concurrent requests, the reference's F.linear call sites of a decode step (qwen2_navit.py:515-517,591-594;
+// modeling_qwen2.py:54-59,200-201; bagel.py:978) and the marker-row side path of a denoise forward (16 und rows per layer).
+//
+// Why a third small-M kernel: decode.hip's lane-FMA gemv is VALU-bound from two rows, and skinny.hip's MFMA kernel loads the
+// ACTIVATION fragment of every 32-deep step from L2 next to the weight fragment -- 1 KB of x per 1 KB of W through the same vector
+// memory pipe, which is why 16 requests streamed the weights at 3.3 TB/s where one request gets 6.4.  Here the activations never
+// touch the memory pipe inside the loop:
+//   * the 8 waves of a workgroup PARTITION K (K = 3584: 14 steps of 32 per wave); a wave loads its x fragments ONCE into registers
+//     (mfma_f32_16x16x32_bf16 B operand: lane = (request r = lane % 16, k chunk q = lane / 16), 4 VGPRs per step), applies the fused
+//     Qwen2RMSNorm there (row sum of squares: two lane exchanges + one pass through LDS across the waves), and keeps them for every
+//     column block the workgroup processes;
+//   * per column block (16 weight rows) a wave issues NS fragment loads of 1 KB (row lane % 16, 16 bytes at chunk lane / 16: row-major
+//     W IS the A-operand layout) and refills each register quad in place right behind the MFMA that consumed it, so NS KB per wave
+//     (112-152 KB per CU) are in flight for the whole life of the workgroup and the loop holds nothing but loads and MFMAs;
+//   * the eight K partials of a block meet in LDS (1 KB per wave and block); wave g sums block g in a fixed order and runs the epilogue
+//     with gemm.hip's rounding points (lane owns 4 consecutive output columns of one request: 8-byte stores);
+//   * SwiGLU16 needs no special loop: with the gate/up rows interleaved in blocks of 16, block b is ALWAYS weight rows [16 b, 16 b + 16);
+//     the reducing wave pairs blocks 2 j (gate) and 2 j + 1 (up);
+//   * long rows (the down projection, K = 18944 = 592 steps) are cut over KS workgroups as well; those write fp32 slabs [KS][16][N] and a
+//     small second kernel sums them in slice order and applies the epilogue -- deterministic (no atomics), one extra graph node per layer.
+// Results are independent of the launch geometry only up to the fp32 summation order (8 K partials instead of one chain), like the
+// K-split tiles of gemm.hip; tests pin it to the fp32 product within 2 bf16 ulp.
+#include "common.h"
+#include <stdlib.h>
+
+#define EPI_NONE 0
+#define EPI_GELU_TANH 1
+#define EPI_SILU 2
+#define EPI_SWIGLU16 3
+
+struct MbParams {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    const bf16_t* bias;
+    const bf16_t* R; long ldr;
+    bf16_t* C; long ldc;
+    const bf16_t* norm_w; float eps;
+    float* part;      // KS > 1: fp32 slabs [KS][16][N]
+    int M, N, K, epi;
+
+    int per;          // 32-deep k-steps per wave (<= NS)
+    int KS;           // K slices over workgroups (gridDim.y)
+};
+
+__device__ __forceinline__ void mb_epilogue(const MbParams& p, f32x4_t a, int m, int n) {
+    float o[4] = {a[0], a[1], a[2], a[3]};
+    if (p.bias) {
+        const u32x2_t bv = *(const u32x2_t*)(p.bias + n);
+        o[0] += lo2f(bv[0]); o[1] += hi2f(bv[0]); o[2] += lo2f(bv[1]); o[3] += hi2f(bv[1]);
+    }
+    if (p.epi == EPI_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bfround(o[e]));
+    } else if (p.epi == EPI_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = silu_f(bfround(o[e]));
+    }
+    if (p.R) {
+        const u32x2_t rv = *(const u32x2_t*)(p.R + (long)m * p.ldr + n);
+        o[0] = bfround(o[0]) + lo2f(rv[0]); o[1] = bfround(o[1]) + hi2f(rv[0]);
+        o[2] = bfround(o[2]) + lo2f(rv[1]); o[3] = bfround(o[3]) + hi2f(rv[1]);
+    }
+    const u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    *(u32x2_t*)(p.C + (long)m * p.ldc + n) = v;
+}
+
+template <int NS, bool NORM>
+__global__ __launch_bounds__(512) void gemv_mb_kernel(const MbParams p) {
+    constexpr int CH = 6;                                      // blocks between two reductions (LDS: CH x 8 waves x 1 KB = 48 KB static)
+    __shared__ __attribute__((aligned(16))) f32x4_t part[CH * 8 * 64];
+    __shared__ float red[8 * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const bool swiglu = p.epi == EPI_SWIGLU16;
+    const int nsteps = p.K >> 5;
+    const int s0 = (blockIdx.y * 8 + wave) * p.per;
+    int ns = nsteps - s0;
+    ns = ns < 0 ? 0 : (ns > p.per ? p.per : ns);
+    // fragment i of this wave = step sb + i, sb = min(s0, nsteps - NS) (the host guarantees nsteps >= NS): every address is ONE lane base +
+    // a compile-time offset i * 64 bytes and stays inside the row; fragments outside [s0, s0 + ns) belong to a neighbour and get x = 0
+    const int sb = s0 < nsteps - NS ? s0 : nsteps - NS;
+    const int lo = s0 - sb, hi = lo + ns;                      // live fragments: lo <= i < hi
+    // this workgroup's blocks: units (a block; SwiGLU16: a gate/up pair of blocks) [u0, u1) of the launch's even split over gridDim.x
+    const int unit = swiglu ? 2 : 1;
+    const int nunits = (p.N >> 4) / unit;
+    const int bA = (int)((long)nunits * blockIdx.x / gridDim.x) * unit;
+    const int bB = (int)((long)nunits * (blockIdx.x + 1) / gridDim.x) * unit;
+    if (bA >= bB) return;                                      // (whole workgroup: no barrier is skipped by a part of it)
+
+    // ---- (1) this wave's activation fragments, the norm weights at the same k positions, the first block's weight fragments ----
+    const int m = r < p.M ? r : p.M - 1;                       // requests >= M compute a duplicate that is never stored
+    const bf16_t* xa = p.A + (long)m * p.lda + q * 8 + (long)sb * 32;
+    bf16x8_t xf[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) xf[i] = *(const bf16x8_t*)(xa + i * 32);
+    const bf16_t* wrow = p.W + (long)r * p.ldw + q * 8 + (long)sb * 32;       // + block * 16 rows
+    const long blk_stride = 16 * p.ldw;
+    bf16x8_t wf[NS];
+    if constexpr (NORM) {
+        // Qwen2RMSNorm of the request rows (modeling_qwen2.py:54-59: fp32 statistics, bf16(x * inv) * w rounded to bf16).  The weight
+        // stream starts underneath it: loads return in order, so the activations and norm weights (L2) come back first.
+        u32x4_t gw[NS];
+        const bf16_t* ga = p.norm_w + q * 8 + (long)sb * 32;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) gw[i] = *(const u32x4_t*)(ga + i * 32);
+        {
+            const bf16_t* wb = wrow + (long)bA * blk_stride;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) wf[i] = *(const bf16x8_t*)(wb + i * 32);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const u32x4_t v = __builtin_bit_cast(u32x4_t, xf[i]);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = lo2f(v[e]), b = hi2f(v[e]);
+                t += a * a + b * b;
+            }
+            ss += (i >= lo && i < hi) ? t : 0.f;
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (lane < 16) red[wave * 16 + lane] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += red[w * 16 + r];
+        const float inv = rsqrtf(tot / (float)p.K + p.eps);
+        float invo = inv;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            u32x4_t v = __builtin_bit_cast(u32x4_t, xf[i]);
+            if (i % 4 == 0) asm volatile("" : "+v"(invo));     // four fragments at a time: hipcc otherwise unpacks all NS at once and spills
+            const float inv = invo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = pack2bf(bfround(lo2f(v[e]) * inv) * lo2f(gw[i][e]), bfround(hi2f(v[e]) * inv) * hi2f(gw[i][e]));
+            xf[i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    } else {
+        const bf16_t* wb = wrow + (long)bA * blk_stride;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) wf[i] = *(const bf16x8_t*)(wb + i * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+        if (i < lo || i >= hi) xf[i] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- (2) the stream.  Per block NS MFMAs; every fragment register is refilled in place, right behind the MFMA that consumed it, with
+    //      the same fragment of the NEXT block (across chunk seams too: the stream never stops for a reduction).  Every CH blocks the
+    //      eight K partials meet in LDS: wave j sums output j (a block; SwiGLU16: gate block 2 j + up block 2 j + 1) and finishes it. ----
+    for (int c0 = bA; c0 < bB; c0 += CH) {
+        const int cb = bB - c0 < CH ? bB - c0 : CH;             // blocks of this chunk
+        for (int g = 0; g < cb; ++g) {
+            const int bn = c0 + g + 1;                         // the block to prefetch (the last one re-reads itself: L2 hits, never used)
+            const bf16_t* wn = wrow + (long)(bn < bB ? bn : bB - 1) * blk_stride;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            if (bn < bB) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[i], acc, 0, 0, 0);
+                    wf[i] = *(const bf16x8_t*)(wn + i * 32);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[i], acc, 0, 0, 0);
+            }
+            part[(g * 8 + wave) * 64 + lane] = acc;
+        }
+        __syncthreads();
+        const int nout = swiglu ? cb >> 1 : cb;
+        if (wave < nout) {
+            const int j = wave;
+            if (swiglu) {
+                f32x4_t ag = part[((2 * j) * 8) * 64 + lane], au = part[((2 * j + 1) * 8) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) {
+                    ag = ag + part[((2 * j) * 8 + w) * 64 + lane];
+                    au = au + part[((2 * j + 1) * 8 + w) * 64 + lane];
+                }
+                if (r < p.M) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = bfround(silu_f(bfround(ag[e]))) * bfround(au[e]);
+                    const u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    *(u32x2_t*)(p.C + (long)r * p.ldc + ((c0 >> 1) + j) * 16 + q * 4) = v;
+                }
+            } else {
+                f32x4_t a = part[(j * 8) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) a = a + part[(j * 8 + w) * 64 + lane];
+                const int n = (c0 + j) * 16 + q * 4;
+                if (p.KS > 1) *(f32x4_t*)(p.part + ((long)blockIdx.y * 16 + r) * p.N + n) = a;      // all 16 rows: the slab has them
+                else if (r < p.M) mb_epilogue(p, a, r, n);
+            }
+        }
+        if (c0 + CH < bB) __syncthreads();                     // the partials are consumed before the next chunk overwrites them
+    }
+}
+
+// KS > 1: C = epilogue(sum over the K slices, in slice order)
+__global__ __launch_bounds__(256) void gemv_mb_reduce_kernel(const MbParams p) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int nq = p.N >> 2;
+    if (idx >= p.M * nq) return;
+    const int m = idx / nq, n = (idx - m * nq) * 4;
+    f32x4_t a = *(const f32x4_t*)(p.part + (long)m * p.N + n);
+    for (int s = 1; s < p.KS; ++s) a = a + *(const f32x4_t*)(p.part + ((long)s * 16 + m) * p.N + n);
+    mb_epilogue(p, a, m, n);
+}
+
+// Geometry.  NS = 4 serves short rows (K <= 1024: the tiny test models), NS = 14 serves K <= 3584 in one slice (14 steps per wave at the 7B
+// hidden size), NS = 19 the long rows (18944 = 592 steps = 4 slices x 8 waves x 19, the last wave 3 live steps).  The launch is
+// PERSISTENT: one workgroup per CU (its ~170 registers x 8 waves leave no room for a second one), each taking an even share of the column
+// blocks of its K slice, so the activation prologue is paid once per workgroup and launch, not per block.  BAGEL_MB_WGS overrides the
+// workgroup count (tuning / tests).
+static void mb_geometry(int K, int* per, int* KS) {
+    const int nsteps = K / 32;
+    int ks = (nsteps + 8 * 19 - 1) / (8 * 19);
+    if (nsteps <= 8 * 14) ks = 1;
+    *per = (nsteps + 8 * ks - 1) / (8 * ks);
+    *KS = ks;
+}
+
+extern "C" int bagel_gemv_mb_workspace_bytes(int32_t N, int32_t K, int64_t* bytes) {
+    BAGEL_REQUIRE(bytes && N > 0 && K > 0, "gemv_mb_workspace_bytes: bad argument");
+    int per, KS;
+    mb_geometry(K, &per, &KS);
+    *bytes = KS > 1 ? (int64_t)KS * 16 * N * 4 : 0;
+    return BAGEL_OK;
+}
+
+template <int NS>
+static int mb_launch(const MbParams& p, dim3 grid, hipStream_t stream) {
+    if (p.norm_w) hipLaunchKernelGGL((gemv_mb_kernel<NS, true>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((gemv_mb_kernel<NS, false>), grid, dim3(512), 0, stream, p);
+    return bagel_check_launch("gemv_mb_kernel");
+}
+
+extern "C" int bagel_gemv_mb_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr,
+                                  void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                                  void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    BAGEL_REQUIRE(A && W && C, "gemv_mb: null pointer");
+    BAGEL_REQUIRE(M >= 1 && M <= 16, "gemv_mb: M=%d not in [1,16]", M);
+    BAGEL_REQUIRE(K > 0 && (K % 32) == 0 && (lda % 8) == 0 && (ldw % 8) == 0, "gemv_mb: K %% 32 == 0 and 16-byte rows required");
+    BAGEL_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemv_mb: unknown epilogue %d", epilogue);
+    BAGEL_REQUIRE(epilogue == EPI_SWIGLU16 ? ((N % 32) == 0 && !bias && !R) : (N % 16) == 0, "gemv_mb: N %% 16 (SwiGLU: N %% 32, no bias/residual)");
+    BAGEL_REQUIRE((ldc % 4) == 0 && (ldr % 4) == 0, "gemv_mb: ldc/ldr must be multiples of 4");
+    BAGEL_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)norm_w) & 15) == 0 && (((uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 7) == 0, "gemv_mb: alignment");
+    MbParams p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = (const bf16_t*)bias;
+    p.R = (const bf16_t*)R; p.ldr = ldr; p.C = (bf16_t*)C; p.ldc = ldc; p.norm_w = (const bf16_t*)norm_w; p.eps = eps;
+    p.M = M; p.N = N; p.K = K; p.epi = epilogue;
+    const bool sw = epilogue == EPI_SWIGLU16;
+    mb_geometry(K, &p.per, &p.KS);
+
+    const int NS = p.per <= 4 ? 4 : p.per <= 14 ? 14 : 19;       // the instantiation that runs; its fragments must fit the row
+    if (p.per > 19 || K / 32 < NS) return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "gemv_mb: K=%d (%d steps per wave) has no instantiation", K, p.per);
+    if (p.KS > 1) {
+        if (norm_w || sw) return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "gemv_mb: fused RMSNorm / SwiGLU need the whole row in one slice (K=%d)", K);
+        BAGEL_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (int64_t)p.KS * 16 * N * 4,
+                      "gemv_mb: K=%d runs as %d slices and needs a 16-byte aligned fp32 workspace of %lld bytes", K, p.KS, (long long)p.KS * 16 * N * 4);
+    }
+    p.part = (float*)workspace;
+    static int wgs_env = -1, cus_of_dev[16] = {0};
+    if (wgs_env < 0) {
+        const char* e = getenv("BAGEL_MB_WGS");
+        wgs_env = (e && atoi(e) > 0) ? atoi(e) : 0;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    if (cus_of_dev[dev] == 0) {
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus_of_dev[dev] = cus > 0 ? cus : 256;
+    }
+    const int wgs = wgs_env ? wgs_env : cus_of_dev[dev];
+    const int nunits = (N / 16) / (sw ? 2 : 1);
+    int gx = wgs / p.KS;
+    if (gx < 1) gx = 1;
+    if (gx > nunits) gx = nunits;
+    const dim3 grid(gx, p.KS);
+    if (int rc = NS == 4 ? mb_launch<4>(p, grid, stream) : NS == 14 ? mb_launch<14>(p, grid, stream) : mb_launch<19>(p, grid, stream)) return rc;
+    if (p.KS > 1) {
+        hipLaunchKernelGGL(gemv_mb_reduce_kernel, dim3(ceil_div((long)M * (N / 4), 256)), dim3(256), 0, stream, p);
+        return bagel_check_launch("gemv_mb_reduce_kernel");
+    }
+    return BAGEL_OK;
+}

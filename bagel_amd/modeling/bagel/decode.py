@@ -113,6 +113,9 @@ class DecodeSession:
         self.cos = e(B, eng.hd // 2)
         self.sin = e(B, eng.hd // 2)
         self.part_o, self.part_ml = ops.attn_decode_workspace(B, nq, dp, self.max_len, dev)
+        # fp32 K-slice slabs of bagel_gemv_mb_bf16 for the longest row a layer has (the down projection)
+        ks = ops._mb_steps(eng.I)[1]
+        self.mb_ws = torch.empty(max(ks * 16 * eng.H, 4), dtype=torch.float32, device=dev) if 1 < B <= ops.MB_MAX_ROWS else None
         self.pos = position_ids.to(device=dev, dtype=torch.long).clone().contiguous()
         st = start_tokens.to(device=dev, dtype=torch.long).contiguous()
         self.cur32 = st.to(torch.int32)
@@ -176,7 +179,7 @@ class DecodeSession:
         scale = hd ** -0.5
         ops.rope_table_into(self.pos, self.inv_freq, self.cos, self.sin)
         ops.copy_rows(self.table, x, B, eng.H, src_rows=self.cur32)
-        fused = B == 1      # one request: lane-FMA kernel with the RMSNorm fused in; a batch: RMSNorm kernel + skinny MFMA GEMM
+        fused = B == 1      # one request: lane-FMA kernel with the RMSNorm fused in; 2..16: the register-resident MFMA stream (gemv_mb); more: RMSNorm kernel + skinny MFMA GEMM
         h = self.h
 
         def proj(inp, w, out, norm_w=None, **kw):
@@ -188,6 +191,11 @@ class DecodeSession:
                 return ops.gemv_w8(inp, w[0], w[1], out, norm_w=norm_w, eps=eng.eps, M=B, **kw)
             if fused:
                 return ops.gemv(inp, w, out, norm_w=norm_w, eps=eng.eps, **kw)
+            if B <= ops.MB_MAX_ROWS and ops.gemv_mb_supported(inp, w, out, kw.get("bias"), kw.get("residual"), kw.get("epilogue", ops.EPI_NONE),
+                                                              norm_w is not None):
+                # 2..16 requests: the weight stream with the activations in registers and the RMSNorm fused (csrc/gemv_mb.hip); the K-slice
+                # workspace of the long rows is the session's own, so the captured graph keeps a stable pointer
+                return ops.gemv_mb(inp, w, out, norm_w=norm_w, eps=eng.eps, M=B, workspace=self.mb_ws, **kw)
             if norm_w is not None:
                 ops.rmsnorm(inp, norm_w, h, eng.eps)
                 inp = h

@@ -88,6 +88,9 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
     if residual is not None:
         _req(residual, BF16, "gemm.residual")
     dense1 = variant is None and W1 is None and M1 == 0 and a_rows0 is None and c_rows0 is None
+    if dense1 and 2 <= M0 <= MB_MAX_ROWS and gemv_mb_supported(A, W0, C, bias0, residual, epilogue, False):
+        # 2..16 rows (batched decode steps, the marker rows of a denoise forward): weight stream with the activations in registers
+        return gemv_mb(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if (dense1 and 2 <= M0 <= SKINNY_MAX_ROWS and K % 32 == 0 and N % (32 if epilogue == EPI_SWIGLU16 else 16) == 0
             and A.data_ptr() % 16 == 0 and W0.data_ptr() % 16 == 0 and C.data_ptr() % 8 == 0 and _ld(C) % 4 == 0
             and (bias0 is None or bias0.data_ptr() % 8 == 0)
@@ -116,8 +119,15 @@ GEMM_SPLITK = os.environ.get("BAGEL_GEMM_SPLITK", "1") != "0"
 _GEMM_WS = {}
 
 
+def _ws_key(device):
+    """Workspaces are keyed by (device, stream): two streams (or threads on their own streams) launching at the same time must not share
+    partial tiles, and a buffer is only ever replaced by a larger one while no launch on ITS stream can still be reading it (launches on
+    one stream are ordered)."""
+    return (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+
+
 def _gemm_workspace(device):
-    key = torch.device(device).index
+    key = _ws_key(device)
     ws = _GEMM_WS.get(key)
     if ws is None:
         ws = _GEMM_WS[key] = torch.empty(256 * 256 * 256, dtype=torch.float32, device=device)
@@ -127,6 +137,62 @@ def _gemm_workspace(device):
 GEMV_MAX_ROWS = 8
 GEMV_MAX_K_BYTES = 144 * 1024
 SKINNY_MAX_ROWS = 64
+MB_MAX_ROWS = 16
+# BAGEL_GEMV_MB=0: 2..16 rows go back to rmsnorm + skinny.hip (same-box A/B of the batched decode step)
+GEMV_MB = os.environ.get("BAGEL_GEMV_MB", "1") != "0"
+_MB_WS = {}
+
+
+def _mb_steps(K):
+    """(steps per wave, K slices over workgroups) of bagel_gemv_mb_bf16 -- mirrors mb_geometry in csrc/gemv_mb.hip."""
+    nsteps = K // 32
+    ks = 1 if nsteps <= 8 * 14 else -(-nsteps // (8 * 19))
+    return -(-nsteps // (8 * ks)), ks
+
+
+def gemv_mb_supported(A, W, C, bias, residual, epilogue, has_norm):
+    if not GEMV_MB:
+        return False
+    N, K = W.shape
+    if K % 32 or N % (32 if epilogue == EPI_SWIGLU16 else 16):
+        return False
+    per, ks = _mb_steps(K)
+    ns = 4 if per <= 4 else 14 if per <= 14 else 19
+    if per > 19 or K // 32 < ns or (ks > 1 and (has_norm or epilogue == EPI_SWIGLU16)):
+        return False
+    if epilogue == EPI_SWIGLU16 and (bias is not None or residual is not None):
+        return False
+    ok = A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0 and _ld(A) % 8 == 0 and W.stride(0) % 8 == 0 and C.data_ptr() % 8 == 0 and _ld(C) % 4 == 0
+    ok = ok and (bias is None or bias.data_ptr() % 8 == 0)
+    return ok and (residual is None or (residual.data_ptr() % 8 == 0 and _ld(residual) % 4 == 0))
+
+
+def gemv_mb(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0, workspace=None):
+    """C[M <= 16, N] = norm(A) W^T with the epilogues of ``gemm``: the batched-decode weight stream (bagel_gemv_mb_bf16): the waves of a
+    workgroup partition K and hold their activation fragments in registers, optional fused RMSNorm.  Long rows (K > 3584 at 7B: the down
+    projection) run as K slices through an fp32 workspace (``workspace`` or a per-(device, stream) one) and a second, tiny launch."""
+    _req(A, BF16, "gemv_mb.A"); _req(W, BF16, "gemv_mb.W"); _req(C, BF16, "gemv_mb.C")
+    N, K = W.shape
+    if A.shape[-1] != K:
+        raise BagelHipError(f"gemv_mb: A has K={A.shape[-1]}, W has K={K}")
+    if M is None:
+        M = A.shape[0]
+    if residual is not None:
+        _req(residual, BF16, "gemv_mb.residual")
+    if norm_w is not None:
+        _req(norm_w, BF16, "gemv_mb.norm_w")
+    ks = _mb_steps(K)[1]
+    need = ks * 16 * N * 4 if ks > 1 else 0          # bagel_gemv_mb_workspace_bytes
+    ws = workspace
+    if need and ws is None:
+        key = _ws_key(A.device)
+        ws = _MB_WS.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = _MB_WS[key] = torch.empty(max(need // 4, 1 << 20), dtype=torch.float32, device=A.device)
+    check(lib().bagel_gemv_mb_bf16(_ptr(A), _ld(A), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
+                                   _ld(residual) if residual is not None else 0, _ptr(C), _ld(C), _ptr(norm_w), float(eps), M, N, K,
+                                   epilogue, _ptr(ws) if need else None, ws.numel() * 4 if need else 0, _stream()), "bagel_gemv_mb_bf16")
+    return C
 
 
 def gemm_skinny(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None):
@@ -844,9 +910,10 @@ _ATTN_PARTIALS = {}
 
 
 def _attn_partials(device, n_slots, head_dim):
-    """Shared fp32 workspace of the key-split items (one attention launch at a time per device stream)."""
+    """fp32 workspace of the key-split items, one per (device, stream): launches on one stream are ordered, so a buffer is never replaced
+    while a launch that reads it can still be running."""
     need = n_slots * 256 * (head_dim + 2)
-    key = torch.device(device).index
+    key = _ws_key(device)
     ws = _ATTN_PARTIALS.get(key)
     if ws is None or ws.numel() < need:
         ws = _ATTN_PARTIALS[key] = torch.empty(need, dtype=torch.float32, device=device)

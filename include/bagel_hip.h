@@ -180,6 +180,20 @@ int bagel_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ld
                            int64_t ldr, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                            bagel_stream_t stream);
 
+/* Batched-decode projection: C[M <= 16, N] = norm(A) W^T with the epilogues and rounding points of bagel_gemm_bf16 (bias, activation,
+ * SwiGLU16 pairing, residual; R == C allowed) and an optional fused Qwen2RMSNorm of the A rows (norm_w != NULL).  Replaces, for 2..16
+ * concurrent requests, the F.linear call sites of a decode step (modeling/bagel/qwen2_navit.py:515-517,591-594;
+ * modeling/qwen2/modeling_qwen2.py:54-59,200-201; modeling/bagel/bagel.py:978) and serves the und marker rows of a denoise forward.
+ * A pure weight stream through the MFMA: the 8 waves of a persistent workgroup (one per CU) partition K and keep their activation
+ * fragments in registers, every weight byte is loaded once, straight into the matrix-core operand layout.  K % 32 == 0, N % 16 == 0
+ * (SwiGLU16: N % 32 == 0, no bias / residual).  Rows longer than 4864 elements run as K slices over workgroups through a caller-owned
+ * fp32 workspace (bagel_gemv_mb_workspace_bytes; 16-byte aligned; only touched by this call) and a second small launch; such rows
+ * take neither the fused norm nor SwiGLU16 (BAGEL_ERR_UNSUPPORTED).  Deterministic: fixed summation order, no atomics. */
+int bagel_gemv_mb_workspace_bytes(int32_t N, int32_t K, int64_t* bytes);
+int bagel_gemv_mb_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr,
+                       void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                       void* workspace, int64_t workspace_bytes, bagel_stream_t stream);
+
 /* Weight-only INT8 for the decode path (MI355X analogue of the reference's quantised inference modes, app.py:114-131,
  * bitsandbytes NF4 / LLM.int8).  An OPTION that changes results; the bf16 path is the default.
  * quantize: q[n,k] = round(W[n,k] / scale[n]) + 128 (u8), scale[n] = max_k |W[n,k]| / 127 (row-wise absmax). */

@@ -62,6 +62,10 @@ def gemv(A, W, C, *, bias=None, residual=None, epilogue=0, M=None, norm_w=None, 
     return gemm(A, W, C, bias0=bias, residual=residual, epilogue=epilogue, M0=M if M is not None else A.shape[0])
 
 
+def gemv_mb(A, W, C, *, bias=None, residual=None, epilogue=0, M=None, norm_w=None, eps=0.0, workspace=None):
+    return gemv(A, W, C, bias=bias, residual=residual, epilogue=epilogue, M=M, norm_w=norm_w, eps=eps)
+
+
 def gemm_skinny(A, W, C, *, bias=None, residual=None, epilogue=0, M=None):
     return gemm(A, W, C, bias0=bias, residual=residual, epilogue=epilogue, M0=M if M is not None else A.shape[0])
 
@@ -689,7 +693,7 @@ def chw_f32_to_u8(src):
     return v.to(torch.uint8).permute(1, 2, 0).contiguous()
 
 
-_NAMES = ["gemm", "gemv", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
+_NAMES = ["gemm", "gemv", "gemv_mb", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
           "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
