@@ -654,14 +654,19 @@ __device__ __forceinline__ void dec_post_head(const u32x4_t raw, const bf16_t* _
 // FUSED: the q/k norm + RoPE of decode_qkv_post_kernel runs in the prologue -- 16-lane groups own one head each (G query heads + the
 // new key: 8 items = two waves at 7B), same arithmetic (dec_post_head), results handed to all waves through LDS; the workgroup whose
 // chunk holds position kv_len[b] uses the new K/V row from LDS / the projection and stores both into the page.
+// cpw > 1 (batched decode: many requests x many chunks): a workgroup walks `cpw` consecutive 128-key chunks with a running (max, sum, O)
+// per wave and leaves ONE partial -- the single-shot form sends B x nkv x 39 workgroups through the chip in rounds whose load and
+// compute phases line up (49.5 us per layer at 16 requests = 3.3 TB/s); with a loop the resident workgroups drift apart and the
+// page loads of one overlap the MFMAs of another, and the combine pass reads cpw times fewer partials.  The block-table entries of
+// the NEXT chunk are fetched under the current one (the table -> page -> row chain is two dependent latencies otherwise).
 template <int DP, bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kpool,
                                                           const bf16_t* __restrict__ vpool, long ldp,
                                                           const int* __restrict__ block_table, int bt_stride,
                                                           const int* __restrict__ kv_len, int len_add, float* __restrict__ part_o,
                                                           float* __restrict__ part_ml, int nq, int G, int nsplit, float scale_log2e,
-                                                          DecFuse fu) {
-    constexpr int CH = DEC_CH;           // keys per workgroup
+                                                          DecFuse fu, int cpw) {
+    constexpr int CH = DEC_CH;           // keys per chunk
     constexpr int KS = DP / 32;          // k-steps of S^T
     constexpr int NDB = DP / 16;         // 16-wide d blocks of O^T
     constexpr int VST = DP + 8;          // LDS row stride of the V tile, elements
@@ -670,12 +675,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     constexpr int NVL = 32 / RPI;        // V loads per lane
     const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int L = kv_len[b] + len_add;
-    const int j0 = split * CH;
-    const int j1 = (L < j0 + CH) ? L : j0 + CH;
+    const int j0 = split * CH * cpw;                                 // this workgroup's key range [j0, j1)
+    const int j1 = (L < j0 + CH * cpw) ? L : j0 + CH * cpw;
     if (j0 >= j1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int jw = j0 + 32 * wave;
     __shared__ __attribute__((aligned(16))) bf16_t sm_v[4][32 * VST];      // V tiles; afterwards the waves' O partials [16][DP] fp32
     __shared__ __attribute__((aligned(16))) bf16_t sm_q[17][DP];           // FUSED: finished q heads [0, G) and the new key [G]
     __shared__ float sm_m[4][16], sm_l[4][16];
@@ -683,37 +687,46 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 
     const int* bt = block_table + (long)b * bt_stride;
     const int jn = L - 1;                // FUSED: the position this step appends
-    // ---- one latency round: block-table entries -> K fragments and V rows (clamped past the range), the query heads beside them
-    long krow[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const int j = jw + 16 * blk + c16;
-        const int jc = j < j1 ? j : j1 - 1;
-        krow[blk] = (long)bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
-    }
-    long vrow[NVL];
-#pragma unroll
-    for (int i = 0; i < NVL; ++i) {
-        const int j = jw + lane / CPR + RPI * i;
-        const int jc = j < j1 ? j : j1 - 1;
-        vrow[i] = (long)bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
-    }
-    u32x4_t kf[2][KS], vr[NVL];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            kf[blk][kk] = ld_stream_kv<u32x4_t>(kpool + krow[blk] * ldp + (long)kvh * DP + 32 * kk + 8 * g);
     const bf16_t* qrow = q + (long)b * ldq;
+    // page rows of the K fragments / V rows of the chunk that starts at key c0 (clamped past the workgroup's range)
+    int krow[2], vrow[NVL];              // page ROW indices (pool rows) of the chunk whose loads go out next
+    auto rows_of = [&](int c0) {
+        const int jw = c0 + 32 * wave;
 #pragma unroll
-    for (int i = 0; i < NVL; ++i) {
-        const bf16_t* src = vpool + vrow[i] * ldp + (long)kvh * DP + (lane % CPR) * 8;
-        if (FUSED) {         // the new V row is not in the page yet: take it from the projection
-            const int j = jw + lane / CPR + RPI * i;
-            if (j == jn || (j >= j1 && j1 - 1 == jn)) src = qrow + (long)(nq + fu.nkv + kvh) * DP + (lane % CPR) * 8;
+        for (int blk = 0; blk < 2; ++blk) {
+            const int j = jw + 16 * blk + c16;
+            const int jc = j < j1 ? j : j1 - 1;
+            krow[blk] = bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
         }
-        vr[i] = ld_stream_kv<u32x4_t>(src);
-    }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int j = jw + lane / CPR + RPI * i;
+            const int jc = j < j1 ? j : j1 - 1;
+            vrow[i] = bt[jc / BAGEL_KV_PAGE] * BAGEL_KV_PAGE + (jc % BAGEL_KV_PAGE);
+        }
+    };
+    u32x4_t kf[2][KS], vr[NVL];
+    auto load_kv = [&](int c0) {
+        const int jw = c0 + 32 * wave;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                kf[blk][kk] = ld_stream_kv<u32x4_t>(kpool + (long)krow[blk] * ldp + (long)kvh * DP + 32 * kk + 8 * g);
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const bf16_t* src = vpool + (long)vrow[i] * ldp + (long)kvh * DP + (lane % CPR) * 8;
+            if (FUSED) {         // the new V row is not in the page yet: take it from the projection
+                const int j = jw + lane / CPR + RPI * i;
+                if (j == jn || (j >= j1 && j1 - 1 == jn)) src = qrow + (long)(nq + fu.nkv + kvh) * DP + (lane % CPR) * 8;
+            }
+            vr[i] = ld_stream_kv<u32x4_t>(src);
+        }
+    };
+    // ---- one latency round: block-table entries -> K fragments and V rows of the first chunk, the query heads beside them
+    rows_of(j0);
+    load_kv(j0);
+    if (j0 + CH < j1) rows_of(j0 + CH);          // the table entries of chunk 2 travel under chunk 1's page loads
     u32x4_t qf[KS];
     if (!FUSED) {
 #pragma unroll
@@ -756,74 +769,95 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             qf[kk] = u32x4_t{0u, 0u, 0u, 0u};
             if (c16 < G) qf[kk] = *(const u32x4_t*)(&sm_q[c16][32 * kk + 8 * g]);
         }
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const int j = jw + 16 * blk + c16;
-            if (j == jn || (j >= j1 && j1 - 1 == jn)) {
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) kf[blk][kk] = *(const u32x4_t*)(&sm_q[G][32 * kk + 8 * g]);
-            }
-        }
     }
 
-    // ---- S^T = K Q^T: lane (head c16) gets keys 4g + r of both blocks
-    f32x4_t sacc[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        sacc[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            sacc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[blk][kk]), __builtin_bit_cast(bf16x8_t, qf[kk]),
-                                                               sacc[blk], 0, 0, 0);
-    }
-    // ---- V tile -> LDS (row major), while the scores settle
-    bf16_t* svw = sm_v[wave];
-#pragma unroll
-    for (int i = 0; i < NVL; ++i) *(u32x4_t*)(svw + (lane / CPR + RPI * i) * VST + (lane % CPR) * 8) = vr[i];
-    // ---- softmax over the wave's 32 keys, base 2, one max per head
-    float sc[2][4];
-    bool ok[2][4];
-    float mx = -1e30f;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ok[blk][r] = (jw + 16 * blk + 4 * g + r) < j1;
-            sc[blk][r] = ok[blk][r] ? sacc[blk][r] * scale_log2e : -1e30f;
-            mx = fmaxf(mx, sc[blk][r]);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // -1e30 when the wave holds no key of the chunk
-    float pw[2][4], ls = 0.f;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pw[blk][r] = ok[blk][r] ? exp2f(sc[blk][r] - mx) : 0.f;
-            ls += pw[blk][r];
-        }
-    ls += __shfl_xor(ls, 16, 64);
-    ls += __shfl_xor(ls, 32, 64);
-    const u32x4_t pfrag = {pack2bf(pw[0][0], pw[0][1]), pack2bf(pw[0][2], pw[0][3]), pack2bf(pw[1][0], pw[1][1]), pack2bf(pw[1][2], pw[1][3])};
-    // ---- O^T = V^T P^T: the lane's 8 keys are rows 4g..4g+3 and 16+4g..16+4g+3 of the tile, column = d
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own ds_writes above (other lanes' rows) have landed
-    __builtin_amdgcn_wave_barrier();
+    // running state of this wave over its chunks: one (max, sum) per head (lane column c16), O^T[d, head] in oacc
+    float m_run = -1e30f, l_run = 0.f;
     f32x4_t oacc[NDB];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-        const bf16_t* col = svw + 16 * db + c16;
-        unsigned short e[8];
+    for (int db = 0; db < NDB; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16_t* svw = sm_v[wave];
+    for (int c0 = j0; c0 < j1; c0 += CH) {
+        const int jw = c0 + 32 * wave;
+        const bool more = c0 + CH < j1;
+        if (FUSED) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            e[t] = col[(4 * g + t) * VST];
-            e[4 + t] = col[(16 + 4 * g + t) * VST];
+            for (int blk = 0; blk < 2; ++blk) {
+                const int j = jw + 16 * blk + c16;
+                if (j == jn || (j >= j1 && j1 - 1 == jn)) {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) kf[blk][kk] = *(const u32x4_t*)(&sm_q[G][32 * kk + 8 * g]);
+                }
+            }
         }
-        const u32x4_t vfrag = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                               (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
-        oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vfrag), __builtin_bit_cast(bf16x8_t, pfrag),
-                                                          f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // ---- S^T = K Q^T: lane (head c16) gets keys 4g + r of both blocks
+        f32x4_t sacc[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            sacc[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                sacc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[blk][kk]), __builtin_bit_cast(bf16x8_t, qf[kk]),
+                                                                   sacc[blk], 0, 0, 0);
+        }
+        // ---- V tile -> LDS (row major), while the scores settle; then the next chunk's page rows and loads go out
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) *(u32x4_t*)(svw + (lane / CPR + RPI * i) * VST + (lane % CPR) * 8) = vr[i];
+        if (more) {
+            load_kv(c0 + CH);                             // its page rows were resolved one chunk ago
+            if (c0 + 2 * CH < j1) rows_of(c0 + 2 * CH);
+        }
+        // ---- softmax over the wave's 32 keys, base 2, one max per head
+        float sc[2][4];
+        bool ok[2][4];
+        float mx = -1e30f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ok[blk][r] = (jw + 16 * blk + 4 * g + r) < j1;
+                sc[blk][r] = ok[blk][r] ? sacc[blk][r] * scale_log2e : -1e30f;
+                mx = fmaxf(mx, sc[blk][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // -1e30 when the wave holds no key of the chunk
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);        // 1 on the first chunk's empty state (both -1e30), 0 when the first keys arrive
+        float pw[2][4], ls = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pw[blk][r] = ok[blk][r] ? exp2f(sc[blk][r] - m_new) : 0.f;
+                ls += pw[blk][r];
+            }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+        const u32x4_t pfrag = {pack2bf(pw[0][0], pw[0][1]), pack2bf(pw[0][2], pw[0][3]), pack2bf(pw[1][0], pw[1][1]), pack2bf(pw[1][2], pw[1][3])};
+        // ---- O^T = O^T alpha + V^T P^T: the lane's 8 keys are rows 4g..4g+3 and 16+4g..16+4g+3 of the tile, column = d
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own ds_writes above (other lanes' rows) have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const bf16_t* col = svw + 16 * db + c16;
+            unsigned short e[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                e[t] = col[(4 * g + t) * VST];
+                e[4 + t] = col[(16 + 4 * g + t) * VST];
+            }
+            const u32x4_t vfrag = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                                   (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+            oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vfrag), __builtin_bit_cast(bf16x8_t, pfrag),
+                                                              oacc[db] * alpha, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();                  // every lane's reads of the tile are issued before the next chunk's rows overwrite it
     }
     // ---- the wave's (max, sum, O) -> LDS (O over its own V tile: every read of the tile is older than these writes), merge
+    const float mx = m_run, ls = l_run;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float* so = (float*)svw;
     if (c16 < G) {
 #pragma unroll
@@ -900,9 +934,9 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
 template <int DP, bool FUSED>
 static int launch_attn_decode(int G, dim3 grid, hipStream_t stream, const bf16_t* q, long ldq, const bf16_t* kpool, const bf16_t* vpool,
                               long ldp, const int* bt, int bt_stride, const int* kv_len, int len_add, float* po, float* pml, int nq,
-                              int nsplit, float sl2e, DecFuse fu) {
+                              int nsplit, float sl2e, DecFuse fu, int cpw) {
     hipLaunchKernelGGL((attn_decode_kernel<DP, FUSED>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, kv_len,
-                       len_add, po, pml, nq, G, nsplit, sl2e, fu);
+                       len_add, po, pml, nq, G, nsplit, sl2e, fu, cpw);
     return bagel_check_launch("attn_decode_kernel");
 }
 
@@ -916,7 +950,20 @@ static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, con
     BAGEL_REQUIRE((ldq % 8) == 0 && (ld_pool % 8) == 0 && (ldo % 4) == 0 && (((uintptr_t)out) & 7) == 0, "attn_decode: leading dims / out alignment");
     BAGEL_REQUIRE((((uintptr_t)q | (uintptr_t)kpool | (uintptr_t)vpool) & 15) == 0, "attn_decode: 16-byte alignment");
     if (batch <= 0 || max_len <= 0) return BAGEL_OK;
-    const int ch = DEC_CH;
+    // chunks per workgroup: one while the launch is a single round of workgroups anyway (one request: 156 of them at 7B / 4 936 keys --
+    // latency-bound, most parallel form), more once requests x KV heads x chunks would go through the chip in several rounds
+    // (BAGEL_DEC_CPW overrides: tuning / tests)
+    static int cpw_env = -1;
+    if (cpw_env < 0) {
+        const char* e = getenv("BAGEL_DEC_CPW");
+        cpw_env = (e && atoi(e) > 0) ? atoi(e) : 0;
+    }
+    const int nchunks = ceil_div(max_len, DEC_CH);
+    int cpw = cpw_env ? cpw_env : ceil_div((long)nchunks * nkv * batch, 512);     // two resident workgroups per CU, one round
+    if (cpw > 8) cpw = 8;
+    if (cpw > nchunks) cpw = nchunks;
+    if (cpw < 1) cpw = 1;
+    const int ch = DEC_CH * cpw;                   // keys per workgroup = per partial slot
     const int nsplit = ceil_div(max_len, ch);
     const float sl2e = softmax_scale * 1.4426950408889634f;
     const dim3 grid(nsplit, nkv, batch);
@@ -932,9 +979,9 @@ static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, con
     int rc;
 #define DEC_GO(DPV)                                                                                                              \
     rc = fuse ? launch_attn_decode<DPV, true>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
-                                              len_add, part_o, part_ml, nq, nsplit, sl2e, fu)                                    \
+                                              len_add, part_o, part_ml, nq, nsplit, sl2e, fu, cpw)                               \
               : launch_attn_decode<DPV, false>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
-                                               len_add, part_o, part_ml, nq, nsplit, sl2e, fu)
+                                               len_add, part_o, part_ml, nq, nsplit, sl2e, fu, cpw)
     if (head_dim == 128) { DEC_GO(128); }
     else { DEC_GO(64); }
 #undef DEC_GO

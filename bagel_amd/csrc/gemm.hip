@@ -594,11 +594,9 @@ static int launch_gemm_pp(const GemmParams& p0, hipStream_t stream) {
 //     instructions may be in flight) covers k-tile 0 and every store, whatever order loads and stores retire in.
 // Tile order: work item w keeps its XCD (gridDim.x is a multiple of 8), same band walk as variant 3.
 // =========================================================================================================
-// SGPR-base form of the LDS-DMA: address = wave-uniform 64-bit base + the lane's unsigned 32-bit byte offset.  One address VGPR per
-// instruction instead of a register pair (the k advance moves to the scalar unit).  BAGEL_PQ_SADDR=1 builds gemm_pq_kernel on it;
-// contract of that build: every operand row the launch touches lies within 4 GiB of the operand's base pointer.
-#ifndef BAGEL_PQ_SADDR
-#define BAGEL_PQ_SADDR 0
+// SGPR-base form of the LDS-DMA: address = wave-uniform 64-bit base + the lane's unsigned 32-bit byte offset (gemm_pq_kernel<.., SADDR>).
+#ifndef BAGEL_PQ_M0MODE
+#define BAGEL_PQ_M0MODE 0              /* experiment: how the SGPR-base DMA handles M0 (see issue() in gemm_pq_kernel) */
 #endif
 #ifndef BAGEL_PQ_ABL
 #define BAGEL_PQ_ABL 0                 /* timing-only ablations of the SwiGLU epilogue (tools/ab_build.sh): 1 no exp/rcp, 2 no global stores */
@@ -637,7 +635,7 @@ __device__ __forceinline__ i32x8_t cat_frag(const bf16x8_t& lo, const bf16x8_t& 
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int MODE, bool FP8 = false>
+template <int MODE, bool FP8 = false, bool SADDR = false>
 __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     constexpr bool SWIGLU = MODE == 0, HAS_R = MODE == 1, HAS_BIAS = MODE == 2, PARTIAL = MODE == 4;
     constexpr int BM = 256, BN = 256;
@@ -691,13 +689,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
         if (lst) glds4_asm(lst + m, smem_base + off);
         else *(int*)(smem + off + lane * 4) = m;
     };
-#if BAGEL_PQ_SADDR
-    unsigned src[4][2];      // [piece][i]: byte offset from the operand's base (A: pieces 0 / 3, W: pieces 1 / 2)
-    const char* baseA = nullptr;   // wave-uniform bases of the current tile (operand base + the item's first k-tile)
+    // SADDR (variant 5): every DMA address = wave-uniform operand base (SGPR pair, advanced along K on the scalar unit) + the lane's
+    // unsigned 32-bit byte offset -- ONE address VGPR per instruction instead of a pair.  The kernel is LDS-DMA-ISSUE bound (per wave and
+    // k-tile 8 DMA + 24 ds_read instructions have to fit under two 32-MFMA slots of the partner group): round 4 measured gate+up at
+    // M = 32 768 6.83 -> 6.31 ms (1 304 -> 1 411 TFLOP/s) from this alone.  Contract: every row the launch touches lies within 4 GiB of its
+    // operand's base pointer (the host checks what it can see; gathered rows are the caller's promise: bagel_gemm_bf16 variant 5).
+    unsigned soff[4][2];           // SADDR: [piece][i] byte offset from the operand base (A: pieces 0 / 3, W: pieces 1 / 2)
+    const char* baseA = nullptr;   // SADDR: wave-uniform bases of the current tile (operand base + the item's first k-tile)
     const char* baseW = nullptr;
-#else
-    const char* src[4][2];   // [piece][i]
-#endif
+    const char* src[4][2];         // !SADDR: [piece][i] per-lane pointers
     // DMA sources of tile (tm, tn): piece-local row lr = 8*j + lane/8 (j = wave + 8*i), LDS chunk lane%8, global chunk
     // swizzled; A rows come from the table in ring slot `buf`.  `ln` is an opaque copy of the lane id (keeps hipcc from
     // hoisting this arithmetic out of the tile loop and spilling it across the k-loop).
@@ -706,10 +706,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
         const long kb = (long)kt0 * 128;           // byte offset of the item's first k-tile inside a row
         const int n0 = tn * BN;
         const int* atab = (const int*)(smem + TBL + buf * 2048);
-#if BAGEL_PQ_SADDR
-        baseA = pq_uniform((const char*)p.A + kb);
-        baseW = pq_uniform((const char*)Wg + kb);
-#endif
+        if constexpr (SADDR) {
+            baseA = pq_uniform((const char*)p.A + kb);
+            baseW = pq_uniform((const char*)Wg + kb);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int lr = (wave + 8 * i) * 8 + (ln >> 3);
@@ -719,13 +719,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
                 const int row = atab[(lr >> 6) * 128 + half * 64 + (lr & 63)];
                 int n = n0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
                 n = n < p.N ? n : p.N - 1;
-#if BAGEL_PQ_SADDR
-                src[half ? 3 : 0][i] = (unsigned)row * (unsigned)(p.lda * 2) + gch16;
-                src[half ? 2 : 1][i] = (unsigned)n * (unsigned)(p.ldw * 2) + gch16;
-#else
-                src[half ? 3 : 0][i] = (const char*)(p.A + (long)row * p.lda) + gch16 + kb;
-                src[half ? 2 : 1][i] = (const char*)(Wg + (long)n * p.ldw) + gch16 + kb;
-#endif
+                if constexpr (SADDR) {
+                    soff[half ? 3 : 0][i] = (unsigned)row * (unsigned)(p.lda * 2) + gch16;
+                    soff[half ? 2 : 1][i] = (unsigned)n * (unsigned)(p.ldw * 2) + gch16;
+                } else {
+                    src[half ? 3 : 0][i] = (const char*)(p.A + (long)row * p.lda) + gch16 + kb;
+                    src[half ? 2 : 1][i] = (const char*)(Wg + (long)n * p.ldw) + gch16 + kb;
+                }
             }
         }
     };
@@ -733,21 +733,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(src[pc][i]));
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (SADDR) asm volatile("" ::"v"(soff[pc][i]));
+                else asm volatile("" ::"v"(src[pc][i]));
+            }
     };
     auto issue = [&](int piece, unsigned stage_base, long koff) {
-#if BAGEL_PQ_SADDR
-        const char* sb = ((piece == 0 || piece == 3) ? baseA : baseW) + koff;
+        const unsigned d0 = (piece == 0 ? OFF_A0 : piece == 1 ? OFF_B0 : piece == 2 ? OFF_B1 : OFF_A1) + wave * 1024;
+        if constexpr (SADDR) {
+            const char* sb = ((piece == 0 || piece == 3) ? baseA : baseW) + koff;
+#if BAGEL_PQ_M0MODE == 0
+            glds16_saddr(soff[piece][0], sb, stage_base + d0);
+            glds16_saddr(soff[piece][1], sb, stage_base + d0 + 8192);
+#elif BAGEL_PQ_M0MODE == 1          /* the two DMA instructions of a piece share one save / restore of M0 */
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(soff[piece][0]), "v"(soff[piece][1]), "s"(sb), "s"(stage_base + d0) : "memory", "scc");
+#else                               /* M0 is not preserved at all (hipcc uses it nowhere in this kernel: checked on the ISA) */
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\ts_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2"
+                         :: "v"(soff[piece][0]), "v"(soff[piece][1]), "s"(sb), "s"(stage_base + d0) : "memory", "scc");
 #endif
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = wave + 8 * i;
-            const unsigned d = (piece == 0 ? OFF_A0 : piece == 1 ? OFF_B0 : piece == 2 ? OFF_B1 : OFF_A1) + j * 1024;
-#if BAGEL_PQ_SADDR
-            glds16_saddr(src[piece][i], sb, stage_base + d);
-#else
-            glds16_asm(src[piece][i] + koff, stage_base + d);
-#endif
+        } else {
+            glds16_asm(src[piece][0] + koff, stage_base + d0);
+            glds16_asm(src[piece][1] + koff, stage_base + d0 + 8192);
         }
     };
 
@@ -1184,7 +1194,7 @@ static int pq_leftover_split(int nblk, int wgs, int nk, size_t ws_bytes, int* n_
     return s < 2 ? 1 : s;
 }
 
-template <int MODE, bool FP8 = false>
+template <int MODE, bool FP8 = false, bool SADDR = false>
 static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream, void* ws = nullptr, size_t ws_bytes = 0) {
     GemmParams p = p0;
     int t = 0;
@@ -1213,7 +1223,7 @@ static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream, void* ws = n
     const int wgs = wgs_of_dev[dev];
     p.gm = gm;
     constexpr int smem = 2 * 4 * 128 * 128 + 3 * 2048;   // two k-tile stages + the three-deep row-table ring
-    if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<MODE, FP8>, smem, "gemm_pq_kernel")) return rc;
+    if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<MODE, FP8, SADDR>, smem, "gemm_pq_kernel")) return rc;
     const int nblk = p.tiles_m * p.tiles_n;
     p.w_begin = 0; p.w_count = nblk; p.ksplit = 1; p.part = nullptr;
     if constexpr (!FP8 && MODE != 0) {
@@ -1223,19 +1233,19 @@ static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream, void* ws = n
             // (1) the full rounds, one pass; (2) the leftover tiles as K parts -> fp32 partials; (3) sum + epilogue
             if (n_full > 0) {
                 p.w_count = n_full;
-                hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8>), dim3(wgs), dim3(512), smem, stream, p);
+                hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8, SADDR>), dim3(wgs), dim3(512), smem, stream, p);
                 if (int rc = bagel_check_launch("gemm_pq_kernel")) return rc;
             }
-            if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<4, false>, smem, "gemm_pq_kernel<4>")) return rc;
+            if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<4, false, SADDR>, smem, "gemm_pq_kernel<4>")) return rc;
             p.w_begin = n_full; p.w_count = nblk - n_full; p.ksplit = s; p.part = (float*)ws;
             const int items = p.w_count * s;
-            hipLaunchKernelGGL((gemm_pq_kernel<4, false>), dim3(items < wgs ? items : wgs), dim3(512), smem, stream, p);
+            hipLaunchKernelGGL((gemm_pq_kernel<4, false, SADDR>), dim3(items < wgs ? items : wgs), dim3(512), smem, stream, p);
             if (int rc = bagel_check_launch("gemm_pq_kernel<4>")) return rc;
             hipLaunchKernelGGL((gemm_splitk_reduce_kernel<MODE>), dim3(8 * p.w_count), dim3(512), 0, stream, p);
             return bagel_check_launch("gemm_splitk_reduce_kernel");
         }
     }
-    hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8>), dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
+    hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8, SADDR>), dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
     return bagel_check_launch("gemm_pq_kernel");
 }
 
@@ -1321,11 +1331,22 @@ static int gemm_bf16_impl(const void* A, int64_t lda,
         case 3:
             if ((K & 63) != 0) return launch_gemm<256, 256, 2, 4>(p, stream);   // the ping-pong kernel has no K tail
             return launch_gemm_pp<0>(p, stream);
-        case 4: {   // persistent ping-pong; epilogue combinations it does not instantiate go to variant 3
+        case 4:     // persistent ping-pong; epilogue combinations it does not instantiate go to variant 3
+        case 5: {   // the same with SGPR-base DMA addresses: the CALLER promises that every A / W row of the launch lies within 4 GiB of the
+                    // operand's base pointer (dense rows are checked here; gathered rows cannot be seen from the host side of the ABI)
             if ((K & 63) != 0) return launch_gemm<256, 256, 2, 4>(p, stream);
             const bool has_bias = p.g[0].bias != nullptr || p.g[1].bias != nullptr;
             const bool all_bias = p.g[0].bias != nullptr && p.g[1].bias != nullptr;
             if (K < 128 || epilogue == EPI_GELU_TANH || epilogue == EPI_SILU || (has_bias && (R || !all_bias))) return launch_gemm_pp<0>(p, stream);
+            bool saddr = variant == 5 && (uint64_t)N * (uint64_t)ldw * 2 < (1ull << 32);
+            for (int g = 0; g < p.ngroups && saddr; ++g)
+                if (!p.g[g].a_rows && (uint64_t)p.g[g].M * (uint64_t)lda * 2 >= (1ull << 32)) saddr = false;
+            if (saddr) {
+                if (epilogue == EPI_SWIGLU16) return launch_gemm_pq<0, false, true>(p, stream);
+                if (R) return launch_gemm_pq<1, false, true>(p, stream, ws, ws_bytes);
+                if (has_bias) return launch_gemm_pq<2, false, true>(p, stream, ws, ws_bytes);
+                return launch_gemm_pq<3, false, true>(p, stream, ws, ws_bytes);
+            }
             if (epilogue == EPI_SWIGLU16) return launch_gemm_pq<0>(p, stream);
             if (R) return launch_gemm_pq<1>(p, stream, ws, ws_bytes);
             if (has_bias) return launch_gemm_pq<2>(p, stream, ws, ws_bytes);
@@ -1361,6 +1382,7 @@ extern "C" int bagel_gemm_fp8_bf16(const void* Aq, int64_t lda_bytes, const floa
     p.ngroups = 1;
     p.g[0] = GemmGroup{(const bf16_t*)Wq, (const bf16_t*)bias, a_rows, c_rows, M, 0};
     p.g[1] = p.g[0];
+    // (the fp8 path keeps per-lane 64-bit DMA addresses: its gathered A rows carry no extent promise in this entry point)
     if (epilogue == EPI_SWIGLU16) return launch_gemm_pq<0, true>(p, stream);
     if (R) return launch_gemm_pq<1, true>(p, stream);
     if (bias) return launch_gemm_pq<2, true>(p, stream);

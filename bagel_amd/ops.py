@@ -105,7 +105,13 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
         return gemv(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if variant is None:
         variant = default_gemm_variant(M0 + M1, N, K)
-    ws = _gemm_workspace(A.device) if (variant == 4 and splitk and GEMM_SPLITK) else None
+        # variant 5 = variant 4 with SGPR-base DMA addresses (one address register per LDS-DMA instruction: the persistent kernel is
+        # DMA-issue bound, gate+up 1 304 -> 1 411 TFLOP/s at M = 32 768): legal when every operand row lies within 4 GiB of the operand's
+        # base pointer, which the tensors' extents tell here (gathered rows index into A, so A's extent bounds them).  Same arithmetic,
+        # bit-identical results.  BAGEL_GEMM_SADDR=0 keeps variant 4 (same-box A/B).
+        if variant == 4 and GEMM_SADDR and A.shape[0] * _ld(A) * 2 < 2 ** 32 and N * W0.stride(0) * 2 < 2 ** 32:
+            variant = 5
+    ws = _gemm_workspace(A.device) if (variant in (4, 5) and splitk and GEMM_SPLITK) else None
     check(lib().bagel_gemm_bf16_ws(_ptr(A), _ld(A), _ptr(W0), _ptr(bias0), _ptr(a_rows0), _ptr(c_rows0), M0,
                                    _ptr(W1), _ptr(bias1), _ptr(a_rows1), _ptr(c_rows1), M1, W0.stride(0),
                                    _ptr(residual), _ld(residual) if residual is not None else 0, _ptr(C), _ld(C),
@@ -116,6 +122,7 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
 # K-split of a nearly empty last round of the persistent GEMM (bagel_gemm_bf16_ws): one fp32 workspace per device, 64 MB = 256 partial
 # tiles of 256 x 256 (every leftover tile cut into at most 256 / leftover parts).  BAGEL_GEMM_SPLITK=0 switches it off (same-box A/B).
 GEMM_SPLITK = os.environ.get("BAGEL_GEMM_SPLITK", "1") != "0"
+GEMM_SADDR = os.environ.get("BAGEL_GEMM_SADDR", "1") != "0"
 _GEMM_WS = {}
 
 

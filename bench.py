@@ -386,8 +386,12 @@ def full_depth_step(args, cfg, model, tok, ids, threads, layers=None):
     else:
         # depth-reduced run (tests): the engine stops after L layers, no final norm / llm2vae -- compare the residual stream instead
         raise NotImplementedError("full_depth_step compares whole-model velocities: build the model with the depth to test")
-    out["within_tolerance"] = bool(out["rel_l2"] <= FULL_DEPTH_TOL and out["rel_l2_sequential_forward_flow"] <= FULL_DEPTH_TOL
-                                   and out["rel_l2_cond_forward"] <= FULL_DEPTH_TOL_FORWARD and out["rel_l2_cfg_text_forward"] <= FULL_DEPTH_TOL_FORWARD)
+    # THE GATE is the per-forward bound (round-3 verdict): the CFG-combined figure amplifies the difference of two forwards ~5x on random-init
+    # weights and a 12 % band would pass a real bug of that size -- it is reported (with whether it sits inside its own noise band), not gated on
+    out["within_tolerance"] = bool(out["rel_l2_cond_forward"] <= FULL_DEPTH_TOL_FORWARD and out["rel_l2_cfg_text_forward"] <= FULL_DEPTH_TOL_FORWARD)
+    out["gate"] = (f"rel_l2_cond_forward and rel_l2_cfg_text_forward <= {FULL_DEPTH_TOL_FORWARD} (1.5 x the reference's own single-forward accumulation-order "
+                   "noise); the CFG-combined rel_l2 is information only")
+    out["cfg_combined_inside_noise_band"] = bool(out["rel_l2"] <= FULL_DEPTH_TOL and out["rel_l2_sequential_forward_flow"] <= FULL_DEPTH_TOL)
     out["noise_floor"] = {"cfg_combined_velocity": 0.080, "single_forward_velocity": 0.016, "source": "profiles/r03_full_depth_noise_floor.log"}
     return out
 
@@ -704,6 +708,9 @@ def pmc_traffic(kernel):
         return None
 
 
+PMC_SOURCE = "committed PMC pass (separate rocprofv3 --pmc runs of the same kernels on the same shapes), digest-checked against the kernel sources"
+
+
 def attention_object(arecords, args, R):
     """Second kernel of the denoise path: the planned persistent attention kernel (csrc/attention2.hip), timed live like the GEMM (HIP
     events around every launch of the timed region; the big launches = the stream-batched denoise forwards) + the PMC figures of the
@@ -721,6 +728,7 @@ def attention_object(arecords, args, R):
     if k:
         out["traffic"] = k.get("traffic_bytes_per_launch_corrected")
         out["pmc"] = {x: k.get(x) for x in ("mfma_busy_frac", "l2_hit_rate", "wave_cycles_split", "algorithmic_bytes_per_launch")}
+        out["pmc"]["source"] = PMC_SOURCE
     else:
         out["traffic"] = None
     return out
@@ -969,10 +977,15 @@ def main():
     ops.gemm = orig_gemm
     ops.attn_planned = orig_attn
     bcast_timed = list(bcast)
+    dt_rank = dt
+    per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        # every rank's own clock around the same barrier-fenced region: MAX is the job's time, the spread shows a straggler
+        tt = torch.zeros(world, dtype=torch.float64, device=dev)
+        tt[rank] = dt_rank
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(x) / args.steps * 1e3 for x in tt.tolist()]
+        dt = float(tt.max().item())
     finite = all(torch.isfinite(x).all().item() for x in latents)
     ts = None
     if not args.no_taylorseer:
@@ -1132,7 +1145,7 @@ def main():
     if rank == 0:
         # the dominant kernel = the GEMM variant that carries the most FLOPs in the timed region
         names = {0: "gemm_tn_kernel<128,128,2,2>", 1: "gemm_tn_kernel<256,256,2,4>", 2: "gemm_tn_kernel<256,128,2,2>",
-                 3: "gemm_pp_kernel<0>", 4: "gemm_pq_kernel<*>"}
+                 3: "gemm_pp_kernel<0>", 4: "gemm_pq_kernel<*>", 5: "gemm_pq_kernel<*>"}
         by_v = {}
         for r in records:
             by_v[r[3]] = by_v.get(r[3], 0.0) + r[0]
@@ -1157,13 +1170,15 @@ def main():
                        "options": {"cfg_batched": bool(getattr(model, "cfg_batched", False)),
                                    "und_side_path": bool(getattr(model, "cfg_batched", False) and getattr(model, "und_side_path", False))}},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                         "traffic": pmc_traffic(names.get(dom, str(dom))) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None, "kernel": names.get(dom, str(dom)), "launches": len(records),
+                         "traffic": pmc_traffic(names.get(dom, str(dom))) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None,
+                         "traffic_source": PMC_SOURCE + f" ({os.path.relpath(PMC_SUMMARY, ROOT)}); null when the sources changed since", "kernel": names.get(dom, str(dom)), "launches": len(records),
                          "avg_launch_ms": ms / max(len(records), 1), "gemm_time_share": ms * 1e-3 / dt},
             "attention": attention_object(arecords, args, R),
             "outputs_finite": bool(finite),
             # the job as the collective library saw it (an all-reduce of ones at start-up) and the conditioning-KV broadcast of the timed
             # steps as rank 0 timed it (HIP events on the launch stream; null at N = 1: there is no exchange)
             "ranks_seen": ranks_seen, "collective_backend": backend, "rccl_version": rccl_version,
+            "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms), "ranks": per_rank_ms},
             "broadcast": None if not bcast_timed else {
                 "calls": len(bcast_timed), "bytes_per_call": bcast_timed[0][2],
                 "ms_per_call": (sum(a.elapsed_time(b) for a, b, _ in bcast_timed) if cuda else sum((b - a) * 1e3 for a, b, _ in bcast_timed)) / len(bcast_timed),
@@ -1197,10 +1212,22 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, cfg, gpu)
             except Exception as e:   # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        if ranks_seen != args.gpus or ranks_seen != world:
+            # a job that did not run on the N ranks it was asked for has no line: a throughput quoted for N GPUs over fewer (or more) ranks
+            # would be read as a scaling point
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) and its all-reduce saw {ranks_seen}: refusing to print a "
+                             "benchmark line (launch with torch.distributed.run --nproc-per-node N, or let bench.py --gpus N start the ranks itself)\n")
+            refused = True
+        else:
+            refused = False
+            print(json.dumps(out), flush=True)
+    else:
+        refused = False
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if refused:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

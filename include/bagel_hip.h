@@ -36,7 +36,10 @@ const char* bagel_hip_arch(void);
  * Replaces F.linear at qwen2_navit.py:515-517,529-536,591-594; modeling_qwen2.py:200-201; bagel.py:803,832,978;
  * modeling_utils.py:107-110,120-124; siglip_navit.py:190,216-218,243,256-258.
  * variant: 0 = 128x128 tile/256 threads, 1 = 256x256/512, 2 = 256x128/256, 3 = 256x256 two-group ping-pong (K % 64 == 0,
- * else falls back to 1).  K % 8 == 0, N % 8 == 0. */
+ * else falls back to 1), 4 = its persistent form (one workgroup per CU walks the tile list), 5 = variant 4 with SGPR-base LDS-DMA
+ * addresses (one address register per DMA instruction: the kernel is DMA-issue bound) -- by passing 5 the CALLER PROMISES that every
+ * A row and every W row the launch touches lies within 4 GiB of the A / W base pointer (dense rows are checked and fall back to 4;
+ * gathered rows cannot be seen from this side of the ABI).  Variants 3, 4 and 5 give bit-identical results.  K % 8 == 0, N % 8 == 0. */
 int bagel_gemm_bf16(const void* A, int64_t lda,
                     const void* W0, const void* bias0, const int32_t* a_rows0, const int32_t* c_rows0, int32_t M0,
                     const void* W1, const void* bias1, const int32_t* a_rows1, const int32_t* c_rows1, int32_t M1,

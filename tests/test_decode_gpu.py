@@ -654,3 +654,21 @@ def test_generate_text_mxfp4_weights_option():
     finally:
         model.decode_weight_quant = None
     assert torch.equal(c, a)
+
+
+@pytest.mark.parametrize("cpw", ["2", "3", "8"])
+def test_decode_attention_with_several_chunks_per_workgroup(cpw):
+    """The batched-decode form of the attention kernel: a workgroup walks `cpw` consecutive 128-key chunks with a running (max, sum, O) and
+    the next chunk's page rows prefetched (BAGEL_DEC_CPW; chosen automatically once requests x KV heads x chunks exceed one round of
+    workgroups).  The attention tests of this file -- ragged lengths, scattered pages, NaN-filled never-written slots, the fused q/k-norm +
+    RoPE + append prologue bit-identical to the two-kernel form, the sharp-softmax merge -- re-run in a process with the loop forced on
+    (the knob is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BAGEL_DEC_CPW=cpw)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_decode_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "paged_append_and_decode_attention or fused_decode_attention_equals or sharp_softmax"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

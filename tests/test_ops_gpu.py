@@ -68,7 +68,7 @@ def ref_gemm(A, W, bias=None, epi=0, residual=None):
     return c
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(1, 128, 64), (7, 136, 128), (300, 520, 200), (1000, 256, 144), (513, 384, 3584), (130, 64, 512)])
 def test_gemm_plain_bias(M, N, K, variant):
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
@@ -89,7 +89,7 @@ def test_gemm_activation_and_residual(epi):
     close(X, ref_gemm(A, W, b, 0, R), ulps=2, what="gemm residual in place")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
 def test_gemm_swiglu(variant):
     from bagel_amd.modeling.bagel.qwen2_navit import interleave_gate_up
     M, I, K = 333, 416, 256
@@ -101,7 +101,7 @@ def test_gemm_swiglu(variant):
     close(C, ref, ulps=2, what="gemm swiglu")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
 def test_gemm_two_expert_groups(variant):
     """MoT routing: text rows -> W0, latent rows -> W1, rows interleaved like <start> latents <end> per sample."""
     H, N = 256, 392

@@ -1,5 +1,5 @@
 """Bitwise cross-check of the persistent ping-pong GEMM (variant 4) against the one-tile-per-workgroup ping-pong kernel
-(variant 3): same MFMA order, same rounding points, so every output must be IDENTICAL.  Run with BAGEL_GEMM_PERSIST_WGS=8
+(variant 3), and of its SGPR-base-DMA form (variant 5): same MFMA order, same rounding points, so every output must be IDENTICAL.  Run with BAGEL_GEMM_PERSIST_WGS=8
 to make every workgroup walk several tiles even on small problems (tests/test_ops_gpu.py does), and at the default grid.
 python tools/gemm_persist_check.py [--bench]"""
 import os
@@ -25,7 +25,7 @@ def it32(x):
 
 def both(what, call, out_shape, init=None, repeats=3):
     outs = []
-    for variant in (3, 4, 4, 4)[:1 + repeats]:
+    for variant in (3, 4, 5, 4, 5)[:2 + repeats]:        # 5 = variant 4 with SGPR-base DMA addresses: same arithmetic
         C = init.clone() if init is not None else torch.full(out_shape, float("nan"), dtype=BF16, device=DEV)
         call(C, variant)
         torch.cuda.synchronize()
