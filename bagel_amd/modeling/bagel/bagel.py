@@ -130,6 +130,7 @@ class Bagel(nn.Module):
         # accumulation order (bf16 noise).  BAGEL_CFG_BATCH=0 / BAGEL_UND_SIDE=0 switch them off.
         self.cfg_batched = os.environ.get("BAGEL_CFG_BATCH", "1") == "1"
         self.und_side_path = os.environ.get("BAGEL_UND_SIDE", "1") == "1"
+        self.step_hook = None          # optional callable(steps_taken, x_t) inside generate_image (trajectory tests / tooling)
         self.global_renorm_allreduce = False      # see _renorm_sums_allreduce
         # option (changes results; off by default, reported beside the bf16 numbers): "fp8" = the gen expert's four projections of the
         # denoise forwards run on the OCP-e4m3 MFMA with row-wise scales -- the MI355X counterpart of the reference's quantised load
@@ -454,6 +455,8 @@ class Bagel(nn.Module):
                             plan_t if s_t > 1.0 else None, cfg_text_past_key_values,
                             plan_i if (s_t > 1.0 and s_i > 1.0) else None, cfg_img_past_key_values,
                             s_t, s_i, cfg_renorm_min, mode, taylor, multi)
+            if self.step_hook is not None:     # test / tooling aid (trajectory parity): called with (Euler steps taken, x_t) -- x_t is the LIVE buffer
+                self.step_hook(i + 1, x_t)
         return x_t.split([int(n) - 2 for n in packed_seqlens.tolist()])
 
     def _renorm_sums_allreduce(self, partials, nparts, mode):
@@ -660,7 +663,6 @@ class Bagel(nn.Module):
 
     _TRAINABLE_PREFIXES = ("language_model.", "llm2vae.", "vae2llm.", "time_embedder.", "connector.", "vit_model.")
 
-    @_bf16_weights
     def forward(self, sequence_length, packed_text_ids, packed_text_indexes, sample_lens, packed_position_ids,
                 nested_attention_masks=None, split_lens=None, attn_modes=None, ce_loss_indexes=None, packed_label_ids=None,
                 packed_vit_tokens=None, packed_vit_token_indexes=None, packed_vit_position_ids=None, vit_token_seqlens=None,
@@ -685,6 +687,17 @@ class Bagel(nn.Module):
                   packed_vae_token_indexes=packed_vae_token_indexes, packed_timesteps=packed_timesteps, mse_loss_indexes=mse_loss_indexes,
                   noise=noise)
         named = [(n, p) for n, p in self.named_parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        fp32 = [n for n, p in named if p.dtype == torch.float32]
+        if fp32:
+            # The inference entry points cast fp32 weights to bf16 in place; doing that to TRAINABLE parameters would destroy the caller's
+            # master copy and leave the optimizer updating bf16 values (updates below bf16 resolution are rounded away) -- the reference
+            # trains fp32 masters with bf16 compute (FSDP MixedPrecision, train/fsdp_utils.py).  Refuse instead of changing the recipe.
+            raise TypeError(
+                f"Bagel.forward with grad: {len(fp32)} trainable parameter(s) are fp32 (first: {fp32[0]}).  The MI355X engines compute on bf16 "
+                "parameters; keep the fp32 MASTER copies in the optimizer: model.to(torch.bfloat16), then wrap the optimizer with "
+                "bagel_amd.train_utils.MasterWeightOptimizer(model, lambda ps: torch.optim.AdamW(ps, ...)) -- fp32 masters and optimizer "
+                "state, bf16 compute copies refreshed in place after every step.")
+        self._ensure_bf16()
         if not named:
             with torch.no_grad():
                 return self._forward_losses(tape=None, **kw)
@@ -808,7 +821,7 @@ class Bagel(nn.Module):
             head = lm.lm_head.weight
             dlogits = ops.cross_entropy_bwd(F_["logits"], F_["labels"], d_ce.to(device=dev, dtype=torch.float32).contiguous())
             n = dlogits.shape[0]
-            ops.gemm(dlogits, TS._wt(head.data), d_last, c_rows0=F_["ce_rows"], M0=n, residual=d_last)
+            ops.gemm(dlogits, eng.wt_of("lm_head", head), d_last, c_rows0=F_["ce_rows"], M0=n, residual=d_last)
             if head.requires_grad:
                 Xt = ops.transpose(last, rows=F_["ce_rows"], n=n)
                 dW = torch.empty(tuple(head.shape), dtype=BF16, device=dev)
@@ -817,7 +830,7 @@ class Bagel(nn.Module):
             lin = self.llm2vae
             dpred = ops.mse_rows_bwd(F_["preds"], F_["noise"], F_["clean"], F_["mse_src"], d_mse.to(device=dev, dtype=torch.float32).contiguous())
             n = dpred.shape[0]
-            ops.gemm(dpred, TS._wt(lin.weight.data), d_last, c_rows0=F_["mse_rows"], M0=n, residual=d_last)
+            ops.gemm(dpred, eng.wt_of("llm2vae", lin.weight), d_last, c_rows0=F_["mse_rows"], M0=n, residual=d_last)
             if lin.weight.requires_grad or lin.bias.requires_grad:
                 Xt = ops.transpose(last, rows=F_["mse_rows"], n=n)
                 dW = torch.empty(tuple(lin.weight.shape), dtype=BF16, device=dev)

@@ -682,6 +682,7 @@ class MoTEngine:
         self._ws_side = {}
         self._fp8 = None
         self._ws_fp8 = {}
+        self._wt_extra = {}            # name -> (transposed image, parameter): see wt_of()
 
     def _pack_layer(self, L):
         nq, nkv, hd, dp = self.nq, self.nkv, self.hd, self.dp
@@ -707,6 +708,43 @@ class MoTEngine:
             P.wgu.append(interleave_gate_up(m.gate_proj.weight.data, m.up_proj.weight.data))
             P.wd.append(m.down_proj.weight.data.contiguous())
         return P
+
+    def refresh(self):
+        """The parameters were rewritten IN PLACE (an optimizer step: same storage, new values): re-pack every layer INTO the packed
+        tensors that exist, rewrite the cached transposed images of the training backward in place, forget the quantised copies.
+        Workspaces, plans and the tape pool stay -- a training loop pays one re-pack pass per step (~2 bytes read + written per
+        parameter and image), not a rebuild of the engine, re-allocation of 28 GB of packed weights and a fresh set of transposes."""
+        from . import train_step as TS
+        for P, L in zip(self.layers, self.model.layers):
+            fresh = self._pack_layer(L)
+            for name in ("wqkv", "bqkv", "wo", "wgu", "wd", "qn", "kn", "ln_in", "ln_post"):
+                for old, new in zip(getattr(P, name), getattr(fresh, name)):
+                    if old.data_ptr() != new.data_ptr():        # (norm weights are views of the parameters themselves: already current)
+                        old.copy_(new)
+            for name, imgs in P.wt.items():
+                for img, w in zip(imgs, getattr(P, name)):
+                    img.copy_(TS._wt(w))
+            del fresh
+        for name, (img, src, _) in list(self._wt_extra.items()):
+            img.copy_(TS._wt(src.data))
+            self._wt_extra[name] = (img, src, src._version)
+        self._fp8 = None
+        self._ws_fp8 = {}
+        for attr in ("_w8_cache", "_w4_cache", "_nf4_cache"):
+            if hasattr(self, attr):
+                delattr(self, attr)
+
+    def wt_of(self, name, param):
+        """Cached transposed image of a parameter outside the decoder layers (lm_head, llm2vae, connector, time embedder) for the
+        training backward; refreshed in place by ``refresh()``."""
+        from . import train_step as TS
+        ent = self._wt_extra.get(name)
+        if ent is None or ent[1] is not param or ent[0].shape[0] != param.shape[1]:
+            ent = self._wt_extra[name] = (TS._wt(param.data), param, param._version)
+        elif ent[2] != param._version:      # rewritten in place since (these parameters are outside the language model's own signature)
+            ent[0].copy_(TS._wt(param.data))
+            ent = self._wt_extra[name] = (ent[0], param, param._version)
+        return ent[0]
 
     # -- workspaces (cached per row count; everything stays resident in HBM)
     def workspace(self, M, vt_cols):
@@ -1023,6 +1061,24 @@ class Qwen2ForCausalLM(PackedWeights):
     def _drop_packed(self):
         self._engine = None
         self._plans = {}
+
+    def _check_packed(self):
+        """Parameters rewritten in place (every tensor still at its address, version counters moved: an optimizer step, ``param.copy_``)
+        refresh the packed copies IN PLACE; anything else (re-seated storage, a different set of tensors) drops them as before."""
+        if self._packed_sig is None or self._engine is None:
+            return super()._check_packed()
+        ptrs = tuple(t.data_ptr() for t in self.parameters()) + tuple(t.data_ptr() for t in self.buffers())
+        if self._packed_sig != self._signature():
+            if getattr(self, "_packed_ptrs", None) == ptrs:
+                with torch.no_grad():
+                    self._engine.refresh()
+                self._packed_fresh()
+            else:
+                self.invalidate_packed()
+
+    def _packed_fresh(self):
+        super()._packed_fresh()
+        self._packed_ptrs = tuple(t.data_ptr() for t in self.parameters()) + tuple(t.data_ptr() for t in self.buffers())
 
     def engine(self, check=False) -> MoTEngine:
         """``check=True`` (the public entry points: once per prefill / generate_image / generate_text call) compares the

@@ -34,8 +34,9 @@ BF16 = torch.bfloat16
 #   KEEP_GATE_UP  the tape keeps the un-activated gate/up projection (76 KB per token and layer) and the forward applies SwiGLU as a
 #                 kernel of its own, instead of recomputing the largest GEMM of the layer in the backward (3.8 of 31 ms per layer at
 #                 18 k tokens).  "auto": when the projections of all layers fit a third of the memory that is free when the tape starts.
-#   CACHE_WT      the transposed weight images (the B operands of dX = dY W) stay with the packed layer until the parameters change
-#                 (the engine is re-packed then): +2 bytes per parameter, -2 ms per layer for every micro-step after the first.
+#   CACHE_WT      the transposed weight images (the B operands of dX = dY W) stay with the packed layer: +2 bytes per parameter; when the
+#                 parameters change (an optimizer step) MoTEngine.refresh() rewrites them IN PLACE together with the packed weights, so a
+#                 training loop neither re-allocates them nor pays the transposes inside its backward.
 KEEP_GATE_UP = {"0": False, "1": True}.get(os.environ.get("BAGEL_TRAIN_KEEP_GATE_UP", ""), "auto")
 CACHE_WT = os.environ.get("BAGEL_TRAIN_CACHE_WT", "1") != "0"
 
@@ -95,37 +96,44 @@ class TrainTape:
         self.front = {}         # embedding / ViT / latent front end and the loss heads (Bagel._forward_losses)
         self._store, self._pool, self._key = {}, None, None
 
-    # The tape's buffers are RESIDENT: a step takes the buffer set of its shape from the engine's pool and hands it back when its backward
-    # has run, so step after step reuses the same 35-75 GB instead of sending 150+ multi-GB requests through the allocator (a fresh
-    # hipMalloc of 1.4 GB is milliseconds).  A forward that starts while another tape is still alive simply gets a set of its own.
+    # The tape's buffers are RESIDENT and owned by the MODEL (the Qwen2Model module -- it outlives the packed engine, which is refreshed
+    # after every optimizer step): a step takes a buffer SET from the model's pool and hands it back when its backward has run, so step
+    # after step reuses the same 35-75 GB instead of sending 150+ multi-GB requests through the allocator.  A set is a dict of FLAT
+    # buffers with capacity: a request of another shape (the reference's packs have a different sequence_length every step) gets a view
+    # of the same storage, which only grows when a larger pack arrives -- the pool holds at most TAPE_POOL_SETS sets whatever shapes come
+    # (a forward that starts while the pooled sets are all in use simply allocates one of its own and drops it afterwards).
+    TAPE_POOL_SETS = 2
+
     def begin(self, eng, key):
-        self._pool = eng.__dict__.setdefault("_tape_pool", {})
+        self._pool = eng.model.__dict__.setdefault("_tape_pool", [])
         self._key = key
-        sets = self._pool.get(key)
-        self._store = sets.pop() if sets else {}
+        self._store = self._pool.pop() if self._pool else {}
 
     def buf(self, name, li, *shape, dtype=BF16, device=None):
-        t = self._store.get((name, li))
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = self._store[(name, li)] = torch.empty(shape, dtype=dtype, device=device)
-        return t
+        need = 1
+        for d in shape:
+            need *= int(d)
+        k = (name, li, dtype)
+        t = self._store.get(k)
+        if t is None or t.numel() < need or (device is not None and t.device != torch.device(device)):
+            self._store[k] = None                       # free the smaller buffer before the larger one is requested
+            t = self._store[k] = torch.empty((max(need, 1),), dtype=dtype, device=device)
+        return t[:need].view(*shape)
 
     def release(self):
-        if self._pool is not None and self._store:
-            sets = self._pool.setdefault(self._key, [])
-            if len(sets) < 2:
-                sets.append(self._store)
+        if self._pool is not None and self._store and len(self._pool) < self.TAPE_POOL_SETS:
+            self._pool.append(self._store)
         self._store, self._pool = {}, None
 
 
 def _decide_gate_up(self, eng, M):
-    """KEEP_GATE_UP = "auto": decided once per (engine, row count), on the first step, when neither the gradients nor the transposed
+    """KEEP_GATE_UP = "auto": decided once per (model, row count), on the first step, when neither the gradients nor the transposed
     weight images exist yet: the kept projections + the rest of the tape + three more copies of the decoder's weights (gradients, the
     weight images, slack for the backward's transients) have to fit 80 % of what is free."""
     if KEEP_GATE_UP != "auto":
         self.keep_gate_up = bool(KEEP_GATE_UP)
         return
-    memo = eng.__dict__.setdefault("_keep_gate_up", {})
+    memo = eng.model.__dict__.setdefault("_keep_gate_up", {})        # on the model: survives the engine's refresh after an optimizer step
     if M not in memo:
         if torch.device(eng.device).type != "cuda":
             memo[M] = False
@@ -212,8 +220,9 @@ def engine_backward_train(eng, tape, g, grads):
                         W1=w[1], bias1=None if b is None else b[1], a_rows1=tp.vae_idx, c_rows1=tp.vae_idx, M1=tp.n_vae)
         return dict(W0=w[0], bias0=None if b is None else b[0], M0=M)
 
-    def wgrads(dY, X):
-        return [_wgrad(dY, X, rows, n) for rows, n in sel]
+    def wgrads(dY, X, need):
+        """dW per expert; experts whose parameter is frozen are skipped (``_Grads.add`` ignores None)."""
+        return [_wgrad(dY, X, rows, n) if nd else None for (rows, n), nd in zip(sel, need)]
 
     def wts(P, name):
         ws = getattr(P, name)[:len(sel)]
@@ -223,7 +232,9 @@ def engine_backward_train(eng, tape, g, grads):
             P.wt[name] = [_wt(w) for w in ws]
         return P.wt[name]
 
-    bplan = AttnBackwardPlan(dev, tp.sample_lens, tp.sample_splits)
+    bplan = getattr(tp, "_bplan", None)
+    if bplan is None:                    # built once per TrainPlan (host loops + a host-to-device copy), reused by every backward of that pack
+        bplan = tp._bplan = AttnBackwardPlan(dev, tp.sample_lens, tp.sample_splits)
     m = eng.model
     # final norm (qwen2_navit.py:1011-1015)
     gx = e(M, H)
@@ -237,10 +248,18 @@ def engine_backward_train(eng, tape, g, grads):
     for li in range(len(eng.layers) - 1, -1, -1):
         P, Lm = eng.layers[li], m.layers[li]
         x_in, x_mid, act, att, qkv_raw = tape.x[li], tape.x_mid[li], tape.act[li], tape.att[li], tape.qkv_raw[li]
+        # which weight gradients this layer owes, per expert (frozen parameters: no dW launch, no column sum)
+        a = Lm.self_attn
+        rq = lambda *ps: any(p_ is not None and p_.requires_grad for p_ in ps)  # noqa: E731
+        need_qkv = [rq(*(getattr(a, n_ + sufs[ei]).weight for n_ in ("q_proj", "k_proj", "v_proj"))) for ei in range(len(sel))]
+        need_bqkv = [rq(*(getattr(a, n_ + sufs[ei]).bias for n_ in ("q_proj", "k_proj", "v_proj"))) for ei in range(len(sel))]
+        need_o = [rq(getattr(a, "o_proj" + sufs[ei]).weight) for ei in range(len(sel))]
+        need_gu = [rq(getattr(Lm, "mlp" + sufs[ei]).gate_proj.weight, getattr(Lm, "mlp" + sufs[ei]).up_proj.weight) for ei in range(len(sel))]
+        need_d = [rq(getattr(Lm, "mlp" + sufs[ei]).down_proj.weight) for ei in range(len(sel))]
         # ---- MLP block: x_out = x_mid + down(swiglu(gate_up(rmsnorm(x_mid))))   (qwen2_navit.py:744-753)
         d_act = e(M, I)
         ops.gemm(g, C=d_act, **groups(wts(P, "wd")))
-        dWd = wgrads(g, act)
+        dWd = wgrads(g, act, need_d)
         ops.rmsnorm(x_mid, P.ln_post[0], h, eng.eps, w1=P.ln_post[1] if two else None, expert=expert)
         if tape.gu:
             gu, tape.gu[li] = tape.gu[li], None                  # kept by the forward; consumed (overwritten with its gradient) here
@@ -249,14 +268,14 @@ def engine_backward_train(eng, tape, g, grads):
             ops.gemm(h, C=gu, **groups(P.wgu))                   # the un-activated projection, recomputed
         ops.swiglu_bwd(gu, d_act)
         del d_act
-        dWgu = wgrads(gu, h)
+        dWgu = wgrads(gu, h, need_gu)
         ops.gemm(gu, C=d_h, **groups(wts(P, "wgu")))
         del gu
         dpost = ops.rmsnorm_bwd(x_mid, d_h, P.ln_post[0], g, eng.eps, w1=P.ln_post[1] if two else None, expert=expert)
         # ---- attention block: x_mid = x_in + o(attn(rope(qknorm(qkv(rmsnorm(x_in))))))   (qwen2_navit.py:406-497, 713-743)
         d_att = e(M, qw)
         ops.gemm(g, C=d_att, **groups(wts(P, "wo")))
-        dWo = wgrads(g, att)
+        dWo = wgrads(g, att, need_o)
         qkv = qkv_raw.clone()
         ops.qknorm_rope(qkv, tp.cos, tp.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
                         P.qn[1] if (eng.use_norm and two) else None, P.kn[1] if (eng.use_norm and two) else None,
@@ -269,29 +288,28 @@ def engine_backward_train(eng, tape, g, grads):
                                   P.qn[1] if (eng.use_norm and two) else None, P.kn[1] if (eng.use_norm and two) else None,
                                   expert, nq, nkv, hd, dp, eng.eps, eng.use_norm)
         ops.rmsnorm(x_in, P.ln_in[0], h, eng.eps, w1=P.ln_in[1] if two else None, expert=expert)
-        dWqkv = wgrads(dqkv, h)
-        dbqkv = [ops.colsum(dqkv, rows, n) for rows, n in sel]
+        dWqkv = wgrads(dqkv, h, need_qkv)
+        dbqkv = [ops.colsum(dqkv, rows, n) if nd else None for (rows, n), nd in zip(sel, need_bqkv)]
         ops.gemm(dqkv, C=d_h, **groups(wts(P, "wqkv")))
         del dqkv
         din = ops.rmsnorm_bwd(x_in, d_h, P.ln_in[0], g, eng.eps, w1=P.ln_in[1] if two else None, expert=expert)
         # ---- unpack the MI355X layouts into the reference's parameter shapes
-        a = Lm.self_attn
         for ei in range(len(sel)):
             s = sufs[ei]
-            wq, wk, wv = dWqkv[ei][:qw], dWqkv[ei][qw:qw + kw_], dWqkv[ei][qw + kw_:]
-            bq, bk, bv = dbqkv[ei][:qw], dbqkv[ei][qw:qw + kw_], dbqkv[ei][qw + kw_:]
+            cut = lambda t: (None, None, None) if t is None else (t[:qw], t[qw:qw + kw_], t[qw + kw_:])  # noqa: E731
+            (wq, wk, wv), (bq, bk, bv) = cut(dWqkv[ei]), cut(dbqkv[ei])
             for name, w_, b_, nh in (("q_proj", wq, bq, nq), ("k_proj", wk, bk, nkv), ("v_proj", wv, bv, nkv)):
                 lin = getattr(a, name + s)
-                grads.add(lin.weight, _unpad_rows(w_, nh, hd, dp))
-                grads.add(lin.bias, _unpad_rows(b_, nh, hd, dp))
-            grads.add(getattr(a, "o_proj" + s).weight, _unpad_cols(dWo[ei], nq, hd, dp))
+                grads.add(lin.weight, None if w_ is None else _unpad_rows(w_, nh, hd, dp))
+                grads.add(lin.bias, None if b_ is None else _unpad_rows(b_, nh, hd, dp))
+            grads.add(getattr(a, "o_proj" + s).weight, None if dWo[ei] is None else _unpad_cols(dWo[ei], nq, hd, dp))
             if eng.use_norm:
                 grads.add(getattr(a, "q_norm" + s).weight, dqn[2 * ei])
                 grads.add(getattr(a, "k_norm" + s).weight, dqn[2 * ei + 1])
             grads.add(getattr(Lm, "input_layernorm" + s).weight, din[ei])
             grads.add(getattr(Lm, "post_attention_layernorm" + s).weight, dpost[ei])
             mlp = getattr(Lm, "mlp" + s)
-            dg, du = _deinterleave_gate_up(dWgu[ei])
+            dg, du = (None, None) if dWgu[ei] is None else _deinterleave_gate_up(dWgu[ei])
             grads.add(mlp.gate_proj.weight, dg)
             grads.add(mlp.up_proj.weight, du)
             grads.add(mlp.down_proj.weight, dWd[ei])

@@ -57,6 +57,33 @@ def oracle_request(W, VW, cfg, ovi, oti, enc_noise, l2, r2, li, ct, cim, tok):
     return c, c_text, c_img, v0, lat
 
 
+IMG_SEED = 11
+
+
+def images():
+    """The two views of the source image (vae_transform / vit_transform outputs): a seeded draw, re-made by the test (the fixture keeps
+    only a checksum of each)."""
+    g = torch.Generator().manual_seed(IMG_SEED)
+    img_vae = torch.rand(3, *VAE_HW, generator=g) * 2 - 1
+    img_vit = torch.rand(3, *VIT_HW, generator=g) * 2 - 1
+    return img_vae, img_vit
+
+
+def compact(d):
+    """What the fixture does not need to carry: the images (seeded), the packer outputs that hold them again, and the cfg-text context --
+    the first lens[1] rows of the cond context bit for bit (prefill appends; checked here)."""
+    L = len(d["key_cache"])
+    n = d["key_cache_img"][0].shape[0]
+    for i in range(L):
+        assert torch.equal(d["key_cache"][i][:n], d["key_cache_img"][i]) and torch.equal(d["value_cache"][i][:n], d["value_cache_img"][i])
+    a, b = images()
+    assert torch.equal(a, d["img_vae"]) and torch.equal(b, d["img_vit"])
+    d["img_seed"], d["img_checksum"], d["n_img_ctx"] = IMG_SEED, [float(a.double().sum()), float(b.double().sum())], n
+    for k in ("img_vae", "img_vit", "key_cache_img", "value_cache_img", "vae_inputs", "vit_inputs"):
+        d.pop(k, None)
+    return d
+
+
 def main():
     cfg = WIDE7B
     t0 = time.time()
@@ -65,9 +92,7 @@ def main():
     L = cfg["llm"]["num_hidden_layers"]
     tok = StubTokenizer(cfg["llm"]["vocab_size"])
     ds = cfg["vae"]["downsample"] * cfg["bagel"]["latent_patch_size"]
-    g = torch.Generator().manual_seed(11)
-    img_vae = torch.rand(3, *VAE_HW, generator=g) * 2 - 1      # vae_transform(image) output
-    img_vit = torch.rand(3, *VIT_HW, generator=g) * 2 - 1      # vit_transform(image) output (14-px patches)
+    img_vae, img_vit = images()                                # vae_transform(image) / vit_transform(image) outputs (14-px patches)
     ident = lambda t: t  # noqa: E731
     fvae = MG._Fp32Vae(vae)
     rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
@@ -122,11 +147,11 @@ def main():
     print("reference accumulation-order noise floor (fp32-accumulating oracle vs reference, rel-L2):", noise)
     kct, vct = MG.cache_to_lists(cfg_text_cache, L)
     kci, vci = MG.cache_to_lists(cimg_cache, L)
-    out = dict(prompt=PROMPT, img_vae=img_vae, img_vit=img_vit, enc_noise=enc_noise, vae_inputs=vi, vit_inputs=ti, lens=[l1, l2, l3, l4],
-               ropes=[r1, r2, r3, r4], image_size=size, key_cache=kc, value_cache=vc, key_cache_img=kct, value_cache_img=vct,
-               key_cache_txt=kci, value_cache_txt=vci, latent_inputs=li, cfg_text_inputs=ct, cfg_img_inputs=cim, gen_kwargs=KW,
-               latents=list(lat), v_first_step=v0, noise_floor=noise, v_first_step_f32acc=v0_32, latents_f32acc=list(olat32),
-               host=dict(torch=torch.__version__))
+    out = compact(dict(prompt=PROMPT, img_vae=img_vae, img_vit=img_vit, enc_noise=enc_noise, vae_inputs=vi, vit_inputs=ti, lens=[l1, l2, l3, l4],
+                       ropes=[r1, r2, r3, r4], image_size=size, key_cache=kc, value_cache=vc, key_cache_img=kct, value_cache_img=vct,
+                       key_cache_txt=kci, value_cache_txt=vci, latent_inputs=li, cfg_text_inputs=ct, cfg_img_inputs=cim, gen_kwargs=KW,
+                       latents=list(lat), v_first_step=v0, noise_floor=noise, v_first_step_f32acc=v0_32, latents_f32acc=list(olat32),
+                       host=dict(torch=torch.__version__)))
     path = os.path.join(MG.GOLD, "wide7b_edit.pt")
     torch.save(out, path)
     print(f"wrote {path} ({os.path.getsize(path) / 1e6:.1f} MB) in {time.time() - t0:.0f} s")

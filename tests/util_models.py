@@ -13,7 +13,8 @@ WEIGHT_SEED = 0
 @functools.lru_cache(maxsize=4)
 def _weights(name):
     from oracle import configs
-    cfg = {"tiny": configs.TINY, "tiny_d128": configs.TINY_D128, "tiny_rope": configs.TINY_ROPE, "tiny_dense": configs.TINY_DENSE, "tiny_moe": configs.TINY_MOE}[name]
+    cfg = {"tiny": configs.TINY, "tiny_d128": configs.TINY_D128, "tiny_rope": configs.TINY_ROPE, "tiny_dense": configs.TINY_DENSE, "tiny_moe": configs.TINY_MOE,
+           "wide7b": configs.WIDE7B}[name]
     W = {k: v.to(torch.bfloat16) for k, v in synth_state_dict(bagel_shapes(cfg), WEIGHT_SEED).items()}
     if cfg["vit"].get("rope", False):
         v = cfg["vit"]
@@ -37,7 +38,8 @@ def oracle_weights(cfg):
 def _product(name):
     from oracle import configs
     from bagel_amd.factory import build_bagel
-    cfg = {"tiny": configs.TINY, "tiny_d128": configs.TINY_D128, "tiny_rope": configs.TINY_ROPE, "tiny_dense": configs.TINY_DENSE, "tiny_moe": configs.TINY_MOE}[name]
+    cfg = {"tiny": configs.TINY, "tiny_d128": configs.TINY_D128, "tiny_rope": configs.TINY_ROPE, "tiny_dense": configs.TINY_DENSE, "tiny_moe": configs.TINY_MOE,
+           "wide7b": configs.WIDE7B}[name]
     W, VW = _weights(name)
     model, vae = build_bagel(cfg, device="cuda")
     missing, unexpected = model.load_state_dict(W, strict=True), None
