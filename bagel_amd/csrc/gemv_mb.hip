@@ -214,24 +214,73 @@ __global__ __launch_bounds__(256) void gemv_mb_reduce_kernel(const MbParams p) {
     mb_epilogue(p, a, m, n);
 }
 
-// Geometry.  NS = 4 serves short rows (K <= 1024: the tiny test models), NS = 14 serves K <= 3584 in one slice (14 steps per wave at the 7B
-// hidden size), NS = 19 the long rows (18944 = 592 steps = 4 slices x 8 waves x 19, the last wave 3 live steps).  The launch is
-// PERSISTENT: one workgroup per CU (its ~170 registers x 8 waves leave no room for a second one), each taking an even share of the column
-// blocks of its K slice, so the activation prologue is paid once per workgroup and launch, not per block.  BAGEL_MB_WGS overrides the
-// workgroup count (tuning / tests).
-static void mb_geometry(int K, int* per, int* KS) {
-    const int nsteps = K / 32;
-    int ks = (nsteps + 8 * 19 - 1) / (8 * 19);
-    if (nsteps <= 8 * 14) ks = 1;
-    *per = (nsteps + 8 * ks - 1) / (8 * ks);
-    *KS = ks;
+// Geometry.  Instantiations: NS = 4 (short rows, K <= 1024: the tiny test models), 10, 14 (K = 3584 in one slice: 14 steps per wave at the 7B
+// hidden size), 19.  The launch is PERSISTENT: one workgroup per CU (its ~170 registers x 8 waves leave no room for a second one), each
+// taking an even share of the column blocks of its K slice, so the activation prologue is paid once per workgroup and launch.
+// Rows too long for one slice (nsteps > 8 x 19) are cut over KS workgroups; KS and the workgroups per slice are chosen together so that
+// the blocks divide evenly and the whole chip is used: the 7B down projection (592 steps, 224 blocks, 256 CUs) runs as 8 slices x 32
+// workgroups x 7 blocks x 10 steps per wave -- 4 slices x 64 workgroups would leave 3 or 4 blocks per workgroup (makespan 4 of 3.5).
+// BAGEL_MB_WGS overrides the workgroup count (tuning / tests).
+static const int MB_NS[] = {4, 10, 14, 19};
+
+static int mb_ns_for(int per) {
+    for (int ns : MB_NS)
+        if (per <= ns) return ns;
+    return 0;
+}
+
+static void mb_geometry(int N, int K, int wgs, int* per, int* KS, int* gx_out) {
+    const int nsteps = K / 32, nblk = N / 16;
+    if (nsteps <= 8 * 19) {                            // one slice: the fused norm / SwiGLU need the whole row in one workgroup
+        *KS = 1;
+        *per = (nsteps + 7) / 8;
+        *gx_out = wgs < nblk ? wgs : nblk;
+        return;
+    }
+    const int ks_min = (nsteps + 8 * 19 - 1) / (8 * 19);
+    int best_ks = ks_min, best_gx = 1;
+    double best_cost = 1e30;
+    for (int ks = ks_min; ks <= 4 * ks_min && ks <= wgs; ++ks) {
+        const int pw = (nsteps + 8 * ks - 1) / (8 * ks);
+        const int ns = mb_ns_for(pw);
+        if (ns == 0 || nsteps < ns) continue;
+        int gx = wgs / ks;
+        if (gx < 1) gx = 1;
+        if (gx > nblk) gx = nblk;
+        const int blocks = (nblk + gx - 1) / gx;       // of the busiest workgroup
+        // time ~ the busiest workgroup's stream (blocks x fragments it LOADS, live or not) + a fixed cost per slice of slab traffic
+        const double cost = (double)blocks * ns * (1.0 + 0.02 * ks);
+        if (cost < best_cost) { best_cost = cost; best_ks = ks; best_gx = gx; }
+    }
+    *KS = best_ks;
+    *per = (nsteps + 8 * best_ks - 1) / (8 * best_ks);
+    *gx_out = best_gx;
+}
+
+static int mb_wgs() {
+    static int wgs_env = -1, cus_of_dev[16] = {0};
+    if (wgs_env < 0) {
+        const char* e = getenv("BAGEL_MB_WGS");
+        wgs_env = (e && atoi(e) > 0) ? atoi(e) : 0;
+    }
+    if (wgs_env) return wgs_env;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    if (cus_of_dev[dev] == 0) {
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus_of_dev[dev] = cus > 0 ? cus : 256;
+    }
+    return cus_of_dev[dev];
 }
 
 extern "C" int bagel_gemv_mb_workspace_bytes(int32_t N, int32_t K, int64_t* bytes) {
-    BAGEL_REQUIRE(bytes && N > 0 && K > 0, "gemv_mb_workspace_bytes: bad argument");
-    int per, KS;
-    mb_geometry(K, &per, &KS);
-    *bytes = KS > 1 ? (int64_t)KS * 16 * N * 4 : 0;
+    BAGEL_REQUIRE(bytes && N > 0 && K > 0 && (K % 32) == 0 && (N % 16) == 0, "gemv_mb_workspace_bytes: bad argument");
+    // the slice count depends on the device's CU count: an upper bound that holds for every geometry the launcher may pick (4 x the minimum)
+    const int nsteps = K / 32;
+    const int ks_min = (nsteps + 8 * 19 - 1) / (8 * 19);
+    *bytes = nsteps <= 8 * 19 ? 0 : (int64_t)4 * ks_min * 16 * N * 4;
     return BAGEL_OK;
 }
 
@@ -257,36 +306,24 @@ extern "C" int bagel_gemv_mb_bf16(const void* A, int64_t lda, const void* W, int
     p.R = (const bf16_t*)R; p.ldr = ldr; p.C = (bf16_t*)C; p.ldc = ldc; p.norm_w = (const bf16_t*)norm_w; p.eps = eps;
     p.M = M; p.N = N; p.K = K; p.epi = epilogue;
     const bool sw = epilogue == EPI_SWIGLU16;
-    mb_geometry(K, &p.per, &p.KS);
-
-    const int NS = p.per <= 4 ? 4 : p.per <= 14 ? 14 : 19;       // the instantiation that runs; its fragments must fit the row
-    if (p.per > 19 || K / 32 < NS) return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "gemv_mb: K=%d (%d steps per wave) has no instantiation", K, p.per);
+    int gx = 1;
+    mb_geometry(N, K, mb_wgs(), &p.per, &p.KS, &gx);
+    const int NS = mb_ns_for(p.per);                                // the instantiation that runs; its fragments must fit the row
+    if (NS == 0 || K / 32 < NS) return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "gemv_mb: K=%d (%d steps per wave) has no instantiation", K, p.per);
     if (p.KS > 1) {
         if (norm_w || sw) return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "gemv_mb: fused RMSNorm / SwiGLU need the whole row in one slice (K=%d)", K);
         BAGEL_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (int64_t)p.KS * 16 * N * 4,
-                      "gemv_mb: K=%d runs as %d slices and needs a 16-byte aligned fp32 workspace of %lld bytes", K, p.KS, (long long)p.KS * 16 * N * 4);
+                      "gemv_mb: K=%d runs as %d slices and needs a 16-byte aligned fp32 workspace of %lld bytes (bagel_gemv_mb_workspace_bytes)", K, p.KS,
+                      (long long)p.KS * 16 * N * 4);
     }
     p.part = (float*)workspace;
-    static int wgs_env = -1, cus_of_dev[16] = {0};
-    if (wgs_env < 0) {
-        const char* e = getenv("BAGEL_MB_WGS");
-        wgs_env = (e && atoi(e) > 0) ? atoi(e) : 0;
+    if (sw) {                                                       // units are gate/up PAIRS of blocks
+        const int nunits = N / 32;
+        if (gx > nunits) gx = nunits;
     }
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev &= 15;
-    if (cus_of_dev[dev] == 0) {
-        int cus = 0;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        cus_of_dev[dev] = cus > 0 ? cus : 256;
-    }
-    const int wgs = wgs_env ? wgs_env : cus_of_dev[dev];
-    const int nunits = (N / 16) / (sw ? 2 : 1);
-    int gx = wgs / p.KS;
-    if (gx < 1) gx = 1;
-    if (gx > nunits) gx = nunits;
     const dim3 grid(gx, p.KS);
-    if (int rc = NS == 4 ? mb_launch<4>(p, grid, stream) : NS == 14 ? mb_launch<14>(p, grid, stream) : mb_launch<19>(p, grid, stream)) return rc;
+    if (int rc = NS == 4 ? mb_launch<4>(p, grid, stream) : NS == 10 ? mb_launch<10>(p, grid, stream) : NS == 14 ? mb_launch<14>(p, grid, stream)
+                                                                                                     : mb_launch<19>(p, grid, stream)) return rc;
     if (p.KS > 1) {
         hipLaunchKernelGGL(gemv_mb_reduce_kernel, dim3(ceil_div((long)M * (N / 4), 256)), dim3(256), 0, stream, p);
         return bagel_check_launch("gemv_mb_reduce_kernel");

@@ -114,8 +114,7 @@ class DecodeSession:
         self.sin = e(B, eng.hd // 2)
         self.part_o, self.part_ml = ops.attn_decode_workspace(B, nq, dp, self.max_len, dev)
         # fp32 K-slice slabs of bagel_gemv_mb_bf16 for the longest row a layer has (the down projection)
-        ks = ops._mb_steps(eng.I)[1]
-        self.mb_ws = torch.empty(max(ks * 16 * eng.H, 4), dtype=torch.float32, device=dev) if 1 < B <= ops.MB_MAX_ROWS else None
+        self.mb_ws = torch.empty(max(ops.mb_workspace_floats(eng.H, eng.I), 4), dtype=torch.float32, device=dev) if 1 < B <= ops.MB_MAX_ROWS else None
         self.pos = position_ids.to(device=dev, dtype=torch.long).clone().contiguous()
         st = start_tokens.to(device=dev, dtype=torch.long).contiguous()
         self.cur32 = st.to(torch.int32)

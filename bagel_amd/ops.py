@@ -150,11 +150,20 @@ GEMV_MB = os.environ.get("BAGEL_GEMV_MB", "1") != "0"
 _MB_WS = {}
 
 
-def _mb_steps(K):
-    """(steps per wave, K slices over workgroups) of bagel_gemv_mb_bf16 -- mirrors mb_geometry in csrc/gemv_mb.hip."""
+def _mb_slices(K):
+    """(steps per wave if the row runs as ONE K slice else None, minimum K slices) of bagel_gemv_mb_bf16 -- mirrors mb_geometry in
+    csrc/gemv_mb.hip (rows of more than 8 x 19 steps of 32 are cut over workgroups; the launcher picks the slice count between the
+    minimum and 4 x the minimum so that the column blocks divide evenly over the CUs)."""
     nsteps = K // 32
-    ks = 1 if nsteps <= 8 * 14 else -(-nsteps // (8 * 19))
-    return -(-nsteps // (8 * ks)), ks
+    if nsteps <= 8 * 19:
+        return -(-nsteps // 8), 1
+    return None, -(-nsteps // (8 * 19))
+
+
+def mb_workspace_floats(N, K):
+    """fp32 elements of the K-slice workspace bagel_gemv_mb_bf16 may need for an [N, K] weight (0: the row runs in one slice)."""
+    per, ks = _mb_slices(K)
+    return 0 if per is not None else 4 * ks * 16 * N
 
 
 def gemv_mb_supported(A, W, C, bias, residual, epilogue, has_norm):
@@ -163,9 +172,12 @@ def gemv_mb_supported(A, W, C, bias, residual, epilogue, has_norm):
     N, K = W.shape
     if K % 32 or N % (32 if epilogue == EPI_SWIGLU16 else 16):
         return False
-    per, ks = _mb_steps(K)
-    ns = 4 if per <= 4 else 14 if per <= 14 else 19
-    if per > 19 or K // 32 < ns or (ks > 1 and (has_norm or epilogue == EPI_SWIGLU16)):
+    per, ks = _mb_slices(K)
+    if per is not None:
+        ns = next(n for n in (4, 10, 14, 19) if per <= n)
+        if K // 32 < ns:
+            return False
+    elif has_norm or epilogue == EPI_SWIGLU16:
         return False
     if epilogue == EPI_SWIGLU16 and (bias is not None or residual is not None):
         return False
@@ -188,8 +200,7 @@ def gemv_mb(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, nor
         _req(residual, BF16, "gemv_mb.residual")
     if norm_w is not None:
         _req(norm_w, BF16, "gemv_mb.norm_w")
-    ks = _mb_steps(K)[1]
-    need = ks * 16 * N * 4 if ks > 1 else 0          # bagel_gemv_mb_workspace_bytes
+    need = mb_workspace_floats(N, K) * 4                # bagel_gemv_mb_workspace_bytes
     ws = workspace
     if need and ws is None:
         key = _ws_key(A.device)

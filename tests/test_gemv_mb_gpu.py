@@ -60,11 +60,11 @@ def test_gemv_mb_geometry_edges(M, N, K):
 
 
 def test_gemv_mb_k_slices_are_deterministic_and_match_the_tile_kernel():
-    """K = 18944 runs as 4 K slices + the reduce launch: same bits on every call (fixed summation order, no atomics), within an ulp of the
+    """K = 18944 runs as K slices over workgroups + the reduce launch: same bits on every call (fixed summation order, no atomics), within an ulp of the
     128x128 tile kernel on the same operands, and a NaN-filled workspace from an earlier, larger call cannot leak into the result."""
     M, N, K = 16, 3584, 18944
     A, W, R = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=K ** -0.5).to(DEV), rnd(M, N, seed=3).to(DEV)
-    ws = torch.full((4 * 16 * N + 1024,), float("nan"), dtype=torch.float32, device=DEV)
+    ws = torch.full((ops().mb_workspace_floats(N, K) + 1024,), float("nan"), dtype=torch.float32, device=DEV)
     outs = []
     for _ in range(3):
         C = R.clone()
