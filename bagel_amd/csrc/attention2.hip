@@ -93,6 +93,9 @@ __device__ __forceinline__ void a2_glds16s(unsigned voff, const void* sbase_unif
 #ifndef A2_ABL
 #define A2_ABL 0             // timing-only ablations (WRONG results; tools/ab_build.sh): bit 0 no barrier / vmcnt waits, bit 1 no softmax / row-max VALU,
 #endif                       // bit 2 no LDS fragment reads inside the phases, bit 3 no LDS-DMA after the priming
+#ifndef A2_WIDE_STORE
+#define A2_WIDE_STORE 1      // epilogue: half-wave exchange -> 16-byte stores (0 = the 8-byte form, same bytes; tools/ab_build.sh A/B)
+#endif
 #ifndef A2_SLOTS
 #define A2_SLOTS 4          // LDS ring slots (3 = fetch at the top of a step, two tiles ahead; 4 = fetch inside phase B, three tiles ahead)
 #endif
@@ -460,6 +463,27 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
             const float l_tot = a2_sum_halves(l_run);
             if (!partial) {
                 const float inv = 1.0f / l_tot;
+#if A2_WIDE_STORE
+                // The store tail is store-ISSUE bound (cdna_hip_programming.md T21): a lane owns d = 32 db + 8 u + 4 hi + (0..3) of its row -- 8 bytes
+                // per (db, u), 16 dwordx2 stores -- while lane ^ 32 owns the other half of the same 16 bytes.  One v_permlane32_swap per dword
+                // trades group u + 1 of the lower half-wave against group u of the upper one: lanes < 32 end up with d = 8 (u + 1) .. + 7,
+                // lanes >= 32 with d = 8 u .. + 7 -- 8 dwordx4 stores per lane, same bytes.  (Executed by the whole wave: the swap ignores no lane.)
+                {
+                    bf16_t* op = p.out + (long)(q_row0 + (row_ok ? wrow0 + qi : 0)) * p.ldo + (long)hw * D;
+#pragma unroll
+                    for (int db = 0; db < DB; ++db)
+#pragma unroll
+                        for (int u = 0; u < 4; u += 2) {
+                            const unsigned a0 = pack2bf(o[db][4 * u] * inv, o[db][4 * u + 1] * inv), a1 = pack2bf(o[db][4 * u + 2] * inv, o[db][4 * u + 3] * inv);
+                            const unsigned b0 = pack2bf(o[db][4 * u + 4] * inv, o[db][4 * u + 5] * inv), b1 = pack2bf(o[db][4 * u + 6] * inv, o[db][4 * u + 7] * inv);
+                            // swap(d = B, s = A): d' = [B.lower | A.lower], s' = [B.upper | A.upper]  ->  lanes < 32: (d', s') = (B(l), B(l + 32)); lanes >= 32: (A(l - 32), A(l))
+                            const auto r0 = __builtin_amdgcn_permlane32_swap(b0, a0, false, false);
+                            const auto r1 = __builtin_amdgcn_permlane32_swap(b1, a1, false, false);
+                            const u32x4_t v = {r0[0], r1[0], r0[1], r1[1]};
+                            if (row_ok) *(u32x4_t*)(op + 32 * db + 8 * (hi ? u : u + 1)) = v;
+                        }
+                }
+#else
                 if (row_ok) {
                     bf16_t* op = p.out + (long)(q_row0 + wrow0 + qi) * p.ldo + (long)hw * D + 4 * hi;
 #pragma unroll
@@ -471,6 +495,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
                             *(u32x2_t*)(op + 32 * db + 8 * u) = v;
                         }
                 }
+#endif
             } else if (row_ok) {
                 // un-normalised fp32 partials of this key range: O (relative to m_use), the max in use (log2 units) and the row sum
                 float* pp = p.part + (long)part_slot * PSLOT;
