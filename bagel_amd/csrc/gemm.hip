@@ -606,16 +606,6 @@ __device__ __forceinline__ const char* pq_uniform(const char* ptr) {          //
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const char*)(((unsigned long)hi << 32) | lo);
 }
-#ifndef BAGEL_PQ_BUF
-#define BAGEL_PQ_BUF 0                 /* experiment: buffer_load_dwordx4 ... offen lds instead of global_load_lds_dwordx4 (SADDR kernels only) */
-#endif
-typedef __attribute__((ext_vector_type(4))) int pq_i32x4_t;
-// raw buffer descriptor over [base, base + 4 GiB): stride 0, num_records 0xffffffff, gfx9 data format word 0x00020000
-__device__ __forceinline__ pq_i32x4_t pq_rsrc(const char* base_uniform) {
-    const unsigned long v = (unsigned long)base_uniform;
-    pq_i32x4_t r = {(int)__builtin_amdgcn_readfirstlane((unsigned)v), (int)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32) & 0xffffu), -1, 0x00020000};
-    return r;
-}
 __device__ __forceinline__ void glds16_saddr(unsigned voff, const void* sbase_uniform, unsigned lds_dst_uniform) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -707,9 +697,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     unsigned soff[4][2];           // SADDR: [piece][i] byte offset from the operand base (A: pieces 0 / 3, W: pieces 1 / 2)
     const char* baseA = nullptr;   // SADDR: wave-uniform bases of the current tile (operand base + the item's first k-tile)
     const char* baseW = nullptr;
-#if BAGEL_PQ_BUF
-    pq_i32x4_t rsrcA = {0, 0, 0, 0}, rsrcW = {0, 0, 0, 0};   // experiment: buffer_load ... lds through raw buffer descriptors, the k advance in soffset
-#endif
     const char* src[4][2];         // !SADDR: [piece][i] per-lane pointers
     // DMA sources of tile (tm, tn): piece-local row lr = 8*j + lane/8 (j = wave + 8*i), LDS chunk lane%8, global chunk
     // swizzled; A rows come from the table in ring slot `buf`.  `ln` is an opaque copy of the lane id (keeps hipcc from
@@ -722,10 +709,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
         if constexpr (SADDR) {
             baseA = pq_uniform((const char*)p.A + kb);
             baseW = pq_uniform((const char*)Wg + kb);
-#if BAGEL_PQ_BUF
-            rsrcA = pq_rsrc(baseA);
-            rsrcW = pq_rsrc(baseW);
-#endif
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -759,17 +742,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
         const unsigned d0 = (piece == 0 ? OFF_A0 : piece == 1 ? OFF_B0 : piece == 2 ? OFF_B1 : OFF_A1) + wave * 1024;
         if constexpr (SADDR) {
             const char* sb = ((piece == 0 || piece == 3) ? baseA : baseW) + koff;
-#if BAGEL_PQ_BUF
-            const pq_i32x4_t rs = (piece == 0 || piece == 3) ? rsrcA : rsrcW;
-            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)koff);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(soff[piece][i]), "s"(rs), "s"(so), "s"(stage_base + d0 + i * 8192) : "memory");
-            }
-            (void)sb;
-#elif BAGEL_PQ_M0MODE == 0
+#if BAGEL_PQ_M0MODE == 0
             glds16_saddr(soff[piece][0], sb, stage_base + d0);
             glds16_saddr(soff[piece][1], sb, stage_base + d0 + 8192);
 #elif BAGEL_PQ_M0MODE == 1          /* the two DMA instructions of a piece share one save / restore of M0 */

@@ -114,3 +114,28 @@ extern "C" int bagel_chw_f32_to_u8(const float* in, int64_t chan_stride, int64_t
                        (unsigned char*)out, (long)out_stride, W, C);
     return bagel_check_launch("chw_f32_to_u8_kernel");
 }
+
+// decode_image under the inferencer's bf16 autocast (inferencer.py:233 -> :182-183): the decoder output is bf16 and every elementwise op of
+// ``(image * 0.5 + 0.5).clamp(0, 1) * 255`` rounds to bf16 before the truncating uint8 cast.  The source may have any element strides (the
+// VAE engine hands over its NHWC buffer as a CHW view: no layout copy).
+__global__ __launch_bounds__(256) void chw_bf16_to_u8_kernel(const bf16_t* __restrict__ in, long chan_stride, long row_stride, long col_stride,
+                                                             unsigned char* __restrict__ out, long out_stride, int W, int C) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    for (int c = 0; c < C; ++c) {
+        float v = bfround(bfround(bf2f(in[(long)c * chan_stride + (long)y * row_stride + (long)x * col_stride]) * 0.5f) + 0.5f);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        out[(long)y * out_stride + (long)x * C + c] = (unsigned char)(int)bfround(v * 255.0f);   // truncation, as .to(uint8)
+    }
+}
+
+extern "C" int bagel_chw_bf16_to_u8(const void* in, int64_t chan_stride, int64_t row_stride, int64_t col_stride, void* out, int64_t out_stride,
+                                    int32_t H, int32_t W, int32_t C, hipStream_t stream) {
+    BAGEL_REQUIRE(in && out, "chw_bf16_to_u8: null pointer");
+    BAGEL_REQUIRE(C >= 1 && C <= 4 && H <= 65535, "chw_bf16_to_u8: C=%d H=%d", C, H);
+    if (H <= 0 || W <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(chw_bf16_to_u8_kernel, dim3(ceil_div(W, 256), H), dim3(256), 0, stream, (const bf16_t*)in, (long)chan_stride, (long)row_stride,
+                       (long)col_stride, (unsigned char*)out, (long)out_stride, W, C);
+    return bagel_check_launch("chw_bf16_to_u8_kernel");
+}

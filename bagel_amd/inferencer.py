@@ -3,7 +3,7 @@
 Contexts are plain dicts {'kv_lens': [int], 'ropes': [int], 'past_key_values': NaiveCache}; the three CFG contexts
 are kept in step exactly as the reference does (inferencer.py:229-256).  Differences are execution-only: tensors
 live on the model's GPU, the VAE runs through the HIP kernels, and no torch.autocast region is needed (the kernels
-own their precision)."""
+own their precision; what the reference's region does to the VAE -- bf16 convolutions -- is ``vae_precision_in_autocast``)."""
 from copy import deepcopy
 
 import torch
@@ -25,7 +25,26 @@ def _is_pil(x):
         return False
 
 
+class _VaeAt:
+    """The VAE pinned to one precision for the calls made through it (AutoEncoder.encode / decode ``precision=``)."""
+
+    def __init__(self, vae, precision):
+        self.vae, self.precision = vae, precision
+
+    def encode(self, x, *a, **k):
+        return self.vae.encode(x, *a, precision=self.precision, **k)
+
+    def decode(self, z):
+        return self.vae.decode(z, precision=self.precision)
+
+
 class InterleaveInferencer:
+    # How the VAE runs inside ``interleave_inference`` / ``__call__``.  The reference opens ``torch.autocast("cuda", bfloat16)`` around that
+    # whole method (inferencer.py:233), so its VAE encode (edit requests) and decode run with bf16 convolutions there, while scripts that
+    # call the VAE outside any autocast region (eval/gen/gen_images_mp.py:93) get fp32.  "bf16" mirrors the former; "fp32" keeps the
+    # decoder in fp32 there too.  Direct calls of ``decode_image`` / ``update_context_image`` follow the caller's own autocast region.
+    vae_precision_in_autocast = "bf16"
+
     def __init__(self, model, vae_model, tokenizer, vae_transform, vit_transform, new_token_ids):
         self.model = model
         self.vae_model = vae_model
@@ -33,6 +52,13 @@ class InterleaveInferencer:
         self.vae_transform = vae_transform
         self.vit_transform = vit_transform
         self.new_token_ids = new_token_ids
+        self._vae_precision = None
+
+    def _vae(self):
+        from .modeling.autoencoder import AutoEncoder
+        if self._vae_precision is not None and isinstance(self.vae_model, AutoEncoder):
+            return _VaeAt(self.vae_model, self._vae_precision)
+        return self.vae_model
 
     # ---- context bookkeeping --------------------------------------------------------------------------
     def init_gen_context(self):
@@ -55,7 +81,7 @@ class InterleaveInferencer:
         assert vae or vit
         if vae:
             self._advance(gen_context, self.model.prepare_vae_images,
-                          lambda kv, gi: self.model.forward_cache_update_vae(self.vae_model, kv, **gi),
+                          lambda kv, gi: self.model.forward_cache_update_vae(self._vae(), kv, **gi),
                           images=[image], transforms=self.vae_transform, new_token_ids=self.new_token_ids)
         if vit:
             self._advance(gen_context, self.model.prepare_vit_images,
@@ -95,14 +121,17 @@ class InterleaveInferencer:
 
     def decode_image(self, latent, image_shape):
         from PIL import Image
-        image = self.vae_model.decode(self.latent_to_chw(latent, image_shape))
+        image = self._vae().decode(self.latent_to_chw(latent, image_shape))
         return Image.fromarray(self.image_to_u8(image).cpu().numpy())
 
     @staticmethod
     def image_to_u8(image):
-        """(1, 3, H, W) fp32 decoder output -> (H, W, 3) uint8 on the GPU: ((x * 0.5 + 0.5).clamp(0, 1) * 255) with the
-        reference's truncating cast (inferencer.py:182-183), one kernel."""
+        """(1, 3, H, W) decoder output -> (H, W, 3) uint8 on the GPU: ((x * 0.5 + 0.5).clamp(0, 1) * 255) with the reference's truncating
+        cast (inferencer.py:182-183), one kernel.  A bf16 image (the decoder inside the autocast region) goes through the eager-bf16
+        rounding points those elementwise ops have on a bf16 tensor."""
         from . import ops
+        if image.dtype == torch.bfloat16:
+            return ops.chw_bf16_to_u8(image[0])
         return ops.chw_f32_to_u8(image[0].float())
 
     @torch.no_grad()
@@ -119,6 +148,18 @@ class InterleaveInferencer:
                              do_sample=False, text_temperature=0.3, cfg_text_scale=3.0, cfg_img_scale=1.5,
                              cfg_interval=[0.4, 1.0], timestep_shift=3.0, num_timesteps=50, cfg_renorm_min=0.0,
                              cfg_renorm_type="global", image_shapes=(1024, 1024), enable_taylorseer=False):
+        # the region the reference wraps in torch.autocast(bfloat16) (inferencer.py:233): the VAE runs at vae_precision_in_autocast in here
+        prev, self._vae_precision = self._vae_precision, self.vae_precision_in_autocast
+        try:
+            return self._interleave_inference(input_lists, think, understanding_output, max_think_token_n, do_sample, text_temperature,
+                                              cfg_text_scale, cfg_img_scale, cfg_interval, timestep_shift, num_timesteps, cfg_renorm_min,
+                                              cfg_renorm_type, image_shapes, enable_taylorseer)
+        finally:
+            self._vae_precision = prev
+
+    def _interleave_inference(self, input_lists, think, understanding_output, max_think_token_n, do_sample, text_temperature, cfg_text_scale,
+                              cfg_img_scale, cfg_interval, timestep_shift, num_timesteps, cfg_renorm_min, cfg_renorm_type, image_shapes,
+                              enable_taylorseer):
         outputs = []
         gen_context = self.init_gen_context()
         cfg_text_context = deepcopy(gen_context)

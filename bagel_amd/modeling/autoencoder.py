@@ -119,27 +119,41 @@ class AutoEncoder(PackedWeights):
         self.scale_factor = params.scale_factor
         self.shift_factor = params.shift_factor
         self._engine = None
+        self._engine_bf16 = None
 
     def _drop_packed(self):
         self._engine = None
+        self._engine_bf16 = None
 
-    def _eng(self):
+    def _eng(self, precision=None):
+        """``precision``: "fp32" (the VAE outside any autocast region: app.py:48,138, gen_images_mp.py:93), "bf16" (the VAE as the
+        reference's InterleaveInferencer runs it, inside torch.autocast(bf16): inferencer.py:233 -> :174-185) or None = FOLLOW THE CALLER
+        like the reference's modules do: bf16 when called inside ``torch.autocast("cuda", dtype=torch.bfloat16)``, fp32 otherwise."""
+        if precision is None:
+            precision = "bf16" if (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16) else "fp32"
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision={precision!r}: 'fp32', 'bf16' or None (follow the caller's autocast region)")
         self._check_packed()
+        from .vae_engine import VaeEngine, VaeEngineBf16
+        if precision == "bf16":
+            if getattr(self, "_engine_bf16", None) is None:
+                self._engine_bf16 = VaeEngineBf16(self)
+                self._packed_fresh()
+            return self._engine_bf16
         if self._engine is None:
-            from .vae_engine import VaeEngine
             self._engine = VaeEngine(self)
             self._packed_fresh()
         return self._engine
 
     @torch.no_grad()
-    def encode(self, x, sample_noise=None):
+    def encode(self, x, sample_noise=None, precision=None):
         """z = scale * (mean + exp(0.5 logvar) * eps - shift)  (autoencoder.py:275-287,315-318).  ``eps`` is drawn with
         torch.randn on the HOST generator (same stream position as the reference's randn_like) unless given."""
-        return self._eng().encode(x, sample_noise)
+        return self._eng(precision).encode(x, sample_noise)
 
     @torch.no_grad()
-    def decode(self, z):
-        return self._eng().decode(z)
+    def decode(self, z, precision=None):
+        return self._eng(precision).decode(z)
 
     def forward(self, x):
         return self.decode(self.encode(x))

@@ -157,3 +157,128 @@ class VaeEngine:
                 h = self.conv(h, d.up[lvl].upsample.conv, 3)
         h = self.conv(self.gn(h, d.norm_out, True), d.conv_out, 1)            # [B,H,W,3]
         return h.permute(0, 3, 1, 2).contiguous()
+
+
+BF16 = torch.bfloat16
+
+
+def _pack3_bf16(w, cin_pad):
+    return _pack3(w, cin_pad).to(BF16)
+
+
+class VaeEngineBf16(VaeEngine):
+    """The same plan under the reference inferencer's bf16 autocast (inferencer.py:233 -> decode_image :174-185, and the VAE-encode of an
+    edit request inside the same region): NHWC **bf16** activations, every conv / the AttnBlock's two products on the bf16 MFMA
+    (``bagel_conv_gemm_bf16``: bf16 weights and bias, fp32 accumulation, bf16 result, residual adds rounded to bf16), GroupNorm + swish in
+    fp32 on the bf16 tensor with ONE rounding on the way out (``bagel_groupnorm_bf16`` -- group_norm is on CUDA autocast's fp32 list).
+    Cast points = oracle.bagel_oracle VAE_AUTOCAST "cuda"; 16x the fp32 path's matrix rate.  Channel counts are padded to multiples of 8."""
+
+    def _conv_w(self, m):
+        w = self._w.get(id(m))
+        if w is None:
+            wt = m.weight.data
+            if wt.shape[-1] == 3:
+                cin_pad = _ceil_to(wt.shape[1], 8)
+                w = (_pack3_bf16(wt, cin_pad), cin_pad, m.bias.data.to(BF16))
+            else:
+                w = (wt.reshape(wt.shape[0], wt.shape[1]).to(BF16).contiguous(), wt.shape[1], m.bias.data.to(BF16))
+            self._w[id(m)] = w
+        return w
+
+    def conv(self, x, m, mode, residual=None, out_hw=None):
+        B, H, W, C = x.shape
+        w, cin, bias = self._conv_w(m)
+        if cin != C:
+            raise ValueError(f"conv expects {cin} (padded) input channels, got {C}")
+        Ho, Wo = (H, W) if mode in (0, 1) else ((H // 2, W // 2) if mode == 2 else (2 * H, 2 * W))
+        cout = w.shape[0]
+        ldo = _ceil_to(cout, 8)          # rows stay 16-byte aligned for the next op's chunk loads (conv_out has 3 channels)
+        if residual is not None and (ldo != cout or residual.shape[-1] != cout or not residual.is_contiguous()):
+            raise ValueError("residual must be a contiguous NHWC tensor with Cout % 8 == 0 channels")
+        out = torch.empty((B, Ho, Wo, ldo), dtype=BF16, device=x.device)
+        ops.conv_gemm_bf16(x, C, w, w.shape[1], bias, residual, out, ldo, B, H, W, C, Ho, Wo, cout, mode)
+        return out if ldo == cout else out[..., :cout]
+
+    def gn(self, x, m, swish):
+        B, H, W, C = x.shape
+        need = B * 32 * (64 * 2 + 2)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=F32, device=x.device)
+        y = torch.empty_like(x)
+        ops.groupnorm_bf16(x, y, self._ws, m.weight.data, m.bias.data, B, H * W, C, 32, 1e-6, swish)
+        return y
+
+    def attn(self, x, m):
+        B, H, W, C = x.shape
+        h = self.gn(x, m.norm, False)
+        q, k, v = self.conv(h, m.q, 0), self.conv(h, m.k, 0), self.conv(h, m.v, 0)
+        N = H * W
+        o = torch.empty((B, N, C), dtype=BF16, device=x.device)
+        # scaled_dot_product_attention on bf16 q / k / v: fp32 scores and softmax, bf16 probabilities into the second product (what the
+        # library kernels do); the score matrix in blocks of ATTN_ROWS query rows as in the fp32 engine
+        R = min(N, self.ATTN_ROWS)
+        N8 = _ceil_to(N, 8)                                    # key axis padded to whole 16-byte chunks (zero probabilities x zero V columns)
+        sbuf = torch.empty((R, N8), dtype=F32, device=x.device)
+        pbuf = torch.zeros((R, N8), dtype=BF16, device=x.device)
+        for b in range(B):
+            qb, kb = q[b].view(N, C), k[b].view(N, C)
+            vt = torch.zeros((C, N8), dtype=BF16, device=x.device)
+            vt[:, :N] = v[b].view(N, C).t()                   # layout copy only
+            for r0 in range(0, N, R):
+                n = min(R, N - r0)
+                s, pr = sbuf[:n], pbuf[:n]
+                ops.conv_gemm_bf16(qb[r0:r0 + n], qb.stride(0), kb, kb.stride(0), None, None, s, N8, 1, 1, n, C, 1, n, N, 0)
+                ops.softmax_rows_bf16(s, pr, n, N, float(C) ** -0.5)
+                ob = o[b, r0:r0 + n]
+                ops.conv_gemm_bf16(pr, N8, vt, N8, None, None, ob, C, 1, 1, n, N8, 1, n, C, 0)
+        return self.conv(o.view(B, H, W, C), m.proj_out, 0, residual=x)
+
+    @staticmethod
+    def to_nhwc(x, cpad):
+        B, C, H, W = x.shape
+        out = torch.zeros((B, H, W, cpad), dtype=BF16, device=x.device)
+        out[..., :C] = x.permute(0, 2, 3, 1)                   # the cast autocast puts in front of conv_in
+        return out
+
+    def encode(self, x, sample_noise=None):
+        P, ae = self.P, self.ae
+        x = x.to(device=self.dev, dtype=F32)
+        B = x.shape[0]
+        e = ae.encoder
+        h = self.conv(self.to_nhwc(x, _ceil_to(x.shape[1], 8)), e.conv_in, 1)
+        nres = len(P.ch_mult)
+        for lvl in range(nres):
+            for blk in e.down[lvl].block:
+                h = self.res(h, blk)
+            if lvl != nres - 1:
+                h = self.conv(h, e.down[lvl].downsample.conv, 2)
+        h = self.res(h, e.mid.block_1)
+        h = self.attn(h, e.mid.attn_1)
+        h = self.res(h, e.mid.block_2)
+        mom = self.conv(self.gn(h, e.norm_out, True), e.conv_out, 1)          # [B,h,w,2z] bf16
+        _, hh, ww, _ = mom.shape
+        zc = P.z_channels
+        if sample_noise is None:
+            sample_noise = torch.randn(B, zc, hh, ww, dtype=BF16)          # randn_like(mean) of the bf16 moments, host generator
+        noise = sample_noise.to(device=self.dev, dtype=BF16).permute(0, 2, 3, 1).contiguous()
+        z = torch.empty((B, hh, ww, zc), dtype=BF16, device=self.dev)
+        ops.vae_reparam_bf16(mom, noise, z, B * hh * ww, zc, P.scale_factor, P.shift_factor)
+        return z.permute(0, 3, 1, 2).contiguous()
+
+    def decode(self, z):
+        P, ae = self.P, self.ae
+        z = z.to(device=self.dev, dtype=F32).contiguous()
+        zz = torch.empty_like(z)
+        ops.vae_unscale_f32(z, zz, z.numel(), P.scale_factor, P.shift_factor)        # fp32 like the reference (z arrives fp32; conv_in casts)
+        d = ae.decoder
+        h = self.conv(self.to_nhwc(zz, _ceil_to(zz.shape[1], 8)), d.conv_in, 1)
+        h = self.res(h, d.mid.block_1)
+        h = self.attn(h, d.mid.attn_1)
+        h = self.res(h, d.mid.block_2)
+        for lvl in reversed(range(len(P.ch_mult))):
+            for blk in d.up[lvl].block:
+                h = self.res(h, blk)
+            if lvl != 0:
+                h = self.conv(h, d.up[lvl].upsample.conv, 3)
+        h = self.conv(self.gn(h, d.norm_out, True), d.conv_out, 1)            # [B,H,W,3] bf16 (a view of the 8-channel padded rows)
+        return h.permute(0, 3, 1, 2)                                          # CHW VIEW of the NHWC buffer: image_to_u8 reads it strided

@@ -45,6 +45,13 @@ def _req(t, dtype, name):
         raise BagelHipError(f"{name}: innermost dimension must be contiguous")
 
 
+def _req_any_stride(t, dtype, name):
+    if not t.is_cuda:
+        raise BagelHipError(f"{name}: expected a GPU tensor (bagel_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise BagelHipError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
 def _ld(t):
     return t.stride(0) if t.dim() == 2 else t.shape[-1]
 
@@ -1043,6 +1050,46 @@ def softmax_rows_f32(x, ld, rows, cols, scale):
     _req(x, torch.float32, "softmax_rows_f32.x")
     check(lib().bagel_softmax_rows_f32(_ptr(x), ld, rows, cols, float(scale), _stream()), "bagel_softmax_rows_f32")
     return x
+
+
+def conv_gemm_bf16(x, ld_in, w, ld_w, bias, residual, out, ld_out, B, Hin, Win, Cin, Hout, Wout, Cout, mode):
+    """bagel_conv_gemm_bf16 (the VAE under the inferencer's bf16 autocast): modes as conv_gemm_f32; ``out`` bf16, or fp32 for raw scores."""
+    _req(x, BF16, "conv_gemm_bf16.x"); _req(w, BF16, "conv_gemm_bf16.w")
+    if out.dtype not in (BF16, torch.float32):
+        raise BagelHipError("conv_gemm_bf16: out must be bf16 or fp32")
+    check(lib().bagel_conv_gemm_bf16(_ptr(x), ld_in, _ptr(w), ld_w, _ptr(bias), _ptr(residual), _ptr(out), ld_out, int(out.dtype == torch.float32),
+                                     B, Hin, Win, Cin, Hout, Wout, Cout, mode, _stream()), "bagel_conv_gemm_bf16")
+    return out
+
+
+def groupnorm_bf16(x, y, workspace, gamma, beta, B, HW, C, groups, eps, swish):
+    _req(x, BF16, "groupnorm_bf16.x"); _req(y, BF16, "groupnorm_bf16.y"); _req(gamma, torch.float32, "groupnorm_bf16.gamma")
+    check(lib().bagel_groupnorm_bf16(_ptr(x), _ptr(y), _ptr(workspace), _ptr(gamma), _ptr(beta), B, HW, C, groups, float(eps),
+                                     int(swish), _stream()), "bagel_groupnorm_bf16")
+    return y
+
+
+def softmax_rows_bf16(x, y, rows, cols, scale):
+    _req(x, torch.float32, "softmax_rows_bf16.x"); _req(y, BF16, "softmax_rows_bf16.y")
+    check(lib().bagel_softmax_rows_bf16(_ptr(x), x.stride(0), _ptr(y), y.stride(0), rows, cols, float(scale), _stream()), "bagel_softmax_rows_bf16")
+    return y
+
+
+def vae_reparam_bf16(moments, noise, z, n_pix, z_channels, scale, shift):
+    _req(moments, BF16, "vae_reparam_bf16.moments"); _req(z, BF16, "vae_reparam_bf16.z")
+    check(lib().bagel_vae_reparam_bf16(_ptr(moments), moments.stride(-2), _ptr(noise), _ptr(z), n_pix, z_channels, float(scale), float(shift), _stream()),
+          "bagel_vae_reparam_bf16")
+    return z
+
+
+def chw_bf16_to_u8(src):
+    """(C, H, W) bf16 (any strides) -> (H, W, C) uint8 with the eager-bf16 rounding points of decode_image under autocast."""
+    _req_any_stride(src, BF16, "chw_bf16_to_u8.src")
+    C, H, W = src.shape
+    out = torch.empty((H, W, C), dtype=torch.uint8, device=src.device)
+    check(lib().bagel_chw_bf16_to_u8(_ptr(src), src.stride(0), src.stride(1), src.stride(2), _ptr(out), out.stride(0), H, W, C, _stream()),
+          "bagel_chw_bf16_to_u8")
+    return out
 
 
 def vae_reparam_f32(moments, noise, z, n_pix, z_channels, scale, shift):

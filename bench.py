@@ -880,7 +880,8 @@ def main():
         imgs = []
         if not args.no_vae:
             for lat in latents:
-                img = vae.decode(inf.latent_to_chw(lat, (R, R)))
+                # the VAE OUTSIDE any autocast region, in fp32: how the reference's batch driver decodes (eval/gen/gen_images_mp.py:93)
+                img = vae.decode(inf.latent_to_chw(lat, (R, R)), **({} if args.standins else {"precision": "fp32"}))
                 imgs.append(inf.image_to_u8(img))
         return latents, imgs
 
@@ -899,8 +900,8 @@ def main():
         ident = lambda t: t  # noqa: E731
 
         class _FixedNoiseVae:      # the reference draws randn_like inside encode; feed a seeded CPU draw
-            def encode(self, x):
-                return vae.encode(x, sample_noise=edit_state["enc_noise"])
+            def encode(self, x):       # the edit request is the app's / inferencer's path: its VAE runs inside torch.autocast(bf16) (inferencer.py:233)
+                return vae.encode(x, sample_noise=edit_state["enc_noise"], **({} if args.standins else {"precision": "bf16"}))
 
         ctx = dict(kv_lens=[0], ropes=[0], past_key_values=NaiveCache(L))
         vi, l1, r1 = model.prepare_vae_images(ctx["kv_lens"], ctx["ropes"], [edit_state["src_vae"]], ident, ids)
@@ -927,7 +928,7 @@ def main():
         imgs = []
         if not args.no_vae:
             for lat in latents:
-                imgs.append(inf.image_to_u8(vae.decode(inf.latent_to_chw(lat, (R, R)))))
+                imgs.append(inf.image_to_u8(vae.decode(inf.latent_to_chw(lat, (R, R)), **({} if args.standins else {"precision": "bf16"}))))
         edit_state["context_tokens"] = (l3[0], l2[0], l4[0])     # cond, cfg-text, cfg-img contexts
         return latents, imgs
 
@@ -1057,6 +1058,7 @@ def main():
                                             "frac": pf / dt_e / 1e12 / PEAK_BF16_TFLOPS,
                                             "note": "denoise FLOPs only (linear + attention of the 147 forwards) over the WHOLE request time incl. VAE encode, ViT, prefill and VAE decode"},
                     "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_e),
+                    "vae_precision": "bf16 convolutions, fp32 GroupNorm (the VAE inside the inferencer's autocast region, inferencer.py:233), encode and decode",
                     "workload": f"BASELINE configs[4]: VAE-encode + SigLIP(980^2) + {args.prompt_tokens}+2 prompt tokens, {T} timesteps x [cond + CFG-text 4.0 + "
                                 f"CFG-img 2.0], text_channel renorm, VAE decode included, 1 request/GPU"}
         except Exception as e:
@@ -1179,6 +1181,8 @@ def main():
                                    f"BAGEL-7B-MoT text->image {R}x{R}, {T} timesteps ({T - 1} Euler steps x [cond + CFG-text 4.0]), "
                                    f"global renorm, timestep_shift 3, prompt {args.prompt_tokens}+2 tokens, {B} samples/GPU, VAE decode included",
                        "global_batch": world * B, "query_tokens_per_sample": n_img + 2, "parallelism": f"dp{world}",
+                       "vae_precision": ("bf16 convolutions, fp32 GroupNorm: the VAE inside the inferencer's autocast region (inferencer.py:233)" if args.workload == "edit"
+                                         else "fp32: the VAE outside any autocast region, as eval/gen/gen_images_mp.py:93 decodes"),
                        # execution options in force (promoted in round 2 after measurement)
                        "options": {"cfg_batched": bool(getattr(model, "cfg_batched", False)),
                                    "und_side_path": bool(getattr(model, "cfg_batched", False) and getattr(model, "und_side_path", False))}},

@@ -339,6 +339,11 @@ int bagel_u8_to_chw_f32(const void* in, int64_t in_stride, float* out, int32_t H
 int bagel_chw_f32_to_u8(const float* in, int64_t chan_stride, int64_t row_stride, void* out, int64_t out_stride,
                         int32_t H, int32_t W, int32_t C, bagel_stream_t stream);
 
+/* The same conversion for the bf16 decoder output of the inferencer's autocast region (inferencer.py:233 -> :182-183): every elementwise
+ * op rounds to bf16 before the truncating uint8 cast.  Element strides of the source are free (an NHWC buffer viewed as CHW). */
+int bagel_chw_bf16_to_u8(const void* in, int64_t chan_stride, int64_t row_stride, int64_t col_stride, void* out, int64_t out_stride,
+                         int32_t H, int32_t W, int32_t C, bagel_stream_t stream);
+
 /* ---- training backward (loss.backward() of train/pretrain_unified_navit.py:683-735 over Bagel.forward, bagel.py:101-229; the
  *      reference gets it from torch autograd, these are the hand-written reverse kernels the product chains) ---------------------- */
 /* bagel_attn_varlen_ranges_bf16 that also leaves the row statistics the attention reverse needs: lse[h * ld_lse + row] = log2 of the
@@ -433,6 +438,27 @@ int bagel_groupnorm_f32(const float* x, float* y, float* partial_ws, const float
 
 /* x = softmax(scale * x) over rows, in place (single-head AttnBlock, autoencoder.py:60). */
 int bagel_softmax_rows_f32(float* x, int64_t ld, int32_t rows, int32_t cols, float scale, bagel_stream_t stream);
+
+/* The VAE under torch.autocast("cuda", bfloat16) -- how the reference's InterleaveInferencer runs it (inferencer.py:233 -> decode_image
+ * :174-185; the VAE-encode of an edit request, modeling/bagel/bagel.py:491-550): conv2d and the AttnBlock's attention in bf16 (inputs,
+ * weights and bias cast to bf16, fp32 accumulation, bf16 result), group_norm in fp32 on the bf16 input, residual adds in bf16
+ * (oracle/bagel_oracle.py VAE_AUTOCAST = "cuda"; tests/golden/vae_full_bf16.pt).
+ * bagel_conv_gemm_bf16: NHWC bf16 implicit-GEMM convolution / plain GEMM on mfma_f32_16x16x32_bf16, modes as bagel_conv_gemm_f32 (0 rows,
+ * 1 conv3 s1 p1, 2 conv3 s2 pad(0,1,0,1), 3 nearest-2x upsample + conv3); out = bf16(acc + bias) [then bf16(that + residual)], or with
+ * out_f32 != 0 the raw fp32 accumulators (attention scores; no bias / residual).  Cin % 8 == 0 (mode 0: K = Cin).
+ * bagel_groupnorm_bf16: GroupNorm (+ swish) of a bf16 NHWC tensor, fp32 statistics and arithmetic, ONE rounding to bf16 on the way out.
+ * bagel_softmax_rows_bf16: y = bf16(softmax(scale * x)) per fp32 score row. */
+int bagel_conv_gemm_bf16(const void* in, int64_t ld_in, const void* w, int64_t ld_w, const void* bias, const void* residual,
+                         void* out, int64_t ld_out, int32_t out_f32, int32_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t Hout,
+                         int32_t Wout, int32_t Cout, int32_t mode, bagel_stream_t stream);
+int bagel_groupnorm_bf16(const void* x, void* y, float* partial_ws, const float* gamma, const float* beta, int32_t B, int32_t HW,
+                         int32_t C, int32_t groups, float eps, int32_t swish, bagel_stream_t stream);
+int bagel_softmax_rows_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, float scale, bagel_stream_t stream);
+/* z = bf16(scale * bf16(bf16(mean + bf16(std * noise)) - shift)), std = bf16(exp(bf16(0.5 * logvar))): DiagonalGaussian.sample + the
+ * latent scale / shift on bf16 moments [n_pix, ld_moments >= 2 zc] (mean | logvar) with eager-bf16 rounding points (autoencoder.py:280-287,
+ * 315-318 under autocast); noise [n_pix, zc] bf16 or NULL (mode of the distribution). */
+int bagel_vae_reparam_bf16(const void* moments, int64_t ld_moments, const void* noise, void* z, int64_t n_pix, int32_t z_channels,
+                           float scale, float shift, bagel_stream_t stream);
 
 /* z = scale * ((mean + exp(0.5 logvar) * noise) - shift)  (autoencoder.py:280-287,315-318); moments [n_pix, 2*zc]. */
 int bagel_vae_reparam_f32(const float* moments, const float* noise, float* z, int64_t n_pix, int32_t z_channels,

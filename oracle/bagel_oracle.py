@@ -839,9 +839,24 @@ def siglip_forward(W, vcfg, pixels, pos_ids, cu_seqlens, max_seqlen):
 
 
 # ----------------------------------------------------------------------------------------------
-# FLUX-style VAE (modeling/autoencoder.py), fp32
+# FLUX-style VAE (modeling/autoencoder.py), fp32 -- or under the inferencer's bf16 autocast (inferencer.py:233 -> :174-185)
 # ----------------------------------------------------------------------------------------------
+# VAE_AUTOCAST selects the cast points of the VAE functions below:
+#   None     the VAE in fp32, outside any autocast region (app.py:48,138; eval/gen/gen_images_mp.py:93);
+#   "cpu"    what ``torch.autocast("cpu", bf16)`` does to the unmodified reference on THIS container's CPU: conv2d and SDPA run in bf16
+#            (autocast's lower-precision list), GroupNorm receives the bf16 tensor and -- being in NO CPU autocast list -- answers in bf16,
+#            swish and the residual adds follow their inputs: pinned bit for bit against the reference by oracle/make_golden_vae_bf16.py;
+#   "cuda"   what ``torch.autocast("cuda", bf16)`` does, i.e. what InterleaveInferencer runs the reference's VAE under: identical, except
+#            that the CUDA autocast policy lists group_norm among the fp32 ops -- the bf16 input is cast up, statistics AND result are
+#            fp32, swish runs on that fp32 tensor, and the next conv casts to bf16.  This is the semantics the MI355X bf16 VAE implements
+#            (csrc/vae.hip bagel_conv_gemm_bf16 / bagel_groupnorm_bf16); it differs from "cpu" only by where the GroupNorm result is
+#            rounded.
+VAE_AUTOCAST = None
+
+
 def _gn(x, W, p):
+    if VAE_AUTOCAST == "cuda":
+        return F.group_norm(x.float(), 32, W[p + ".weight"], W[p + ".bias"], 1e-6)
     return F.group_norm(x, 32, W[p + ".weight"], W[p + ".bias"], 1e-6)
 
 
@@ -850,7 +865,10 @@ def _swish(x):
 
 
 def _conv(x, W, p, stride=1, padding=1):
-    return F.conv2d(x, W[p + ".weight"], W[p + ".bias"], stride=stride, padding=padding)
+    w, b = W[p + ".weight"], W[p + ".bias"]
+    if VAE_AUTOCAST:
+        x, w, b = x.to(torch.bfloat16), w.to(torch.bfloat16), b.to(torch.bfloat16)
+    return F.conv2d(x, w, b, stride=stride, padding=padding)
 
 
 def _resblock(x, W, p):
@@ -892,7 +910,7 @@ def vae_encode(W, vcfg, x, sample_noise=None):
     h = _conv(_swish(_gn(h, W, "encoder.norm_out")), W, "encoder.conv_out")
     mean, logvar = torch.chunk(h, 2, dim=1)
     std = torch.exp(0.5 * logvar)
-    noise = torch.randn_like(mean) if sample_noise is None else sample_noise
+    noise = torch.randn_like(mean) if sample_noise is None else sample_noise.to(mean.dtype)     # randn_like(mean): the moments' dtype
     z = mean + std * noise
     return vcfg["scale_factor"] * (z - vcfg["shift_factor"])
 

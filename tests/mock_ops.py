@@ -660,6 +660,47 @@ def vae_reparam_f32(moments, noise, z, n_pix, z_channels, scale, shift):
     return z
 
 
+# ---- VAE under bf16 autocast (bf16 NHWC): the fp32 stand-ins on up-cast operands, rounded where the kernels round ----------------------
+def conv_gemm_bf16(x, ld_in, w, ld_w, bias, residual, out, ld_out, B, Hin, Win, Cin, Hout, Wout, Cout, mode):
+    M = B * Hout * Wout
+    tmp = torch.zeros((M, ld_out), dtype=torch.float32)
+    conv_gemm_f32(x.float(), ld_in, w.float(), ld_w, None if bias is None else bias.float(), None, tmp, ld_out, B, Hin, Win, Cin, Hout, Wout, Cout, mode)
+    o = torch.as_strided(out, (M, ld_out), (ld_out, 1))
+    if out.dtype == torch.float32:
+        o.copy_(tmp)
+        return out
+    y = _bf(tmp[:, :Cout])
+    if residual is not None:
+        y = _bf(y.float() + residual.reshape(M, -1)[:, :Cout].float())
+    o[:, :Cout] = y
+    o[:, Cout:] = 0
+    return out
+
+
+def groupnorm_bf16(x, y, workspace, gamma, beta, B, HW, C, groups, eps, swish):
+    t = torch.empty(x.shape, dtype=torch.float32)
+    groupnorm_f32(x.float(), t, workspace, gamma, beta, B, HW, C, groups, eps, swish)
+    y.copy_(_bf(t))
+    return y
+
+
+def softmax_rows_bf16(x, y, rows, cols, scale):
+    y[:rows, :cols] = _bf(torch.softmax(x[:rows, :cols] * scale, -1))
+    return y
+
+
+def vae_reparam_bf16(moments, noise, z, n_pix, z_channels, scale, shift):
+    m = moments.reshape(n_pix, -1)
+    mean, logvar = m[:, :z_channels], m[:, z_channels:2 * z_channels]            # bf16 tensors: every op below rounds like eager bf16
+    zz = mean + torch.exp(0.5 * logvar) * noise.reshape(n_pix, z_channels) if noise is not None else mean
+    z.copy_((scale * (zz - shift)).reshape(z.shape))
+    return z
+
+
+def chw_bf16_to_u8(src):
+    return ((src * 0.5 + 0.5).clamp(0, 1).permute(1, 2, 0) * 255).to(torch.uint8).contiguous()
+
+
 def vae_unscale_f32(z, out, n, scale, shift):
     out.copy_(z / scale + shift)
     return out
@@ -697,7 +738,7 @@ _NAMES = ["gemm", "gemv", "gemv_mb", "gemm_skinny", "rmsnorm", "layernorm", "rop
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
           "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
-          "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32",
+          "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32", "conv_gemm_bf16", "groupnorm_bf16", "softmax_rows_bf16", "vae_reparam_bf16", "chw_bf16_to_u8",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "layernorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
           "act_bwd", "swiglu_fwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]
 

@@ -354,6 +354,35 @@ def test_vae_host_path_matches_reference(golden, monkeypatch):
     assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 0.01
 
 
+def test_bf16_autocast_vae_host_path_matches_the_oracle(golden, monkeypatch):
+    """VaeEngineBf16 (the VAE inside the inferencer's bf16 autocast region): bf16 weight packing with channels padded to 8, bf16 NHWC
+    plumbing, every conv mode, the residual folding and the bf16 attention (key axis padded to whole chunks) on the torch stand-ins --
+    against the oracle with CUDA autocast's cast points (oracle VAE_AUTOCAST = "cuda": bf16 convs, fp32 GroupNorm, bf16 adds); precision
+    selection by keyword; the uint8 image with eager-bf16 roundings."""
+    mock_ops.install(monkeypatch)
+    g = golden("tiny_vae")
+    _, vae = cpu_model_and_vae(TINY)
+    _, VW = oracle_weights(TINY)
+    noise = g["enc_noise"].to(torch.bfloat16)
+    from oracle import bagel_oracle as O
+    O.VAE_AUTOCAST = "cuda"
+    try:
+        ref_dec, ref_enc = O.vae_decode(VW, TINY["vae"], g["z"]), O.vae_encode(VW, TINY["vae"], g["x"], noise)
+    finally:
+        O.VAE_AUTOCAST = None
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
+    dec = vae.decode(g["z"], precision="bf16")
+    assert dec.dtype == torch.bfloat16 and dec.shape == ref_dec.shape and rel(dec, ref_dec) < 2e-2, rel(dec, ref_dec)       # (bf16 noise through ~30 convs: two summation orders sit ~1e-2 apart)
+    enc = vae.encode(g["x"], sample_noise=noise.float(), precision="bf16")
+    assert enc.dtype == torch.bfloat16 and enc.shape == ref_enc.shape and rel(enc, ref_enc) < 2e-2, rel(enc, ref_enc)
+    assert vae.decode(g["z"], precision="fp32").dtype == torch.float32 and vae.decode(g["z"]).dtype == torch.float32
+    with pytest.raises(ValueError):
+        vae.decode(g["z"], precision="fp16")
+    from bagel_amd.inferencer import InterleaveInferencer
+    u8 = InterleaveInferencer.image_to_u8(dec)
+    assert torch.equal(u8, ((dec * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8))       # eager-bf16 roundings of inferencer.py:182-183
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
 def test_edit_flow_host_path_matches_reference(golden, monkeypatch, name):
     """BASELINE configs[4] on the host logic: VAE-encode + SigLIP prefill of a source image (two cache appends on a single-sample

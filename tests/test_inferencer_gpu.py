@@ -15,14 +15,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _inferencer(cfg):
+def _inferencer(cfg, vae_precision="fp32"):
     from bagel_amd.data.transforms import ImageTransform
     from bagel_amd.inferencer import InterleaveInferencer
     from oracle.configs import NEW_TOKEN_IDS_TINY, StubTokenizer
     from tests.util_models import product_model
     model, vae = product_model(cfg)
     tok = StubTokenizer(cfg["llm"]["vocab_size"])
-    return InterleaveInferencer(model, vae, tok, ImageTransform(64, 32, 16), ImageTransform(56, 28, 14), NEW_TOKEN_IDS_TINY)
+    inf = InterleaveInferencer(model, vae, tok, ImageTransform(64, 32, 16), ImageTransform(56, 28, 14), NEW_TOKEN_IDS_TINY)
+    # the *_inferencer.pt goldens were produced with the VAE held in fp32 OUTSIDE the reference's autocast region (oracle/make_golden.py
+    # _Fp32Vae); the bf16-autocast VAE (the product's default inside interleave_inference) has its own golden and tests below
+    inf.vae_precision_in_autocast = vae_precision
+    return inf
 
 
 def _compare(img, ref, what, mean_tol, p99_tol):
@@ -142,3 +146,23 @@ def test_think_then_generate_flow(golden, name):
         _compare(r["image"], g["image"], "think -> image", 1.5, 8)
     else:
         print(f"planning text diverged at a near tie ({r['text']} vs {g['thought']}): image not comparable")
+
+
+def test_inferencer_runs_the_vae_in_bf16_inside_its_autocast_region(golden):
+    """inferencer.py:233 wraps interleave_inference in torch.autocast(bfloat16): the reference's VAE encode / decode run with bf16 convolutions
+    there.  The product mirrors that by default (InterleaveInferencer.vae_precision_in_autocast = "bf16": csrc/vae.hip bagel_conv_gemm_bf16);
+    "fp32" keeps the VAE as scripts outside an autocast region run it.  The two must give nearly the same picture (the bf16 VAE is ~1e-2
+    rel-L2 from the fp32 one, tests/golden/vae_full_bf16.pt), and both engines must have been used."""
+    from PIL import Image
+    from oracle.configs import TINY_D128
+    g = golden("tiny_d128_inferencer")
+    imgs = {}
+    for prec in ("bf16", "fp32"):
+        inf = _inferencer(TINY_D128, prec)
+        torch.manual_seed(g["edit"]["seed"])
+        r = inf(image=Image.fromarray(g["source_image"].numpy(), "RGB"), text=g["edit"]["text"], **g["edit"]["kwargs"])
+        imgs[prec] = r["image"]
+        assert inf._vae_precision is None, "the precision override must not outlive interleave_inference"
+    assert inf.vae_model._engine_bf16 is not None and inf.vae_model._engine is not None
+    _compare(imgs["bf16"], torch.from_numpy(np.asarray(imgs["fp32"])), "bf16-autocast VAE vs fp32 VAE, same request", 4.0, 20)
+    _compare(imgs["bf16"], g["edit"]["image"], "image + text -> image with the bf16 VAE vs the reference (fp32 VAE)", 5.0, 24)

@@ -335,3 +335,29 @@ def test_nf4_restatement_known_answers():
     assert p3.shape == (8, 128) and a3.shape == (8, 4) and torch.equal(a3, W.float().view(8, 4, 64).abs().amax(2))
     e = ((nf4.dequantize_nf4(p3, a3).float() - W.float()).norm() / W.float().norm()).item()
     assert 0.05 < e < 0.13, e
+
+
+def test_bf16_autocast_vae_restatement_is_pinned(golden):
+    """tests/golden/vae_full_bf16.pt (oracle/make_golden_vae_bf16.py): the UNMODIFIED reference VAE under torch.autocast("cpu", bfloat16) --
+    the region inferencer.py:233 opens -- and the oracle's two cast-point policies.  "cpu" must reproduce the reference's outputs bit for
+    bit (that is what pins the restatement); "cuda" -- the policy of the device the reference runs on, group_norm in fp32 -- must
+    reproduce its own stored output bit for bit (determinism of the checker) and sit at the recorded ~1e-2 from the other."""
+    from oracle import bagel_oracle as O
+    from oracle.configs import VAE_FULL
+    from oracle.shapes import vae_shapes
+    from oracle.weights import synth_state_dict
+    g = golden("vae_full_bf16")
+    VW = synth_state_dict(vae_shapes(VAE_FULL["vae"]), 0)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
+    try:
+        O.VAE_AUTOCAST = "cpu"
+        dec_cpu = O.vae_decode(VW, VAE_FULL["vae"], g["z"])
+        O.VAE_AUTOCAST = "cuda"
+        dec_cuda = O.vae_decode(VW, VAE_FULL["vae"], g["z"])
+        enc_cuda = O.vae_encode(VW, VAE_FULL["vae"], g["x"], g["enc_noise"].to(torch.bfloat16))
+    finally:
+        O.VAE_AUTOCAST = None
+    assert dec_cpu.dtype == torch.bfloat16 and torch.equal(dec_cpu, g["decoded_cpu"]), "oracle ('cpu' policy) != the reference under cpu autocast"
+    assert torch.equal(dec_cuda, g["decoded_cuda"]) and torch.equal(enc_cuda, g["encoded_cuda"])
+    assert abs(rel(dec_cuda, dec_cpu) - g["distance"]["decode_cuda_vs_cpu"]) < 1e-6 and 1e-3 < g["distance"]["decode_cuda_vs_cpu"] < 3e-2
+    assert O.vae_decode(VW, VAE_FULL["vae"], g["z"]).dtype == torch.float32          # default: the fp32 VAE, untouched

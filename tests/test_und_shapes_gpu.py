@@ -230,6 +230,39 @@ def test_full_size_vae_matches_reference(golden):
     assert enc.shape == g["encoded"].shape and err < 2e-4, f"vae.encode (ch=128, 2 res blocks) max rel error {err:.3g}"
 
 
+def test_full_size_vae_under_bf16_autocast_matches_reference(golden):
+    """The real VAE as the reference's InterleaveInferencer runs it -- inside torch.autocast(bfloat16) (inferencer.py:233): bf16 convolutions
+    and attention, fp32 GroupNorm, bf16 residual adds (csrc/vae.hip bagel_conv_gemm_bf16 / bagel_groupnorm_bf16).  tests/golden/
+    vae_full_bf16.pt (oracle/make_golden_vae_bf16.py): ``*_cuda`` = the oracle with CUDA autocast's op policy, whose "cpu"-policy twin
+    reproduces the UNMODIFIED reference under torch.autocast("cpu", bfloat16) bit for bit; the two policies differ by where the GroupNorm
+    result is rounded (recorded distance ~1e-2, the size of bf16 noise through 30 convolutions).  Tolerance: the product computes the
+    "cuda" semantics with another summation order -- two valid summation orders of this bf16 network sit ~1e-2 apart (the torch stand-ins
+    vs the oracle on the tiny VAE: 8.8e-3) -> rel-L2 <= 2e-2 against it, and <= 2.5e-2 against the reference's CPU-autocast run;
+    selection by the caller's autocast region, like the reference's modules."""
+    g = golden("vae_full_bf16")
+    vae = _full_vae()
+    rel = lambda a, b: float((a.float().cpu() - b.float()).norm() / b.float().norm())  # noqa: E731
+    dec = vae.decode(g["z"], precision="bf16")
+    assert dec.dtype == BF16 and dec.shape == g["decoded_cuda"].shape
+    e_cuda, e_cpu = rel(dec, g["decoded_cuda"]), rel(dec, g["decoded_cpu"])
+    enc = vae.encode(g["x"], sample_noise=g["enc_noise"], precision="bf16")
+    assert enc.dtype == BF16 and enc.shape == g["encoded_cuda"].shape
+    f_cuda, f_cpu = rel(enc, g["encoded_cuda"]), rel(enc, g["encoded_cpu"])
+    print(f"bf16-autocast VAE (rel-L2): decode vs cuda-policy oracle {e_cuda:.2e}, vs the reference under cpu autocast {e_cpu:.2e}; "
+          f"encode {f_cuda:.2e} / {f_cpu:.2e}; policies apart by {g['distance']['decode_cuda_vs_cpu']:.2e} / {g['distance']['encode_cuda_vs_cpu']:.2e}")
+    assert e_cuda <= 2e-2 and f_cuda <= 2e-2 and e_cpu <= 2.5e-2 and f_cpu <= 2.5e-2
+    # precision=None follows the caller's autocast region: bf16 inside torch.autocast("cuda", bfloat16), fp32 outside
+    with torch.autocast("cuda", dtype=BF16):
+        d2 = vae.decode(g["z"])
+    assert d2.dtype == BF16 and torch.equal(d2.cpu(), dec.cpu())
+    assert vae.decode(g["z"]).dtype == torch.float32
+    # decode_image's uint8 conversion with the eager-bf16 rounding points (inferencer.py:182-183 on a bf16 tensor)
+    from bagel_amd.inferencer import InterleaveInferencer
+    u8 = InterleaveInferencer.image_to_u8(dec)
+    ref = ((dec.cpu() * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8)
+    assert torch.equal(u8.cpu(), ref), "bf16 image -> uint8 must follow torch's bf16 elementwise roundings bit for bit"
+
+
 def test_conv3x3_512_channels_and_mid_block_attention_4096_tokens():
     from torch import nn
     from bagel_amd.modeling.vae_engine import VaeEngine

@@ -62,15 +62,24 @@ def main():
                 ops.gemm_skinny(x, Ws[i % copies], C, bias=bias, residual=C if kw.get("resid") else None, epilogue=epi, M=B)
             t_old = timeit(old)
             t_new = timeit(lambda i: ops.gemv_mb(A, Ws[i % copies], C, bias=bias, residual=C if kw.get("resid") else None, epilogue=epi, norm_w=nw, eps=1e-6, M=B))
-            line += f" B={B}: skinny {t_old:6.1f} -> mb {t_new:6.1f} us ({mb / t_new:4.2f} TB/s) |"
+            line += f" B={B}: skinny {t_old:6.1f} -> mb {t_new:6.1f} us ({mb / t_new:4.2f} TB/s)"
+            if B <= ops.GEMV_MAX_ROWS and K * 2 <= ops.GEMV_MAX_K_BYTES:        # the lane-FMA gemv at a few rows
+                t_fma = timeit(lambda i: ops.gemv(A, Ws[i % copies], C, bias=bias, residual=C if kw.get("resid") else None, epilogue=epi, norm_w=nw, eps=1e-6, M=B))
+                line += f" lane-FMA {t_fma:6.1f}"
+                tot.setdefault(("fma", B), [0.0, 0.0])
+                tot[("fma", B)][1] += t_fma * (1 if name == "lm_head" else 28)
+            line += " |"
             tot.setdefault(B, [0.0, 0.0])
             tot[B][0] += t_old * (1 if name == "lm_head" else 28)
             tot[B][1] += t_new * (1 if name == "lm_head" else 28)
         print(line, flush=True)
         del Ws
         torch.cuda.empty_cache()
-    for B, (a, b) in sorted(tot.items()):
-        print(f"projections of one 28-layer step, B={B}: {a / 1e3:.3f} ms" + (f" -> {b / 1e3:.3f} ms" if B > 1 else " (gemv)"))
+    for B, (a, b) in sorted(tot.items(), key=lambda kv: str(kv[0])):
+        if isinstance(B, tuple):
+            print(f"projections of one 28-layer step, B={B[1]} on the lane-FMA gemv: {b / 1e3:.3f} ms")
+        else:
+            print(f"projections of one 28-layer step, B={B}: {a / 1e3:.3f} ms" + (f" -> {b / 1e3:.3f} ms" if B > 1 else " (gemv)"))
 
 
 if __name__ == "__main__":
