@@ -646,25 +646,74 @@ __global__ void gn_finalize_bf16_kernel(const bf16_t* __restrict__ x, const floa
     stats[2 * i + 1] = rsqrtf(var + eps);
 }
 
-__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ stats,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int G,
-                                                            int swish) {
+// Coalesced statistics pass: a thread owns one 16-byte chunk (8 channels) of a pixel row and walks the pixels of its slice, so a wave reads
+// whole 128-byte lines (the per-group form above reads C / G channels out of every 2 C-byte pixel row: 8 of 256 bytes at C = 128); the
+// per-channel partial sums meet in LDS and are folded into per-group sums in a fixed order.  Needs 256 % (C / 8) == 0.
+__global__ __launch_bounds__(256) void gn_stats_rows_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G) {
+    const int b = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G, CH = C >> 3, ppi = 256 / CH;
+    const int ck = tid % CH, pr = tid / CH;
+    const bf16_t* xb = x + (long)b * HW * C;
+    const int per = (HW + GN_SLICES - 1) / GN_SLICES;
+    const int lo = sl * per, hi = min(HW, lo + per);
+    float piv[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        piv[e] = bf2f(xb[((ck * 8 + e) / cpg) * cpg]);
+        s1[e] = s2[e] = 0.f;
+    }
+    for (int p = lo + pr; p < hi; p += ppi) {
+        const u32x4_t v = *(const u32x4_t*)(xb + (long)p * C + ck * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = ((e & 1) ? hi2f(v[e >> 1]) : lo2f(v[e >> 1])) - piv[e];
+            s1[e] += d; s2[e] += d * d;
+        }
+    }
+    __shared__ float red[256][17];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid][e] = s1[e]; red[tid][8 + e] = s2[e]; }
+    __syncthreads();
+    for (int g = tid; g < G; g += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+            for (int r = 0; r < ppi; ++r) { a1 += red[r * CH + (c >> 3)][c & 7]; a2 += red[r * CH + (c >> 3)][8 + (c & 7)]; }
+        float* o = partial + (((long)b * G + g) * GN_SLICES + sl) * 2;
+        o[0] = a1; o[1] = a2;
+    }
+}
+
+// per (image, channel): y = x * a + b with a = rstd * gamma, b = beta - mean * a  (the apply pass then needs no division and no gather)
+__global__ void gn_affine_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 float* __restrict__ ab, int C, int G, int BC) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const int b = i / C, c = i - b * C, g = c / (C / G);
+    const float mean = stats[2 * (b * G + g)], inv = stats[2 * (b * G + g) + 1];
+    const float a = inv * gamma[c];
+    ab[2 * (long)i] = a;
+    ab[2 * (long)i + 1] = beta[c] - mean * a;
+}
+
+__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ ab,
+                                                            int HW, int C, int swish) {
     const int b = blockIdx.y;
-    const int cpg = C / G;
     const long total8 = (long)HW * C / 8;
+    const float* abb = ab + (long)b * C * 2;
     for (long i8 = (long)blockIdx.x * 256 + threadIdx.x; i8 < total8; i8 += (long)gridDim.x * 256) {
         const long i = i8 * 8;
         const int c = (int)(i % C);
         const long off = (long)b * HW * C + i;
         const u32x4_t v = *(const u32x4_t*)(x + off);
+        const f32x4_t q0 = *(const f32x4_t*)(abb + 2 * c), q1 = *(const f32x4_t*)(abb + 2 * c + 4), q2 = *(const f32x4_t*)(abb + 2 * c + 8),
+                      q3 = *(const f32x4_t*)(abb + 2 * c + 12);
+        const float aa[8] = {q0[0], q0[2], q1[0], q1[2], q2[0], q2[2], q3[0], q3[2]}, bb[8] = {q0[1], q0[3], q1[1], q1[3], q2[1], q2[3], q3[1], q3[3]};
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float xv = (e & 1) ? hi2f(v[e >> 1]) : lo2f(v[e >> 1]);
-            const int g = (c + e) / cpg;
-            const float mean = stats[2 * (b * G + g)], inv = stats[2 * (b * G + g) + 1];
-            float t = (xv - mean) * inv * gamma[c + e] + beta[c + e];
-            if (swish) t = t * (1.0f / (1.0f + __expf(-t)));
+            float t = xv * aa[e] + bb[e];
+            if (swish) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
             o[e] = t;
         }
         *(u32x4_t*)(y + off) = (u32x4_t){pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
@@ -677,13 +726,20 @@ extern "C" int bagel_groupnorm_bf16(const void* x, void* y, float* partial_ws, c
     BAGEL_REQUIRE(C % groups == 0 && C % 8 == 0, "groupnorm_bf16: C=%d must divide into %d groups and be a multiple of 8", C, groups);
     BAGEL_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "groupnorm_bf16: 16-byte alignment");
     if (B <= 0 || HW <= 0) return BAGEL_OK;
+    // workspace: [B*G*GN_SLICES*2] partials, [B*G*2] stats, [B*C*2] per-channel (scale, shift)
     float* stats = partial_ws + (long)B * groups * GN_SLICES * 2;
-    hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(GN_SLICES, groups, B), dim3(256), 0, stream, (const bf16_t*)x, partial_ws, HW, C, groups);
+    float* ab = stats + (long)B * groups * 2;
+    const int CH = C / 8;
+    if (CH <= 256 && 256 % CH == 0)
+        hipLaunchKernelGGL(gn_stats_rows_bf16_kernel, dim3(GN_SLICES, B), dim3(256), 0, stream, (const bf16_t*)x, partial_ws, HW, C, groups);
+    else
+        hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(GN_SLICES, groups, B), dim3(256), 0, stream, (const bf16_t*)x, partial_ws, HW, C, groups);
     hipLaunchKernelGGL(gn_finalize_bf16_kernel, dim3(ceil_div(B * groups, 64)), dim3(64), 0, stream, (const bf16_t*)x, partial_ws, stats, HW, C, groups, eps,
                        B * groups);
+    hipLaunchKernelGGL(gn_affine_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, stream, stats, gamma, beta, ab, C, groups, B * C);
     const long total8 = (long)HW * C / 8;
-    const int blocks = (int)min((long)ceil_div(total8, 256), 2048L);
-    hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, stats, gamma, beta, HW, C, groups, swish);
+    const int blocks = (int)min((long)ceil_div(total8, 256), 4096L);
+    hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, ab, HW, C, swish);
     return bagel_check_launch("groupnorm bf16 kernels");
 }
 

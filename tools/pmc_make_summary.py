@@ -54,8 +54,9 @@ def main():
             den.setdefault(k, {}).update(c)
     kernels = {}
     M, H, I = 32768, 3584, 18944
-    algo = {"gemm_pq_kernel<0, false>": 2.0 * (M * H + 2 * I * H) + 2.0 * M * I,                      # gate+up: A + W read, act written
-            "gemm_pq_kernel<2, false>": 2.0 * (M * H + 4608 * H) + 2.0 * M * 4608,                    # qkv
+    algo = {"gemm_pq_kernel<0, false": 2.0 * (M * H + 2 * I * H) + 2.0 * M * I,                       # gate+up: A + W read, act written
+            "gemm_pq_kernel<2, false": 2.0 * (M * H + 4608 * H) + 2.0 * M * 4608,                     # qkv   (keys = name prefixes: the SGPR-base-DMA
+                                                                                                      #        instantiations carry a third argument)
             # the stream-batched denoise launch: Q read + O written (8 x 4098 rows x 28 heads x 128) + K and V^T of every sample once
             "attn2_kernel<128>": 2.0 * 2 * (8 * 4098) * 3584 + 2.0 * 2 * (8 * 4098 + 4 * 32) * 512}
     for k, c in den.items():
@@ -69,8 +70,9 @@ def main():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             e["traffic_bytes_per_launch_corrected"] = int((2 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024)
             e["traffic_bytes_per_launch_raw"] = int((c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024)
-        if k in algo:
-            e["algorithmic_bytes_per_launch"] = int(algo[k])
+        for pre, b in algo.items():
+            if k.startswith(pre):
+                e["algorithmic_bytes_per_launch"] = int(b)
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
             e["tcc_hit"], e["tcc_miss"] = c["TCC_HIT_sum"][0], c["TCC_MISS_sum"][0]
             e["l2_hit_rate"] = round(e["tcc_hit"] / max(e["tcc_hit"] + e["tcc_miss"], 1.0), 4)
@@ -126,8 +128,8 @@ def main():
         commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         commit = ""
-    out = {"source": "tools/gpu_pmc.sh (rocprofv3 --kernel-trace --pmc <one group per pass>); raw per-kernel averages in profiles/r03_pmc_denoise_*.txt / "
-                     "profiles/r03_pmc_decode_*.txt",
+    out = {"source": "tools/gpu_pmc.sh (rocprofv3 --kernel-trace --pmc <one group per pass>); raw per-kernel averages in profiles/r04_pmc_denoise_*.txt / "
+                     "profiles/r04_pmc_decode_*.txt",
            "correction": "FETCH_SIZE (KB) doubled for the 16-B/lane streaming patterns (MI355X_MICROARCH.md, HBM section; cross-checked in round 1 against "
                          "TCC_MISS x 128 B and on an in-place kernel); WRITE_SIZE (KB) as reported",
            "commit": commit,
