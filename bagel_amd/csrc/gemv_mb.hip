@@ -66,6 +66,9 @@ __device__ __forceinline__ void mb_epilogue(const MbParams& p, f32x4_t a, int m,
     *(u32x2_t*)(p.C + (long)m * p.ldc + n) = v;
 }
 
+// Weight fragment loads are PLAIN: the non-temporal policy that helps the one-request gemv (common.h ld_stream) costs this kernel 11-13 %
+// (round 4, same box, interleaved processes: gate+up 53.2 -> 61.5 us, 28-layer step 3.32 -> 3.68 ms) -- a row-major fragment is half a
+// 128-byte line of 16 rows, and the other half (the next step's fragment, already in flight) wants to find the line in the cache.
 template <int NS, bool NORM>
 __global__ __launch_bounds__(512) void gemv_mb_kernel(const MbParams p) {
     constexpr int CH = 6;                                      // blocks between two reductions (LDS: CH x 8 waves x 1 KB = 48 KB static)
@@ -96,6 +99,9 @@ __global__ __launch_bounds__(512) void gemv_mb_kernel(const MbParams p) {
     bf16x8_t xf[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) xf[i] = *(const bf16x8_t*)(xa + i * 32);
+    // W row-major [N][ldw]: fragment (block, step) = 16 rows x 64 bytes.  A fragment-major copy of the weights ([N / 16][K / 32][16][32]: 1 KB
+    // contiguous per fragment) was timed in round 4 and is NOT built: gate+up 53.3 -> 52.3 us at 16 requests, 52.0 -> 50.1 at 2 -- not worth a
+    // second 14 GB image of the weights (profiles/r04_gemv_mb_bench.log).
     const bf16_t* wrow = p.W + (long)r * p.ldw + q * 8 + (long)sb * 32;       // + block * 16 rows
     const long blk_stride = 16 * p.ldw;
     bf16x8_t wf[NS];

@@ -600,14 +600,15 @@ extern "C" int bagel_conv_gemm_bf16(const void* in, int64_t ld_in, const void* w
     return bagel_check_launch("conv_gemm_bf16_kernel");
 }
 
+#define GN_BF16_SLICES 1024
 // ---- GroupNorm of a bf16 NHWC tensor: fp32 statistics (same shifted two-moment scheme and fixed-order reduction as the fp32 kernels) ----
-__global__ __launch_bounds__(256) void gn_stats_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G) {
+__global__ __launch_bounds__(256) void gn_stats_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G, int S) {
     const int b = blockIdx.z, g = blockIdx.y, sl = blockIdx.x;
     const int cpg = C / G;
     const bf16_t* xb = x + (long)b * HW * C + g * cpg;
     const float pivot = bf2f(xb[0]);
     const long n = (long)HW * cpg;
-    const long per = (n + GN_SLICES - 1) / GN_SLICES;
+    const long per = (n + S - 1) / S;
     const long lo = sl * per, hi = min(n, lo + per);
     float s1 = 0.f, s2 = 0.f;
     for (long i = lo + threadIdx.x; i < hi; i += 256) {
@@ -624,20 +625,23 @@ __global__ __launch_bounds__(256) void gn_stats_bf16_kernel(const bf16_t* __rest
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        float* o = partial + (((long)b * G + g) * GN_SLICES + sl) * 2;
+        float* o = partial + (((long)b * G + g) * S + sl) * 2;
         o[0] = r1[0]; o[1] = r2[0];
     }
 }
 
-__global__ void gn_finalize_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial, float* __restrict__ stats, int HW,
-                                        int C, int G, float eps, int BG) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BG) return;
+// one wave per (image, group): lane l sums slices l, l + 64, ...; the 64 lane sums meet in a fixed butterfly order
+__global__ __launch_bounds__(64) void gn_finalize_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial, float* __restrict__ stats,
+                                                              int HW, int C, int G, float eps, int BG, int S) {
+    const int i = blockIdx.x;
     const int b = i / G, g = i - b * G;
     const int cpg = C / G;
-    const float* pp = partial + (long)i * GN_SLICES * 2;
+    const float* pp = partial + (long)i * S * 2;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < GN_SLICES; ++k) { s1 += pp[2 * k]; s2 += pp[2 * k + 1]; }
+    for (int k = threadIdx.x; k < S; k += 64) { s1 += pp[2 * k]; s2 += pp[2 * k + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (threadIdx.x) return;
     const float n = (float)HW * (float)cpg;
     const float pivot = bf2f(x[(long)b * HW * C + g * cpg]);
     const float md = s1 / n;
@@ -649,12 +653,12 @@ __global__ void gn_finalize_bf16_kernel(const bf16_t* __restrict__ x, const floa
 // Coalesced statistics pass: a thread owns one 16-byte chunk (8 channels) of a pixel row and walks the pixels of its slice, so a wave reads
 // whole 128-byte lines (the per-group form above reads C / G channels out of every 2 C-byte pixel row: 8 of 256 bytes at C = 128); the
 // per-channel partial sums meet in LDS and are folded into per-group sums in a fixed order.  Needs 256 % (C / 8) == 0.
-__global__ __launch_bounds__(256) void gn_stats_rows_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G) {
+__global__ __launch_bounds__(256) void gn_stats_rows_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G, int S) {
     const int b = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G, CH = C >> 3, ppi = 256 / CH;
     const int ck = tid % CH, pr = tid / CH;
     const bf16_t* xb = x + (long)b * HW * C;
-    const int per = (HW + GN_SLICES - 1) / GN_SLICES;
+    const int per = (HW + S - 1) / S;
     const int lo = sl * per, hi = min(HW, lo + per);
     float piv[8], s1[8], s2[8];
 #pragma unroll
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(256) void gn_stats_rows_bf16_kernel(const bf16_t* _
         float a1 = 0.f, a2 = 0.f;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c)
             for (int r = 0; r < ppi; ++r) { a1 += red[r * CH + (c >> 3)][c & 7]; a2 += red[r * CH + (c >> 3)][8 + (c & 7)]; }
-        float* o = partial + (((long)b * G + g) * GN_SLICES + sl) * 2;
+        float* o = partial + (((long)b * G + g) * S + sl) * 2;
         o[0] = a1; o[1] = a2;
     }
 }
@@ -726,16 +730,19 @@ extern "C" int bagel_groupnorm_bf16(const void* x, void* y, float* partial_ws, c
     BAGEL_REQUIRE(C % groups == 0 && C % 8 == 0, "groupnorm_bf16: C=%d must divide into %d groups and be a multiple of 8", C, groups);
     BAGEL_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "groupnorm_bf16: 16-byte alignment");
     if (B <= 0 || HW <= 0) return BAGEL_OK;
-    // workspace: [B*G*GN_SLICES*2] partials, [B*G*2] stats, [B*C*2] per-channel (scale, shift)
-    float* stats = partial_ws + (long)B * groups * GN_SLICES * 2;
+    // workspace: [B*G*GN_BF16_SLICES*2] partials (S <= GN_BF16_SLICES of them used), [B*G*2] stats, [B*C*2] per-channel (scale, shift).
+    // S: enough slices that B * S workgroups cover the chip several times over at the 1024^2 sizes (64 left 3/4 of the CUs idle), never
+    // fewer than 64 pixels per slice.
+    float* stats = partial_ws + (long)B * groups * GN_BF16_SLICES * 2;
     float* ab = stats + (long)B * groups * 2;
     const int CH = C / 8;
+    const int S = (int)std::max(1L, std::min((long)GN_BF16_SLICES, (long)HW / 64));
     if (CH <= 256 && 256 % CH == 0)
-        hipLaunchKernelGGL(gn_stats_rows_bf16_kernel, dim3(GN_SLICES, B), dim3(256), 0, stream, (const bf16_t*)x, partial_ws, HW, C, groups);
+        hipLaunchKernelGGL(gn_stats_rows_bf16_kernel, dim3(S, B), dim3(256), 0, stream, (const bf16_t*)x, partial_ws, HW, C, groups, S);
     else
-        hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(GN_SLICES, groups, B), dim3(256), 0, stream, (const bf16_t*)x, partial_ws, HW, C, groups);
-    hipLaunchKernelGGL(gn_finalize_bf16_kernel, dim3(ceil_div(B * groups, 64)), dim3(64), 0, stream, (const bf16_t*)x, partial_ws, stats, HW, C, groups, eps,
-                       B * groups);
+        hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(S, groups, B), dim3(256), 0, stream, (const bf16_t*)x, partial_ws, HW, C, groups, S);
+    hipLaunchKernelGGL(gn_finalize_bf16_kernel, dim3(B * groups), dim3(64), 0, stream, (const bf16_t*)x, partial_ws, stats, HW, C, groups, eps,
+                       B * groups, S);
     hipLaunchKernelGGL(gn_affine_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, stream, stats, gamma, beta, ab, C, groups, B * C);
     const long total8 = (long)HW * C / 8;
     const int blocks = (int)min((long)ceil_div(total8, 256), 4096L);

@@ -12,6 +12,7 @@ Mirrors the loop of ``Bagel.generate_text`` (bagel.py:930-1000) and the Lq = 1 p
     is captured ONCE into a hipGraph and replayed per token: the host issues one call per token and only reads a
     token back when the caller asked for an end-token check (bagel.py:996).
 """
+import numpy as np
 import torch
 
 from ... import ops
@@ -46,37 +47,39 @@ class PagedKVCache:
 
     def physical_rows(self, b, start, stop):
         """Pool rows of tokens [start, stop) of sample b."""
-        bt = self.block_table_host[b]
-        return [bt[j // self.PAGE] * self.PAGE + j % self.PAGE for j in range(start, stop)]
+        bt = np.asarray(self.block_table_host[b], dtype=np.int64)
+        j = np.arange(start, stop, dtype=np.int64)
+        return bt[j // self.PAGE] * self.PAGE + j % self.PAGE
+
+    def rows_index(self, ranges):
+        """Device int32 index of the pool rows of ``ranges`` = [(b, start, stop), ...], in that order (the same for every layer)."""
+        src = [self.physical_rows(b, s, e) for b, s, e in ranges]
+        src = np.concatenate(src) if src else np.zeros((0,), dtype=np.int64)
+        return torch.from_numpy(src.astype(np.int32)).to(self.k.device)
 
     def adopt(self, cache, lens):
         """Copy a NaiveCache (merged layout [ctx_0 | ctx_1 | ...], per-sample ``lens``) into the pages."""
         if max(lens) > self.capacity:
             raise ValueError("context longer than the page capacity")
-        dst = []
-        for b, n in enumerate(lens):
-            dst.extend(self.physical_rows(b, 0, n))
-        total = len(dst)
-        dev = self.k.device
-        dst_t = torch.tensor(dst, dtype=torch.int32, device=dev) if total else None
+        dst_t = self.rows_index([(b, 0, int(n)) for b, n in enumerate(lens)])
+        total = dst_t.numel()
         for li in range(self.num_layers):
             if total:
                 ops.copy_rows(cache._k[li], self.k[li], total, self.width, dst_rows=dst_t)
                 ops.copy_rows(cache._v[li], self.v[li], total, self.width, dst_rows=dst_t)
         self.kv_len.copy_(torch.tensor([int(n) for n in lens], dtype=torch.int32))
 
-    def gather(self, layer, ranges):
-        """Rows of ``ranges`` = [(b, start, stop), ...] of one layer -> contiguous (K, V) tensors."""
-        src = []
-        for b, s, e in ranges:
-            src.extend(self.physical_rows(b, s, e))
-        dev = self.k.device
-        k = torch.empty((len(src), self.width), dtype=BF16, device=dev)
+    def gather(self, layer, ranges, idx=None):
+        """Rows of ``ranges`` = [(b, start, stop), ...] of one layer -> contiguous (K, V) tensors (``idx`` = rows_index(ranges), when the
+        caller gathers the same ranges from every layer)."""
+        if idx is None:
+            idx = self.rows_index(ranges)
+        n = idx.numel()
+        k = torch.empty((n, self.width), dtype=BF16, device=self.k.device)
         v = torch.empty_like(k)
-        if src:
-            idx = torch.tensor(src, dtype=torch.int32, device=dev)
-            ops.copy_rows(self.k[layer], k, len(src), self.width, src_rows=idx)
-            ops.copy_rows(self.v[layer], v, len(src), self.width, src_rows=idx)
+        if n:
+            ops.copy_rows(self.k[layer], k, n, self.width, src_rows=idx)
+            ops.copy_rows(self.v[layer], v, n, self.width, src_rows=idx)
         return k, v
 
 
@@ -278,12 +281,13 @@ class DecodeSession:
             nd, cd, base = [], [], 0
             for b in range(self.B):
                 c = self.ctx_lens[b]
-                cd.extend(range(base, base + c))
-                nd.extend(range(base + c, base + c + n))
+                cd.append(np.arange(base, base + c, dtype=np.int32))
+                nd.append(np.arange(base + c, base + c + n, dtype=np.int32))
                 base += c + n
             dev = eng.device
-            new_dst = torch.tensor(nd, dtype=torch.int32, device=dev)
-            ctx_dst = torch.tensor(cd, dtype=torch.int32, device=dev) if cd else None
+            new_dst = torch.from_numpy(np.concatenate(nd)).to(dev)
+            ctx_dst = torch.from_numpy(np.concatenate(cd)).to(dev) if base > self.B * n else None
+        idx = self.paged.rows_index(ranges)
         for li in range(len(eng.layers)):
-            k, v = self.paged.gather(li, ranges)
+            k, v = self.paged.gather(li, ranges, idx)
             cache.store(li, k, v, [n] * self.B, self.ctx_lens, eng.nkv, eng.hd, eng.dp, new_dst, ctx_dst)

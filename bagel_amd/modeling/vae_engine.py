@@ -201,7 +201,7 @@ class VaeEngineBf16(VaeEngine):
 
     def gn(self, x, m, swish):
         B, H, W, C = x.shape
-        need = B * 32 * (64 * 2 + 2) + B * C * 2           # slice partials + (mean, rstd) per group + (scale, shift) per channel
+        need = ops.groupnorm_bf16_workspace_floats(B, C, 32)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=F32, device=x.device)
         y = torch.empty_like(x)

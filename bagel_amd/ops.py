@@ -1062,8 +1062,16 @@ def conv_gemm_bf16(x, ld_in, w, ld_w, bias, residual, out, ld_out, B, Hin, Win, 
     return out
 
 
+def groupnorm_bf16_workspace_floats(B, C, groups):
+    """[B * groups][1024 slices][2] partial sums + (mean, rstd) per group + (scale, shift) per channel (include/bagel_hip.h)."""
+    return B * groups * 2050 + B * C * 2
+
+
 def groupnorm_bf16(x, y, workspace, gamma, beta, B, HW, C, groups, eps, swish):
     _req(x, BF16, "groupnorm_bf16.x"); _req(y, BF16, "groupnorm_bf16.y"); _req(gamma, torch.float32, "groupnorm_bf16.gamma")
+    _req(workspace, torch.float32, "groupnorm_bf16.workspace")
+    if workspace.numel() < groupnorm_bf16_workspace_floats(B, C, groups):
+        raise BagelHipError(f"groupnorm_bf16: workspace of {workspace.numel()} floats < {groupnorm_bf16_workspace_floats(B, C, groups)}")
     check(lib().bagel_groupnorm_bf16(_ptr(x), _ptr(y), _ptr(workspace), _ptr(gamma), _ptr(beta), B, HW, C, groups, float(eps),
                                      int(swish), _stream()), "bagel_groupnorm_bf16")
     return y

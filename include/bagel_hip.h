@@ -447,7 +447,7 @@ int bagel_softmax_rows_f32(float* x, int64_t ld, int32_t rows, int32_t cols, flo
  * 1 conv3 s1 p1, 2 conv3 s2 pad(0,1,0,1), 3 nearest-2x upsample + conv3); out = bf16(acc + bias) [then bf16(that + residual)], or with
  * out_f32 != 0 the raw fp32 accumulators (attention scores; no bias / residual).  Cin % 8 == 0 (mode 0: K = Cin).
  * bagel_groupnorm_bf16: GroupNorm (+ swish) of a bf16 NHWC tensor, fp32 statistics and arithmetic, ONE rounding to bf16 on the way out;
- *                       partial_ws: fp32 workspace of B * groups * 130 + B * C * 2 elements.
+ *                       partial_ws: fp32 workspace of B * groups * 2050 + B * C * 2 elements.
  * bagel_softmax_rows_bf16: y = bf16(softmax(scale * x)) per fp32 score row. */
 int bagel_conv_gemm_bf16(const void* in, int64_t ld_in, const void* w, int64_t ld_w, const void* bias, const void* residual,
                          void* out, int64_t ld_out, int32_t out_f32, int32_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t Hout,

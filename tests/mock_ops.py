@@ -677,6 +677,10 @@ def conv_gemm_bf16(x, ld_in, w, ld_w, bias, residual, out, ld_out, B, Hin, Win, 
     return out
 
 
+def groupnorm_bf16_workspace_floats(B, C, groups):
+    return B * groups * 2050 + B * C * 2
+
+
 def groupnorm_bf16(x, y, workspace, gamma, beta, B, HW, C, groups, eps, swish):
     t = torch.empty(x.shape, dtype=torch.float32)
     groupnorm_f32(x.float(), t, workspace, gamma, beta, B, HW, C, groups, eps, swish)
@@ -738,7 +742,7 @@ _NAMES = ["gemm", "gemv", "gemv_mb", "gemm_skinny", "rmsnorm", "layernorm", "rop
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
           "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
-          "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32", "conv_gemm_bf16", "groupnorm_bf16", "softmax_rows_bf16", "vae_reparam_bf16", "chw_bf16_to_u8",
+          "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32", "conv_gemm_bf16", "groupnorm_bf16", "groupnorm_bf16_workspace_floats", "softmax_rows_bf16", "vae_reparam_bf16", "chw_bf16_to_u8",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "layernorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
           "act_bwd", "swiglu_fwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]
 

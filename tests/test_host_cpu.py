@@ -214,7 +214,7 @@ def test_vae_launch_wrappers_match_the_header(monkeypatch):
     b = lambda *s: torch.zeros(*s, dtype=torch.bfloat16)  # noqa: E731
     ops.conv_gemm_bf16(b(2, 4, 4, 64), 64, b(8, 576), 576, b(8), b(2, 4, 4, 8), b(2, 4, 4, 8), 8, 2, 4, 4, 64, 4, 4, 8, 1)
     ops.conv_gemm_bf16(b(6, 8), 8, b(7, 8), 8, None, None, f(6, 8), 8, 1, 1, 6, 8, 1, 6, 7, 0)
-    ops.groupnorm_bf16(b(1, 4, 4, 32), b(1, 4, 4, 32), f(4160), f(32), f(32), 1, 16, 32, 32, 1e-6, True)
+    ops.groupnorm_bf16(b(1, 4, 4, 32), b(1, 4, 4, 32), f(65664), f(32), f(32), 1, 16, 32, 32, 1e-6, True)
     ops.softmax_rows_bf16(f(3, 8), b(3, 8), 3, 5, 0.25)
     ops.vae_reparam_bf16(b(16, 8), b(16, 4), b(16, 4), 16, 4, 0.3611, 0.1159)
     ops.chw_bf16_to_u8(b(3, 4, 6))

@@ -442,6 +442,7 @@ def test_interleave_inferencer_host_path_matches_reference(golden, monkeypatch, 
     tok = StubTokenizer(cfg["llm"]["vocab_size"])
     inf = InterleaveInferencer(model, vae, tok, ImageTransform(64, 32, 16, device="cpu"), ImageTransform(56, 28, 14, device="cpu"),
                                NEW_TOKEN_IDS_TINY)
+    inf.vae_precision_in_autocast = "fp32"                 # the fixture's reference ran on CPU, where the CUDA autocast region leaves the VAE in fp32
     src = Image.fromarray(g["source_image"].numpy(), "RGB")
 
     def close(img, ref, mean_tol, p99_tol, what):
