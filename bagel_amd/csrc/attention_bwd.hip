@@ -425,12 +425,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
             f32x16_t s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            // ALL fragment reads of a product group go out before its first MFMA (sched_barrier keeps hipcc from sinking each read next to its
+            // use: it emitted read, read, wait, MFMA, MFMA).  Round 4: 4.96 -> 4.75 ms at the probe's shapes -- the reads were NOT the main loss;
+            // what else was tried on this kernel and did not pay is in profiles/r04_attn_bwd_experiments.log (role-split waves, role-split workgroups)
+            bf16x8_t fa[KS], fb[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                fa[ks] = *(const bf16x8_t*)(Qs + (32 * qb + pm) * RP + 16 * ks + 8 * h);
+                fb[ks] = *(const bf16x8_t*)(dOs + (32 * qb + pm) * RP + 16 * ks + 8 * h);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (AB_ABL & 64) { s[ks] = (float)step; dp[ks] = (float)q0; continue; }
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(Qs + (32 * qb + pm) * RP + 16 * ks + 8 * h), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(dOs + (32 * qb + pm) * RP + 16 * ks + 8 * h), vf[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks], vf[ks], dp, 0, 0, 0);
             }
+            // the transposed fragments of the gradient products land while the softmax arithmetic runs
+            bf16x8_t ft[DB][2], fu[DB][2];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16_t* a0 = dOts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
+                const bf16_t* b0 = Qts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
+                ft[db][0] = *(const bf16x8_t*)a0; ft[db][1] = *(const bf16x8_t*)(a0 + 16);
+                fu[db][0] = *(const bf16x8_t*)b0; fu[db][1] = *(const bf16x8_t*)(b0 + 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             float pr[16], ds[16], lv[16], dl[16];
 #pragma unroll
             for (int a = 0; a < 2; ++a)                      // the lane's 16 queries are two runs of 8: four 16-byte LDS reads each
@@ -465,12 +485,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 if (AB_ABL & 32) { dv[db][0] += pr[db] + pr[db + 8]; dk[db][0] += ds[db] + ds[db + 8]; continue; }
-                const bf16_t* a0 = dOts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)a0, pf0, dv[db], 0, 0, 0);
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(a0 + 16), pf1, dv[db], 0, 0, 0);
-                const bf16_t* b0 = Qts + (32 * db + m) * AB_TP + 32 * qb + 8 * h;
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)b0, dsf0, dk[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(b0 + 16), dsf1, dk[db], 0, 0, 0);
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[db][0], pf0, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fu[db][0], dsf0, dk[db], 0, 0, 0);
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[db][1], pf1, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fu[db][1], dsf1, dk[db], 0, 0, 0);
             }
         }
     }
