@@ -1,5 +1,5 @@
 """Timing of the four denoise GEMMs of the stream-batched forward (M = 2 streams x 4 samples x 4098 rows with the model's MoT row lists and
-epilogues, variant 4) with whichever library BAGEL_HIP_LIB names -- tools/gpu_v1.sh runs it once per A/B build, interleaved.
+epilogues, variant 4) with whichever library BAGEL_HIP_LIB names -- run it once per A/B build (tools/ab_build.sh), interleaved.
     BAGEL_HIP_LIB=bagel_amd/libbagel_hip_saddr.so python tools/gemm_ab.py [rounds]"""
 import os
 import sys
