@@ -617,6 +617,8 @@ class Bagel(nn.Module):
             return torch.empty((0, len(kv_lens)), dtype=torch.long, device=self.device)
         if weight_quant is None:
             weight_quant = getattr(self, "decode_weight_quant", None)    # model-level switch, like the reference's load-time modes (app.py:114-131)
+        self._last_decode_session = None      # release the previous call's page pools BEFORE this call allocates its own (16 requests x 5 k tokens: 9 GB;
+        #                                       holding both made every call pay a fresh hipMalloc of that size, ~100 ms)
         sess = DecodeSession(lm.engine(check=True), lm.model.embed_tokens.weight.data, lm.lm_head.weight.data, past_key_values, kv_lens,
                              packed_start_tokens, packed_query_position_ids, max_length, weight_quant=weight_quant)
         self._last_decode_session = sess
