@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           const int* __restrict__ block_table, int bt_stride,
                                                           const int* __restrict__ kv_len, int len_add, float* __restrict__ part_o,
                                                           float* __restrict__ part_ml, int nq, int G, int nsplit, float scale_log2e,
-                                                          DecFuse fu, int cpw, int* __restrict__ arrive, bf16_t* __restrict__ out, long ldo) {
+                                                          DecFuse fu, int cpw) {
     constexpr int CH = DEC_CH;           // keys per chunk
     constexpr int KS = DP / 32;          // k-steps of S^T
     constexpr int NDB = DP / 16;         // 16-wide d blocks of O^T
@@ -677,11 +677,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const int L = kv_len[b] + len_add;
     const int j0 = split * CH * cpw;                                 // this workgroup's key range [j0, j1)
     const int j1 = (L < j0 + CH * cpw) ? L : j0 + CH * cpw;
-    if (j0 >= j1) {
-        if (arrive && L <= 0 && split == 0)            // no key at all: nobody arrives, so the first workgroup writes the zero rows the combine would
-            for (int i = threadIdx.x; i < G * DP; i += 256) out[(long)b * ldo + (long)kvh * G * DP + i] = f2bf(0.f);
-        return;
-    }
+    if (j0 >= j1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     __shared__ __attribute__((aligned(16))) bf16_t sm_v[4][32 * VST];      // V tiles; afterwards the waves' O partials [16][DP] fp32
@@ -883,47 +879,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             part_ml[slot * 2 + 1] = sm_l[0][h] * c0 + sm_l[1][h] * c1 + sm_l[2][h] * c2 + sm_l[3][h] * c3;
         }
     }
-    if (!arrive) return;                 // two-launch form: attn_decode_combine_kernel follows
-    // ---- LAST-ARRIVER COMBINE (round 4): the workgroup that finishes last among the splits of this (sample, KV head) merges their
-    // partials itself -- one launch and one graph edge fewer per layer (4.8 us kernel + ~1.1 us edge at one request).  Release: every thread
-    // fences its partial stores to device scope before the barrier; one thread counts the arrival; the last one sees ns - 1, resets the
-    // counter for the next launch (nobody else of this pair touches it any more), fences again (acquire) and reads all ns partials.
-    // Deterministic: WHO merges varies, the merge itself is a fixed loop over the splits in index order.
-    __threadfence();
-    __syncthreads();
-    __shared__ int sm_last;
-    const int ns_live = min(nsplit, (L + CH * cpw - 1) / (CH * cpw));       // splits that hold keys (the others returned at the top)
-    if (tid == 0) {
-        int* ctr = arrive + b * gridDim.y + kvh;
-        const int old = atomicAdd(ctr, 1);
-        sm_last = old == ns_live - 1;
-        if (sm_last) *ctr = 0;
-    }
-    __syncthreads();
-    if (!sm_last) return;
-    __threadfence();
-    {
-        constexpr int LPD = DP / 4, NSG = 256 / LPD;         // DP / 4 lanes cover a head (float4 each); 256 / (DP / 4) heads at a time
-        const int d4 = tid % LPD, sg = tid / LPD;
-        for (int h = sg; h < G; h += NSG) {
-            const long base = ((long)b * nq + kvh * G + h) * nsplit;
-            float m = -1e30f, l = 0.f;
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int sp = 0; sp < ns_live; ++sp) {
-                const float ms = part_ml[(base + sp) * 2], lsv = part_ml[(base + sp) * 2 + 1];
-                const f32x4_t ov = *(const f32x4_t*)(part_o + (base + sp) * DP + d4 * 4);
-                const float mn = fmaxf(m, ms);
-                const float c1 = exp2f(m - mn), c2 = exp2f(ms - mn);
-                acc = acc * c1 + ov * c2;
-                l = l * c1 + lsv * c2;
-                m = mn;
-            }
-            const float inv = l > 0.f ? 1.f / l : 0.f;
-            const u32x2_t v = {pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv)};
-            *(u32x2_t*)(out + (long)b * ldo + (long)(kvh * G + h) * DP + d4 * 4) = v;
-        }
-    }
 }
 
 // out[b, h, :] = sum_s part_o[s] 2^(m_s - M) / sum_s l_s 2^(m_s - M)  over the splits that hold keys.  One workgroup per
@@ -979,18 +934,17 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
 template <int DP, bool FUSED>
 static int launch_attn_decode(int G, dim3 grid, hipStream_t stream, const bf16_t* q, long ldq, const bf16_t* kpool, const bf16_t* vpool,
                               long ldp, const int* bt, int bt_stride, const int* kv_len, int len_add, float* po, float* pml, int nq,
-                              int nsplit, float sl2e, DecFuse fu, int cpw, int* arrive, bf16_t* out, long ldo) {
+                              int nsplit, float sl2e, DecFuse fu, int cpw) {
     hipLaunchKernelGGL((attn_decode_kernel<DP, FUSED>), grid, dim3(256), 0, stream, q, ldq, kpool, vpool, ldp, bt, bt_stride, kv_len,
-                       len_add, po, pml, nq, G, nsplit, sl2e, fu, cpw, arrive, out, ldo);
+                       len_add, po, pml, nq, G, nsplit, sl2e, fu, cpw);
     return bagel_check_launch("attn_decode_kernel");
 }
 
 static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
                               const int32_t* block_table, int32_t bt_stride, const int32_t* kv_len, int32_t len_add, int32_t max_len,
                               float* part_o, float* part_ml, void* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nkv,
-                              int32_t head_dim, float softmax_scale, const DecFuse* fuse, int32_t* arrive, hipStream_t stream) {
+                              int32_t head_dim, float softmax_scale, const DecFuse* fuse, hipStream_t stream) {
     BAGEL_REQUIRE(q && kpool && vpool && block_table && kv_len && part_o && part_ml && out, "attn_decode: null pointer");
-    BAGEL_REQUIRE(!arrive || (((uintptr_t)arrive) & 3) == 0, "attn_decode: arrival counters must be 4-byte aligned");
     BAGEL_REQUIRE(head_dim == 64 || head_dim == 128, "attn_decode: head_dim %d not in {64,128} (pad the projection)", head_dim);
     BAGEL_REQUIRE(nkv > 0 && nq % nkv == 0, "attn_decode: nq must be a multiple of nkv");
     BAGEL_REQUIRE((ldq % 8) == 0 && (ld_pool % 8) == 0 && (ldo % 4) == 0 && (((uintptr_t)out) & 7) == 0, "attn_decode: leading dims / out alignment");
@@ -1025,13 +979,13 @@ static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, con
     int rc;
 #define DEC_GO(DPV)                                                                                                              \
     rc = fuse ? launch_attn_decode<DPV, true>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
-                                              len_add, part_o, part_ml, nq, nsplit, sl2e, fu, cpw, arrive, (bf16_t*)out, (long)ldo) \
+                                              len_add, part_o, part_ml, nq, nsplit, sl2e, fu, cpw)                               \
               : launch_attn_decode<DPV, false>(G, grid, stream, qq, (long)ldq, kp, vp, (long)ld_pool, block_table, bt_stride, kv_len, \
-                                               len_add, part_o, part_ml, nq, nsplit, sl2e, fu, cpw, arrive, (bf16_t*)out, (long)ldo)
+                                               len_add, part_o, part_ml, nq, nsplit, sl2e, fu, cpw)
     if (head_dim == 128) { DEC_GO(128); }
     else { DEC_GO(64); }
 #undef DEC_GO
-    if (rc != BAGEL_OK || arrive) return rc;       // with arrival counters the last workgroup of every (sample, KV head) has merged the partials
+    if (rc != BAGEL_OK) return rc;
     if (head_dim == 128)
         hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(nq, batch), dim3(256), 0, stream, part_o, part_ml, kv_len, len_add,
                            (bf16_t*)out, (long)ldo, nq, nsplit, ch);
@@ -1045,9 +999,9 @@ extern "C" int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const vo
                                             const int32_t* block_table, int32_t bt_stride, const int32_t* kv_len,
                                             int32_t len_add, int32_t max_len, float* part_o, float* part_ml, void* out,
                                             int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
-                                            float softmax_scale, int32_t* arrive_counters, hipStream_t stream) {
+                                            float softmax_scale, hipStream_t stream) {
     return attn_decode_common(q, ldq, kpool, vpool, ld_pool, block_table, bt_stride, kv_len, len_add, max_len, part_o, part_ml, out, ldo,
-                              batch, nq, nkv, head_dim, softmax_scale, nullptr, arrive_counters, stream);
+                              batch, nq, nkv, head_dim, softmax_scale, nullptr, stream);
 }
 
 // decode_qkv_post + attn_decode_paged in one launch (+ the combine): qkv = RAW fused projection rows; the new K/V row of every
@@ -1057,7 +1011,7 @@ extern "C" int bagel_attn_decode_fused_bf16(const void* qkv, int64_t ld, const v
                                             int32_t bt_stride, const int32_t* kv_len, int32_t max_len, float* part_o, float* part_ml,
                                             void* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
                                             int32_t head_dim_padded, float eps, int32_t use_norm, float softmax_scale,
-                                            int32_t* arrive_counters, hipStream_t stream) {
+                                            hipStream_t stream) {
     BAGEL_REQUIRE(cos_tab && sin_tab, "attn_decode_fused: null rope tables");
     BAGEL_REQUIRE(!use_norm || (q_w && k_w), "attn_decode_fused: norm weights missing");
     BAGEL_REQUIRE((head_dim == 32 || head_dim == 64 || head_dim == 128) && head_dim <= head_dim_padded, "attn_decode_fused: head_dim %d / padded %d",
@@ -1068,7 +1022,7 @@ extern "C" int bagel_attn_decode_fused_bf16(const void* qkv, int64_t ld, const v
     fu.cosb = (const bf16_t*)cos_tab; fu.sinb = (const bf16_t*)sin_tab; fu.qw = (const bf16_t*)q_w; fu.kw = (const bf16_t*)k_w;
     fu.kpool = (bf16_t*)kpool; fu.vpool = (bf16_t*)vpool; fu.nkv = nkv; fu.hd = head_dim; fu.use_norm = use_norm; fu.eps = eps;
     return attn_decode_common(qkv, ld, kpool, vpool, ld_pool, block_table, bt_stride, kv_len, 1, max_len, part_o, part_ml, out, ldo, batch,
-                              nq, nkv, head_dim_padded, softmax_scale, &fu, arrive_counters, stream);
+                              nq, nkv, head_dim_padded, softmax_scale, &fu, stream);
 }
 
 // Token bookkeeping of one decode step on the device (bagel.py:984-994): the chosen token becomes the next input,

@@ -116,11 +116,6 @@ class DecodeSession:
         self.cos = e(B, eng.hd // 2)
         self.sin = e(B, eng.hd // 2)
         self.part_o, self.part_ml = ops.attn_decode_workspace(B, nq, dp, self.max_len, dev)
-        import os
-        # one-launch decode attention: the last workgroup of a (sample, KV head) merges the split partials (BAGEL_DECODE_ARRIVE=0: the
-        # separate combine launch).  One counter set per layer: a layer's counters are back at zero when its launch ends, but a captured
-        # graph must not make two layers' launches meet on the same words should the runtime ever overlap them.
-        self.arrive = ([ops.attn_decode_counters(B, nkv, dev) for _ in range(L)] if os.environ.get("BAGEL_DECODE_ARRIVE", "1") == "1" else None)
         # fp32 K-slice slabs of bagel_gemv_mb_bf16 for the longest row a layer has (the down projection)
         self.mb_ws = torch.empty(max(ops.mb_workspace_floats(eng.H, eng.I), 4), dtype=torch.float32, device=dev) if 1 < B <= ops.MB_MAX_ROWS else None
         self.pos = position_ids.to(device=dev, dtype=torch.long).clone().contiguous()
@@ -213,12 +208,12 @@ class DecodeSession:
             if self.fused_attention:
                 ops.attn_decode_fused(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
                                       pg.k[li], pg.v[li], pg.block_table, pg.kv_len, self.max_len, self.part_o, self.part_ml, att, B,
-                                      nq, nkv, hd, dp, eng.eps, eng.use_norm, scale, counters=self.arrive[li] if self.arrive else None)
+                                      nq, nkv, hd, dp, eng.eps, eng.use_norm, scale)
             else:
                 ops.decode_qkv_post(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
                                     pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, nq, nkv, hd, dp, eng.eps, eng.use_norm)
                 ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
-                                      self.part_ml, att, B, nq, nkv, dp, scale, counters=self.arrive[li] if self.arrive else None)
+                                      self.part_ml, att, B, nq, nkv, dp, scale)
             proj(att, Q["wo"] if Q else P.wo[0], x, residual=x)
             proj(x, Q["wgu"] if Q else P.wgu[0], act, norm_w=P.ln_post[0], epilogue=ops.EPI_SWIGLU16)
             proj(act, Q["wd"] if Q else P.wd[0], x, residual=x)

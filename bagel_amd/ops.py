@@ -420,22 +420,8 @@ def attn_decode_workspace(batch, nq, head_dim, max_len, device):
             torch.empty((batch * nq * ns * 2,), dtype=torch.float32, device=device))
 
 
-def attn_decode_counters(batch, nkv, device):
-    """Arrival counters of the one-launch decode attention (include/bagel_hip.h: zero before the first call; the kernels leave them zero)."""
-    return torch.zeros((batch * nkv,), dtype=torch.int32, device=device)
-
-
-def _arrive_ptr(counters, batch, nkv, what):
-    if counters is None:
-        return None
-    _req(counters, torch.int32, what + ".counters")
-    if counters.numel() < batch * nkv:
-        raise BagelHipError(f"{what}: {counters.numel()} arrival counters < batch * nkv = {batch * nkv}")
-    return _ptr(counters)
-
-
 def attn_decode_paged(q, kpool, vpool, block_table, kv_len, len_add, max_len, part_o, part_ml, out, batch, nq, nkv, head_dim,
-                      softmax_scale, counters=None):
+                      softmax_scale):
     """Lq = 1 attention over keys [0, kv_len[b] + len_add) of the paged cache; q:[B, >= nq*D] rows, out:[B, nq*D]."""
     _req(q, BF16, "attn_decode.q"); _req(out, BF16, "attn_decode.out")
     _req(kpool, BF16, "attn_decode.kpool"); _req(vpool, BF16, "attn_decode.vpool")
@@ -446,14 +432,13 @@ def attn_decode_paged(q, kpool, vpool, block_table, kv_len, len_add, max_len, pa
         raise BagelHipError("attn_decode_paged: workspace too small for max_len")
     check(lib().bagel_attn_decode_paged_bf16(_ptr(q), q.stride(0), _ptr(kpool), _ptr(vpool), kpool.stride(0), _ptr(block_table),
                                              block_table.stride(0), _ptr(kv_len), len_add, max_len, _ptr(part_o), _ptr(part_ml),
-                                             _ptr(out), out.stride(0), batch, nq, nkv, head_dim, float(softmax_scale),
-                                             _arrive_ptr(counters, batch, nkv, "attn_decode_paged"), _stream()),
+                                             _ptr(out), out.stride(0), batch, nq, nkv, head_dim, float(softmax_scale), _stream()),
           "bagel_attn_decode_paged_bf16")
     return out
 
 
 def attn_decode_fused(qkv, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len, max_len, part_o, part_ml, out, batch, nq, nkv,
-                      head_dim, head_dim_padded, eps, use_norm, softmax_scale, counters=None):
+                      head_dim, head_dim_padded, eps, use_norm, softmax_scale):
     """decode_qkv_post + attn_decode_paged in one launch (+ combine); qkv = raw fused projection rows."""
     _req(qkv, BF16, "attn_decode_fused.qkv"); _req(out, BF16, "attn_decode_fused.out")
     _req(kpool, BF16, "attn_decode_fused.kpool"); _req(vpool, BF16, "attn_decode_fused.vpool")
@@ -464,8 +449,7 @@ def attn_decode_fused(qkv, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len
     check(lib().bagel_attn_decode_fused_bf16(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(q_w), _ptr(k_w), _ptr(kpool), _ptr(vpool),
                                              kpool.stride(0), _ptr(block_table), block_table.stride(0), _ptr(kv_len), max_len,
                                              _ptr(part_o), _ptr(part_ml), _ptr(out), out.stride(0), batch, nq, nkv, head_dim,
-                                             head_dim_padded, float(eps), int(use_norm), float(softmax_scale),
-                                             _arrive_ptr(counters, batch, nkv, "attn_decode_fused"), _stream()),
+                                             head_dim_padded, float(eps), int(use_norm), float(softmax_scale), _stream()),
           "bagel_attn_decode_fused_bf16")
     return out
 

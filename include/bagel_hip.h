@@ -269,25 +269,22 @@ int bagel_decode_qkv_post_bf16(void* qkv, int64_t ld, const void* cos_tab, const
 
 /* flash_attn_varlen_func at Lq = 1 (qwen2_navit.py:579-588) over the paged cache: keys [0, kv_len[b] + len_add) of
  * sample b, split into 128-key chunks (grid sized for max_len), GQA heads share each K/V read; fp32 softmax.
- * part_o: batch*nq*ceil(max_len/128)*head_dim floats, part_ml: batch*nq*ceil(max_len/128)*2 floats (workspace).
- * arrive_counters: NULL = split kernel + combine kernel (two launches); else batch*nkv int32, ZERO before the first call: the workgroup
- * that arrives last among the splits of a (sample, KV head) merges their partials itself and leaves the counter at zero again (one launch;
- * same result up to the fp32 order of the merge: a fixed loop over the splits, whoever runs it). */
+ * part_o: batch*nq*ceil(max_len/128)*head_dim floats, part_ml: batch*nq*ceil(max_len/128)*2 floats (workspace). */
 int bagel_attn_decode_paged_bf16(const void* q, int64_t ldq, const void* kpool, const void* vpool, int64_t ld_pool,
                                  const int32_t* block_table, int32_t bt_stride, const int32_t* kv_len,
                                  int32_t len_add, int32_t max_len, float* part_o, float* part_ml, void* out,
                                  int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
-                                 float softmax_scale, int32_t* arrive_counters, bagel_stream_t stream);
+                                 float softmax_scale, bagel_stream_t stream);
 
 /* bagel_decode_qkv_post_bf16 + bagel_attn_decode_paged_bf16 in one launch (plus the combine): qkv = the RAW fused projection
  * rows; q/k norm + RoPE happen inside the attention workgroups, the new K/V row goes to page slot kv_len[b] and is attended
- * to (keys [0, kv_len[b]]).  Bit-identical to the two-kernel form.  arrive_counters: as for bagel_attn_decode_paged_bf16. */
+ * to (keys [0, kv_len[b]]).  Bit-identical to the two-kernel form. */
 int bagel_attn_decode_fused_bf16(const void* qkv, int64_t ld, const void* cos_tab, const void* sin_tab, const void* q_w,
                                  const void* k_w, void* kpool, void* vpool, int64_t ld_pool, const int32_t* block_table,
                                  int32_t bt_stride, const int32_t* kv_len, int32_t max_len, float* part_o, float* part_ml,
                                  void* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nkv, int32_t head_dim,
                                  int32_t head_dim_padded, float eps, int32_t use_norm, float softmax_scale,
-                                 int32_t* arrive_counters, bagel_stream_t stream);
+                                 bagel_stream_t stream);
 
 /* Device-side bookkeeping of one decode step (bagel.py:984-994): cur_tok32 <- next_tok, tokens_out[step+1] <- next_tok,
  * pos += 1, kv_len += 1, step += 1.  Keeps the host out of the token loop so one captured step can be replayed. */

@@ -260,12 +260,8 @@ def kv_append_paged(k_new, v_new, kpool, vpool, block_table, kv_len, batch, widt
         vpool[r, :width] = v_new[b, :width]
 
 
-def attn_decode_counters(batch, nkv, device):
-    return torch.zeros((batch * nkv,), dtype=torch.int32)
-
-
 def attn_decode_paged(q, kpool, vpool, block_table, kv_len, len_add, max_len, part_o, part_ml, out, batch, nq, nkv, head_dim,
-                      softmax_scale, counters=None):
+                      softmax_scale):
     D, grp = head_dim, nq // nkv
     for b in range(batch):
         n = int(kv_len[b]) + len_add
@@ -279,7 +275,7 @@ def attn_decode_paged(q, kpool, vpool, block_table, kv_len, len_add, max_len, pa
 
 
 def attn_decode_fused(qkv, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len, max_len, part_o, part_ml, out, batch, nq, nkv,
-                      head_dim, head_dim_padded, eps, use_norm, softmax_scale, counters=None):
+                      head_dim, head_dim_padded, eps, use_norm, softmax_scale):
     """decode_qkv_post + attn_decode_paged in one launch; the projection buffer stays untouched (the kernel works on copies in LDS)."""
     tmp = qkv.clone()
     decode_qkv_post(tmp, cos, sin, q_w, k_w, kpool, vpool, block_table, kv_len, batch, nq, nkv, head_dim, head_dim_padded, eps, use_norm)
@@ -745,7 +741,7 @@ def chw_f32_to_u8(src):
 _NAMES = ["gemm", "gemv", "gemv_mb", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
-          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "attn_decode_counters", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
+          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
           "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32", "conv_gemm_bf16", "groupnorm_bf16", "groupnorm_bf16_workspace_floats", "softmax_rows_bf16", "vae_reparam_bf16", "chw_bf16_to_u8",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "layernorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
           "act_bwd", "swiglu_fwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]

@@ -116,14 +116,6 @@ def test_decode_attention_at_benchmark_context(n_keys):
         out = torch.full((B, nq * D), float("nan"), dtype=BF16, device=DEV)
         o.attn_decode_paged(new, pg.k[0], pg.v[0], pg.block_table, pg.kv_len, 1, max_len, po, pml, out, B, nq, nkv, D, scale)
         close(out, ref, what=f"decode attention {n_keys} keys, grid for {max_len}")
-        ctr = o.attn_decode_counters(B, nkv, DEV)                 # one-launch form (last-arriver merge), twice on the same counters
-        for rep in range(2):
-            po.fill_(float("nan")); pml.fill_(float("nan"))
-            out1 = torch.full((B, nq * D), float("nan"), dtype=BF16, device=DEV)
-            o.attn_decode_paged(new, pg.k[0], pg.v[0], pg.block_table, pg.kv_len, 1, max_len, po, pml, out1, B, nq, nkv, D, scale, counters=ctr)
-            close(out1, ref, what=f"one-launch decode attention {n_keys} keys, grid for {max_len}")
-            close(out1, out, ulps=1, what="one-launch vs two-launch form")
-            assert int(ctr.abs().sum()) == 0
     # fused form on RAW projection rows vs decode_qkv_post + attention
     qw, kw = (1.0 + 0.1 * rnd(D, seed=21).float()).to(BF16).to(DEV), (1.0 + 0.1 * rnd(D, seed=22).float()).to(BF16).to(DEV)
     pos = torch.tensor([n_keys - 1], dtype=torch.long, device=DEV)

@@ -29,12 +29,11 @@ def main():
     qw = torch.ones(D, device=DEV, dtype=BF16)
     po, pml = ops.attn_decode_workspace(B, nq, D, ctx + 8, DEV)
     out = torch.empty(B, nq * D, device=DEV, dtype=BF16)
-    ctr = ops.attn_decode_counters(B, nkv, DEV) if os.environ.get("BAGEL_DECODE_ARRIVE", "1") == "1" else None    # one launch (last-arriver merge) vs split + combine
 
     def call(i):
         li = i % L
         ops.attn_decode_fused(qkv, cos, sin, qw, qw, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, ctx + 1, po, pml, out, B, nq, nkv, D, D, 1e-6, True,
-                              D ** -0.5, counters=ctr)
+                              D ** -0.5)
     for i in range(4):
         call(i)
     torch.cuda.synchronize()
@@ -48,7 +47,7 @@ def main():
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 24 * 1e3)
     mb = B * ctx * width * 2 * 2 / 1e6
-    print(f"B={B} ctx={ctx} cpw={os.environ.get('BAGEL_DEC_CPW', 'auto')} {'one launch' if ctr is not None else 'split + combine'}: {best:.1f} us per layer (attention + combine), {mb:.0f} MB of KV = {mb / best:.2f} TB/s", flush=True)
+    print(f"B={B} ctx={ctx} cpw={os.environ.get('BAGEL_DEC_CPW', 'auto')}: {best:.1f} us per layer (attention + combine), {mb:.0f} MB of KV = {mb / best:.2f} TB/s", flush=True)
 
 
 if __name__ == "__main__":
