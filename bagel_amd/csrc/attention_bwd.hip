@@ -25,7 +25,9 @@
 // global -> registers -> LDS (two barriers per tile; not yet the LDS-DMA ring of the forward): in the dkv kernel (one wave per SIMD,
 // its accumulators fill the register file) with the loads of step t + 1 issued before the products of step t, in the dq kernel with
 // two workgroups per CU covering each other's latencies; tiles that every row of the item sees completely
-// take a mask-free path; exponentials in base 2 with scale * log2(e) folded into one multiply (the lse workspace holds log2 values).
+// take a mask-free path; exponentials in base 2 with scale * log2(e) and the row's log-sum-exp folded into ONE fma per score (the lse workspace
+// holds log2 values; the build runs with -ffp-contract=off, so the fma is spelled out: one VALU instruction less per score in kernels whose lone
+// wave is issue-bound).
 #include "common.h"
 #include <stdlib.h>
 
@@ -324,14 +326,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             if (AB_ABL & 2) { ds[i] = s[i] + dp[i]; continue; }
-                            ds[i] = __builtin_amdgcn_exp2f(s[i] * c2 - lse2) * (dp[i] - delta);
+                            ds[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -lse2)) * (dp[i] - delta);
                         }
                     } else {
                         const unsigned ok = mask16(t, nb, kb);
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             if (AB_ABL & 2) { ds[i] = s[i] + dp[i]; continue; }
-                            const float e = __builtin_amdgcn_exp2f(s[i] * c2 - lse2);
+                            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -lse2));
                             ds[i] = (((ok >> i) & 1u) ? e : 0.f) * (dp[i] - delta);
                         }
                     }
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     if (AB_ABL & 2) { pr[i] = s[i]; ds[i] = dp[i]; continue; }
-                    pr[i] = __builtin_amdgcn_exp2f(s[i] * c2 - lv[i]);
+                    pr[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -lv[i]));
                     ds[i] = pr[i] * (dp[i] - dl[i]);
                 }
             } else {
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
                     const unsigned ok = (unsigned)kvalid & (unsigned)(qrow >= qbeg) & (unsigned)(qrow < qend) &
                                         ((unsigned)(qrow >= send) | (unsigned)(causal == 0) | (unsigned)(krow <= qrow));
                     if (AB_ABL & 2) { pr[i] = s[i]; ds[i] = dp[i]; continue; }
-                    const float e = __builtin_amdgcn_exp2f(s[i] * c2 - lv[i]);
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -lv[i]));
                     pr[i] = ok ? e : 0.f;
                     ds[i] = pr[i] * (dp[i] - dl[i]);
                 }

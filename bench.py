@@ -625,7 +625,9 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             nb, nn = 16, 160         # (step 0 runs eagerly and the hipGraph capture follows it: amortised over the run)
             cb, lb, rb, _ = prefill(nb)
             sb = model.prepare_start_tokens(lb, rb, ids)
-            model.generate_text(past_key_values=cb, max_length=4, do_sample=False, end_token_id=None, **sb)
+            # warm-up with the SAME length: the call re-allocates the merged caches on the way out (16 x (4936 + 160) rows x 28 layers), and a warm-up
+            # of another length left the timed call ~80 ms of first-time hipMalloc (0.5 ms per step of 160) -- a serving process is past that
+            model.generate_text(past_key_values=cb, max_length=nn, do_sample=False, end_token_id=None, **sb)
             cb, lb, rb, _ = prefill(nb)
             sb = model.prepare_start_tokens(lb, rb, ids)
             fence()
