@@ -16,7 +16,9 @@ batches.  That bound is set against the REFERENCE'S OWN noise: tools/train_grad_
 fp32-accumulating linears (same bf16 operands and rounding points, another summation order -- what another CPU backend or a GPU does) and
 the reference's gradients move by up to 1.9e-2 at 7B width, 8.7e-3 on tiny_d128, 2.1e-3 on tiny (profiles/r03_train_grad_noise_floor.log);
 the product adds flash-attn's bf16 P / dS and its own rounding points on top: measured 2.8e-2 (tiny), 1.7e-2 (tiny_d128), 2.4e-2 (7B width),
-2.9e-2 (SigLIP width).  Frozen rule: <= max(4e-2, 2 x floor); 6e-2 for the text-only / RoPE-variant packs, 8e-2 in the CPU fuzz."""
+2.9e-2 (SigLIP width).  Round 4 (the last review called 4e-2 loose for 107 tensors): per tensor <= 3.5e-2 (measured worst 2.4e-2 - 2.9e-2: the tail is
+1-D norm weights / biases) AND the median over the tensors <= 1.6e-2 (measured 1.1e-2 - 1.25e-2; a wrong kernel moves the bulk, not the tail); 6e-2 for
+the text-only / RoPE-variant packs, 8e-2 in the CPU fuzz."""
 import pytest
 import torch
 
@@ -275,8 +277,9 @@ def _step(model, batch, noise, w_ce):
     return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
 
 
-def _compare(grads, ref, names, tol, what, key_bias_is_zero=True):
+def _compare(grads, ref, names, tol, what, key_bias_is_zero=True, median_tol=None):
     worst = ("", 0.0)
+    every = []
     for n in names:
         rn = float(ref[n].float().norm())
         if key_bias_is_zero and n.startswith("vit_model.") and n.endswith("k_proj.bias"):
@@ -291,8 +294,15 @@ def _compare(grads, ref, names, tol, what, key_bias_is_zero=True):
         assert n in grads, (what, n, "no gradient")
         assert torch.isfinite(grads[n].float()).all(), (what, n)
         d = rel(grads[n], ref[n])
+        every.append(d)
         worst = max(worst, (n, d), key=lambda x: x[1])
         assert d < tol, (what, n, d)
+    if every:
+        med = sorted(every)[len(every) // 2]
+        print(f"{what}: {len(every)} gradient tensors, rel-L2 median {med:.2e}, worst {worst[1]:.2e} ({worst[0]})")
+        # the per-tensor bound is set by the noisiest tensors (1-D norm weights and biases that sum few, large terms); the BULK has to sit well
+        # below it -- a wrong kernel moves every tensor, not the tail
+        assert median_tol is None or med < median_tol, (what, "median", med)
     return worst
 
 
@@ -315,10 +325,10 @@ def test_training_step_gradients_match_the_oracle(golden, monkeypatch, name, kee
         rloss, rgrads, _ = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
         loss, grads = _step(model, batch, noise, w_ce)
         assert abs(loss - rloss) < 2e-2 * abs(rloss)
-        worst = _compare(grads, rgrads, names, 4e-2, name)
+        worst = _compare(grads, rgrads, names, 3.5e-2, name, median_tol=1.6e-2)
         print(f"[{name}] {len(names)} gradients, worst rel-L2 {worst[1]:.2e} at {worst[0]}")
         if name == "tiny":
-            _compare(grads, golden("tiny_train_grads")["grads"], names, 4e-2, "reference fixture")
+            _compare(grads, golden("tiny_train_grads")["grads"], names, 3.5e-2, "reference fixture", median_tol=1.6e-2)
         loss2, grads2 = _step(model, batch, noise, w_ce)               # (d) no atomics: bit-identical on a second run
         assert loss2 == loss
         for n in grads:
@@ -411,7 +421,7 @@ def test_training_step_gradients_at_7b_width():
     rloss, rgrads, _ = O.training_step_grads(W, cfg, batch, noise, w_ce, names=set(names))
     loss, grads = _step(model, batch, noise, w_ce)
     assert abs(loss - rloss) < 2e-2 * abs(rloss)
-    worst = _compare(grads, rgrads, names, 4e-2, "wide7b")
+    worst = _compare(grads, rgrads, names, 3.5e-2, "wide7b", median_tol=1.6e-2)
     print(f"[wide7b] {len(names)} gradients, worst rel-L2 {worst[1]:.2e} at {worst[0]}")
 
 
