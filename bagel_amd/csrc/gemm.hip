@@ -598,9 +598,6 @@ static int launch_gemm_pp(const GemmParams& p0, hipStream_t stream) {
 #ifndef BAGEL_PQ_M0MODE
 #define BAGEL_PQ_M0MODE 0              /* experiment: how the SGPR-base DMA handles M0 (see issue() in gemm_pq_kernel) */
 #endif
-#ifndef BAGEL_PQ_NTSTORE
-#define BAGEL_PQ_NTSTORE 0             /* experiment: non-temporal stores of the C tile (tools/ab_build.sh) */
-#endif
 #ifndef BAGEL_PQ_ABL
 #define BAGEL_PQ_ABL 0                 /* timing-only ablations of the SwiGLU epilogue (tools/ab_build.sh): 1 no exp/rcp, 2 no global stores */
 #endif
@@ -995,11 +992,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 #if BAGEL_PQ_ABL & 2                 /* timing-only ablation (wrong results): no global stores; the staged tile is kept live */
                     asm volatile("" ::"v"(v));
 #else
-#if BAGEL_PQ_NTSTORE
-                    if (col_ok && m0 + it * 32 + rb < Mg) __builtin_nontemporal_store(v, (u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc));
-#else
                     if (col_ok && m0 + it * 32 + rb < Mg) *(u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc) = v;
-#endif
 #endif
                 }
             }
@@ -1107,11 +1100,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = pack2bf(lo2f(v[e]) + lo2f(rv[it][e]), hi2f(v[e]) + hi2f(rv[it][e]));
                     }
-#if BAGEL_PQ_NTSTORE
-                    if (col_ok && m0 + r < Mg) __builtin_nontemporal_store(v, (u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc));
-#else
                     if (col_ok && m0 + r < Mg) *(u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc) = v;
-#endif
                 }
                 PP_LGKM0();
             }
