@@ -956,8 +956,9 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
     expert, bf16 cast points for BOTH experts' QK-norm (no fp32 path here, unlike forward_inference's gen mode), and the
     block mask executed as per-split sequences (TrainPlan).  With a ``tape`` (train_step.TrainTape) every layer writes its residual
     streams, raw projection, attention output and SwiGLU output into buffers of its own, which the tape keeps for the backward."""
-    if not self.mot:
-        raise NotImplementedError("forward_train is built for Qwen2MoTDecoderLayer (BAGEL's layer_module)")
+    if not self.mot and tape is not None:
+        raise NotImplementedError("the training BACKWARD (tape) is built for Qwen2MoTDecoderLayer (BAGEL's layer_module); the dense and MoE layer "
+                                  "kinds run the training forward only (qwen2_navit.py:620-646,852-883)")
     if seq.shape != (tp.M, self.H):
         raise ValueError(f"packed sequence shape {tuple(seq.shape)} != ({tp.M}, {self.H})")
     dev = self.device
@@ -980,10 +981,14 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
     x.copy_(seq)
     q_v, k_v, v_v = qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:]
     two = tp.n_vae > 0
-    expert = tp.expert if two else None
+    # which parts are per modality: everything for MoT; the MLP and the model's final norm for Qwen2MoEDecoderLayer (shared attention and layer
+    # norms, qwen2_navit.py:852-883,1003-1012); nothing for Qwen2DecoderLayer (:620-646)
+    two_attn, two_mlp = two and self.mot, two and self.moe_mlp
+    expert = tp.expert if two_attn else None
     scale = hd ** -0.5
 
-    def groups(w, b=None):
+    def groups(w, b=None, two=None):
+        two = two_attn if two is None else two
         if two:
             return dict(W0=w[0], bias0=None if b is None else b[0], a_rows0=tp.text_idx, c_rows0=tp.text_idx, M0=tp.n_text,
                         W1=w[1], bias1=None if b is None else b[1], a_rows1=tp.vae_idx, c_rows1=tp.vae_idx, M1=tp.n_vae)
@@ -997,14 +1002,14 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
                                            tb("x", li + 1, M, self.H))
             lse = tb("lse", li, nq, M, dtype=torch.float32)
             tape.qkv_raw.append(raw); tape.att.append(att); tape.act.append(act); tape.x_mid.append(x_mid); tape.x.append(x_out); tape.lse.append(lse)
-        ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if two else None, expert=expert)
+        ops.rmsnorm(x, P.ln_in[0], h, self.eps, w1=P.ln_in[1] if two_attn else None, expert=expert)
         if tape is not None:
             ops.gemm(h, C=raw, **groups(P.wqkv, P.bqkv))
             qkv.copy_(raw)
         else:
             ops.gemm(h, C=qkv, **groups(P.wqkv, P.bqkv))
         ops.qknorm_rope(qkv, tp.cos, tp.sin, P.qn[0] if self.use_norm else None, P.kn[0] if self.use_norm else None,
-                        P.qn[1] if (self.use_norm and two) else None, P.kn[1] if (self.use_norm and two) else None,
+                        P.qn[1] if (self.use_norm and two_attn) else None, P.kn[1] if (self.use_norm and two_attn) else None,
                         expert, nq, nkv, hd, dp, self.eps, gen_mode=False, use_norm=self.use_norm)
         ops.v_transpose(v_v, vt, tp.cu_splits, tp.new_col, tp.n_splits, tp.max_split, nkv, dp)
         if tp.n_clean:
@@ -1016,19 +1021,19 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
                                    k_ctx=k_clean, vt_ctx=vt_clean, ctx_start=g["cs"], ctx_end=g["ce"], vt_ctx_col=g["ccol"],
                                    lse=lse if tape is not None else None)
         ops.gemm(att, C=x_mid, residual=x, **groups(P.wo))
-        ops.rmsnorm(x_mid, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if two else None, expert=expert)
+        ops.rmsnorm(x_mid, P.ln_post[0], h, self.eps, w1=P.ln_post[1] if two_attn else None, expert=expert)
         if tape is not None and tape.keep_gate_up:
             gu = tb("gu", len(tape.gu), M, 2 * self.I)        # the tape keeps the un-activated projection: no recompute in the backward
             tape.gu.append(gu)
             ops.gemm(h, C=gu, **groups(P.wgu))
             ops.swiglu_fwd(gu, act)                           # same bits as the fused epilogue
         else:
-            ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu))
-        ops.gemm(act, C=x_out, residual=x_mid, **groups(P.wd))
+            ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu, two=two_mlp))
+        ops.gemm(act, C=x_out, residual=x_mid, **groups(P.wd, two=two_mlp))
         x = x_out
     out = torch.empty_like(x)
     m = self.model
-    ops.rmsnorm(x, m.norm.weight.data, out, self.eps, w1=m.norm_moe_gen.weight.data if two else None, expert=expert)
+    ops.rmsnorm(x, m.norm.weight.data, out, self.eps, w1=m.norm_moe_gen.weight.data if two_mlp else None, expert=tp.expert if two_mlp else None)
     return out
 
 

@@ -646,11 +646,61 @@ def mot_attention_train(W, pre, cfg, x, sample_lens, masks, cos_sin, und_idx, ge
 
 
 @_explicit_casts
+def shared_attention_train(W, pre, cfg, x, sample_lens, masks, cos_sin):
+    """PackedAttention.forward_train, qwen2_navit.py:252-320: ONE set of projections / QK-norms over the whole packed sequence (the attention of
+    Qwen2DecoderLayer and of Qwen2MoEDecoderLayer); everything after the projections is mot_attention_train's."""
+    nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    hd = cfg["hidden_size"] // nh
+    eps = cfg["rms_norm_eps"]
+    a = pre + ".self_attn."
+    q = linear(x, W[a + "q_proj.weight"], W[a + "q_proj.bias"]).view(-1, nh, hd)
+    k = linear(x, W[a + "k_proj.weight"], W[a + "k_proj.bias"]).view(-1, nkv, hd)
+    v = linear(x, W[a + "v_proj.weight"], W[a + "v_proj.bias"]).view(-1, nkv, hd)
+    q_, k_ = rmsnorm(q, W[a + "q_norm.weight"], eps), rmsnorm(k, W[a + "k_norm.weight"], eps)
+    cos, sin = cos_sin
+    q_, k_ = apply_rope(q_, k_, cos, sin)
+    g = nh // nkv
+    k_ = k_[:, :, None, :].repeat(1, 1, g, 1).reshape(-1, nh, hd)
+    vv = v[:, :, None, :].repeat(1, 1, g, 1).reshape(-1, nh, hd)
+    outs = []
+    for qs, ks, vs, m in zip(q_.transpose(0, 1).split(sample_lens, dim=1), k_.transpose(0, 1).split(sample_lens, dim=1),
+                             vv.transpose(0, 1).split(sample_lens, dim=1), masks):
+        o = F.scaled_dot_product_attention(qs.to(BF16).unsqueeze(0), ks.to(BF16).unsqueeze(0), vs.to(BF16).unsqueeze(0),
+                                           m.to(BF16).unsqueeze(0))
+        outs.append(o.squeeze(0))
+    o = torch.cat(outs, dim=1).transpose(0, 1).reshape(-1, nh * hd)
+    return linear(o, W[a + "o_proj.weight"])
+
+
+@_explicit_casts
 def llm_forward_train(W, cfg, x, sample_lens, masks, position_ids, und_idx, gen_idx):
-    """Qwen2Model.forward_train + Qwen2MoTDecoderLayer.forward_train, qwen2_navit.py:970-1016,713-755."""
+    """Qwen2Model.forward_train + Qwen2MoTDecoderLayer.forward_train, qwen2_navit.py:970-1016,713-755; with ``cfg['layer_module']`` also
+    Qwen2DecoderLayer.forward_train (:620-646: no routing at all) and Qwen2MoEDecoderLayer.forward_train (:852-883: shared attention and
+    layer norms, per-modality MLP; the model's final norm is per modality for both "Mo" kinds, :1003-1012)."""
     hd = cfg["hidden_size"] // cfg["num_attention_heads"]
     eps = cfg["rms_norm_eps"]
     cos_sin = rope_tables(position_ids, hd, cfg["rope_theta"], x.dtype)
+    kind = cfg.get("layer_module", "Qwen2MoTDecoderLayer")
+    if kind != "Qwen2MoTDecoderLayer":
+        for i in range(cfg["num_hidden_layers"]):
+            pre = f"language_model.model.layers.{i}"
+            res = x
+            x = res + shared_attention_train(W, pre, cfg, rmsnorm(x, W[pre + ".input_layernorm.weight"], eps), sample_lens, masks, cos_sin)
+            res = x
+            h = rmsnorm(x, W[pre + ".post_attention_layernorm.weight"], eps)
+            if kind == "Qwen2MoEDecoderLayer":
+                hn = h.new_zeros(h.shape)
+                hn[und_idx] = silu_mlp(h[und_idx], W, pre + ".mlp")
+                hn[gen_idx] = silu_mlp(h[gen_idx], W, pre + ".mlp_moe_gen")
+                x = res + hn
+            else:
+                x = res + silu_mlp(h, W, pre + ".mlp")
+        if kind == "Qwen2MoEDecoderLayer":
+            y = torch.zeros_like(x)
+            y[und_idx] = rmsnorm(x[und_idx], W["language_model.model.norm.weight"], eps)
+            y[gen_idx] = rmsnorm(x[gen_idx], W["language_model.model.norm_moe_gen.weight"], eps)
+            return y
+        return rmsnorm(x, W["language_model.model.norm.weight"], eps)
     for i in range(cfg["num_hidden_layers"]):
         pre = f"language_model.model.layers.{i}"
         res = x

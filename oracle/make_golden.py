@@ -551,6 +551,10 @@ def main():
         path = os.path.join(GOLD, f"{cfg['name']}_t2i.pt")
         torch.save(data, path)
         print(f"[golden] {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  oracle == reference bit-exact")
+        data = scenario_train(cfg, model, vae, W, VW)              # the training forward of the dense / MoE layer kinds (qwen2_navit.py:620-646,852-883)
+        path = os.path.join(GOLD, f"{cfg['name']}_train.pt")
+        torch.save(data, path)
+        print(f"[golden] {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  oracle == reference bit-exact")
     for cfg in (TINY, TINY_D128, TINY_ROPE):
         if args.only == "kinds":
             continue

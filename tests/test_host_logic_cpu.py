@@ -181,11 +181,12 @@ def test_taylorseer_host_path_matches_reference(golden, monkeypatch, name):
             assert rel(a, b) < 4e-2, tag
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_dense", "tiny_moe"])
 @pytest.mark.parametrize("mask_api", ["nested", "splits"])
 def test_training_forward_host_path_matches_reference(golden, monkeypatch, name, mask_api):
     """Bagel.forward: TrainPlan (block mask decomposed into per-split sequences with overlapping clean-key prefixes), und / gen
-    routing, per-image timestep embedding rows, loss row selection -- vs the reference's per-token losses."""
+    routing, per-image timestep embedding rows, loss row selection -- vs the reference's per-token losses.  tiny_dense / tiny_moe: the
+    training forward of Qwen2DecoderLayer (no routing) and Qwen2MoEDecoderLayer (shared attention, per-modality MLP + final norm)."""
     mock_ops.install(monkeypatch)
     cfg = CFGS[name]
     g = golden(f"{name}_train")
@@ -197,6 +198,17 @@ def test_training_forward_host_path_matches_reference(golden, monkeypatch, name,
     out = model(noise=g["noise"], **batch)
     assert out["mse"].shape == g["mse"].shape and out["ce"].shape == g["ce"].shape
     assert rel(out["ce"], g["ce"]) < 2e-2 and rel(out["mse"], g["mse"]) < 5e-2
+
+
+def test_training_backward_of_the_dense_and_moe_layer_kinds_is_refused(golden, monkeypatch):
+    """The reverse kernels are built for BAGEL's MoT layer kind; the other two kinds run the training forward only and say so."""
+    mock_ops.install(monkeypatch)
+    g = golden("tiny_moe_train")
+    model = cpu_model(CFGS["tiny_moe"])
+    model.to(torch.bfloat16)
+    next(p for n, p in model.named_parameters() if n.endswith("layers.0.mlp.down_proj.weight")).requires_grad_(True)
+    with torch.enable_grad(), pytest.raises(NotImplementedError, match="training BACKWARD"):
+        model(noise=g["noise"], **g["batch"])
 
 
 def _tokens_match(ours, ref, ref_logits, what):

@@ -178,9 +178,10 @@ def test_taylorseer_schedule_known_answer():
     assert st.activated_steps[:8] == [0, 0, 1, 2, 3, 4, 7, 10]
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_dense", "tiny_moe"])
 def test_training_forward_matches_reference(golden, name):
-    """Bagel.forward (bagel.py:101-229) with nested masks: per-token MSE and CE losses bit-exact; the mask rule restated."""
+    """Bagel.forward (bagel.py:101-229) with nested masks: per-token MSE and CE losses bit-exact; the mask rule restated.  tiny_dense / tiny_moe:
+    the dense and MoE layer kinds' forward_train (qwen2_navit.py:620-646,852-883)."""
     cfg = CFGS[name]
     g = golden(f"{name}_train")
     W, _ = oracle_weights(cfg)

@@ -60,6 +60,8 @@ def test_oracle_bit_exact_vs_live_reference_variants(cfg):
     model, vae, W, VW = G.build(cfg)
     fn = G.scenario_siglip if cfg is TINY_ROPE else G.scenario_layer_kind
     assert fn(cfg, model, vae, W, VW)
+    if cfg is not TINY_ROPE:                       # the TRAINING forward of the dense / MoE kinds (qwen2_navit.py:620-646,852-883) against the live reference
+        assert G.scenario_train(cfg, model, vae, W, VW)
 
 
 def _same_out(a, b, what):
