@@ -386,6 +386,69 @@ extern "C" int bagel_quantize_nf4(const void* w, int64_t ldw, void* q, int64_t l
     return bagel_check_launch("quantize_nf4_kernel");
 }
 
+// De-quantise NF4 codes to bf16 weights: w = bf16(code_book[code] * absmax[block]) -- what bitsandbytes' matmul_4bit does in front of F.linear whenever
+// more than one activation row is multiplied (app.py:114-125's model at prefill / denoise sizes): the WHOLE-MODEL 4-bit mode of the engines
+// (MoTEngine weight_store="nf4") keeps the codes resident and materialises one layer's bf16 matrices at a time with this kernel.
+// One thread per 16 codes (8 bytes in, 32 bytes out).
+__global__ __launch_bounds__(256) void dequantize_nf4_kernel(const unsigned char* __restrict__ q, long ldq, const float* __restrict__ absmax,
+                                                             bf16_t* __restrict__ out, long ldo, int rows, int cols) {
+    const int per_row = cols >> 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * per_row) return;
+    const int row = (int)(i / per_row), c16 = (int)(i % per_row);
+    const float am = absmax[(long)row * (cols >> 6) + (c16 >> 2)];
+    const u32x2_t v = *(const u32x2_t*)(q + (long)row * ldq + (long)c16 * 8);
+    unsigned o[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned byte = (v[b >> 2] >> (8 * (b & 3))) & 0xffu;
+        o[b] = pack2bf(NF4_CODE_DEV[byte >> 4] * am, NF4_CODE_DEV[byte & 15u] * am);          // even element in the high nibble
+    }
+    bf16_t* dst = out + (long)row * ldo + (long)c16 * 16;
+    *(u32x4_t*)dst = (u32x4_t){o[0], o[1], o[2], o[3]};
+    *(u32x4_t*)(dst + 8) = (u32x4_t){o[4], o[5], o[6], o[7]};
+}
+
+extern "C" int bagel_dequantize_nf4_bf16(const void* q, int64_t ldq_bytes, const float* absmax, void* out, int64_t ld_out, int32_t rows,
+                                         int32_t cols, hipStream_t stream) {
+    BAGEL_REQUIRE(q && absmax && out, "dequantize_nf4: null pointer");
+    BAGEL_REQUIRE(cols > 0 && (cols % 64) == 0 && (ldq_bytes % 8) == 0 && (ld_out % 8) == 0, "dequantize_nf4: cols %% 64, ldq %% 8 bytes, ld_out %% 8");
+    BAGEL_REQUIRE((((uintptr_t)q) & 7) == 0 && (((uintptr_t)out) & 15) == 0, "dequantize_nf4: q must be 8-byte, out 16-byte aligned");
+    if (rows <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(dequantize_nf4_kernel, dim3(ceil_div((long)rows * (cols / 16), 256)), dim3(256), 0, stream, (const unsigned char*)q,
+                       (long)ldq_bytes, absmax, (bf16_t*)out, (long)ld_out, rows, cols);
+    return bagel_check_launch("dequantize_nf4_kernel");
+}
+
+// De-quantise row-wise absmax INT8 (bagel_quantize_rows_i8) to bf16: w = bf16((q - 128) * scale[row]); one thread per 8 weights.
+__global__ __launch_bounds__(256) void dequantize_rows_i8_kernel(const unsigned char* __restrict__ q, long ldq, const float* __restrict__ scale,
+                                                                 bf16_t* __restrict__ out, long ldo, int rows, int cols) {
+    const int per_row = cols >> 3;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * per_row) return;
+    const int row = (int)(i / per_row), c8 = (int)(i % per_row);
+    const float sc = scale[row];
+    const u32x2_t v = *(const u32x2_t*)(q + (long)row * ldq + (long)c8 * 8);
+    unsigned o[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int lo = (int)((v[b >> 1] >> (16 * (b & 1))) & 0xffu) - 128, hi = (int)((v[b >> 1] >> (16 * (b & 1) + 8)) & 0xffu) - 128;
+        o[b] = pack2bf((float)lo * sc, (float)hi * sc);
+    }
+    *(u32x4_t*)(out + (long)row * ldo + (long)c8 * 8) = (u32x4_t){o[0], o[1], o[2], o[3]};
+}
+
+extern "C" int bagel_dequantize_rows_i8_bf16(const void* q, int64_t ldq, const float* scale, void* out, int64_t ld_out, int32_t rows, int32_t cols,
+                                             hipStream_t stream) {
+    BAGEL_REQUIRE(q && scale && out, "dequantize_rows_i8: null pointer");
+    BAGEL_REQUIRE(cols > 0 && (cols % 8) == 0 && (ldq % 8) == 0 && (ld_out % 8) == 0, "dequantize_rows_i8: cols %% 8, ldq %% 8, ld_out %% 8");
+    BAGEL_REQUIRE((((uintptr_t)q) & 7) == 0 && (((uintptr_t)out) & 15) == 0, "dequantize_rows_i8: q must be 8-byte, out 16-byte aligned");
+    if (rows <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(dequantize_rows_i8_kernel, dim3(ceil_div((long)rows * (cols / 8), 256)), dim3(256), 0, stream, (const unsigned char*)q, (long)ldq,
+                       scale, (bf16_t*)out, (long)ld_out, rows, cols);
+    return bagel_check_launch("dequantize_rows_i8_kernel");
+}
+
 struct GemvNf4Params {
     const bf16_t* A; long lda;
     const unsigned char* W; long ldw;      // packed codes [N, K / 2]

@@ -596,6 +596,30 @@ class Bagel(nn.Module):
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     @_bf16_weights
+    def quantize_language_model(self, kind="nf4", release_bf16=True):
+        """The reference's quantised LOAD MODES (app.py:114-131: bitsandbytes NF4 resp. INT8 over every nn.Linear of the language model) for the whole
+        forward path -- prefill, the denoise loop and text decode.  The decoder layers' projections are kept as NF4 codes + fp32 block absmax ("nf4":
+        blocks of 64, no double quantisation) or row-wise absmax INT8 ("int8"); a layer's bf16 matrices are materialised right before its GEMMs
+        (``w = bf16(code_book[code] * absmax)``: bitsandbytes' matmul_4bit in front of F.linear) and the Lq = 1 decode streams the codes themselves.
+        Embeddings, lm_head, norms, biases, ViT / connector / VAE stay bf16 like the library leaves non-Linear and skipped modules.
+        ``release_bf16=True`` frees the bf16 projection weights afterwards (28.3 -> 8.6 GB at 7B with "nf4"); reload the checkpoint to go back.
+        An option that changes results, like the reference's modes; parity with bitsandbytes' binaries is unpinned (oracle/nf4.py)."""
+        lm = self.language_model
+        self._ensure_bf16()
+        lm.weight_store = kind
+        lm.invalidate_packed()
+        eng = lm.engine()
+        if release_bf16:
+            for L in lm.model.layers:
+                mods = [getattr(L.self_attn, n + s) for n in ("q_proj", "k_proj", "v_proj", "o_proj") for s in (("", "_moe_gen") if eng.mot else ("",))]
+                for s in (("", "_moe_gen") if eng.moe_mlp else ("",)):
+                    m = getattr(L, "mlp" + s)
+                    mods += [m.gate_proj, m.up_proj, m.down_proj]
+                for m in mods:
+                    m.weight.data = torch.empty(0, dtype=m.weight.dtype, device=m.weight.device)
+            lm._packed_fresh()
+        return eng.layers.resident_bytes()
+
     def generate_text(self, past_key_values, packed_key_value_indexes, key_values_lens, packed_start_tokens,
                       packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None,
                       use_graph=None, weight_quant=None):

@@ -141,6 +141,10 @@ class DecodeSession:
         # modes keep it): "int8" = row-wise absmax W8A16, de-quantised on the VALU (csrc/quant.hip); "mxfp4" = OCP-MX FP4 blocks of 32
         # with E8M0 scales x FP8 activations on the block-scaled MFMA (csrc/mxfp4.hip), the counterpart of the reference's NF4 mode.
         # The engine caches the quantised copies next to the bf16 ones.
+        if weight_quant is None and getattr(eng, "weight_store", None) is not None:
+            weight_quant = eng.weight_store            # a quantised engine decodes on its stored codes (the 4- / 8-bit gemv kernels), not on scratch copies
+        if getattr(eng, "weight_store", None) is not None and weight_quant != eng.weight_store:
+            raise NotImplementedError(f"the engine holds {eng.weight_store} weights: weight_quant={weight_quant!r} would re-quantise de-quantised copies")
         if weight_quant not in (None, "int8", "mxfp4", "nf4"):
             raise NotImplementedError(f"weight_quant={weight_quant!r}: 'int8' (row-wise absmax, W8A16), 'mxfp4' (OCP-MX FP4, W4A8) and 'nf4' "
                                       "(bitsandbytes NF4 blocks of 64, W4A16: the reference's own 4-bit mode) are built")
@@ -163,6 +167,10 @@ class DecodeSession:
         eng = self.eng
         attr = {"int8": "_w8_cache", "mxfp4": "_w4_cache", "nf4": "_nf4_cache"}[self.weight_quant]
         cache = getattr(eng, attr, None)
+        if cache is None and getattr(eng, "weight_store", None) == self.weight_quant:
+            # whole-model load mode: the und expert's stored codes ARE the decode weights
+            cache = [{name: st[name][0] for name in ("wqkv", "wo", "wgu", "wd")} for st in eng.layers.stored]
+            setattr(eng, attr, cache)
         if cache is None:
             qz = {"int8": ops.quantize_rows_i8, "mxfp4": ops.quantize_rows_mxfp4, "nf4": ops.quantize_nf4}[self.weight_quant]
             cache = [dict(wqkv=qz(P.wqkv[0]), wo=qz(P.wo[0]), wgu=qz(P.wgu[0]), wd=qz(P.wd[0])) for P in eng.layers]
@@ -202,7 +210,8 @@ class DecodeSession:
                 ops.rmsnorm(inp, norm_w, h, eng.eps)
                 inp = h
             return ops.gemm(inp, w, out, bias0=kw.get("bias"), residual=kw.get("residual"), epilogue=kw.get("epilogue", ops.EPI_NONE), M0=B)
-        for li, P in enumerate(eng.layers):
+        layers = eng.layers.small_views() if getattr(eng, "weight_store", None) is not None else eng.layers      # (a quantised engine: no scratch copies here)
+        for li, P in enumerate(layers):
             Q = self.w8[li] if self.w8 is not None else None
             proj(x, Q["wqkv"] if Q else P.wqkv[0], qkv, norm_w=P.ln_in[0], bias=P.bqkv[0])
             if self.fused_attention:

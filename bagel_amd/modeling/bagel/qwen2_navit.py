@@ -655,10 +655,69 @@ class _PackedLayer:
     __slots__ = ("wqkv", "bqkv", "wo", "wgu", "wd", "qn", "kn", "ln_in", "ln_post", "wt")    # wt: transposed images for the training backward
 
 
+class _StoredLayers:
+    """``MoTEngine.layers`` of a quantised engine: a sequence whose items are materialised on access.  Layer i's packed bf16 matrices are
+    de-quantised into scratch set i % 2 (two sets: a consumer may still hold the previous layer's view while it asks for the next), small
+    tensors (biases, norm weights) are kept as they are.  Only the inference forwards iterate it; training and the fp8 option refuse."""
+    MATS = ("wqkv", "wo", "wgu", "wd")
+
+    def __init__(self, eng, modules, kind):
+        self.eng, self.kind = eng, kind
+        quant = ops.quantize_nf4 if kind == "nf4" else ops.quantize_rows_i8
+        self.stored, self.small = [], []
+        for L in modules:
+            P = eng._pack_layer(L)
+            for name in self.MATS:
+                for w in getattr(P, name):
+                    if kind == "nf4" and w.shape[1] % 64:
+                        raise NotImplementedError("nf4 weight_store needs row lengths that are multiples of the 64-weight block")
+            self.stored.append({name: [quant(w) for w in getattr(P, name)] for name in self.MATS})
+            self.small.append({n: getattr(P, n) for n in ("bqkv", "qn", "kn", "ln_in", "ln_post")})
+            del P                                              # the bf16 copies of this layer are gone before the next one is packed
+        self.scratch = [None, None]
+
+    def __len__(self):
+        return len(self.stored)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self.stored)))
+
+    def __getitem__(self, i):
+        st = self.stored[i]
+        slot = i % 2
+        if self.scratch[slot] is None:
+            self.scratch[slot] = {name: [torch.empty((q.shape[0], q.shape[1] * (2 if self.kind == "nf4" else 1)), dtype=BF16, device=q.device)
+                                         for q, _ in st[name]] for name in self.MATS}
+        deq = ops.dequantize_nf4 if self.kind == "nf4" else ops.dequantize_rows_i8
+        P = _PackedLayer()
+        for name in self.MATS:
+            setattr(P, name, [deq(q, sc, out) for (q, sc), out in zip(st[name], self.scratch[slot][name])])
+        for n, v in self.small[i].items():
+            setattr(P, n, v)
+        P.wt = {}
+        return P
+
+    def small_views(self):
+        """The layers WITHOUT their matrices (biases and norm weights only): what the Lq = 1 decode needs beside the stored codes."""
+        out = []
+        for sm in self.small:
+            P = _PackedLayer()
+            for name in self.MATS:
+                setattr(P, name, None)
+            for n, v in sm.items():
+                setattr(P, n, v)
+            P.wt = {}
+            out.append(P)
+        return out
+
+    def resident_bytes(self):
+        return sum(q.numel() * q.element_size() + sc.numel() * sc.element_size() for st in self.stored for ms in st.values() for q, sc in ms)
+
+
 class MoTEngine:
     """Owns the MI355X-layout copies of a Qwen2Model's weights and runs forward_inference on them."""
 
-    def __init__(self, model: "Qwen2Model", lm_head: "_Linear"):
+    def __init__(self, model: "Qwen2Model", lm_head: "_Linear", weight_store=None):
         cfg = model.config
         self.cfg = cfg
         self.H, self.I = cfg.hidden_size, cfg.intermediate_size
@@ -677,7 +736,18 @@ class MoTEngine:
         self.device = p0.device
         self.model = model
         self.lm_head = lm_head
-        self.layers = [self._pack_layer(l) for l in model.layers]
+        # WHOLE-MODEL 4- / 8-bit load modes (app.py:114-131: bitsandbytes NF4 / INT8 over every nn.Linear of the language model).  weight_store =
+        # "nf4" | "int8": the four matrices of every decoder layer (both experts) stay resident as codes + scales; `layers[i]` materialises that
+        # layer's bf16 matrices into one of two scratch sets right before they are used (_StoredLayers) -- exactly what bitsandbytes' matmul_4bit
+        # does in front of F.linear for more than one activation row -- and the Lq = 1 decode runs its own 4- / 8-bit gemv kernels on the stored
+        # codes.  Biases, norm weights, embeddings, lm_head stay bf16 (llm_int8_skip_modules / the library never touches non-Linear weights).
+        if weight_store not in (None, "nf4", "int8"):
+            raise NotImplementedError(f"weight_store={weight_store!r}: 'nf4' (bitsandbytes NF4: blocks of 64, fp32 absmax) and 'int8' (row-wise absmax) are built")
+        self.weight_store = weight_store
+        if weight_store is None:
+            self.layers = [self._pack_layer(l) for l in model.layers]
+        else:
+            self.layers = _StoredLayers(self, model.layers, weight_store)
         self._ws = {}
         self._ws_side = {}
         self._fp8 = None
@@ -715,6 +785,8 @@ class MoTEngine:
         Workspaces, plans and the tape pool stay -- a training loop pays one re-pack pass per step (~2 bytes read + written per
         parameter and image), not a rebuild of the engine, re-allocation of 28 GB of packed weights and a fresh set of transposes."""
         from . import train_step as TS
+        if self.weight_store is not None:
+            raise NotImplementedError("a quantised engine is rebuilt, not refreshed (weight_store is an inference load mode)")
         for P, L in zip(self.layers, self.model.layers):
             fresh = self._pack_layer(L)
             for name in ("wqkv", "bqkv", "wo", "wgu", "wd", "qn", "kn", "ln_in", "ln_post"):
@@ -768,6 +840,8 @@ class MoTEngine:
         """OCP e4m3 copies (row-wise absmax scales) of the gen expert's four projections, quantised on first use (option
         ``gen_weight_quant = "fp8"``: the MI355X counterpart of the reference's quantised load modes, app.py:114-131)."""
         if self._fp8 is None:
+            if self.weight_store is not None:
+                raise NotImplementedError("gen_weight_quant='fp8' and weight_store are two different load modes: pick one")
             if not self.mot:
                 raise NotImplementedError("gen_weight_quant='fp8' is built for the MoT layer kind (a separate gen expert)")
             for n, k in (("H", self.H), ("I", self.I), ("nq*dp", self.nq * self.dp)):
@@ -956,6 +1030,8 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
     expert, bf16 cast points for BOTH experts' QK-norm (no fp32 path here, unlike forward_inference's gen mode), and the
     block mask executed as per-split sequences (TrainPlan).  With a ``tape`` (train_step.TrainTape) every layer writes its residual
     streams, raw projection, attention output and SwiGLU output into buffers of its own, which the tape keeps for the backward."""
+    if self.weight_store is not None:
+        raise NotImplementedError("training runs on bf16 weights; weight_store is an inference load mode (app.py:114-131)")
     if not self.mot and tape is not None:
         raise NotImplementedError("the training BACKWARD (tape) is built for Qwen2MoTDecoderLayer (BAGEL's layer_module); the dense and MoE layer "
                                   "kinds run the training forward only (qwen2_navit.py:620-646,852-883)")
@@ -1074,7 +1150,7 @@ class Qwen2ForCausalLM(PackedWeights):
             return super()._check_packed()
         ptrs = tuple(t.data_ptr() for t in self.parameters()) + tuple(t.data_ptr() for t in self.buffers())
         if self._packed_sig != self._signature():
-            if getattr(self, "_packed_ptrs", None) == ptrs:
+            if getattr(self, "_packed_ptrs", None) == ptrs and self._engine.weight_store is None:
                 with torch.no_grad():
                     self._engine.refresh()
                 self._packed_fresh()
@@ -1091,7 +1167,7 @@ class Qwen2ForCausalLM(PackedWeights):
         if check:
             self._check_packed()
         if self._engine is None:
-            self._engine = MoTEngine(self.model, self.lm_head)
+            self._engine = MoTEngine(self.model, self.lm_head, weight_store=getattr(self, "weight_store", None))
             self._packed_fresh()
         return self._engine
 

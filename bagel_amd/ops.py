@@ -336,6 +336,33 @@ def quantize_nf4(W):
     return q, a
 
 
+def dequantize_nf4(q, absmax, out=None):
+    """(u8 [N, K/2] NF4 codes, fp32 absmax [N, K/64]) -> bf16 [N, K] = bf16(code_book[code] * absmax): bagel_dequantize_nf4_bf16, what bitsandbytes'
+    matmul_4bit does in front of F.linear for more than one activation row.  ``out``: a bf16 tensor with >= N rows of >= K columns (a view is fine)."""
+    _req(q, torch.uint8, "dequantize_nf4.q"); _req(absmax, torch.float32, "dequantize_nf4.absmax")
+    N, K = q.shape[0], 2 * q.shape[1]
+    if out is None:
+        out = torch.empty((N, K), dtype=BF16, device=q.device)
+    _req(out, BF16, "dequantize_nf4.out")
+    if out.shape[0] < N or out.shape[1] < K or out.stride(1) != 1:
+        raise BagelHipError(f"dequantize_nf4: out {tuple(out.shape)} cannot hold [{N}, {K}]")
+    check(lib().bagel_dequantize_nf4_bf16(_ptr(q), q.stride(0), _ptr(absmax), _ptr(out), out.stride(0), N, K, _stream()), "bagel_dequantize_nf4_bf16")
+    return out[:N, :K]
+
+
+def dequantize_rows_i8(q, scale, out=None):
+    """(u8 [N, K], fp32 row scales [N]) of quantize_rows_i8 -> bf16 [N, K] = bf16((q - 128) * scale[row]); bagel_dequantize_rows_i8_bf16."""
+    _req(q, torch.uint8, "dequantize_rows_i8.q"); _req(scale, torch.float32, "dequantize_rows_i8.scale")
+    N, K = q.shape
+    if out is None:
+        out = torch.empty((N, K), dtype=BF16, device=q.device)
+    _req(out, BF16, "dequantize_rows_i8.out")
+    if out.shape[0] < N or out.shape[1] < K or out.stride(1) != 1:
+        raise BagelHipError(f"dequantize_rows_i8: out {tuple(out.shape)} cannot hold [{N}, {K}]")
+    check(lib().bagel_dequantize_rows_i8_bf16(_ptr(q), q.stride(0), _ptr(scale), _ptr(out), out.stride(0), N, K, _stream()), "bagel_dequantize_rows_i8_bf16")
+    return out[:N, :K]
+
+
 def gemv_nf4(A, Wq, absmax, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0):
     """``gemv`` on NF4 weights (packed codes + fp32 block absmax), activations bf16; see bagel_gemv_nf4_bf16."""
     _req(A, BF16, "gemv_nf4.A"); _req(Wq, torch.uint8, "gemv_nf4.Wq"); _req(absmax, torch.float32, "gemv_nf4.absmax"); _req(C, BF16, "gemv_nf4.C")

@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no-int8", action="store_true", help="understanding leg: skip the extra weight_quant='int8' / 'mxfp4' decodes")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra gen_weight_quant='fp8' measurement")
     ap.add_argument("--no-edit", action="store_true", help="skip the extra configs[4] measurement (one image-edit request per GPU)")
+    ap.add_argument("--weight-store", choices=["nf4", "int8"], default=None,
+                    help="option that changes results (line flagged invalid): the reference's quantised load modes (app.py:114-131) over the WHOLE forward "
+                         "path -- Bagel.quantize_language_model before the timed region; skips the fp8 / training / understanding legs")
     ap.add_argument("--only-understanding", action="store_true", help="debug only: skip the text->image leg (result flagged invalid)")
     ap.add_argument("--und-new-tokens", type=int, default=256)
     ap.add_argument("--und-batch", type=int, default=1, help="requests decoded together per GPU (reference: 1, bagel.py:996)")
@@ -819,6 +822,13 @@ def main():
     if vae is not None:
         init_random_(vae, seed=0)
     model.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device=dev).manual_seed(1))
+    store_info = None
+    if args.weight_store:
+        args.no_fp8 = args.no_train_forward = args.no_understanding = True
+        before = torch.cuda.memory_allocated(dev) if cuda else 0
+        resident = model.quantize_language_model(args.weight_store)
+        store_info = {"kind": args.weight_store, "resident_gb": resident / 1e9,
+                      "hbm_freed_gb": (before - torch.cuda.memory_allocated(dev)) / 1e9 if cuda else None}
     # who is really here: an all-reduce of ones over the job's process group (RCCL on the GPUs), and the collective library's version
     ranks_seen, rccl_version, backend = 1, None, None
     if world > 1:
@@ -1220,6 +1230,10 @@ def main():
         if args.layers is not None or args.no_vae or R != 1024 or T != 50 or args.standins:
             out["valid"] = False
             out["note"] = "debug flags reduce the workload: not a benchmark number"
+        if store_info is not None:
+            out["valid"] = False
+            out["weight_store"] = store_info
+            out["note"] = "weight_store option (quantised decoder projections: changes results): beside the bf16 headline, never as it"
         if args.standins:
             out["standins"] = "tests/mock_ops.py torch stand-ins on the CPU, tiny model, gloo: exercises bench.main()'s host logic only"
             out["latents_checksum"] = [float(x.double().sum()) for x in latents]

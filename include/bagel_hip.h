@@ -216,6 +216,14 @@ int bagel_gemv_w8_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldw, 
  * roundings).  An OPTION that changes results (generate_text(weight_quant="nf4")); ldw in bytes % 16 == 0. */
 int bagel_quantize_nf4(const void* w, int64_t ldw, void* q, int64_t ldq_bytes, float* absmax, int32_t rows, int32_t cols,
                        bagel_stream_t stream);
+
+/* Whole-model 4-/8-bit load modes (app.py:114-131: bitsandbytes quantises EVERY nn.Linear of the language model): the engines keep the codes resident and
+ * materialise one decoder layer's bf16 matrices at a time -- what bitsandbytes' matmul_4bit does in front of F.linear for more than one activation
+ * row: w = bf16(code_book[code] * absmax[block]) (NF4) resp. bf16((q - 128) * scale[row]) (row-wise INT8); cols % 64 (NF4) / % 8 (INT8). */
+int bagel_dequantize_nf4_bf16(const void* q, int64_t ldq_bytes, const float* absmax, void* out, int64_t ld_out, int32_t rows,
+                              int32_t cols, bagel_stream_t stream);
+int bagel_dequantize_rows_i8_bf16(const void* q, int64_t ldq, const float* scale, void* out, int64_t ld_out, int32_t rows, int32_t cols,
+                                  bagel_stream_t stream);
 int bagel_gemv_nf4_bf16(const void* A, int64_t lda, const void* Wq, int64_t ldw_bytes, const float* absmax, const void* bias,
                         const void* R, int64_t ldr, void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N,
                         int32_t K, int32_t epilogue, bagel_stream_t stream);

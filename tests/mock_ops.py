@@ -306,6 +306,34 @@ def quantize_nf4(W):
     return nf4.quantize_nf4(W)
 
 
+def dequantize_nf4(q, absmax, out=None):
+    from oracle import nf4
+    w = nf4.dequantize_nf4(q, absmax)
+    if out is None:
+        return w
+    out[:w.shape[0], :w.shape[1]] = w
+    return out[:w.shape[0], :w.shape[1]]
+
+
+def quantize_rows_i8(W):
+    s_ = W.float().abs().amax(1) / 127.0
+    s_ = torch.where(s_ > 0, s_, torch.ones_like(s_))
+    q = (torch.round(W.float() / s_[:, None]).clamp(-127, 127) + 128).to(torch.uint8)
+    return q, s_
+
+
+def gemv_w8(A, Wq, scale, C, *, bias=None, residual=None, epilogue=0, M=None, norm_w=None, eps=0.0):
+    return gemv(A, dequantize_rows_i8(Wq, scale), C, bias=bias, residual=residual, epilogue=epilogue, M=M, norm_w=norm_w, eps=eps)
+
+
+def dequantize_rows_i8(q, scale, out=None):
+    w = _bf((q.float() - 128.0) * scale[:, None])
+    if out is None:
+        return w
+    out[:w.shape[0], :w.shape[1]] = w
+    return out[:w.shape[0], :w.shape[1]]
+
+
 def gemv_nf4(A, Wq, absmax, C, *, bias=None, residual=None, epilogue=0, M=None, norm_w=None, eps=0.0):
     """The reference's Linear4bit with bf16 compute: the bf16 projection on the de-quantised bf16 weight (oracle/nf4.py)."""
     from oracle import nf4
@@ -741,7 +769,7 @@ def chw_f32_to_u8(src):
 _NAMES = ["gemm", "gemv", "gemv_mb", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
-          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4",
+          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4", "dequantize_nf4", "quantize_rows_i8", "dequantize_rows_i8", "gemv_w8",
           "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32", "conv_gemm_bf16", "groupnorm_bf16", "groupnorm_bf16_workspace_floats", "softmax_rows_bf16", "vae_reparam_bf16", "chw_bf16_to_u8",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "layernorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
           "act_bwd", "swiglu_fwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]

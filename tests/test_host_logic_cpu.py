@@ -64,6 +64,62 @@ def test_text_to_image_host_path_matches_reference(golden, monkeypatch, name):
             assert rel(a, b) < 2e-2, key
 
 
+def _roundtrip_linears(model, kind):
+    """Every decoder projection W <- dequantise(quantise(W)) in place: what a bf16 engine has to compute on to equal a quantised engine."""
+    from oracle import nf4
+    for L in model.language_model.model.layers:
+        mods = [getattr(L.self_attn, n + s) for n in ("q_proj", "k_proj", "v_proj", "o_proj") for s in ("", "_moe_gen")]
+        for s in ("", "_moe_gen"):
+            m = getattr(L, "mlp" + s)
+            mods += [m.gate_proj, m.up_proj, m.down_proj]
+        for m in mods:
+            w = m.weight.data
+            if kind == "nf4":
+                m.weight.data = nf4.dequantize_nf4(*nf4.quantize_nf4(w)).to(w.dtype)
+            else:
+                m.weight.data = mock_ops.dequantize_rows_i8(*mock_ops.quantize_rows_i8(w)).to(w.dtype)
+    model.language_model.invalidate_packed()
+
+
+@pytest.mark.parametrize("kind", ["nf4", "int8"])
+def test_whole_model_quantised_load_mode_equals_the_bf16_engine_on_dequantised_weights(golden, monkeypatch, kind):
+    """Bagel.quantize_language_model (app.py:114-131's load modes for the WHOLE forward path): prefill, denoise loop and text decode of a model whose
+    decoder projections are stored as NF4 / INT8 codes give exactly what the bf16 engine gives on the de-quantised weights -- the layer-by-layer
+    materialisation is bitsandbytes' dequantise-then-F.linear, nothing else changes -- and the bf16 projection weights are really gone."""
+    mock_ops.install(monkeypatch)
+    monkeypatch.setenv("BAGEL_DECODE_GRAPH", "0")
+    cfg = CFGS["tiny_d128"]          # head_dim 128 like 7B: no head padding, so the 64-weight blocks of the packed matrices are the nn.Linear's own
+    g = golden("tiny_d128_t2i")
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    qm, bm = cpu_model(cfg), cpu_model(cfg)
+    qm.to(torch.bfloat16); bm.to(torch.bfloat16)
+    _roundtrip_linears(bm, kind)
+    resident = qm.quantize_language_model(kind)
+    full = sum(p.numel() * 2 for n, p in bm.language_model.model.layers.named_parameters() if "proj" in n and n.endswith("weight"))
+    assert resident < (0.30 if kind == "nf4" else 0.52) * full          # 4 bits + an fp32 absmax per 64 weights = 0.28; 8 bits + a scale per row = 0.50
+    assert all(p.numel() == 0 for n, p in qm.language_model.model.layers.named_parameters() if "proj" in n and n.endswith("weight"))
+    outs = []
+    for model in (qm, bm):
+        gi, newlens, newrope = model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+        cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+        lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **g["gen_kwargs"], **g["latent_inputs"])
+        prefill = [(cache.key_cache[i].clone(), cache.value_cache[i].clone()) for i in range(cfg["llm"]["num_hidden_layers"])]
+        st = model.prepare_start_tokens(newlens, newrope, NEW_TOKEN_IDS_TINY)
+        # the quantised engine decodes on its stored codes (the stand-in's 4- / 8-bit gemv = the bf16 gemv on the de-quantised weight, which is what
+        # the bf16 engine holds here); on the GPU the codes are expanded in fp32 inside the kernel (tests/test_nf4_gpu.py: tokens up to near ties)
+        toks = model.generate_text(past_key_values=cache, max_length=5, do_sample=False, end_token_id=None, **st)
+        outs.append((prefill, lat, toks))
+    (ca, la, ta), (cb, lb, tb) = outs
+    for (ka, va), (kb, vb) in zip(ca, cb):
+        assert torch.equal(ka, kb) and torch.equal(va, vb), "prefill KV of the quantised engine differs from the bf16 engine on de-quantised weights"
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b), "latents of the quantised engine differ from the bf16 engine on de-quantised weights"
+    assert torch.equal(ta, tb)
+    assert qm._last_decode_session.weight_quant == kind          # the decode streamed the stored codes
+    with pytest.raises(NotImplementedError):
+        qm.language_model.engine().refresh()
+
+
 def _three_stream_setup(model, cfg, sizes):
     """cond / cfg-text / cfg-img contexts of DIFFERENT lengths from three prompts (what the edit flow produces, without the
     ViT / VAE prefill): exercises ragged contexts and NaiveCache.concat with three live caches."""

@@ -113,3 +113,73 @@ def test_generate_text_nf4_weights_option():
     finally:
         model.decode_weight_quant = None
     assert torch.equal(c, a)
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 64), (37, 640), (300, 3584), (33, 18944)])
+def test_dequantize_kernels_bit_exact(rows, cols):
+    """bagel_dequantize_nf4_bf16 = oracle/nf4.py's dequantize_4bit with a bf16 output (code_book[code] * absmax in fp32, ONE rounding), also into a
+    wider destination; bagel_dequantize_rows_i8_bf16 = bf16((q - 128) * scale[row])."""
+    g = torch.Generator().manual_seed(rows + 1)
+    w = (torch.randn(rows, cols, generator=g) * torch.rand(rows, 1, generator=g) * 0.2).to(BF16)
+    w[0, :64] = 0
+    q, a = ops().quantize_nf4(w.to(DEV))
+    d = ops().dequantize_nf4(q, a)
+    assert torch.equal(d.cpu().view(torch.int16), NF.dequantize_nf4(q.cpu(), a.cpu()).view(torch.int16))
+    wide = torch.full((rows + 3, cols + 64), 7.0, dtype=BF16, device=DEV)
+    d2 = ops().dequantize_nf4(q, a, wide)
+    assert torch.equal(d2, d) and (wide[:, cols:] == 7.0).all() and (wide[rows:] == 7.0).all()
+    q8, s8 = ops().quantize_rows_i8(w.to(DEV))
+    d8 = ops().dequantize_rows_i8(q8, s8)
+    ref8 = ((q8.cpu().float() - 128.0) * s8.cpu()[:, None]).to(BF16)
+    assert torch.equal(d8.cpu().view(torch.int16), ref8.view(torch.int16))
+
+
+@pytest.mark.parametrize("kind", ["nf4", "int8"])
+def test_whole_model_quantised_load_mode(kind):
+    """Bagel.quantize_language_model (app.py:114-131's load modes over the whole forward path): prefill KV and denoise latents of the quantised engine
+    are BIT-IDENTICAL to the bf16 engine on the de-quantised weights (a layer's matrices are materialised with the dequantise kernel right before
+    its GEMMs: bitsandbytes' dequantise-then-F.linear), the decode streams the stored codes (tokens equal up to near ties: the gemv expands codes in
+    fp32), and the bf16 projection weights are released."""
+    from oracle.configs import TINY_D128 as cfg, NEW_TOKEN_IDS_TINY, StubTokenizer
+    from tests.test_model_gpu import cfg_kwargs, new_cache
+    from tests.util_models import _product
+    g = torch.load(__file__.rsplit("/", 1)[0] + "/golden/tiny_d128_t2i.pt", weights_only=False)
+    qm, _ = _product.__wrapped__(cfg["name"])                     # two FRESH models: product_model() hands every test the same cached instance
+    bm, _ = _product.__wrapped__(cfg["name"])
+    o = ops()
+    for L in bm.language_model.model.layers:                      # W <- dequantise(quantise(W)) on every decoder projection
+        mods = [getattr(L.self_attn, n + s) for n in ("q_proj", "k_proj", "v_proj", "o_proj") for s in ("", "_moe_gen")]
+        for s in ("", "_moe_gen"):
+            m = getattr(L, "mlp" + s)
+            mods += [m.gate_proj, m.up_proj, m.down_proj]
+        for m in mods:
+            w = m.weight.data
+            m.weight.data = (o.dequantize_nf4(*o.quantize_nf4(w)) if kind == "nf4" else o.dequantize_rows_i8(*o.quantize_rows_i8(w))).contiguous()
+    bm.language_model.invalidate_packed()
+    free0 = torch.cuda.memory_allocated()
+    resident = qm.quantize_language_model(kind)
+    full = sum(p.numel() * 2 for n, p in bm.language_model.model.layers.named_parameters() if "proj" in n and n.endswith("weight"))
+    assert resident < (0.30 if kind == "nf4" else 0.52) * full
+    assert all(p.numel() == 0 for n, p in qm.language_model.model.layers.named_parameters() if "proj" in n and n.endswith("weight"))
+    assert torch.cuda.memory_allocated() < free0, "releasing the bf16 projection weights must free more than the codes take"
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    outs = []
+    for model in (qm, bm):
+        gi, newlens, newrope = model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
+        cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+        kv = [(cache.key_cache[i].clone(), cache.value_cache[i].clone()) for i in range(cfg["llm"]["num_hidden_layers"])]
+        lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **g["gen_kwargs"], **g["latent_inputs"])
+        st = model.prepare_start_tokens(newlens, newrope, NEW_TOKEN_IDS_TINY)
+        toks = model.generate_text(past_key_values=cache, max_length=6, do_sample=False, end_token_id=None, **st)
+        outs.append((kv, lat, toks, model._last_decode_session))
+    (ka, la, ta, sa), (kb, lb, tb, sb) = outs
+    for (k1, v1), (k2, v2) in zip(ka, kb):
+        assert torch.equal(k1, k2) and torch.equal(v1, v2), "prefill KV differs"
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b), "latents differ"
+    assert sa.weight_quant == kind and sa.graph is not None and sb.weight_quant is None
+    assert ta.shape == tb.shape and torch.equal(ta[:2], tb[:2])          # first decoded token from the same prefill: the codes expanded in fp32 vs bf16 weights
+    lg = (sa.logits.float() - sb.logits.float()).norm() / sb.logits.float().norm()
+    assert torch.equal(ta, tb) or lg < 3e-2, f"decode on the stored codes drifts from the bf16 decode on de-quantised weights: logits rel-L2 {lg:.3g}"
+    with pytest.raises(NotImplementedError):
+        qm.language_model.engine().refresh()
