@@ -353,7 +353,7 @@ def test_hip_graph_replay():
     o = ops()
     K, N = 256, 64
     W = rnd(N, K, seed=1, scale=K ** -0.5).to(DEV)
-    table = rnd(16, K, seed=2).to(DEV)
+    table = rnd(N, K, seed=2).to(DEV)             # one row per possible token: the argmax over N logits indexes it (16 rows read out of bounds for tokens >= 16)
     x = torch.zeros((1, K), dtype=BF16, device=DEV)
     y = torch.zeros((1, N), dtype=BF16, device=DEV)
     cur = torch.zeros(1, dtype=torch.int32, device=DEV)
