@@ -757,6 +757,9 @@ class MoTEngine:
     def _pack_layer(self, L):
         nq, nkv, hd, dp = self.nq, self.nkv, self.hd, self.dp
         a = L.self_attn
+        if a.q_proj.weight.numel() == 0:
+            raise RuntimeError("the bf16 projection weights of this model were released by quantize_language_model(release_bf16=True) and the quantised "
+                               "engine built from them has since been dropped (module.to() / load_state_dict / an in-place rewrite): reload the checkpoint")
         P = _PackedLayer()
         P.wqkv, P.bqkv, P.wo, P.wgu, P.wd, P.qn, P.kn, P.ln_in, P.ln_post = [], [], [], [], [], [], [], [], []
         P.wt = {}

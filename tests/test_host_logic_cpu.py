@@ -118,6 +118,9 @@ def test_whole_model_quantised_load_mode_equals_the_bf16_engine_on_dequantised_w
     assert qm._last_decode_session.weight_quant == kind          # the decode streamed the stored codes
     with pytest.raises(NotImplementedError):
         qm.language_model.engine().refresh()
+    qm.language_model.invalidate_packed()            # the codes were the only copy: rebuilding from the released parameters has to say so
+    with pytest.raises(RuntimeError, match="reload the checkpoint"):
+        qm.language_model.engine()
 
 
 def _three_stream_setup(model, cfg, sizes):
