@@ -727,10 +727,6 @@ class Bagel(nn.Module):
         if not named:
             with torch.no_grad():
                 return self._forward_losses(tape=None, **kw)
-        if self.language_model.config.layer_module != "Qwen2MoTDecoderLayer":
-            raise NotImplementedError(
-                f"the training BACKWARD is built for Qwen2MoTDecoderLayer (BAGEL's layer_module); {self.language_model.config.layer_module} runs the "
-                "training forward only (call it under torch.no_grad(), or freeze every parameter)")
         bad = [n for n, _ in named if not n.startswith(self._TRAINABLE_PREFIXES)]
         if bad:
             raise NotImplementedError(

@@ -1035,9 +1035,6 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
     streams, raw projection, attention output and SwiGLU output into buffers of its own, which the tape keeps for the backward."""
     if self.weight_store is not None:
         raise NotImplementedError("training runs on bf16 weights; weight_store is an inference load mode (app.py:114-131)")
-    if not self.mot and tape is not None:
-        raise NotImplementedError("the training BACKWARD (tape) is built for Qwen2MoTDecoderLayer (BAGEL's layer_module); the dense and MoE layer "
-                                  "kinds run the training forward only (qwen2_navit.py:620-646,852-883)")
     if seq.shape != (tp.M, self.H):
         raise ValueError(f"packed sequence shape {tuple(seq.shape)} != ({tp.M}, {self.H})")
     dev = self.device
@@ -1104,7 +1101,7 @@ def _engine_forward_train(self, seq, tp: "TrainPlan", tape=None):
         if tape is not None and tape.keep_gate_up:
             gu = tb("gu", len(tape.gu), M, 2 * self.I)        # the tape keeps the un-activated projection: no recompute in the backward
             tape.gu.append(gu)
-            ops.gemm(h, C=gu, **groups(P.wgu))
+            ops.gemm(h, C=gu, **groups(P.wgu, two=two_mlp))
             ops.swiglu_fwd(gu, act)                           # same bits as the fused epilogue
         else:
             ops.gemm(h, C=act, epilogue=ops.EPI_SWIGLU16, **groups(P.wgu, two=two_mlp))

@@ -208,23 +208,27 @@ def engine_backward_train(eng, tape, g, grads):
     qw, kw_ = nq * dp, nkv * dp
     M, H, I = tp.M, eng.H, eng.I
     two = tp.n_vae > 0
-    expert = tp.expert if two else None
+    # what is per modality: everything for Qwen2MoTDecoderLayer; the MLP and the model's final norm for Qwen2MoEDecoderLayer (shared attention and
+    # layer norms); nothing for Qwen2DecoderLayer -- the same switches as MoTEngine.forward_train
+    two_a, two_m = two and eng.mot, two and eng.moe_mlp
+    expert_a, expert_m = (tp.expert if two_a else None), (tp.expert if two_m else None)
     scale = hd ** -0.5
     e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
-    sel = [(tp.text_idx, tp.n_text), (tp.vae_idx, tp.n_vae)] if two else [(None, M)]
+    sel2, sel1 = [(tp.text_idx, tp.n_text), (tp.vae_idx, tp.n_vae)], [(None, M)]
+    sel_a, sel_m = (sel2 if two_a else sel1), (sel2 if two_m else sel1)
     sufs = ("", "_moe_gen")
 
-    def groups(w, b=None):
-        if two:
-            return dict(W0=w[0], bias0=None if b is None else b[0], a_rows0=tp.text_idx, c_rows0=tp.text_idx, M0=tp.n_text,
-                        W1=w[1], bias1=None if b is None else b[1], a_rows1=tp.vae_idx, c_rows1=tp.vae_idx, M1=tp.n_vae)
-        return dict(W0=w[0], bias0=None if b is None else b[0], M0=M)
+    def groups(w, two_):
+        if two_:
+            return dict(W0=w[0], bias0=None, a_rows0=tp.text_idx, c_rows0=tp.text_idx, M0=tp.n_text,
+                        W1=w[1], bias1=None, a_rows1=tp.vae_idx, c_rows1=tp.vae_idx, M1=tp.n_vae)
+        return dict(W0=w[0], bias0=None, M0=M)
 
-    def wgrads(dY, X, need):
+    def wgrads(dY, X, need, sel):
         """dW per expert; experts whose parameter is frozen are skipped (``_Grads.add`` ignores None)."""
         return [_wgrad(dY, X, rows, n) if nd else None for (rows, n), nd in zip(sel, need)]
 
-    def wts(P, name):
+    def wts(P, name, sel):
         ws = getattr(P, name)[:len(sel)]
         if not CACHE_WT:
             return [_wt(w) for w in ws]
@@ -238,10 +242,10 @@ def engine_backward_train(eng, tape, g, grads):
     m = eng.model
     # final norm (qwen2_navit.py:1011-1015)
     gx = e(M, H)
-    dw0, dw1 = ops.rmsnorm_bwd(tape.x[-1], g, m.norm.weight.data, gx, eng.eps, w1=m.norm_moe_gen.weight.data if two else None, expert=expert,
+    dw0, dw1 = ops.rmsnorm_bwd(tape.x[-1], g, m.norm.weight.data, gx, eng.eps, w1=m.norm_moe_gen.weight.data if two_m else None, expert=expert_m,
                                accumulate=False)
     grads.add(m.norm.weight, dw0)
-    if two:
+    if two_m:
         grads.add(m.norm_moe_gen.weight, dw1)
     g = gx
     h, d_h = e(M, H), e(M, H)
@@ -251,50 +255,56 @@ def engine_backward_train(eng, tape, g, grads):
         # which weight gradients this layer owes, per expert (frozen parameters: no dW launch, no column sum)
         a = Lm.self_attn
         rq = lambda *ps: any(p_ is not None and p_.requires_grad for p_ in ps)  # noqa: E731
-        need_qkv = [rq(*(getattr(a, n_ + sufs[ei]).weight for n_ in ("q_proj", "k_proj", "v_proj"))) for ei in range(len(sel))]
-        need_bqkv = [rq(*(getattr(a, n_ + sufs[ei]).bias for n_ in ("q_proj", "k_proj", "v_proj"))) for ei in range(len(sel))]
-        need_o = [rq(getattr(a, "o_proj" + sufs[ei]).weight) for ei in range(len(sel))]
-        need_gu = [rq(getattr(Lm, "mlp" + sufs[ei]).gate_proj.weight, getattr(Lm, "mlp" + sufs[ei]).up_proj.weight) for ei in range(len(sel))]
-        need_d = [rq(getattr(Lm, "mlp" + sufs[ei]).down_proj.weight) for ei in range(len(sel))]
-        # ---- MLP block: x_out = x_mid + down(swiglu(gate_up(rmsnorm(x_mid))))   (qwen2_navit.py:744-753)
+        need_qkv = [rq(*(getattr(a, n_ + sufs[ei]).weight for n_ in ("q_proj", "k_proj", "v_proj"))) for ei in range(len(sel_a))]
+        need_bqkv = [rq(*(getattr(a, n_ + sufs[ei]).bias for n_ in ("q_proj", "k_proj", "v_proj"))) for ei in range(len(sel_a))]
+        need_o = [rq(getattr(a, "o_proj" + sufs[ei]).weight) for ei in range(len(sel_a))]
+        need_gu = [rq(getattr(Lm, "mlp" + sufs[ei]).gate_proj.weight, getattr(Lm, "mlp" + sufs[ei]).up_proj.weight) for ei in range(len(sel_m))]
+        need_d = [rq(getattr(Lm, "mlp" + sufs[ei]).down_proj.weight) for ei in range(len(sel_m))]
+        # ---- MLP block: x_out = x_mid + down(swiglu(gate_up(rmsnorm(x_mid))))   (qwen2_navit.py:744-753; MoE kind :873-881; dense :641-644)
         d_act = e(M, I)
-        ops.gemm(g, C=d_act, **groups(wts(P, "wd")))
-        dWd = wgrads(g, act, need_d)
-        ops.rmsnorm(x_mid, P.ln_post[0], h, eng.eps, w1=P.ln_post[1] if two else None, expert=expert)
+        ops.gemm(g, C=d_act, **groups(wts(P, "wd", sel_m), two_m))
+        dWd = wgrads(g, act, need_d, sel_m)
+        ops.rmsnorm(x_mid, P.ln_post[0], h, eng.eps, w1=P.ln_post[1] if two_a else None, expert=expert_a)
         if tape.gu:
             gu, tape.gu[li] = tape.gu[li], None                  # kept by the forward; consumed (overwritten with its gradient) here
         else:
             gu = e(M, 2 * I)
-            ops.gemm(h, C=gu, **groups(P.wgu))                   # the un-activated projection, recomputed
+            ops.gemm(h, C=gu, **groups(P.wgu, two_m))            # the un-activated projection, recomputed
         ops.swiglu_bwd(gu, d_act)
         del d_act
-        dWgu = wgrads(gu, h, need_gu)
-        ops.gemm(gu, C=d_h, **groups(wts(P, "wgu")))
+        dWgu = wgrads(gu, h, need_gu, sel_m)
+        ops.gemm(gu, C=d_h, **groups(wts(P, "wgu", sel_m), two_m))
         del gu
-        dpost = ops.rmsnorm_bwd(x_mid, d_h, P.ln_post[0], g, eng.eps, w1=P.ln_post[1] if two else None, expert=expert)
-        # ---- attention block: x_mid = x_in + o(attn(rope(qknorm(qkv(rmsnorm(x_in))))))   (qwen2_navit.py:406-497, 713-743)
+        dpost = ops.rmsnorm_bwd(x_mid, d_h, P.ln_post[0], g, eng.eps, w1=P.ln_post[1] if two_a else None, expert=expert_a)
+        # ---- attention block: x_mid = x_in + o(attn(rope(qknorm(qkv(rmsnorm(x_in))))))   (qwen2_navit.py:406-497, 713-743; shared form :252-320)
         d_att = e(M, qw)
-        ops.gemm(g, C=d_att, **groups(wts(P, "wo")))
-        dWo = wgrads(g, att, need_o)
+        ops.gemm(g, C=d_att, **groups(wts(P, "wo", sel_a), two_a))
+        dWo = wgrads(g, att, need_o, sel_a)
         qkv = qkv_raw.clone()
         ops.qknorm_rope(qkv, tp.cos, tp.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
-                        P.qn[1] if (eng.use_norm and two) else None, P.kn[1] if (eng.use_norm and two) else None,
-                        expert, nq, nkv, hd, dp, eng.eps, gen_mode=False, use_norm=eng.use_norm)
+                        P.qn[1] if (eng.use_norm and two_a) else None, P.kn[1] if (eng.use_norm and two_a) else None,
+                        expert_a, nq, nkv, hd, dp, eng.eps, gen_mode=False, use_norm=eng.use_norm)
         dqkv = e(M, qw + 2 * kw_)
         ops.attn_bwd_blockmask(qkv[:, :qw], qkv[:, qw:qw + kw_], qkv[:, qw + kw_:], att, d_att, dqkv[:, :qw], dqkv[:, qw:qw + kw_],
                                dqkv[:, qw + kw_:], bplan.q_items, bplan.k_items, bplan.noise_bits, nq, nkv, dp, scale, lse=tape.lse[li])
         del qkv, d_att
         dqn = ops.qknorm_rope_bwd(dqkv, qkv_raw, tp.cos, tp.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
-                                  P.qn[1] if (eng.use_norm and two) else None, P.kn[1] if (eng.use_norm and two) else None,
-                                  expert, nq, nkv, hd, dp, eng.eps, eng.use_norm)
-        ops.rmsnorm(x_in, P.ln_in[0], h, eng.eps, w1=P.ln_in[1] if two else None, expert=expert)
-        dWqkv = wgrads(dqkv, h, need_qkv)
-        dbqkv = [ops.colsum(dqkv, rows, n) if nd else None for (rows, n), nd in zip(sel, need_bqkv)]
-        ops.gemm(dqkv, C=d_h, **groups(wts(P, "wqkv")))
+                                  P.qn[1] if (eng.use_norm and two_a) else None, P.kn[1] if (eng.use_norm and two_a) else None,
+                                  expert_a, nq, nkv, hd, dp, eng.eps, eng.use_norm)
+        ops.rmsnorm(x_in, P.ln_in[0], h, eng.eps, w1=P.ln_in[1] if two_a else None, expert=expert_a)
+        dWqkv = wgrads(dqkv, h, need_qkv, sel_a)
+        dbqkv = [ops.colsum(dqkv, rows, n) if nd else None for (rows, n), nd in zip(sel_a, need_bqkv)]
+        ops.gemm(dqkv, C=d_h, **groups(wts(P, "wqkv", sel_a), two_a))
         del dqkv
-        din = ops.rmsnorm_bwd(x_in, d_h, P.ln_in[0], g, eng.eps, w1=P.ln_in[1] if two else None, expert=expert)
+        din = ops.rmsnorm_bwd(x_in, d_h, P.ln_in[0], g, eng.eps, w1=P.ln_in[1] if two_a else None, expert=expert_a)
         # ---- unpack the MI355X layouts into the reference's parameter shapes
-        for ei in range(len(sel)):
+        for ei in range(len(sel_m)):
+            mlp = getattr(Lm, "mlp" + sufs[ei])
+            dg, du = (None, None) if dWgu[ei] is None else _deinterleave_gate_up(dWgu[ei])
+            grads.add(mlp.gate_proj.weight, dg)
+            grads.add(mlp.up_proj.weight, du)
+            grads.add(mlp.down_proj.weight, dWd[ei])
+        for ei in range(len(sel_a)):
             s = sufs[ei]
             cut = lambda t: (None, None, None) if t is None else (t[:qw], t[qw:qw + kw_], t[qw + kw_:])  # noqa: E731
             (wq, wk, wv), (bq, bk, bv) = cut(dWqkv[ei]), cut(dbqkv[ei])
@@ -308,11 +318,6 @@ def engine_backward_train(eng, tape, g, grads):
                 grads.add(getattr(a, "k_norm" + s).weight, dqn[2 * ei + 1])
             grads.add(getattr(Lm, "input_layernorm" + s).weight, din[ei])
             grads.add(getattr(Lm, "post_attention_layernorm" + s).weight, dpost[ei])
-            mlp = getattr(Lm, "mlp" + s)
-            dg, du = (None, None) if dWgu[ei] is None else _deinterleave_gate_up(dWgu[ei])
-            grads.add(mlp.gate_proj.weight, dg)
-            grads.add(mlp.up_proj.weight, du)
-            grads.add(mlp.down_proj.weight, dWd[ei])
     return g
 
 

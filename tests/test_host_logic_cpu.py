@@ -259,17 +259,6 @@ def test_training_forward_host_path_matches_reference(golden, monkeypatch, name,
     assert rel(out["ce"], g["ce"]) < 2e-2 and rel(out["mse"], g["mse"]) < 5e-2
 
 
-def test_training_backward_of_the_dense_and_moe_layer_kinds_is_refused(golden, monkeypatch):
-    """The reverse kernels are built for BAGEL's MoT layer kind; the other two kinds run the training forward only and say so."""
-    mock_ops.install(monkeypatch)
-    g = golden("tiny_moe_train")
-    model = cpu_model(CFGS["tiny_moe"])
-    model.to(torch.bfloat16)
-    next(p for n, p in model.named_parameters() if n.endswith("layers.0.mlp.down_proj.weight")).requires_grad_(True)
-    with torch.enable_grad(), pytest.raises(NotImplementedError, match="training BACKWARD"):
-        model(noise=g["noise"], **g["batch"])
-
-
 def _tokens_match(ours, ref, ref_logits, what):
     """Greedy ids equal the oracle's up to the first near tie in the oracle's logits (the rule of test_model_gpu.py)."""
     assert ours.shape == ref.shape and ours.dtype == torch.int64

@@ -9,11 +9,11 @@ import pytest
 import torch
 
 from oracle import bagel_oracle as O
-from oracle.configs import TINY, TINY_D128, TINY_ROPE
+from oracle.configs import TINY, TINY_D128, TINY_DENSE, TINY_MOE, TINY_ROPE
 from tests import mock_ops
 from tests.util_models import oracle_weights, pack_training_batch
 
-CFGS = {"tiny": TINY, "tiny_d128": TINY_D128, "tiny_rope": TINY_ROPE}
+CFGS = {"tiny": TINY, "tiny_d128": TINY_D128, "tiny_rope": TINY_ROPE, "tiny_dense": TINY_DENSE, "tiny_moe": TINY_MOE}
 FROZEN = ("vit_pos_embed.", "latent_pos_embed.")
 
 
@@ -71,10 +71,11 @@ def compare(grads, ref, names, tol, what, key_bias_is_zero=True):
     return worst
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_dense", "tiny_moe"])
 def test_training_step_gradients_match_the_reference_batch(golden, monkeypatch, name):
     """The hand-packed batch of oracle/make_golden.scenario_train (und sample + gen sample with causal / full / noise splits): every
-    trainable parameter's gradient vs the oracle's autograd; for 'tiny' also vs the committed reference gradients."""
+    trainable parameter's gradient vs the oracle's autograd; for 'tiny' also vs the committed reference gradients.  tiny_dense / tiny_moe: the
+    reverse of Qwen2DecoderLayer (no routing) and Qwen2MoEDecoderLayer (shared attention and layer norms, per-modality MLP and final norm)."""
     mock_ops.install(monkeypatch)
     cfg = CFGS[name]
     g = golden(f"{name}_train")

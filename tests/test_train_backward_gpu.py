@@ -307,14 +307,16 @@ def _compare(grads, ref, names, tol, what, key_bias_is_zero=True, median_tol=Non
 
 
 @pytest.mark.parametrize("keep_gate_up", [False, True], ids=["recompute_gate_up", "keep_gate_up"])
-@pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_d128", "tiny_dense", "tiny_moe"])
 def test_training_step_gradients_match_the_oracle(golden, monkeypatch, name, keep_gate_up):
+    """(tiny_dense / tiny_moe: forward_train + its reverse for Qwen2DecoderLayer and Qwen2MoEDecoderLayer, qwen2_navit.py:620-646,852-883 -- the oracle's
+    training forward of these kinds is bit-exact vs the live reference, tests/test_reference_crosscheck.py.)"""
     from bagel_amd.modeling.bagel import train_step as TS
     from oracle import bagel_oracle as O
     monkeypatch.setattr(TS, "KEEP_GATE_UP", keep_gate_up)
-    from oracle.configs import TINY, TINY_D128
+    from oracle.configs import TINY, TINY_D128, TINY_DENSE, TINY_MOE
     from tests.util_models import oracle_weights, product_model
-    cfg = {"tiny": TINY, "tiny_d128": TINY_D128}[name]
+    cfg = {"tiny": TINY, "tiny_d128": TINY_D128, "tiny_dense": TINY_DENSE, "tiny_moe": TINY_MOE}[name]
     g = golden(f"{name}_train")
     batch, noise = g["batch"], g["noise"]
     w_ce = torch.rand(g["ce"].shape[0], generator=torch.Generator().manual_seed(5)) + 0.5
