@@ -1,0 +1,552 @@
+// Batch-1 text decode: a CHAIN of projections as ONE persistent launch on a loader / consumer weight-streaming engine.
+//
+// The launch form of a decoded token (decode.py, decode.hip) is 6 kernels per layer -- qkv, attention, combine, o, gate+up, down -- each
+// of which ramps the chip up, streams its weights and drains: 35 of the 107 us of a 7B layer are launch floors and graph edges
+// (DESIGN 3.5).  This kernel runs a list of up to 4 dependent projections  y_p = epilogue_p(W_p . norm_p(y_{p-1}))  -- for a decoder
+// layer: o_proj(+residual) -> RMSNorm + gate/up (SwiGLU) -> down(+residual) -> RMSNorm + the NEXT layer's qkv (or the final norm +
+// lm_head) -- replacing Qwen2MLP.forward / the F.linear calls of qwen2_navit.py:591-594,515-517 and modeling_qwen2.py:200-201 at Lq = 1
+// (bagel.py:930-1000).  The attention stays its own two launches: that seam is an all-to-all over keys, the cut the guide prescribes.
+//
+// Structure (MI355X_MICROARCH.md rows ldsdma-fill / nt-weights / engine-vs-launches; cdna_hip_programming.md 5.6, Guideline 16):
+//   * one workgroup per CU, all co-resident (grid == CU count); wave N-1 is the LOADER, waves 0..N-2 are CONSUMERS;
+//   * every workgroup owns a fixed, contiguous share of the weight-row pairs of every phase.  Its loader walks that static list of units
+//     (unit = one row PAIR of K <= 5120, or one K-quarter of a pair for the long rows of the down projection) and streams them with
+//     `global_load_lds_dwordx4 ... nt` into a ring of LDS slots -- it never waits for an activation, so while the consumers sit in the
+//     hand-off between two projections the ring fills with the next projection's weights (the "prefetch credit" that pays for the hop);
+//   * consumer c takes units c, c + NC, c + 2 NC ... of the same list: waits for the slot's `full` word (LDS), runs the lane-FMA body of
+//     gemv_kernel on the slot image and the staged activation vector (same chunk -> lane map, same accumulation order, same wave
+//     reduction, same epilogue roundings: the engine is BIT-IDENTICAL to the chain of bagel_gemv_bf16 launches, tests/test_engine_gpu.py),
+//     hands the slot back (`freed`), and lane 0 writes the outputs write-through (`sc1`: agent-scope relaxed atomic stores);
+//   * hand-off between phases (Guideline 16, form R1): when the last consumer of a workgroup has drained its stores it sets the
+//     workgroup's flag word of that phase (agent-scope relaxed store).  Consumer 0 of every workgroup polls the n_wg flag words with ONE
+//     wave (relaxed `sc1` loads, s_sleep between sweeps), then the activation vector is read with `sc1` loads (no acquire fence: the
+//     payload was stored write-through and the loads bypass L1) and staged in LDS -- with the Qwen2RMSNorm of gemv_kernel fused in.
+//   * every spin is bounded: on a timeout the workgroup records a code in `status` and all of its waves leave; the host checks it.
+//
+// Flags live in caller memory that must be ZERO when the launch starts (one memset per token covers every layer's slice).
+#include "common.h"
+#include "../../include/bagel_hip.h"
+#include <stdlib.h>
+
+#define EPI_NONE 0
+#define EPI_GELU_TANH 1
+#define EPI_SILU 2
+#define EPI_SWIGLU16 3
+
+#define ENG_MAXPH 4
+#define ENG_MAX_SLOTS 8
+#define ENG_MAX_DPAIRS 32                 // split-K pairs one workgroup may own (partials live in LDS)
+#define ENG_SYNC_BYTES 2048
+#define ENG_LDS_MAX (160 * 1024)
+#define ENG_SPIN_LDS (1u << 23)           // bound of an LDS poll loop (~1 s)
+#define ENG_SPIN_GLOBAL (1u << 19)        // bound of a flag sweep loop (~1-2 s)
+
+struct EngPhase {
+    const bf16_t* A;          // activation vector [K] (phase 0: written by an earlier launch; later phases: the previous phase's C)
+    const bf16_t* W; long ldw;
+    const bf16_t* bias;       // [N] or null
+    const bf16_t* norm_w;     // [K] or null: Qwen2RMSNorm fused into the staging
+    const bf16_t* R;          // [N] residual or null (may alias C)
+    bf16_t* C;                // [N] ([N/2] for SwiGLU16)
+    int N, K, epi;
+    int kind;                 // 0: a unit = one row pair; 2: a unit = one K-quarter of a row pair (gemv_kernel<., 4>)
+    int in_launch;            // A is produced by the previous phase of THIS launch -> wait for every workgroup's flag first
+    int ngr;                  // 64-chunk groups per row = ceil(K / 512)
+    int gq;                   // groups per K-quarter (kind 2)
+};
+
+struct EngParams {
+    EngPhase ph[ENG_MAXPH];
+    int nph;
+    float eps;
+    unsigned* flags;          // [nph][n_wg], zero at launch
+    unsigned* status;         // [4]: first failure code (0 = ok), never cleared by the kernel
+    int xs_bytes, slot_bytes, nslot, depth, nt;
+};
+
+struct EngSync {              // at smem + xs_bytes + nslot * slot_bytes
+    unsigned full[ENG_MAX_SLOTS];
+    unsigned freed[ENG_MAX_SLOTS];
+    unsigned abort_;
+    unsigned go[ENG_MAXPH];
+    unsigned staged[ENG_MAXPH];
+    unsigned done[ENG_MAXPH];
+    unsigned pair_cnt[ENG_MAX_DPAIRS];
+    float part[ENG_MAX_DPAIRS][4][2];
+    int pair0[ENG_MAXPH], ubeg[ENG_MAXPH + 1];      // this workgroup's first pair of every phase; its units' position in the workgroup's sequence
+};
+static_assert(sizeof(EngSync) <= ENG_SYNC_BYTES, "EngSync does not fit its LDS reservation");
+
+#define ENG_WG __HIP_MEMORY_SCOPE_WORKGROUP
+#define ENG_AG __HIP_MEMORY_SCOPE_AGENT
+
+typedef __attribute__((address_space(1))) unsigned eng_gu32;
+typedef __attribute__((address_space(1))) unsigned short eng_gu16;
+typedef __attribute__((address_space(1))) unsigned long long eng_gu64;
+
+__device__ __forceinline__ unsigned eng_ld_u32(const void* p) { return __hip_atomic_load((const eng_gu32*)p, __ATOMIC_RELAXED, ENG_AG); }
+__device__ __forceinline__ u32x4_t eng_ld_chunk(const bf16_t* p) {          // 16 bytes past L1 (two sc1 8-byte loads)
+    const unsigned long long a = __hip_atomic_load((const eng_gu64*)p, __ATOMIC_RELAXED, ENG_AG);
+    const unsigned long long b = __hip_atomic_load((const eng_gu64*)p + 1, __ATOMIC_RELAXED, ENG_AG);
+    return u32x4_t{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+}
+__device__ __forceinline__ void eng_st_u32(void* p, unsigned v) { __hip_atomic_store((eng_gu32*)p, v, __ATOMIC_RELAXED, ENG_AG); }
+__device__ __forceinline__ void eng_st_u16(void* p, unsigned short v) { __hip_atomic_store((eng_gu16*)p, v, __ATOMIC_RELAXED, ENG_AG); }
+
+// ---- failure path: record the first code, tell the other waves of this workgroup to leave -----------------------------------------
+__device__ __forceinline__ void eng_fail(EngSync* sy, unsigned* status, unsigned code, int lane) {
+    if (lane == 0) {
+        unsigned expected = 0u;
+        __hip_atomic_compare_exchange_strong(status, &expected, code | (blockIdx.x << 8), __ATOMIC_RELAXED, __ATOMIC_RELAXED, ENG_AG);
+        __hip_atomic_store(&sy->abort_, 1u, __ATOMIC_RELAXED, ENG_WG);
+    }
+}
+// wait until the LDS word reaches `want` (monotonic words); false = aborted / timed out
+__device__ __forceinline__ bool eng_wait_lds(unsigned* word, unsigned want, EngSync* sy, unsigned* status, unsigned code, int lane) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, ENG_WG) >= want) return true;
+        if (__hip_atomic_load(&sy->abort_, __ATOMIC_RELAXED, ENG_WG)) return false;
+        if (spins > ENG_SPIN_LDS) { eng_fail(sy, status, code, lane); return false; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the LDS-DMA instructions below are invisible to hipcc's own counting)
+__device__ __forceinline__ void eng_wait_vmcnt(int n) {
+    switch (n) {
+#define ENG_VM(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+        ENG_VM(0) ENG_VM(1) ENG_VM(2) ENG_VM(3) ENG_VM(4) ENG_VM(5) ENG_VM(6) ENG_VM(7) ENG_VM(8) ENG_VM(9) ENG_VM(10) ENG_VM(11) ENG_VM(12)
+        ENG_VM(13) ENG_VM(14) ENG_VM(15) ENG_VM(16) ENG_VM(17) ENG_VM(18) ENG_VM(19) ENG_VM(20) ENG_VM(21) ENG_VM(22) ENG_VM(23) ENG_VM(24)
+        ENG_VM(25) ENG_VM(26) ENG_VM(27) ENG_VM(28) ENG_VM(29) ENG_VM(30) ENG_VM(31) ENG_VM(32) ENG_VM(33) ENG_VM(34) ENG_VM(35) ENG_VM(36)
+        ENG_VM(37) ENG_VM(38) ENG_VM(39) ENG_VM(40) ENG_VM(41) ENG_VM(42) ENG_VM(43) ENG_VM(44) ENG_VM(45) ENG_VM(46) ENG_VM(47) ENG_VM(48)
+        ENG_VM(49) ENG_VM(50) ENG_VM(51) ENG_VM(52) ENG_VM(53) ENG_VM(54) ENG_VM(55) ENG_VM(56) ENG_VM(57) ENG_VM(58) ENG_VM(59) ENG_VM(60)
+        ENG_VM(61) ENG_VM(62) ENG_VM(63)
+#undef ENG_VM
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// 1 KB of one weight row -> LDS (lane l: 16 bytes at lds_dst + 16 l).  M0 carries the LDS address and is restored (hipcc reserves it).
+__device__ __forceinline__ void eng_dma(const void* gsrc, unsigned lds_dst_uniform, int nt) {
+    unsigned keep;
+    if (nt)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+// ---- the static unit list of this workgroup: contiguous shares of the row pairs of every phase (tables in LDS: read back through
+//      readfirstlane, so that every index derived from them stays in scalar registers and no kernel-argument access turns into a
+//      vector-memory load that the DMA accounting below would not know about) --------------------------------------------------------
+__device__ __forceinline__ void eng_share_init(const EngParams& p, EngSync* sy) {
+    const long G = gridDim.x, b = blockIdx.x;
+    int u = 0;
+    for (int i = 0; i < ENG_MAXPH; ++i) {
+        sy->ubeg[i] = u;
+        int lo = 0, hi = 0;
+        if (i < p.nph) {
+            const long NP = p.ph[i].N >> 1;
+            lo = (int)(b * NP / G);
+            hi = (int)((b + 1) * NP / G);
+            u += (hi - lo) * (p.ph[i].kind == 2 ? 4 : 1);
+        }
+        sy->pair0[i] = lo;
+    }
+    sy->ubeg[ENG_MAXPH] = u;
+}
+__device__ __forceinline__ int eng_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// groups [g_lo, g_hi) of 64 chunks a unit covers
+__device__ __forceinline__ void eng_unit_groups(const EngPhase& P, int lu, int& g_lo, int& g_hi) {
+    if (P.kind == 2) {
+        const int j = lu & 3;
+        g_lo = j * P.gq;
+        g_hi = (g_lo + P.gq < P.ngr) ? g_lo + P.gq : P.ngr;
+        if (g_lo > g_hi) g_lo = g_hi;
+    } else {
+        g_lo = 0;
+        g_hi = P.ngr;
+    }
+}
+__device__ __forceinline__ void eng_unit_rows(const EngPhase& P, int pp, int& r0, int& r1) {
+    if (P.epi == EPI_SWIGLU16) { r0 = ((pp >> 4) << 5) + (pp & 15); r1 = r0 + 16; }
+    else { r0 = 2 * pp; r1 = r0 + 1; }
+}
+
+// =====================================================================================================================
+// LOADER wave.  Walks phase by phase, unit by unit; before a unit is issued it retires (waits for, then publishes) the oldest units in
+// flight until (a) fewer than `depth` units are unpublished, (b) the counted wait for the oldest stays encodable (<= 63 younger DMA
+// instructions) and (c) the ring slot has been handed back.  The per-unit instruction counts of the units in flight travel in one
+// 64-bit scalar (8 bits each), so retiring needs no second walk over the unit list.
+// =====================================================================================================================
+__device__ __forceinline__ void eng_loader(const EngParams& p, unsigned char* smem, EngSync* sy, int lane) {
+    const unsigned ring_base = eng_uni((int)(unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)smem) + (unsigned)p.xs_bytes;
+    int issued = 0, published = 0, inflight = 0;
+    int islot = 0, pslot = 0;
+    unsigned long long counts = 0ull;            // instruction count of unit u at bits 8 (u & 7)
+    __builtin_amdgcn_s_setprio(3);
+    auto retire = [&]() {                          // oldest unit in flight: landed once only the younger units' DMAs are outstanding
+        const int n_old = (int)((counts >> (8 * (published & 7))) & 0xffull);
+        eng_wait_vmcnt(inflight - n_old);
+        __hip_atomic_store(&sy->full[pslot], (unsigned)(published + 1), __ATOMIC_RELAXED, ENG_WG);
+        inflight -= n_old;
+        ++published;
+        if (++pslot == p.nslot) pslot = 0;
+    };
+    for (int ph = 0; ph < p.nph; ++ph) {
+        const EngPhase& P = p.ph[ph];
+        const int nunit = eng_uni(sy->ubeg[ph + 1]) - eng_uni(sy->ubeg[ph]);
+        const int pair0 = eng_uni(sy->pair0[ph]);
+        const int nch = P.K >> 3;
+        for (int lu = 0; lu < nunit; ++lu) {
+            int g_lo, g_hi;
+            eng_unit_groups(P, lu, g_lo, g_hi);
+            const int n_new = 2 * (g_hi - g_lo);
+            // ---- make room
+            for (unsigned spins = 0;;) {
+                bool can = true;
+                if (published < issued) {
+                    const int n_old = (int)((counts >> (8 * (published & 7))) & 0xffull);
+                    if (issued - published >= p.depth || inflight + n_new - n_old > 63) can = false;
+                }
+                if (can && issued >= p.nslot &&
+                    __hip_atomic_load(&sy->freed[islot], __ATOMIC_RELAXED, ENG_WG) < (unsigned)(issued - p.nslot + 1))
+                    can = false;                                                               // slot still being read
+                if (can) break;
+                if (published < issued) { retire(); spins = 0; continue; }
+                // nothing in flight and no free slot: the consumers sit in a hand-off
+                if (__hip_atomic_load(&sy->abort_, __ATOMIC_RELAXED, ENG_WG)) return;
+                if (++spins > ENG_SPIN_LDS) { eng_fail(sy, p.status, 0x10u + (unsigned)ph, lane); return; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            // ---- issue the unit: row r0's groups, then row r1's, 1 KB per instruction
+            const int pp = pair0 + (P.kind == 2 ? (lu >> 2) : lu);
+            int r0, r1;
+            eng_unit_rows(P, pp, r0, r1);
+            const unsigned dst0 = ring_base + (unsigned)islot * (unsigned)p.slot_bytes;
+            const unsigned rowimg = (unsigned)(g_hi - g_lo) * 1024u;
+            const bf16_t* w0 = P.W + (long)r0 * P.ldw;
+            const bf16_t* w1 = P.W + (long)r1 * P.ldw;
+            for (int g = g_lo; g < g_hi; ++g) {
+                int ch = g * 64 + lane;
+                if (ch >= nch) ch = nch - 1;                       // ragged last group: re-read the last chunk (its activations are 0)
+                eng_dma(w0 + (long)ch * 8, dst0 + (unsigned)(g - g_lo) * 1024u, p.nt);
+            }
+            for (int g = g_lo; g < g_hi; ++g) {
+                int ch = g * 64 + lane;
+                if (ch >= nch) ch = nch - 1;
+                eng_dma(w1 + (long)ch * 8, dst0 + rowimg + (unsigned)(g - g_lo) * 1024u, p.nt);
+            }
+            counts = (counts & ~(0xffull << (8 * (issued & 7)))) | ((unsigned long long)n_new << (8 * (issued & 7)));
+            inflight += n_new;
+            ++issued;
+            if (++islot == p.nslot) islot = 0;
+        }
+    }
+    while (published < issued) retire();
+}
+
+// =====================================================================================================================
+// CONSUMER waves
+// =====================================================================================================================
+// Stage the activation vector of phase `ph` in LDS.  Normalised inputs: consumer 0 alone, reproducing the thread -> chunk map and the
+// summation tree of gemv_kernel's RMSNorm (256 virtual threads: chunks t and t + 256; wave sums of 64 consecutive threads; the four wave
+// sums added left to right).  Plain inputs: every consumer copies its share.
+__device__ __forceinline__ bool eng_stage(const EngParams& p, int ph, unsigned char* smem, EngSync* sy, int cw, int nc, int lane) {
+    const EngPhase& P = p.ph[ph];
+    const int nch = P.K >> 3;
+    bf16_t* xs = (bf16_t*)smem;
+    const int G = gridDim.x;
+    if (cw == 0) {
+        if (P.in_launch) {                                          // every workgroup has published the previous phase's outputs
+            const unsigned* fl = p.flags + (long)(ph - 1) * G;
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+                for (int i = lane; i < G; i += 64) ok &= eng_ld_u32(fl + i) != 0u;
+                if (__all(ok)) break;
+                if (__hip_atomic_load(&sy->abort_, __ATOMIC_RELAXED, ENG_WG)) return false;
+                if (spins > ENG_SPIN_GLOBAL) { eng_fail(sy, p.status, 0x20u + (unsigned)ph, lane); return false; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        if (P.norm_w) {
+            u32x4_t xr[4][2], gw[4][2];
+            float red[4];
+#pragma unroll
+            for (int vw = 0; vw < 4; ++vw)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = vw * 64 + lane + 256 * i;
+                    xr[vw][i] = c < nch ? eng_ld_chunk(P.A + (long)c * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                    gw[vw][i] = c < nch ? *(const u32x4_t*)(P.norm_w + (long)c * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+            for (int vw = 0; vw < 4; ++vw) {
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = lo2f(xr[vw][i][e]), b = hi2f(xr[vw][i][e]);
+                        ss += a * a + b * b;
+                    }
+                red[vw] = wave_sum(ss);
+            }
+            const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)P.K + p.eps);
+#pragma unroll
+            for (int vw = 0; vw < 4; ++vw)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = vw * 64 + lane + 256 * i;
+                    if (c < nch) {
+                        u32x4_t v = xr[vw][i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = pack2bf(bfround(lo2f(v[e]) * inv) * lo2f(gw[vw][i][e]), bfround(hi2f(v[e]) * inv) * hi2f(gw[vw][i][e]));
+                        *(u32x4_t*)(xs + (long)c * 8) = v;
+                    }
+                }
+            if (lane == 0) __hip_atomic_fetch_add(&sy->staged[ph], (unsigned)nc, __ATOMIC_RELEASE, ENG_WG);
+            return true;
+        }
+        if (lane == 0) __hip_atomic_store(&sy->go[ph], 1u, __ATOMIC_RELEASE, ENG_WG);
+    } else {
+        if (P.norm_w) return eng_wait_lds(&sy->staged[ph], (unsigned)nc, sy, p.status, 0x30u + (unsigned)ph, lane);
+        if (!eng_wait_lds(&sy->go[ph], 1u, sy, p.status, 0x40u + (unsigned)ph, lane)) return false;
+    }
+    // plain copy, split over the consumers (16 chunks per lane and batch in flight)
+    for (int c0 = cw * 64 + lane; c0 < nch; c0 += nc * 64 * 16) {
+        u32x4_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = c0 + j * nc * 64;
+            if (c < nch) v[j] = eng_ld_chunk(P.A + (long)c * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = c0 + j * nc * 64;
+            if (c < nch) *(u32x4_t*)(xs + (long)c * 8) = v[j];
+        }
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&sy->staged[ph], 1u, __ATOMIC_RELEASE, ENG_WG);
+    return eng_wait_lds(&sy->staged[ph], (unsigned)nc, sy, p.status, 0x50u + (unsigned)ph, lane);
+}
+
+// epilogue of one row pair by lane 0: the rounding points of gemv_body (bias, activation, residual, SwiGLU16)
+__device__ __forceinline__ void eng_epilogue(const EngPhase& P, int pp, int r0, float s0, float s1, float eb0, float eb1, float er0, float er1) {
+    if (P.epi == EPI_SWIGLU16) {
+        const float gg = bfround(s0), uu = bfround(s1);
+        eng_st_u16(P.C + pp, f2bf(bfround(silu_f(gg)) * uu));
+    } else {
+        float o[2] = {s0, s1};
+        const float eb[2] = {eb0, eb1}, er[2] = {er0, er1};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (P.bias) o[t] += eb[t];
+            if (P.epi == EPI_GELU_TANH) o[t] = gelu_tanh_f(bfround(o[t]));
+            else if (P.epi == EPI_SILU) o[t] = silu_f(bfround(o[t]));
+            if (P.R) o[t] = bfround(o[t]) + er[t];
+        }
+        eng_st_u32(P.C + r0, pack2bf(o[0], o[1]));                  // rows r0, r0 + 1: one aligned dword
+    }
+}
+
+__device__ __forceinline__ void eng_consumer(const EngParams& p, unsigned char* smem, EngSync* sy, int cw, int nc, int lane) {
+    const bf16_t* xs = (const bf16_t*)smem;
+    const unsigned char* ring = smem + p.xs_bytes;
+    int q = cw;
+    int slot = cw % p.nslot;
+    const int slot_step = nc % p.nslot;
+    for (int ph = 0; ph < p.nph; ++ph) {
+        const EngPhase& P = p.ph[ph];
+        if (!eng_stage(p, ph, smem, sy, cw, nc, lane)) return;
+        const int ubeg = eng_uni(sy->ubeg[ph]), uend = eng_uni(sy->ubeg[ph + 1]);
+        const int pair0 = eng_uni(sy->pair0[ph]);
+        const int nch = P.K >> 3;
+        const bool swiglu = P.epi == EPI_SWIGLU16;
+        for (; q < uend; q += nc) {
+            const int lu = q - ubeg;
+            const int pp = pair0 + (P.kind == 2 ? (lu >> 2) : lu);
+            int r0, r1, g_lo, g_hi;
+            eng_unit_rows(P, pp, r0, r1);
+            eng_unit_groups(P, lu, g_lo, g_hi);
+            // epilogue operands first: their latency hides under the wait for the slot
+            // (raw dwords, converted in the epilogue: a use here would make hipcc wait for them here)
+            unsigned bias_raw = 0u, r_raw = 0u;
+            if (lane == 0 && P.kind != 2 && !swiglu) {               // (split-K: whoever completes the pair loads them then)
+                if (P.bias) bias_raw = *(const unsigned*)(P.bias + r0);          // r0 is even: rows r0, r0 + 1 in one aligned dword
+                if (P.R) r_raw = eng_ld_u32(P.R + r0);
+            }
+            if (!eng_wait_lds(&sy->full[slot], (unsigned)(q + 1), sy, p.status, 0x60u + (unsigned)ph, lane)) return;
+            const unsigned char* sl = ring + (long)slot * p.slot_bytes + lane * 16;
+            const int rowimg = (g_hi - g_lo) * 1024;
+            const int ch_hi = (g_hi * 64 < nch) ? g_hi * 64 : nch;
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+            // one group ahead in registers: the LDS latency of group g + 1 hides under the FMAs of group g
+            u32x4_t wa, wb, xv;
+            {
+                const int ch = g_lo * 64 + lane;
+                const bool ok = ch < ch_hi;
+                wa = *(const u32x4_t*)(sl);
+                wb = *(const u32x4_t*)(sl + rowimg);
+                xv = *(const u32x4_t*)(xs + (long)(ok ? ch : 0) * 8);
+                if (!ok) xv = u32x4_t{0u, 0u, 0u, 0u};
+            }
+            for (int g = g_lo; g < g_hi; ++g) {
+                u32x4_t na = wa, nb = wb, nx = xv;
+                if (g + 1 < g_hi) {
+                    const int ch = (g + 1) * 64 + lane;
+                    const bool ok = ch < ch_hi;
+                    na = *(const u32x4_t*)(sl + (g + 1 - g_lo) * 1024);
+                    nb = *(const u32x4_t*)(sl + rowimg + (g + 1 - g_lo) * 1024);
+                    nx = *(const u32x4_t*)(xs + (long)(ok ? ch : 0) * 8);
+                    if (!ok) nx = u32x4_t{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xl = lo2f(xv[e]), xh = hi2f(xv[e]);
+                    a00 = fmaf(lo2f(wa[e]), xl, a00);
+                    a01 = fmaf(hi2f(wa[e]), xh, a01);
+                    a10 = fmaf(lo2f(wb[e]), xl, a10);
+                    a11 = fmaf(hi2f(wb[e]), xh, a11);
+                }
+                wa = na; wb = nb; xv = nx;
+            }
+            // the slot's bytes are in registers: hand it back before the reduction
+            if (lane == 0) __hip_atomic_store(&sy->freed[slot], (unsigned)(q + 1), __ATOMIC_RELEASE, ENG_WG);
+            slot += slot_step;
+            if (slot >= p.nslot) slot -= p.nslot;
+            float s0 = wave_sum(a00 + a01);
+            float s1 = wave_sum(a10 + a11);
+            if (lane == 0) {
+                if (P.kind == 2) {
+                    const int lp = lu >> 2, j = lu & 3;
+                    sy->part[lp][j][0] = s0;
+                    sy->part[lp][j][1] = s1;
+                    const unsigned old = __hip_atomic_fetch_add(&sy->pair_cnt[lp], 1u, __ATOMIC_ACQ_REL, ENG_WG);
+                    if ((old & 3u) == 3u) {                            // the four K quarters have met: fixed summation order
+                        s0 = (sy->part[lp][0][0] + sy->part[lp][1][0]) + (sy->part[lp][2][0] + sy->part[lp][3][0]);
+                        s1 = (sy->part[lp][0][1] + sy->part[lp][1][1]) + (sy->part[lp][2][1] + sy->part[lp][3][1]);
+                        if (P.bias) bias_raw = *(const unsigned*)(P.bias + r0);
+                        if (P.R) r_raw = eng_ld_u32(P.R + r0);
+                        eng_epilogue(P, pp, r0, s0, s1, lo2f(bias_raw), hi2f(bias_raw), lo2f(r_raw), hi2f(r_raw));
+                    }
+                } else {
+                    eng_epilogue(P, pp, r0, s0, s1, lo2f(bias_raw), hi2f(bias_raw), lo2f(r_raw), hi2f(r_raw));
+                }
+            }
+        }
+        // publish: every consumer drains its own stores, the last one to arrive sets the workgroup's flag of this phase
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&sy->done[ph], 1u, __ATOMIC_ACQ_REL, ENG_WG);
+            if (old == (unsigned)(nc - 1) && ph + 1 < p.nph) eng_st_u32(p.flags + (long)ph * gridDim.x + blockIdx.x, 1u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void decode_engine_kernel(const EngParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem[];
+    EngSync* sy = (EngSync*)(eng_smem + p.xs_bytes + (long)p.nslot * p.slot_bytes);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = eng_uni(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    for (int i = tid; i < (int)(sizeof(EngSync) / 4); i += blockDim.x) ((unsigned*)sy)[i] = 0u;
+    __syncthreads();
+    if (tid == 0) eng_share_init(p, sy);
+    __syncthreads();
+    if (wave == nwaves - 1) eng_loader(p, eng_smem, sy, lane);
+    else eng_consumer(p, eng_smem, sy, wave, nwaves - 1, lane);
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------------------------
+static int eng_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+extern "C" int bagel_decode_engine_workgroups(void) {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return bagel_set_error(BAGEL_ERR_LAUNCH, "decode_engine: cannot query the device");
+        n = prop.multiProcessorCount;
+    }
+    return n;
+}
+
+extern "C" int bagel_decode_engine_sync_bytes(int32_t n_phases) {
+    const int n_wg = bagel_decode_engine_workgroups();
+    if (n_wg <= 0) return n_wg;
+    if (n_phases <= 0) return 0;
+    return (n_phases * n_wg * 4 + 255) / 256 * 256;
+}
+
+extern "C" int bagel_decode_engine_bf16(const void* const* ptrs, const int64_t* dims, int32_t n_phases, float eps, void* sync_ws,
+                                        void* status, hipStream_t stream) {
+    BAGEL_REQUIRE(ptrs && dims && sync_ws && status, "decode_engine: null pointer");
+    BAGEL_REQUIRE(n_phases >= 1 && n_phases <= ENG_MAXPH, "decode_engine: 1..%d phases (got %d)", ENG_MAXPH, n_phases);
+    const int n_wg = bagel_decode_engine_workgroups();
+    if (n_wg <= 0) return n_wg;
+    EngParams p;
+    p.nph = n_phases;
+    p.eps = eps;
+    p.flags = (unsigned*)sync_ws;
+    p.status = (unsigned*)status;
+    int max_k = 0, slot = 0;
+    for (int i = 0; i < n_phases; ++i) {
+        EngPhase& P = p.ph[i];
+        const void* const* q = ptrs + 6 * i;
+        const int64_t* d = dims + 4 * i;
+        P.A = (const bf16_t*)q[0]; P.W = (const bf16_t*)q[1]; P.bias = (const bf16_t*)q[2]; P.norm_w = (const bf16_t*)q[3];
+        P.R = (const bf16_t*)q[4]; P.C = (bf16_t*)q[5];
+        P.N = (int)d[0]; P.K = (int)d[1]; P.ldw = d[2]; P.epi = (int)d[3];
+        BAGEL_REQUIRE(P.A && P.W && P.C, "decode_engine: phase %d: null A / W / C", i);
+        BAGEL_REQUIRE(P.K > 0 && (P.K % 8) == 0 && (P.ldw % 8) == 0, "decode_engine: phase %d: K / ldw must be multiples of 8", i);
+        BAGEL_REQUIRE(P.N > 0 && (P.N % 2) == 0, "decode_engine: phase %d: N = %d must be even", i, P.N);
+        BAGEL_REQUIRE(P.epi >= 0 && P.epi <= 3, "decode_engine: phase %d: unknown epilogue %d", i, P.epi);
+        BAGEL_REQUIRE(P.epi != EPI_SWIGLU16 || ((P.N % 32) == 0 && !P.bias && !P.R), "decode_engine: phase %d: swiglu needs N %% 32 == 0, no bias / residual", i);
+        BAGEL_REQUIRE((((uintptr_t)P.A | (uintptr_t)P.W | (uintptr_t)P.norm_w) & 15) == 0, "decode_engine: phase %d: A / W / norm_w must be 16-byte aligned", i);
+        BAGEL_REQUIRE((((uintptr_t)P.C | (uintptr_t)P.R) & 3) == 0, "decode_engine: phase %d: C / R must be 4-byte aligned", i);
+        BAGEL_REQUIRE(!P.norm_w || (P.K >> 3) <= 512, "decode_engine: phase %d: the fused RMSNorm serves K <= 4096", i);
+        BAGEL_REQUIRE(i == 0 || P.A == (const bf16_t*)p.ph[i - 1].C, "decode_engine: phase %d must read the previous phase's output", i);
+        BAGEL_REQUIRE(i == 0 || P.K == (p.ph[i - 1].epi == EPI_SWIGLU16 ? p.ph[i - 1].N / 2 : p.ph[i - 1].N),
+                      "decode_engine: phase %d: K = %d does not match the previous phase's output length", i, P.K);
+        P.in_launch = i > 0;
+        P.ngr = (P.K / 8 + 63) / 64;
+        // the split-K form of bagel_gemv_bf16 (launch_gemv_any): long un-normalised rows, few of them
+        P.kind = (!P.norm_w && P.K >= 8192 && P.N / 2 <= 8192) ? 2 : 0;
+        P.gq = (P.ngr + 3) / 4;
+        const int unit_groups = P.kind == 2 ? P.gq : P.ngr;
+        BAGEL_REQUIRE(2 * unit_groups <= 60, "decode_engine: phase %d: K = %d gives %d KB units (at most 60 LDS-DMA instructions in flight)", i, P.K, 2 * unit_groups);
+        if (P.kind == 2) {
+            const long max_pairs = ((long)P.N / 2 + n_wg - 1) / n_wg;
+            BAGEL_REQUIRE(max_pairs <= ENG_MAX_DPAIRS, "decode_engine: phase %d: %ld split-K pairs per workgroup (at most %d)", i, max_pairs, ENG_MAX_DPAIRS);
+        }
+        if (2 * unit_groups * 1024 > slot) slot = 2 * unit_groups * 1024;
+        if (P.K > max_k) max_k = P.K;
+    }
+    p.xs_bytes = (max_k * 2 + 1023) / 1024 * 1024;
+    p.slot_bytes = slot;
+    int nslot = (ENG_LDS_MAX - p.xs_bytes - ENG_SYNC_BYTES) / slot;
+    const int want = eng_env("BAGEL_ENGINE_SLOTS", ENG_MAX_SLOTS);
+    if (nslot > want) nslot = want;
+    if (nslot > ENG_MAX_SLOTS) nslot = ENG_MAX_SLOTS;
+    BAGEL_REQUIRE(nslot >= 3, "decode_engine: the LDS ring holds %d slots of %d bytes beside a %d-byte activation vector (need 3)", nslot, slot, p.xs_bytes);
+    p.nslot = nslot;
+    p.depth = eng_env("BAGEL_ENGINE_DEPTH", 3);
+    if (p.depth < 1) p.depth = 1;
+    if (p.depth > nslot) p.depth = nslot;
+    p.nt = eng_env("BAGEL_ENGINE_NT", 1);
+    int waves = eng_env("BAGEL_ENGINE_WAVES", 4);
+    if (waves < 2) waves = 2;
+    if (waves > 8) waves = 8;
+    const int smem = p.xs_bytes + nslot * slot + ENG_SYNC_BYTES;
+    if (smem > 48 * 1024)
+        if (int rc = bagel_enable_lds((const void*)decode_engine_kernel, ENG_LDS_MAX, "decode_engine_kernel")) return rc;
+    hipLaunchKernelGGL(decode_engine_kernel, dim3(n_wg), dim3(64 * waves), smem, stream, p);
+    return bagel_check_launch("decode_engine_kernel");
+}

@@ -620,6 +620,8 @@ class Bagel(nn.Module):
             lm._packed_fresh()
         return eng.layers.resident_bytes()
 
+    @torch.no_grad()
+    @_bf16_weights
     def generate_text(self, past_key_values, packed_key_value_indexes, key_values_lens, packed_start_tokens,
                       packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None,
                       use_graph=None, weight_quant=None):
@@ -661,6 +663,7 @@ class Bagel(nn.Module):
             if end_token_id is not None and sess.last_token(0) == end_token_id:   # only support batch=1 (bagel.py:996)
                 break
         sess.write_back(past_key_values)
+        sess.check_engine_status()          # (the persistent decode engine reports a spin that gave up through a device word; one sync here)
         return sess.tokens_so_far()
 
     @torch.no_grad()

@@ -12,6 +12,8 @@ Mirrors the loop of ``Bagel.generate_text`` (bagel.py:930-1000) and the Lq = 1 p
     is captured ONCE into a hipGraph and replayed per token: the host issues one call per token and only reads a
     token back when the caller asked for an end-token check (bagel.py:996).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -126,7 +128,6 @@ class DecodeSession:
         self.next_tok = torch.zeros((B,), dtype=torch.long, device=dev)
         self.step_ctr = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.inv_freq = eng.model.rotary_emb.inv_freq(dev)
-        import os
         # q/k norm + RoPE + page append run in the prologue of the attention workgroups (16-lane groups own one head each, results
         # handed round through LDS): one launch fewer per layer, bit-identical to the two-kernel form, 3.31 -> 3.23 ms/token under
         # the profiler at 7B (profiles/r02_decode_mfma_attention.log).  BAGEL_DECODE_FUSED=0 keeps decode_qkv_post as its own launch;
@@ -159,6 +160,15 @@ class DecodeSession:
             if B > 4:
                 raise NotImplementedError("mxfp4 weights: the projection kernel quantises at most 4 activation rows per launch (batch <= 4)")
         self.w8 = self._quantised_weights() if weight_quant else None
+        # One request on bf16 weights: o_proj -> norm + gate/up -> down -> the next layer's norm + qkv (the last layer: final norm + lm_head) run as
+        # ONE persistent launch per layer on the loader / consumer weight-streaming engine (csrc/engine.hip), bit-identical to the gemv launches it
+        # replaces; 3 launches per layer instead of 6.  BAGEL_DECODE_ENGINE=0 keeps the launch form (also taken for shapes the engine refuses).
+        self.engine_mode = bool(B == 1 and weight_quant is None and os.environ.get("BAGEL_DECODE_ENGINE", "1") == "1"
+                                and self._engine_phases_supported())
+        if self.engine_mode:
+            self._eng_words = ops.decode_engine_sync_words(4)
+            self.eng_sync = torch.zeros((L, self._eng_words), dtype=torch.int32, device=dev)
+            self.eng_status = torch.zeros((4,), dtype=torch.int32, device=dev)
         self.steps_done = 0
         self.graph = None
         self.graph_error = None
@@ -176,6 +186,41 @@ class DecodeSession:
             cache = [dict(wqkv=qz(P.wqkv[0]), wo=qz(P.wo[0]), wgu=qz(P.wgu[0]), wd=qz(P.wd[0])) for P in eng.layers]
             setattr(eng, attr, cache)
         return cache
+
+    # ---- persistent-engine form of the projections of one request -----------------------------------------------
+    def _engine_phases(self, li):
+        """The chain of layer ``li``: o_proj(+x) -> post-norm + gate/up (SwiGLU) -> down(+x) -> [next layer's input norm + qkv | final norm + lm_head]."""
+        eng = self.eng
+        layers = eng.layers
+        P = layers[li]
+        x = self.x
+        ph = [dict(A=self.att, W=P.wo[0], C=x, residual=x),
+              dict(A=x, W=P.wgu[0], C=self.act, norm_w=P.ln_post[0], epilogue=ops.EPI_SWIGLU16),
+              dict(A=self.act, W=P.wd[0], C=x, residual=x)]
+        if li + 1 < len(layers):
+            Pn = layers[li + 1]
+            ph.append(dict(A=x, W=Pn.wqkv[0], C=self.qkv, norm_w=Pn.ln_in[0], bias=Pn.bqkv[0]))
+        else:
+            ph.append(dict(A=x, W=self.head, C=self.logits, norm_w=eng.model.norm.weight.data))
+        return ph
+
+    def _engine_phases_supported(self):
+        eng = self.eng
+        if getattr(eng, "weight_store", None) is not None:
+            return False
+        try:
+            n = len(eng.layers)
+            return all(ops.decode_engine_supported(self._engine_phases(li)) for li in sorted({0, n - 1}))
+        except Exception:
+            return False
+
+    def check_engine_status(self):
+        """Raise if a workgroup of the persistent engine gave up a bounded wait (the outputs of that call are then undefined)."""
+        if getattr(self, "engine_mode", False):
+            code = int(self.eng_status[0])
+            if code:
+                raise ops.BagelHipError(f"decode engine: a bounded wait timed out (code 0x{code & 0xff:x}, workgroup {code >> 8}); "
+                                        "set BAGEL_DECODE_ENGINE=0 for the launch form")
 
     # ---- the launch sequence of one token (no host-dependent values: safe to capture) ---------------------------
     def forward_launches(self):
@@ -210,6 +255,24 @@ class DecodeSession:
                 ops.rmsnorm(inp, norm_w, h, eng.eps)
                 inp = h
             return ops.gemm(inp, w, out, bias0=kw.get("bias"), residual=kw.get("residual"), epilogue=kw.get("epilogue", ops.EPI_NONE), M0=B)
+        if self.engine_mode:
+            # qkv of layer 0, then per layer: attention (split + combine) and ONE engine launch; the flag words of every layer are cleared once per token
+            self.eng_sync.zero_()
+            P0 = eng.layers[0]
+            ops.gemv(x, P0.wqkv[0], qkv, norm_w=P0.ln_in[0], eps=eng.eps, bias=P0.bqkv[0])
+            for li, P in enumerate(eng.layers):
+                if self.fused_attention:
+                    ops.attn_decode_fused(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
+                                          pg.k[li], pg.v[li], pg.block_table, pg.kv_len, self.max_len, self.part_o, self.part_ml, att, B,
+                                          nq, nkv, hd, dp, eng.eps, eng.use_norm, scale)
+                else:
+                    ops.decode_qkv_post(qkv, self.cos, self.sin, P.qn[0] if eng.use_norm else None, P.kn[0] if eng.use_norm else None,
+                                        pg.k[li], pg.v[li], pg.block_table, pg.kv_len, B, nq, nkv, hd, dp, eng.eps, eng.use_norm)
+                    ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
+                                          self.part_ml, att, B, nq, nkv, dp, scale)
+                ops.decode_engine(self._engine_phases(li), eng.eps, self.eng_sync[li], self.eng_status)
+            ops.argmax_into(self.logits, self.next_tok)
+            return
         layers = eng.layers.small_views() if getattr(eng, "weight_store", None) is not None else eng.layers      # (a quantised engine: no scratch copies here)
         for li, P in enumerate(layers):
             Q = self.w8[li] if self.w8 is not None else None

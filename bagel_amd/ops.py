@@ -255,6 +255,72 @@ def gemv(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w
     return C
 
 
+def decode_engine_workgroups():
+    n = lib().bagel_decode_engine_workgroups()
+    if n <= 0:
+        check(n, "bagel_decode_engine_workgroups")
+    return n
+
+
+def decode_engine_sync_words(n_phases):
+    """uint32 words of hand-off flags one bagel_decode_engine_bf16 launch of ``n_phases`` phases needs (zero at launch)."""
+    n = lib().bagel_decode_engine_sync_bytes(int(n_phases))
+    if n < 0:
+        check(n, "bagel_decode_engine_sync_bytes")
+    return n // 4
+
+
+def decode_engine_supported(phases):
+    """The shapes the persistent decode engine serves (csrc/engine.hip): what bagel_decode_engine_bf16 would refuse is refused here
+    without a launch, so callers can fall back to the launch form."""
+    if not 1 <= len(phases) <= 4:
+        return False
+    for ph in phases:
+        N, K = ph["W"].shape
+        if K % 8 or N % 2 or ph["W"].stride(0) % 8:
+            return False
+        if ph.get("norm_w") is not None and K > 4096:
+            return False
+        split = ph.get("norm_w") is None and K >= 8192 and N // 2 <= 8192
+        groups = -(-(K // 8) // 64)
+        if 2 * (-(-groups // 4) if split else groups) > 60:
+            return False
+        if ph.get("epilogue", EPI_NONE) == EPI_SWIGLU16 and (N % 32 or ph.get("bias") is not None or ph.get("residual") is not None):
+            return False
+    return True
+
+
+def decode_engine(phases, eps, sync_ws, status):
+    """ONE persistent launch for a chain of batch-1 projections; see bagel_decode_engine_bf16.  ``phases``: list of dicts with the keys of
+    ``gemv`` -- A, W, C and optionally bias, residual, norm_w, epilogue -- where A of phase i > 0 is C of phase i - 1.  ``sync_ws``: int32 /
+    uint32 words, at least decode_engine_sync_words(len(phases)), ZERO at launch; ``status``: 4 words, checked by the caller."""
+    n = len(phases)
+    ptrs = (ctypes.c_void_p * (6 * n))()
+    dims = (ctypes.c_int64 * (4 * n))()
+    for i, ph in enumerate(phases):
+        A, W, C = ph["A"], ph["W"], ph["C"]
+        _req(A, BF16, "decode_engine.A"); _req(W, BF16, "decode_engine.W"); _req(C, BF16, "decode_engine.C")
+        N, K = W.shape
+        if A.numel() != K:
+            raise BagelHipError(f"decode_engine: phase {i}: A has {A.numel()} elements, W has K={K} (one activation row)")
+        for key in ("bias", "residual", "norm_w"):
+            if ph.get(key) is not None:
+                _req(ph[key], BF16, f"decode_engine.{key}")
+        ptrs[6 * i + 0] = _ptr(A)
+        ptrs[6 * i + 1] = _ptr(W)
+        ptrs[6 * i + 2] = _ptr(ph.get("bias"))
+        ptrs[6 * i + 3] = _ptr(ph.get("norm_w"))
+        ptrs[6 * i + 4] = _ptr(ph.get("residual"))
+        ptrs[6 * i + 5] = _ptr(C)
+        dims[4 * i + 0], dims[4 * i + 1], dims[4 * i + 2], dims[4 * i + 3] = N, K, W.stride(0), int(ph.get("epilogue", EPI_NONE))
+    if sync_ws.numel() * sync_ws.element_size() < 4 * decode_engine_sync_words(n) or sync_ws.element_size() != 4:
+        raise BagelHipError("decode_engine: sync_ws is smaller than decode_engine_sync_words(len(phases)) 4-byte words")
+    if status.numel() < 4 or status.element_size() != 4:
+        raise BagelHipError("decode_engine: status needs 4 4-byte words")
+    check(lib().bagel_decode_engine_bf16(ctypes.addressof(ptrs), ctypes.addressof(dims), n, float(eps), _ptr(sync_ws), _ptr(status),
+                                         _stream()), "bagel_decode_engine_bf16")
+
+
 def quantize_rows_i8(W):
     """bf16 [N, K] -> (u8 [N, K] = round(W / s) + 128, fp32 s [N] = rowwise absmax / 127); see bagel_quantize_rows_i8."""
     _req(W, BF16, "quantize_rows_i8.W")

@@ -294,6 +294,27 @@ int bagel_attn_decode_fused_bf16(const void* qkv, int64_t ld, const void* cos_ta
                                  int32_t head_dim_padded, float eps, int32_t use_norm, float softmax_scale,
                                  bagel_stream_t stream);
 
+/* A CHAIN of 1..4 dependent batch-1 projections as ONE persistent launch (csrc/engine.hip): phase i computes what
+ * bagel_gemv_bf16(A_i, W_i, bias_i, R_i, C_i, norm_w_i, eps, M = 1, N_i, K_i, epilogue_i) computes, bit for bit, with A_0 written by an
+ * earlier launch and A_i == C_{i-1} for i > 0 -- for a decoder layer at Lq = 1 (bagel.py:930-1000): o_proj(+residual)
+ * (qwen2_navit.py:591-594) -> post-attention RMSNorm + gate/up with SwiGLU -> down(+residual) (modeling_qwen2.py:200-201, 54-59) -> the
+ * NEXT layer's input RMSNorm + qkv (qwen2_navit.py:515-517), or the final norm + lm_head (bagel.py:978).  One workgroup per CU: a loader
+ * wave streams the workgroup's share of every phase's weight rows through an LDS ring with non-temporal LDS-DMA and never waits for an
+ * activation (the next phase's weights arrive while the consumers hand over), the other waves run the lane-FMA body of the gemv kernel;
+ * hand-offs between phases are write-through stores + one flag word per workgroup and phase.
+ *   ptrs: HOST array [n_phases][6] = {A, W, bias | NULL, norm_w | NULL, R | NULL, C} (device pointers; R may alias C);
+ *   dims: HOST array [n_phases][4] = {N, K, ldw, epilogue};
+ *   sync_ws: bagel_decode_engine_sync_bytes(n_phases) bytes of device memory that are ZERO when the launch starts (the caller clears it,
+ *            e.g. one memset per token over every layer's slice); status: 4 device uint32, written only on failure (a bounded spin
+ *            gave up: code | workgroup << 8) -- the caller clears it once and checks it when it next synchronises.
+ * The launch occupies EVERY CU (grid = bagel_decode_engine_workgroups()) and its workgroups wait for each other: nothing else may be
+ * running on the device's other streams that could keep a CU from it for long.  K % 8 == 0, N even; a fused RMSNorm needs K <= 4096;
+ * un-normalised rows of K >= 8192 take the 4-way K split of bagel_gemv_bf16 (the down projection). */
+int bagel_decode_engine_workgroups(void);
+int bagel_decode_engine_sync_bytes(int32_t n_phases);
+int bagel_decode_engine_bf16(const void* const* ptrs, const int64_t* dims, int32_t n_phases, float eps, void* sync_ws, void* status,
+                             bagel_stream_t stream);
+
 /* Device-side bookkeeping of one decode step (bagel.py:984-994): cur_tok32 <- next_tok, tokens_out[step+1] <- next_tok,
  * pos += 1, kv_len += 1, step += 1.  Keeps the host out of the token loop so one captured step can be replayed. */
 int bagel_decode_advance(const int64_t* next_tok, int32_t* cur_tok32, int64_t* tokens_out, int64_t* pos,
