@@ -163,7 +163,7 @@ class DecodeSession:
         # One request on bf16 weights: o_proj -> norm + gate/up -> down -> the next layer's norm + qkv (the last layer: final norm + lm_head) run as
         # ONE persistent launch per layer on the loader / consumer weight-streaming engine (csrc/engine.hip), bit-identical to the gemv launches it
         # replaces; 3 launches per layer instead of 6.  BAGEL_DECODE_ENGINE=0 keeps the launch form (also taken for shapes the engine refuses).
-        self.engine_mode = bool(B == 1 and weight_quant is None and os.environ.get("BAGEL_DECODE_ENGINE", "1") == "1"
+        self.engine_mode = bool(B == 1 and weight_quant is None and os.environ.get("BAGEL_DECODE_ENGINE", "0") == "1"
                                 and self._engine_phases_supported())
         if self.engine_mode:
             self._eng_words = ops.decode_engine_sync_words(4)

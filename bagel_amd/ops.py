@@ -290,7 +290,7 @@ def decode_engine_supported(phases):
     return True
 
 
-def decode_engine(phases, eps, sync_ws, status):
+def decode_engine(phases, eps, sync_ws, status, trace=None):
     """ONE persistent launch for a chain of batch-1 projections; see bagel_decode_engine_bf16.  ``phases``: list of dicts with the keys of
     ``gemv`` -- A, W, C and optionally bias, residual, norm_w, epilogue -- where A of phase i > 0 is C of phase i - 1.  ``sync_ws``: int32 /
     uint32 words, at least decode_engine_sync_words(len(phases)), ZERO at launch; ``status``: 4 words, checked by the caller."""
@@ -317,6 +317,12 @@ def decode_engine(phases, eps, sync_ws, status):
         raise BagelHipError("decode_engine: sync_ws is smaller than decode_engine_sync_words(len(phases)) 4-byte words")
     if status.numel() < 4 or status.element_size() != 4:
         raise BagelHipError("decode_engine: status needs 4 4-byte words")
+    if trace is not None:          # diagnostic: int64 [workgroups, 4, 16] event times, see bagel_decode_engine_traced_bf16
+        if trace.numel() < decode_engine_workgroups() * 64 or trace.element_size() != 8:
+            raise BagelHipError("decode_engine: trace needs workgroups x 4 x 16 8-byte words")
+        check(lib().bagel_decode_engine_traced_bf16(ctypes.addressof(ptrs), ctypes.addressof(dims), n, float(eps), _ptr(sync_ws), _ptr(status),
+                                                    _ptr(trace), _stream()), "bagel_decode_engine_traced_bf16")
+        return
     check(lib().bagel_decode_engine_bf16(ctypes.addressof(ptrs), ctypes.addressof(dims), n, float(eps), _ptr(sync_ws), _ptr(status),
                                          _stream()), "bagel_decode_engine_bf16")
 

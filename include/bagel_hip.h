@@ -314,6 +314,12 @@ int bagel_decode_engine_workgroups(void);
 int bagel_decode_engine_sync_bytes(int32_t n_phases);
 int bagel_decode_engine_bf16(const void* const* ptrs, const int64_t* dims, int32_t n_phases, float eps, void* sync_ws, void* status,
                              bagel_stream_t stream);
+/* Diagnostic form: the same launch, and every workgroup leaves its event times (100 MHz ticks of s_memrealtime) in
+ * trace[workgroup][4 phases][16] uint64: 0 loader first issue, 1 last issue, 2 ticks blocked on a free ring slot, 3 ticks blocked in counted DMA
+ * waits, 4 consumer 0 hand-off begin, 5 flags seen, 6 activation staged, 7..9 consumer c's last unit done, 10..12 ticks consumer c waited for
+ * full slots, 13 the workgroup's flag store (tools/decode_engine_probe.py --trace). */
+int bagel_decode_engine_traced_bf16(const void* const* ptrs, const int64_t* dims, int32_t n_phases, float eps, void* sync_ws, void* status,
+                                    void* trace, bagel_stream_t stream);
 
 /* Device-side bookkeeping of one decode step (bagel.py:984-994): cur_tok32 <- next_tok, tokens_out[step+1] <- next_tok,
  * pos += 1, kv_len += 1, step += 1.  Keeps the host out of the token loop so one captured step can be replayed. */

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--sets", type=int, default=6)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--quick", action="store_true", help="the launch form and the default engine only (PMC passes)")
+    ap.add_argument("--trace", action="store_true", help="one traced engine launch per weight set: where a layer's time goes (event times of every workgroup)")
     a = ap.parse_args()
     g = torch.Generator(device=DEV).manual_seed(0)
     rn = lambda *s, scale=1.0: (torch.randn(*s, generator=g, device=DEV) * scale).to(BF16)  # noqa: E731
@@ -76,21 +78,64 @@ def main():
         print(f"{label:58s} {med:9.1f} us / {a.layers} layers = {per:7.2f} us per layer = {bytes_layer / per / 1e6:5.2f} TB/s of weights   (min {ts[0] * 1e6 / a.layers:.2f})", flush=True)
         return res
 
+    if a.trace:
+        trace_report(a, sets, phases, sync, status, x, x0)
+        return
     print(f"# chain o -> gate/up -> down -> qkv at H={H} I={I}: {bytes_layer / 1e6:.1f} MB of bf16 weights per layer; {a.sets} weight sets cycled; "
           f"{ops.decode_engine_workgroups()} workgroups; median of {a.reps} graph replays (host-timed: + ~10-16 us of replay floor per graph, /{a.layers} per layer)")
     ref = timed(launch_form, "launch form: 4 x bagel_gemv_bf16 per layer")
-    for env in [dict(), dict(BAGEL_ENGINE_DEPTH="2"), dict(BAGEL_ENGINE_DEPTH="4"), dict(BAGEL_ENGINE_DEPTH="6"), dict(BAGEL_ENGINE_NT="0"),
-                dict(BAGEL_ENGINE_WAVES="8"), dict(BAGEL_ENGINE_WAVES="8", BAGEL_ENGINE_DEPTH="4"), dict(BAGEL_ENGINE_WAVES="3"),
-                dict(BAGEL_ENGINE_SLOTS="4"), dict(BAGEL_ENGINE_WAVES="6")]:
-        for k in ("BAGEL_ENGINE_DEPTH", "BAGEL_ENGINE_NT", "BAGEL_ENGINE_WAVES", "BAGEL_ENGINE_SLOTS"):
+    for env in [dict(), dict(BAGEL_ENGINE_DEPTH="1"), dict(BAGEL_ENGINE_LOADERS="1", BAGEL_ENGINE_WAVES="4", BAGEL_ENGINE_DEPTH="3"), dict(BAGEL_ENGINE_NT="0"),
+                dict(BAGEL_ENGINE_WAVES="5"), dict(BAGEL_ENGINE_WAVES="6"), dict(BAGEL_ENGINE_WAVES="4"),
+                dict(BAGEL_ENGINE_SLOTS="4"),
+                # timing-only ablations (wrong results by construction): what is left when one of the three parties is taken out
+                dict(BAGEL_ENGINE_ABL="1"), dict(BAGEL_ENGINE_ABL="2"), dict(BAGEL_ENGINE_ABL="4"), dict(BAGEL_ENGINE_ABL="5"), dict(BAGEL_ENGINE_ABL="6"),
+                dict(BAGEL_ENGINE_ABL="3"), dict(BAGEL_ENGINE_ABL="7")]:
+        for k in ("BAGEL_ENGINE_DEPTH", "BAGEL_ENGINE_NT", "BAGEL_ENGINE_WAVES", "BAGEL_ENGINE_SLOTS", "BAGEL_ENGINE_ABL", "BAGEL_ENGINE_LOADERS"):
             os.environ.pop(k, None)
+        if a.quick and env:
+            break
         os.environ.update(env)
-        got = timed(engine_form, "engine: " + (" ".join(f"{k[13:]}={v}" for k, v in env.items()) or "defaults (depth 3, nt, 4 waves, 6 slots)"))
+        got = timed(engine_form, "engine: " + (" ".join(f"{k[13:]}={v}" for k, v in env.items()) or "defaults (2 loaders x depth 2, 6 consumers, nt, 6 slots)"))
         code = int(status[0])
         same = all(torch.equal(p, q) for p, q in zip(ref, got))
         print(f"    bit-identical to the launch form: {same}; status 0x{code:x}", flush=True)
         if code:
             status.zero_()
+
+
+def trace_report(a, sets, phases, sync, status, x, x0):
+    """Eager traced launches (one per weight set, the first is a warm-up): per phase, over the workgroups, min / median / max of every event relative to
+    the launch's first event, in microseconds."""
+    import numpy as np
+    nwg = ops.decode_engine_workgroups()
+    names = ["loader first issue", "loader last issue", "loader blocked: no free slot (sum)", "loader blocked: counted DMA wait (sum)",
+             "c0 hand-off begin", "c0 flags seen", "c0 activation staged", "c0 last unit done", "c1 last unit done", "c2 last unit done",
+             "c0 waited for full slots (sum)", "c1 waited for full slots (sum)", "c2 waited for full slots (sum)", "workgroup flag stored"]
+    durations = {2, 3, 10, 11, 12}
+    for it in range(len(sets)):
+        tr = torch.zeros((nwg, 4, 16), dtype=torch.int64, device=DEV)
+        x.copy_(x0)
+        sync.zero_()
+        torch.cuda.synchronize()
+        ops.decode_engine(phases(sets[it]), 1e-6, sync[0], status, trace=tr)
+        torch.cuda.synchronize()
+        if it == 0:
+            continue
+        t = tr.cpu().numpy().astype(np.float64) / 100.0          # 100 MHz ticks -> us
+        ev = [k for k in range(14) if k not in durations]
+        t0 = min(t[:, 0, k][t[:, 0, k] > 0].min() for k in ev if (t[:, 0, k] > 0).any())
+        end = max(t[:, 3, k].max() for k in (7, 8, 9))
+        print(f"## traced launch on weight set {it}: {end - t0:.1f} us from the first event to the last unit; status 0x{int(status[0]):x}")
+        for ph, pname in enumerate(["o_proj", "gate/up", "down", "qkv"]):
+            print(f"  phase {ph} ({pname})")
+            for k in range(14):
+                v = t[:, ph, k]
+                v = v[v > 0] if k not in durations else v
+                if v.size == 0:
+                    continue
+                if k not in durations:
+                    v = v - t0
+                print(f"    {names[k]:42s} min {v.min():8.2f}  p10 {np.percentile(v, 10):8.2f}  med {np.median(v):8.2f}  p90 {np.percentile(v, 90):8.2f}  max {v.max():8.2f}")
 
 
 if __name__ == "__main__":
