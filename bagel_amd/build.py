@@ -60,7 +60,7 @@ def build(force=False, keep_temps=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "bagel_hip.h")]
     manifest = _load_manifest()
-    digests = {s: _digest([os.path.join(CSRC, s)] + [h for h in headers if h.startswith(CSRC)]) for s in sources()}
+    digests = {s: _digest([os.path.join(CSRC, s)] + headers) for s in sources()}       # (common.h includes the public header: it is an input of every object)
     todo = [s for s in sources() if force or manifest.get(s) != digests[s] or not os.path.exists(os.path.join(OBJ, s[:-4] + ".o"))]
     if not todo and os.path.exists(LIB) and manifest.get("__lib__") == sorted(digests.values()):
         return LIB                                     # everything up to date (by content)

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+// the public C ABI: every translation unit sees the prototypes of the entry points it defines, so a definition that drifts from include/bagel_hip.h is a
+// COMPILE error ("conflicting types") instead of a ctypes call with the wrong arguments at run time
+#include "../../include/bagel_hip.h"
 
 typedef unsigned short bf16_t;   // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16 = 4 VGPR)

@@ -25,7 +25,6 @@
 //
 // Flags live in caller memory that must be ZERO when the launch starts (one memset per token covers every layer's slice).
 #include "common.h"
-#include "../../include/bagel_hip.h"
 #include <stdlib.h>
 
 #define EPI_NONE 0

@@ -151,6 +151,12 @@ class Bagel(nn.Module):
             t = torch.tensor(t)
         return t.to(device=self.device, dtype=dtype if dtype is not None else t.dtype).contiguous()
 
+    def state_dict(self, *args, **kwargs):
+        if getattr(self, "_released_bf16", None):
+            raise RuntimeError(f"state_dict(): quantize_language_model({self._released_bf16!r}, release_bf16=True) freed the bf16 projection weights of the language "
+                               "model; a state dict written now would hold 0-element tensors.  Build a new model and load the checkpoint to get one.")
+        return super().state_dict(*args, **kwargs)
+
     def _ensure_bf16(self):
         """The engines run bf16 weights (the app.py:111 / inferencer.py:233 configuration).  A caller that keeps fp32 master weights
         and relies on autocast -- eval/gen/gen_images_mp.py:174 does -- gets them cast ONCE, in place, with a warning: under the
@@ -599,13 +605,23 @@ class Bagel(nn.Module):
     def quantize_language_model(self, kind="nf4", release_bf16=True):
         """The reference's quantised LOAD MODES (app.py:114-131: bitsandbytes NF4 resp. INT8 over every nn.Linear of the language model) for the whole
         forward path -- prefill, the denoise loop and text decode.  The decoder layers' projections are kept as NF4 codes + fp32 block absmax ("nf4":
-        blocks of 64, no double quantisation) or row-wise absmax INT8 ("int8"); a layer's bf16 matrices are materialised right before its GEMMs
+        blocks of 64, no double quantisation) or row-wise absmax INT8 ("int8_rowwise"); a layer's bf16 matrices are materialised right before its GEMMs
         (``w = bf16(code_book[code] * absmax)``: bitsandbytes' matmul_4bit in front of F.linear) and the Lq = 1 decode streams the codes themselves.
         Embeddings, lm_head, norms, biases, ViT / connector / VAE stay bf16 like the library leaves non-Linear and skipped modules.
         ``release_bf16=True`` frees the bf16 projection weights afterwards (28.3 -> 8.6 GB at 7B with "nf4"); reload the checkpoint to go back.
-        An option that changes results, like the reference's modes; parity with bitsandbytes' binaries is unpinned (oracle/nf4.py)."""
+        An option that changes results, like the reference's modes; parity with bitsandbytes' binaries is unpinned (oracle/nf4.py).
+        "int8" -- the reference's mode 3, LLM.int8 with fp16 outlier columns (app.py:126-131) -- is NOT built and is refused by name.
+        With ``release_bf16=True`` the model can no longer produce a state dict (``state_dict()`` raises: the projection weights are gone) and any later
+        invalidation of the packed weights (``.to()``, a second call) needs a NEW model build + checkpoint load."""
+        from .qwen2_navit import LLM_INT8_NOT_BUILT
+        if kind == "int8":
+            raise NotImplementedError(LLM_INT8_NOT_BUILT)
+        if kind not in ("nf4", "int8_rowwise"):
+            raise NotImplementedError(f"quantize_language_model(kind={kind!r}): 'nf4' and 'int8_rowwise' are built")
         lm = self.language_model
         self._ensure_bf16()
+        if hasattr(lm.model, "release_train_buffers"):
+            lm.model.release_train_buffers()          # (tape pool of a previous training step: tens of GB at 7B, train_step.py)
         lm.weight_store = kind
         lm.invalidate_packed()
         eng = lm.engine()
@@ -618,6 +634,7 @@ class Bagel(nn.Module):
                 for m in mods:
                     m.weight.data = torch.empty(0, dtype=m.weight.dtype, device=m.weight.device)
             lm._packed_fresh()
+            self._released_bf16 = kind
         return eng.layers.resident_bytes()
 
     @torch.no_grad()
@@ -630,7 +647,7 @@ class Bagel(nn.Module):
         Execution: a ``DecodeSession`` (decode.py) -- paged KV cache adopted from ``past_key_values``, loop state on the
         device, step 0 launched eagerly, the remaining steps replayed from one captured hipGraph (``use_graph=False``
         or BAGEL_DECODE_GRAPH=0 keeps every step eager).  ``past_key_values`` receives the new K/V rows at the end, as
-        the reference's in-place cache update does.  ``weight_quant="int8"`` (or ``model.decode_weight_quant``) streams row-wise
+        the reference's in-place cache update does.  ``weight_quant="int8_rowwise"`` (or ``model.decode_weight_quant``) streams row-wise
         INT8 copies of the layer weights instead of bf16 -- an option that changes results, like the reference's quantised
         load modes; default off."""
         import os

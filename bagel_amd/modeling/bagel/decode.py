@@ -139,18 +139,21 @@ class DecodeSession:
         # weight-only INT8 for the four projections of every layer (option; lm_head stays bf16 like the reference's quantised
         # modes keep it): the engine caches the quantised copies next to the bf16 ones
         # weight-only quantisation of the four projections of every layer (options; lm_head stays bf16 like the reference's quantised
-        # modes keep it): "int8" = row-wise absmax W8A16, de-quantised on the VALU (csrc/quant.hip); "mxfp4" = OCP-MX FP4 blocks of 32
+        # modes keep it): "int8_rowwise" = row-wise absmax W8A16, de-quantised on the VALU (csrc/quant.hip); "mxfp4" = OCP-MX FP4 blocks of 32
         # with E8M0 scales x FP8 activations on the block-scaled MFMA (csrc/mxfp4.hip), the counterpart of the reference's NF4 mode.
         # The engine caches the quantised copies next to the bf16 ones.
         if weight_quant is None and getattr(eng, "weight_store", None) is not None:
             weight_quant = eng.weight_store            # a quantised engine decodes on its stored codes (the 4- / 8-bit gemv kernels), not on scratch copies
         if getattr(eng, "weight_store", None) is not None and weight_quant != eng.weight_store:
             raise NotImplementedError(f"the engine holds {eng.weight_store} weights: weight_quant={weight_quant!r} would re-quantise de-quantised copies")
-        if weight_quant not in (None, "int8", "mxfp4", "nf4"):
-            raise NotImplementedError(f"weight_quant={weight_quant!r}: 'int8' (row-wise absmax, W8A16), 'mxfp4' (OCP-MX FP4, W4A8) and 'nf4' "
+        if weight_quant == "int8":
+            from .qwen2_navit import LLM_INT8_NOT_BUILT
+            raise NotImplementedError(LLM_INT8_NOT_BUILT)
+        if weight_quant not in (None, "int8_rowwise", "mxfp4", "nf4"):
+            raise NotImplementedError(f"weight_quant={weight_quant!r}: 'int8_rowwise' (row-wise absmax, W8A16), 'mxfp4' (OCP-MX FP4, W4A8) and 'nf4' "
                                       "(bitsandbytes NF4 blocks of 64, W4A16: the reference's own 4-bit mode) are built")
         self.weight_quant = weight_quant
-        if weight_quant == "int8" and (eng.H % 16 or eng.I % 16 or (nq * dp) % 16):
+        if weight_quant == "int8_rowwise" and (eng.H % 16 or eng.I % 16 or (nq * dp) % 16):
             raise NotImplementedError("int8 weights need row lengths that are multiples of 16")
         if weight_quant == "nf4" and (eng.H % 64 or eng.I % 64 or (nq * dp) % 64):
             raise NotImplementedError("nf4 weights need row lengths that are multiples of the 64-weight block")
@@ -169,20 +172,22 @@ class DecodeSession:
             self._eng_words = ops.decode_engine_sync_words(4)
             self.eng_sync = torch.zeros((L, self._eng_words), dtype=torch.int32, device=dev)
             self.eng_status = torch.zeros((4,), dtype=torch.int32, device=dev)
+        # a quantised engine: per-layer views of the small tensors (no scratch copies), built once -- not per eager step
+        self._layers = eng.layers.small_views() if getattr(eng, "weight_store", None) is not None else eng.layers
         self.steps_done = 0
         self.graph = None
         self.graph_error = None
 
     def _quantised_weights(self):
         eng = self.eng
-        attr = {"int8": "_w8_cache", "mxfp4": "_w4_cache", "nf4": "_nf4_cache"}[self.weight_quant]
+        attr = {"int8_rowwise": "_w8_cache", "mxfp4": "_w4_cache", "nf4": "_nf4_cache"}[self.weight_quant]
         cache = getattr(eng, attr, None)
         if cache is None and getattr(eng, "weight_store", None) == self.weight_quant:
             # whole-model load mode: the und expert's stored codes ARE the decode weights
             cache = [{name: st[name][0] for name in ("wqkv", "wo", "wgu", "wd")} for st in eng.layers.stored]
             setattr(eng, attr, cache)
         if cache is None:
-            qz = {"int8": ops.quantize_rows_i8, "mxfp4": ops.quantize_rows_mxfp4, "nf4": ops.quantize_nf4}[self.weight_quant]
+            qz = {"int8_rowwise": ops.quantize_rows_i8, "mxfp4": ops.quantize_rows_mxfp4, "nf4": ops.quantize_nf4}[self.weight_quant]
             cache = [dict(wqkv=qz(P.wqkv[0]), wo=qz(P.wo[0]), wgu=qz(P.wgu[0]), wd=qz(P.wd[0])) for P in eng.layers]
             setattr(eng, attr, cache)
         return cache
@@ -273,8 +278,7 @@ class DecodeSession:
                 ops.decode_engine(self._engine_phases(li), eng.eps, self.eng_sync[li], self.eng_status)
             ops.argmax_into(self.logits, self.next_tok)
             return
-        layers = eng.layers.small_views() if getattr(eng, "weight_store", None) is not None else eng.layers      # (a quantised engine: no scratch copies here)
-        for li, P in enumerate(layers):
+        for li, P in enumerate(self._layers):
             Q = self.w8[li] if self.w8 is not None else None
             proj(x, Q["wqkv"] if Q else P.wqkv[0], qkv, norm_w=P.ln_in[0], bias=P.bqkv[0])
             if self.fused_attention:

@@ -134,6 +134,12 @@ class _LayerView:
         return [self[i] for i in range(len(self))]
 
 
+# the name "int8" is refused everywhere on purpose: it is the reference's load mode 3 and that algorithm is not what "int8_rowwise" computes
+LLM_INT8_NOT_BUILT = ("'int8' names the reference's LLM.int8 load mode (app.py:126-131: vector-wise int8 activations x int8 weights with the outlier columns, "
+                      "|x| >= 6.0, kept in fp16), which is NOT built; the 8-bit option here is 'int8_rowwise' (weight-only row-wise absmax INT8, bf16 "
+                      "activations: a different algorithm with different results)")
+
+
 class NaiveCache:
     """KV container with the reference's protocol (qwen2_navit.py:207-221): ``NaiveCache(num_layers)``,
     ``.key_cache[layer]`` / ``.value_cache[layer]`` -> packed (sum L, nkv, hd) bf16 or None, ``.num_layers``,
@@ -150,6 +156,8 @@ class NaiveCache:
         self._vt = {i: None for i in range(num_layers)}
         self._vt_ok = {i: False for i in range(num_layers)}
         self._lens = {i: None for i in range(num_layers)}   # per-layer per-sample lens (layers fill in one by one)
+        self._own = {i: [1] for i in range(num_layers)}      # [number of caches sharing this layer's K/V buffers] (copy-on-write, __deepcopy__)
+        self._vt_own = {i: [1] for i in range(num_layers)}   # the same for the V^T image
         self._total = 0
         self._nkv = self._hd = self._dp = 0
         self._dev_meta = {}
@@ -172,15 +180,44 @@ class NaiveCache:
         return self._total if self._k[0] is not None else 0
 
     def __deepcopy__(self, memo):
+        """COPY-ON-WRITE: the copy shares every layer's K / V (and valid V^T) buffer with the original; whichever of the sharers writes a layer first
+        (``store``: the in-place append of a one-sample context, or a V^T rebuild) clones that layer for itself -- up to the live rows, keeping the
+        buffer's capacity -- and leaves the others untouched.  The reference deep-copies the whole context for every request stream
+        (inferencer.py:189,230-231,244,253): an image-edit request would hold three copies of a 9 k-token context (0.5 GB each at 7B) of which two
+        are only ever read."""
         c = NaiveCache(self._num_layers)
         c._total, c._nkv, c._hd, c._dp = self._total, self._nkv, self._hd, self._dp
         for i in range(self._num_layers):
             if self._k[i] is not None:
-                n = int(sum(self._lens[i]))
-                c._k[i] = self._k[i][:n].clone()
-                c._v[i] = self._v[i][:n].clone()
+                c._k[i], c._v[i] = self._k[i], self._v[i]
                 c._lens[i] = list(self._lens[i])
+                c._own[i] = self._own[i]
+                self._own[i][0] += 1
+                if self._vt_ok[i]:
+                    c._vt[i], c._vt_ok[i], c._vt_own[i] = self._vt[i], True, self._vt_own[i]
+                    self._vt_own[i][0] += 1
         return c
+
+    def _writable(self, layer):
+        """Make this cache the only owner of the layer's K / V buffers before they are written."""
+        own = self._own[layer]
+        if own[0] > 1:
+            own[0] -= 1
+            n = int(sum(self._lens[layer]))
+            k = torch.empty_like(self._k[layer])
+            v = torch.empty_like(self._v[layer])
+            if n:
+                ops.copy_rows(self._k[layer], k, n, k.shape[1])
+                ops.copy_rows(self._v[layer], v, n, v.shape[1])
+            self._k[layer], self._v[layer] = k, v
+            self._own[layer] = [1]
+
+    def __del__(self):
+        try:
+            for own in list(self._own.values()) + list(self._vt_own.values()):
+                own[0] -= 1
+        except Exception:
+            pass
 
     @staticmethod
     def concat(caches, batch_sizes):
@@ -205,8 +242,14 @@ class NaiveCache:
                 ks.append(c._k[i][:n])
                 vs.append(c._v[i][:n])
                 lens += [int(x) for x in c._lens[i]]
-            out._k[i] = torch.cat(ks).contiguous()
-            out._v[i] = torch.cat(vs).contiguous()
+            if len(ks) == 1:
+                # one stream carries all the context (text->image: the CFG stream has none): share its buffers copy-on-write instead of a second full copy
+                src = next(c for c in caches if c is not None and not c.is_empty(i))
+                out._k[i], out._v[i], out._own[i] = src._k[i], src._v[i], src._own[i]
+                src._own[i][0] += 1
+            else:
+                out._k[i] = torch.cat(ks).contiguous()
+                out._v[i] = torch.cat(vs).contiguous()
             out._lens[i] = lens
         out._total = int(sum(out._lens[0]))
         return out
@@ -241,6 +284,10 @@ class NaiveCache:
         cu, col, cols, mx = self._meta(layer, k.device)
         if not self._vt_ok[layer]:
             vt = self._vt[layer]
+            if vt is not None and self._vt_own[layer][0] > 1:         # shared with a copy that may still read it: rebuild into a buffer of our own
+                self._vt_own[layer][0] -= 1
+                self._vt_own[layer] = [1]
+                vt = None
             if vt is None or vt.shape[1] < cols:
                 vt = torch.zeros((self._nkv * self._dp, _ceil_to(cols, 256)), dtype=BF16, device=k.device)
                 self._vt[layer] = vt
@@ -266,6 +313,8 @@ class NaiveCache:
         elif B == 1:
             old = int(self._lens[layer][0])
             need = old + M
+            if need <= self._k[layer].shape[0]:
+                self._writable(layer)                                  # (a grown buffer below is a fresh one anyway)
             k, v = self._k[layer], self._v[layer]
             if need > k.shape[0]:
                 cap = _ceil_to(max(need * 2, 256), 256)
@@ -275,6 +324,8 @@ class NaiveCache:
                 ops.copy_rows(v, v2, old, width)
                 k, v = k2, v2
                 self._k[layer], self._v[layer] = k, v
+                self._own[layer][0] -= 1
+                self._own[layer] = [1]
             ops.copy_rows(k_rows, k[old:], M, width)
             ops.copy_rows(v_rows, v[old:], M, width)
             self._lens[layer] = [need]
@@ -288,6 +339,8 @@ class NaiveCache:
             ops.copy_rows(k_rows, k2, M, width, dst_rows=new_dst)
             ops.copy_rows(v_rows, v2, M, width, dst_rows=new_dst)
             self._k[layer], self._v[layer] = k2, v2
+            self._own[layer][0] -= 1
+            self._own[layer] = [1]
             self._lens[layer] = [int(a) + int(b) for a, b in zip(ctx_lens, q_lens)]
         self._vt_ok[layer] = False
         self._total = int(sum(self._lens[layer]))
@@ -396,6 +449,13 @@ class Qwen2Model(nn.Module):
             self.norm_moe_gen = _NormWeight(config.hidden_size, config.rms_norm_eps)
         self.rotary_emb = _Rotary(config)
         self.enable_taylorseer = False
+
+    def release_train_buffers(self):
+        """Free what a training step leaves RESIDENT on this module (train_step.TrainTape): up to TAPE_POOL_SETS flat tape-buffer sets -- 35-75 GB each at
+        7B width on 18 k-32 k token packs -- and the keep-gate/up decisions that were taken against the memory that was free then.  Called when the packed
+        engine is dropped and before ``Bagel.quantize_language_model``; call it by hand between a training phase and long-context inference."""
+        self.__dict__.pop("_tape_pool", None)
+        self.__dict__.pop("_keep_gate_up", None)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -737,12 +797,14 @@ class MoTEngine:
         self.model = model
         self.lm_head = lm_head
         # WHOLE-MODEL 4- / 8-bit load modes (app.py:114-131: bitsandbytes NF4 / INT8 over every nn.Linear of the language model).  weight_store =
-        # "nf4" | "int8": the four matrices of every decoder layer (both experts) stay resident as codes + scales; `layers[i]` materialises that
+        # "nf4" | "int8_rowwise": the four matrices of every decoder layer (both experts) stay resident as codes + scales; `layers[i]` materialises that
         # layer's bf16 matrices into one of two scratch sets right before they are used (_StoredLayers) -- exactly what bitsandbytes' matmul_4bit
         # does in front of F.linear for more than one activation row -- and the Lq = 1 decode runs its own 4- / 8-bit gemv kernels on the stored
         # codes.  Biases, norm weights, embeddings, lm_head stay bf16 (llm_int8_skip_modules / the library never touches non-Linear weights).
-        if weight_store not in (None, "nf4", "int8"):
-            raise NotImplementedError(f"weight_store={weight_store!r}: 'nf4' (bitsandbytes NF4: blocks of 64, fp32 absmax) and 'int8' (row-wise absmax) are built")
+        if weight_store == "int8":
+            raise NotImplementedError(LLM_INT8_NOT_BUILT)
+        if weight_store not in (None, "nf4", "int8_rowwise"):
+            raise NotImplementedError(f"weight_store={weight_store!r}: 'nf4' (bitsandbytes NF4: blocks of 64, fp32 absmax) and 'int8_rowwise' (row-wise absmax) are built")
         self.weight_store = weight_store
         if weight_store is None:
             self.layers = [self._pack_layer(l) for l in model.layers]
@@ -1142,6 +1204,7 @@ class Qwen2ForCausalLM(PackedWeights):
     def _drop_packed(self):
         self._engine = None
         self._plans = {}
+        self.model.release_train_buffers()
 
     def _check_packed(self):
         """Parameters rewritten in place (every tensor still at its address, version counters moved: an optimizer step, ``param.copy_``)

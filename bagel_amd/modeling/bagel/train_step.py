@@ -132,6 +132,9 @@ def _decide_gate_up(self, eng, M):
     weight images, slack for the backward's transients) have to fit 80 % of what is free."""
     if KEEP_GATE_UP != "auto":
         self.keep_gate_up = bool(KEEP_GATE_UP)
+        if not self.keep_gate_up:
+            for k in [k for k in self._store if k[0] == "gu"]:
+                del self._store[k]
         return
     memo = eng.model.__dict__.setdefault("_keep_gate_up", {})        # on the model: survives the engine's refresh after an optimizer step
     if M not in memo:
@@ -145,6 +148,9 @@ def _decide_gate_up(self, eng, M):
             base = L * M * 2 * (3 * eng.H + (eng.nq + 2 * eng.nkv) * eng.dp + eng.nq * eng.dp + eng.I)
             memo[M] = L * M * 2 * eng.I * 2 + base + 3 * wbytes <= 0.8 * free
     self.keep_gate_up = memo[M]
+    if not self.keep_gate_up:                              # a set taken from the pool may still carry the 'gu' buffers of a step that kept them
+        for k in [k for k in self._store if k[0] == "gu"]:
+            del self._store[k]
 
 
 TrainTape.decide_gate_up = _decide_gate_up

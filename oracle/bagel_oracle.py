@@ -499,6 +499,28 @@ def flow_schedule(num_timesteps, shift):
 
 
 @_explicit_casts
+def cfg_combine(v_t, v_ct, v_ci, cfg_text_scale, cfg_img_scale=1.0, cfg_renorm_min=0.0, cfg_renorm_type="global"):
+    """The classifier-free-guidance combine + renorm of bagel.py:854-905 on the three velocities (v_ci None when cfg_img_scale <= 1): every operation is
+    an eager op on the inputs' dtype, as in the reference."""
+    if cfg_renorm_type == "text_channel":
+        v_text_ = v_ct + cfg_text_scale * (v_t - v_ct)
+        n0 = torch.norm(v_t, dim=-1, keepdim=True)
+        n1 = torch.norm(v_text_, dim=-1, keepdim=True)
+        scale = (n0 / (n1 + 1e-8)).clamp(min=cfg_renorm_min, max=1.0)
+        v_text = v_text_ * scale
+        return v_ci + cfg_img_scale * (v_text - v_ci) if cfg_img_scale > 1.0 else v_text
+    v_text_ = v_ct + cfg_text_scale * (v_t - v_ct)
+    v_ = v_ci + cfg_img_scale * (v_text_ - v_ci) if cfg_img_scale > 1.0 else v_text_
+    if cfg_renorm_type == "global":
+        n0, n1 = torch.norm(v_t), torch.norm(v_)
+    elif cfg_renorm_type == "channel":
+        n0, n1 = torch.norm(v_t, dim=-1, keepdim=True), torch.norm(v_, dim=-1, keepdim=True)
+    else:
+        raise NotImplementedError(cfg_renorm_type)
+    scale = (n0 / (n1 + 1e-8)).clamp(min=cfg_renorm_min, max=1.0)
+    return v_ * scale
+
+
 def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, cfg_text_scale=1.0,
                  cfg_img_scale=1.0, cfg_renorm_min=0.0, cfg_renorm_type="global", taylor=None,
                  taylor_last_layer_only=False, parts=None):
@@ -540,24 +562,7 @@ def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, 
         if cfg_text_scale > 1.0:
             parts["v_cfg_text"] = v_ct
     if cfg_text_scale > 1.0:
-        if cfg_renorm_type == "text_channel":
-            v_text_ = v_ct + cfg_text_scale * (v_t - v_ct)
-            n0 = torch.norm(v_t, dim=-1, keepdim=True)
-            n1 = torch.norm(v_text_, dim=-1, keepdim=True)
-            scale = (n0 / (n1 + 1e-8)).clamp(min=cfg_renorm_min, max=1.0)
-            v_text = v_text_ * scale
-            v_t = v_ci + cfg_img_scale * (v_text - v_ci) if cfg_img_scale > 1.0 else v_text
-        else:
-            v_text_ = v_ct + cfg_text_scale * (v_t - v_ct)
-            v_ = v_ci + cfg_img_scale * (v_text_ - v_ci) if cfg_img_scale > 1.0 else v_text_
-            if cfg_renorm_type == "global":
-                n0, n1 = torch.norm(v_t), torch.norm(v_)
-            elif cfg_renorm_type == "channel":
-                n0, n1 = torch.norm(v_t, dim=-1, keepdim=True), torch.norm(v_, dim=-1, keepdim=True)
-            else:
-                raise NotImplementedError(cfg_renorm_type)
-            scale = (n0 / (n1 + 1e-8)).clamp(min=cfg_renorm_min, max=1.0)
-            v_t = v_ * scale
+        v_t = cfg_combine(v_t, v_ct, v_ci if cfg_img_scale > 1.0 else None, cfg_text_scale, cfg_img_scale, cfg_renorm_min, cfg_renorm_type)
     return v_t
 
 

@@ -578,7 +578,7 @@ def test_gemv_w8_swiglu_and_fused_norm():
 
 
 def test_generate_text_int8_weights_option():
-    """weight_quant='int8': same loop, graph replay == eager, logits within the quantisation noise of the bf16 path."""
+    """weight_quant='int8_rowwise': same loop, graph replay == eager, logits within the quantisation noise of the bf16 path."""
     from oracle.configs import TINY_D128 as cfg
     from tests.util_models import product_model
     model, _ = product_model(cfg)
@@ -586,17 +586,17 @@ def test_generate_text_int8_weights_option():
     n = 8
     ref = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, **start)
     ref_logits = model._last_decode_session.logits.float().clone()
-    a = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, weight_quant="int8", use_graph=True, **start)
+    a = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, weight_quant="int8_rowwise", use_graph=True, **start)
     sess = model._last_decode_session
-    assert sess.weight_quant == "int8" and sess.graph is not None
+    assert sess.weight_quant == "int8_rowwise" and sess.graph is not None
     q_logits = sess.logits.float().clone()
-    b = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, weight_quant="int8", use_graph=False, **start)
+    b = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, weight_quant="int8_rowwise", use_graph=False, **start)
     assert torch.equal(a, b) and a.shape == ref.shape
     if torch.equal(a, ref):          # same token history -> the last-step logits are comparable
         err = ((q_logits - ref_logits).norm() / ref_logits.norm()).item()
         assert err < 5e-2, f"int8-weight logits differ from bf16-weight logits by rel_l2 {err:.3g}"
     assert torch.equal(a[0], ref[0])
-    model.decode_weight_quant = "int8"                                     # the model-level switch (load-time mode in the reference)
+    model.decode_weight_quant = "int8_rowwise"                                     # the model-level switch (load-time mode in the reference)
     try:
         c = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=n, end_token_id=None, **start)
     finally:
@@ -672,3 +672,46 @@ def test_decode_attention_with_several_chunks_per_workgroup(cpw):
                         "paged_append_and_decode_attention or fused_decode_attention_equals or sharp_softmax"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# NaiveCache.__deepcopy__ is copy-on-write (inferencer.py:189,230-231,244,253 deep-copies the context per request stream)
+# ------------------------------------------------------------------------------------------------------------
+def test_naive_cache_deepcopy_is_copy_on_write_and_isolated():
+    """A 1 100-token context on the tiny model: ``copy.deepcopy`` allocates (almost) nothing; the copy and the original stay independent -- a decode that
+    appends to the COPY leaves the original's rows and length untouched and vice versa -- and the first write pays for ONE clone of the layers it touches.
+    ``NaiveCache.concat`` with a single live stream (text->image: the CFG stream has no context) shares instead of copying."""
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    from oracle.configs import TINY_D128 as cfg
+    from tests.util_models import product_model
+    model, _ = product_model(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    cache, lens, ropes, start = _context(model, cfg, ["w " * 1100])
+    assert lens[0] >= 1000
+    torch.cuda.synchronize()
+    snap_k = [cache.key_cache[i].clone() for i in range(L)]
+    per_cache = sum(cache._k[i].numel() + cache._v[i].numel() for i in range(L)) * 2
+    m0 = torch.cuda.memory_allocated()
+    copies = [copy.deepcopy(cache) for _ in range(3)]
+    m1 = torch.cuda.memory_allocated()
+    assert m1 - m0 < 0.05 * per_cache, f"deepcopy x3 allocated {m1 - m0} bytes for caches of {per_cache} bytes: not copy-on-write"
+    for c in copies:
+        assert c.seq_lens == cache.seq_lens
+        assert all(torch.equal(c.key_cache[i], snap_k[i]) for i in range(L))
+    shared = NaiveCache.concat([copies[2], None], [1, 1])
+    assert torch.cuda.memory_allocated() - m1 < 0.05 * per_cache, "concat with one live stream must share its buffers"
+    assert shared.lens(0) == [lens[0], 0]
+    # decode on copy 0: it must clone (once), everybody else keeps the context bit for bit
+    t0 = model.generate_text(past_key_values=copies[0], max_length=5, end_token_id=None, **start)
+    m2 = torch.cuda.memory_allocated()
+    assert copies[0].seq_lens == cache.seq_lens + 5 and cache.seq_lens == lens[0] and copies[1].seq_lens == lens[0]
+    for c in (cache, copies[1], copies[2]):
+        assert all(torch.equal(c.key_cache[i], snap_k[i]) for i in range(L)), "a write through one copy reached another sharer"
+    assert all(torch.equal(copies[0].key_cache[i][: lens[0]], snap_k[i]) for i in range(L))
+    # the same decode through the ORIGINAL gives the same tokens and does not disturb copy 0's extra rows
+    k0 = [copies[0].key_cache[i].clone() for i in range(L)]
+    t1 = model.generate_text(past_key_values=cache, max_length=5, end_token_id=None, **start)
+    assert torch.equal(t0, t1)
+    assert all(torch.equal(copies[0].key_cache[i], k0[i]) for i in range(L))
+    assert all(torch.equal(cache.key_cache[i], k0[i]) for i in range(L)), "same request, same cache contents"
+    del m2

@@ -81,7 +81,7 @@ def _roundtrip_linears(model, kind):
     model.language_model.invalidate_packed()
 
 
-@pytest.mark.parametrize("kind", ["nf4", "int8"])
+@pytest.mark.parametrize("kind", ["nf4", "int8_rowwise"])
 def test_whole_model_quantised_load_mode_equals_the_bf16_engine_on_dequantised_weights(golden, monkeypatch, kind):
     """Bagel.quantize_language_model (app.py:114-131's load modes for the WHOLE forward path): prefill, denoise loop and text decode of a model whose
     decoder projections are stored as NF4 / INT8 codes give exactly what the bf16 engine gives on the de-quantised weights -- the layer-by-layer

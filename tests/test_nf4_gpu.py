@@ -134,7 +134,7 @@ def test_dequantize_kernels_bit_exact(rows, cols):
     assert torch.equal(d8.cpu().view(torch.int16), ref8.view(torch.int16))
 
 
-@pytest.mark.parametrize("kind", ["nf4", "int8"])
+@pytest.mark.parametrize("kind", ["nf4", "int8_rowwise"])
 def test_whole_model_quantised_load_mode(kind):
     """Bagel.quantize_language_model (app.py:114-131's load modes over the whole forward path): prefill KV and denoise latents of the quantised engine
     are BIT-IDENTICAL to the bf16 engine on the de-quantised weights (a layer's matrices are materialised with the dequantise kernel right before

@@ -109,7 +109,7 @@ def test_training_glue_kernels():
 def test_training_forward_matches_reference(golden, name, mask_api):
     """Bagel.forward on the hand-packed two-sample batch vs the reference's per-token losses.  Tolerances: CE rel-L2 <= 2e-2
     (logits carry one bf16 rounding per op over L layers); MSE rel-L2 <= 5e-2 (a squared bf16 prediction error).  tiny_dense / tiny_moe =
-    the training forward of the dense and MoE layer kinds (qwen2_navit.py:620-646,852-883; their backward is not built: it raises)."""
+    the training forward of the dense and MoE layer kinds (qwen2_navit.py:620-646,852-883; their backward: tests/test_train_backward_gpu.py)."""
     from oracle.configs import TINY, TINY_D128, TINY_DENSE, TINY_MOE
     from tests.util_models import product_model
     cfg = {"tiny": TINY, "tiny_d128": TINY_D128, "tiny_dense": TINY_DENSE, "tiny_moe": TINY_MOE}[name]
