@@ -309,13 +309,70 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
     }
 }
 
+// The same arithmetic with the WHOLE ROW in registers (rows of <= 64 * MAXC chunks): one wave per row issues all of its 16-byte loads before the first
+// use, so a row is read from HBM ONCE with MAXC loads in flight per lane, instead of twice (the second pass from L2) with one load in flight -- the
+// two-pass kernel ran at 3.1-4.1 TB/s of its own 3 bytes per element on the activation matrices of the FP8 denoise path.  Bit-identical.
+template <int MAXC>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_reg_kernel(const bf16_t* __restrict__ x, long ldx, unsigned char* __restrict__ q,
+                                                                    long ldq, float* __restrict__ scale, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (long)row * ldx;
+    const int nch = cols >> 3;
+    u32x4_t v[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nch ? *(const u32x4_t*)(xr + 8 * c) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo2f(v[i][e])), fabsf(hi2f(v[i][e]))));
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? amax / 448.0f : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) scale[row] = s;
+    unsigned char* qr = q + (long)row * ldq;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            u32x2_t o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(lo2f(v[i][2 * h]) * inv, hi2f(v[i][2 * h]) * inv, w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(lo2f(v[i][2 * h + 1]) * inv, hi2f(v[i][2 * h + 1]) * inv, w, true);
+                o[h] = (unsigned)w;
+            }
+            *(u32x2_t*)(qr + 8 * c) = o;
+        }
+    }
+}
+
 extern "C" int bagel_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq_bytes, float* scale, int32_t rows, int32_t cols,
                                        hipStream_t stream) {
     BAGEL_REQUIRE(x && q && scale, "quantize_rows_fp8: null pointer");
     BAGEL_REQUIRE((cols % 8) == 0 && (ldx % 8) == 0 && (ldq_bytes % 8) == 0, "quantize_rows_fp8: cols / leading dims must be multiples of 8");
     if (rows <= 0 || cols <= 0) return BAGEL_OK;
-    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, (long)ldx,
-                       (unsigned char*)q, (long)ldq_bytes, scale, rows, cols);
+    static int two_pass = -1;
+    if (two_pass < 0) {
+        const char* e = getenv("BAGEL_FP8_QUANT_TWO_PASS");      // A/B knob: 1 = the two-pass kernel for every row length
+        two_pass = (e && atoi(e) > 0) ? 1 : 0;
+    }
+    const int nch = cols >> 3;
+    if (!two_pass && nch <= 64 * 8)
+        hipLaunchKernelGGL(quantize_rows_fp8_reg_kernel<8>, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, (long)ldx,
+                           (unsigned char*)q, (long)ldq_bytes, scale, rows, cols);
+    else if (!two_pass && nch <= 64 * 40)
+        hipLaunchKernelGGL(quantize_rows_fp8_reg_kernel<40>, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, (long)ldx,
+                           (unsigned char*)q, (long)ldq_bytes, scale, rows, cols);
+    else
+        hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, (long)ldx,
+                           (unsigned char*)q, (long)ldq_bytes, scale, rows, cols);
     return bagel_check_launch("quantize_rows_fp8_kernel");
 }
 
