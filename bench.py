@@ -658,7 +658,7 @@ def cpu_decode_baseline(cfg, ctx):
 
 # understanding.parity_at_full_depth bounds = 1.5 x the REFERENCE'S OWN accumulation-order noise at full depth (tools/und_full_depth_noise_floor.py: the oracle
 # with bf16 linears vs fp32-accumulating linears on the same 26-layer SigLIP + 28-layer prefill + decode step; profiles/r05_und_full_depth_noise_floor.log)
-UND_DEPTH_NOISE = {"kv": 2.3e-2, "logits": 2.4e-2, "source": "profiles/r05_und_full_depth_noise_floor.log"}
+UND_DEPTH_NOISE = {"kv": 1.504e-2, "logits": 1.371e-2, "source": "profiles/r05_und_full_depth_noise_floor.log"}
 UND_DEPTH_TOL_KV = 1.5 * UND_DEPTH_NOISE["kv"]
 UND_DEPTH_TOL_LOGITS = 1.5 * UND_DEPTH_NOISE["logits"]
 
