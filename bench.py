@@ -862,7 +862,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
                         f"prompt tokens prefill, greedy decode of {n} tokens, bf16, batch {UB}/GPU"}
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
 
 
 def _source_digest(names):
