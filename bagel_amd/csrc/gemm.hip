@@ -1186,12 +1186,48 @@ __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(const GemmParam
 static int pq_leftover_split(int nblk, int wgs, int nk, size_t ws_bytes, int* n_full_out) {
     const int n_full = nblk / wgs * wgs, rest = nblk - n_full;
     *n_full_out = n_full;
-    if (rest == 0 || 2 * rest > wgs + wgs / 4) return 1;                   // nothing left over, or the last round is > 5/8 full anyway
-    if (n_full == 0 && (2 * rest > wgs || nk < 16)) return 1;              // a single round: split only when it fills less than half the chip
-    int s = wgs / rest;                                                    // parts per leftover tile: fill the chip once
-    if (s > nk / 4) s = nk / 4;                                            // a part keeps >= 4 k-tiles (prologue + steady state)
-    while (s > 1 && (size_t)rest * s * (32 * 512 * 16) > ws_bytes) --s;     // 256 KB of fp32 per part
-    return s < 2 ? 1 : s;
+    if (rest == 0) return 1;
+    static int policy = -1, force = 0;
+    if (policy < 0) {
+        const char* e = getenv("BAGEL_GEMM_SPLIT_POLICY");       // 0 = the round-3 rule (fill the chip ONCE with the leftovers), 1 = the round-5 cost model (A/B knob)
+        policy = e ? atoi(e) : 0;
+        const char* f = getenv("BAGEL_GEMM_SPLIT_FORCE");        // experiment: this many parts for every launch with leftovers
+        force = f ? atoi(f) : 0;
+    }
+    if (force > 1) {
+        int sf = force;
+        if (sf > nk / 4) sf = nk / 4;
+        while (sf > 1 && (size_t)rest * sf * (32 * 512 * 16) > ws_bytes) --sf;
+        return sf < 2 ? 1 : sf;
+    }
+    if (policy == 0) {
+        if (2 * rest > wgs + wgs / 4) return 1;                                // the last round is > 5/8 full anyway
+        if (n_full == 0 && (2 * rest > wgs || nk < 16)) return 1;              // a single round: split only when it fills less than half the chip
+        int s = wgs / rest;                                                    // parts per leftover tile: fill the chip once
+        if (s > nk / 4) s = nk / 4;                                            // a part keeps >= 4 k-tiles (prologue + steady state)
+        while (s > 1 && (size_t)rest * s * (32 * 512 * 16) > ws_bytes) --s;     // 256 KB of fp32 per part
+        return s < 2 ? 1 : s;
+    }
+    // Round 5: the parts of the leftover tiles may take SEVERAL passes over the chip (rest * s > wgs), priced with a small model calibrated on the bench's own
+    // launches: a 64-deep k-tile step of a 256 x 256 tile takes 1.52 us (gate+up at M = 32 768: 8.9 TFLOP in 6.32 ms = 4 144 steps), an item pays ~6 us of
+    // pipeline fill + epilogue, a part costs 512 KB of fp32 partial traffic (written here, read by the reduce pass: ~0.13 us when the chip shares it) and the
+    // reduce pass one more launch.  Un-split, the leftovers cost one whole tile time with (wgs - rest) CUs idle.  Example: the 3-stream edit forward has
+    // 672 o / down tiles = 2.63 rounds; o (K = 3 584) is left alone (a 3-way split costs 137 us against 90), down (K = 18 944) is cut three ways: two passes of
+    // third-length items = 380 us against 455.
+    const double t_step = 1.52, t_item = 6.0, t_part = 0.13, t_reduce = 6.0;
+    const double whole = nk * t_step + t_item;
+    if (n_full == 0 && nk < 16) return 1;
+    int best = 1;
+    double best_cost = whole * 0.85;                                           // a split has to win 15 % of the leftover round to be worth a second launch
+    for (int sp = 2; sp <= nk / 4 && sp <= 16; ++sp) {
+        if ((size_t)rest * sp * (32 * 512 * 16) > ws_bytes) break;
+        const int passes = (rest * sp + wgs - 1) / wgs;
+        const double cost = passes * ((double)nk / sp * t_step + t_item) + rest * sp * t_part + t_reduce;
+        // several passes (rest * sp > wgs) have to win a quarter of the round, not 15 %: measured on the edit request, the modelled 16 % of the three-way split of
+        // its `down` leftovers (160 tiles) came out as +1 % of the request (profiles/r05_gemm_split_policy.log)
+        if (cost < (passes > 1 ? whole * 0.75 : best_cost)) { best_cost = cost; best = sp; }
+    }
+    return best;
 }
 
 template <int MODE, bool FP8 = false, bool SADDR = false>

@@ -144,7 +144,7 @@ def _gemm_workspace(device):
     key = _ws_key(device)
     ws = _GEMM_WS.get(key)
     if ws is None:
-        ws = _GEMM_WS[key] = torch.empty(256 * 256 * 256, dtype=torch.float32, device=device)
+        ws = _GEMM_WS[key] = torch.empty(512 * 256 * 256, dtype=torch.float32, device=device)      # 512 partial tiles (the 3-way split of 160 leftover tiles needs 480)
     return ws
 
 

@@ -663,7 +663,7 @@ UND_DEPTH_TOL_KV = 1.5 * UND_DEPTH_NOISE["kv"]
 UND_DEPTH_TOL_LOGITS = 1.5 * UND_DEPTH_NOISE["logits"]
 
 
-def understanding_full_depth(args, cfg, model, ids, image, tok, threads, n_tokens=8):
+def understanding_full_depth(args, cfg, model, ids, image, tok, threads, n_tokens=6):
     """configs[1] at the DEPTH it is measured at (VERDICT r04 missing-2): the 26-layer SigLIP encoder + connector + the 28-layer non-causal prefill of the
     ViT block + the causal text prefill + ``n_tokens`` greedy decode steps through the oracle on this box's host cores WITH THE GPU MODEL'S OWN WEIGHTS, against
     the product on the same inputs: per-layer K / V of the whole context (max rel-L2), the first decode step's logits (rel-L2), and the greedy ids up to the

@@ -28,7 +28,8 @@ def main():
     H, I = 3584, 18944
     g = torch.Generator(device=DEV).manual_seed(0)
     rn = lambda *s: torch.randn(*s, generator=g, device=DEV).to(BF16)  # noqa: E731
-    for M in (4936, 2050):
+    Ms = [int(x) for x in os.environ["PROBE_M"].split(",")] if os.environ.get("PROBE_M") else (4936, 2050, 12294, 16392, 4902, 9066)
+    for M in Ms:      # understanding prefill, a short prompt, the 3-stream edit forward, one denoise stream, the ViT block, the edit context
         tot = [0.0, 0.0]
         for name, N, K, bias, resid in (("qkv", 4608, H, True, False), ("o", H, H, False, True), ("down", H, I, False, True)):
             A, W = rn(M, K), rn(N, K)
@@ -36,11 +37,11 @@ def main():
             C = rn(M, N)
             t = []
             for sk in (False, True):
-                t.append(timeit(lambda: ops.gemm(A, W, C, bias0=b, residual=C if resid else None, variant=4, splitk=sk)))
+                t.append(timeit(lambda: ops.gemm(A, W, C, bias0=b, residual=C if resid else None, variant=5, splitk=sk)))
             fl = 2.0 * M * N * K
             tot[0] += t[0]; tot[1] += t[1]
             print(f"M={M} {name:5s} one pass {t[0]:7.1f} us {fl / t[0] / 1e6:7.1f} TF | k-split leftovers {t[1]:7.1f} us {fl / t[1] / 1e6:7.1f} TF  ({t[0] / t[1]:.3f}x)", flush=True)
-        print(f"M={M} qkv + o + down per layer: {tot[0]:.0f} -> {tot[1]:.0f} us ({(tot[0] - tot[1]) * 28 / 1e3:.1f} ms over 28 layers)")
+        print(f"(BAGEL_GEMM_SPLIT_POLICY={os.environ.get('BAGEL_GEMM_SPLIT_POLICY', '0')} FORCE={os.environ.get('BAGEL_GEMM_SPLIT_FORCE', '-')}) M={M} qkv + o + down per layer: {tot[0]:.0f} -> {tot[1]:.0f} us ({(tot[0] - tot[1]) * 28 / 1e3:.1f} ms over 28 layers)")
 
 
 if __name__ == "__main__":
