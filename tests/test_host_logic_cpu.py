@@ -877,3 +877,71 @@ def test_model_built_under_inference_mode_runs(golden, monkeypatch):
     for i in range(cfg["llm"]["num_hidden_layers"]):
         assert rel(cache.key_cache[i], g["key_cache"][i]) < 1e-2
         assert torch.equal(cache.key_cache[i], cache2.key_cache[i])
+
+
+def test_generate_text_runs_without_autograd_and_refuses_the_llm_int8_name(monkeypatch):
+    """``generate_text`` had lost its ``@torch.no_grad()`` / ``@_bf16_weights`` decorators to a function inserted above it.  Every public inference
+    entry point runs with autograd OFF even when the caller left it on; and the name "int8" -- the reference's LLM.int8 load mode (app.py:126-131), which is not
+    built -- is refused everywhere instead of silently selecting the row-wise option."""
+    from bagel_amd.modeling.bagel import decode as decode_mod
+    mock_ops.install(monkeypatch)
+    cfg = TINY_D128
+    model = cpu_model(cfg)
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    gi, lens, ropes = model.prepare_prompts([0], [0], ["a small red cube"], tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+    si = model.prepare_start_tokens(lens, ropes, NEW_TOKEN_IDS_TINY)
+    seen = []
+    real_init = decode_mod.DecodeSession.__init__
+
+    def spy(self, *a, **k):
+        seen.append(torch.is_grad_enabled())
+        return real_init(self, *a, **k)
+    monkeypatch.setattr(decode_mod.DecodeSession, "__init__", spy)
+    with torch.enable_grad():
+        toks = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=3, do_sample=False, end_token_id=None, use_graph=False, **si)
+        assert torch.is_grad_enabled()
+    assert seen == [False], "generate_text must run under torch.no_grad()"
+    assert toks.shape == (3, 1) and not toks.requires_grad
+    with pytest.raises(NotImplementedError, match="LLM.int8"):
+        model.generate_text(past_key_values=copy.deepcopy(cache), max_length=2, do_sample=False, end_token_id=None, use_graph=False, weight_quant="int8", **si)
+    with pytest.raises(NotImplementedError, match="LLM.int8"):
+        model.quantize_language_model("int8")
+    assert getattr(model.language_model, "weight_store", None) is None, "a refused mode must not leave the model half-switched"
+
+
+def test_naive_cache_deepcopy_copy_on_write_semantics(monkeypatch):
+    """``copy.deepcopy(NaiveCache)`` (inferencer.py:189,230-231,244,253) shares the layers' buffers until one side writes: the copies are equal, a prefill appended
+    to the COPY leaves the original untouched (rows, lengths, buffer identity) and the original can still be extended on its own afterwards; ``concat`` with one live
+    stream shares as well.  (Memory is asserted on the device: tests/test_decode_gpu.py.)"""
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    mock_ops.install(monkeypatch)
+    cfg = TINY_D128
+    model = cpu_model(cfg)
+    L = cfg["llm"]["num_hidden_layers"]
+    tok = StubTokenizer(cfg["llm"]["vocab_size"])
+    gi, lens, ropes = model.prepare_prompts([0], [0], ["a small red cube on a table"], tok, NEW_TOKEN_IDS_TINY)
+    cache = model.forward_cache_update_text(new_cache(cfg), **gi)
+    snap = [(cache.key_cache[i].clone(), cache.value_cache[i].clone()) for i in range(L)]
+    c1, c2 = copy.deepcopy(cache), copy.deepcopy(cache)
+    for c in (c1, c2):
+        assert c.seq_lens == cache.seq_lens
+        for i in range(L):
+            assert c._k[i] is cache._k[i] and cache._own[i][0] == 3                  # shared, three owners
+            assert torch.equal(c.key_cache[i], snap[i][0]) and torch.equal(c.value_cache[i], snap[i][1])
+    joined = NaiveCache.concat([c2, None], [1, 1])
+    assert joined._k[0] is cache._k[0] and joined.lens(0) == [lens[0], 0]
+    # extend the first copy: it must move to buffers of its own
+    gi2, lens2, ropes2 = model.prepare_prompts(lens, ropes, ["and a blue ball"], tok, NEW_TOKEN_IDS_TINY)
+    c1 = model.forward_cache_update_text(c1, **gi2)
+    assert c1.seq_lens == lens2[0] > lens[0]
+    for i in range(L):
+        assert c1._k[i] is not cache._k[i] and c1._own[i][0] == 1
+        assert torch.equal(cache.key_cache[i], snap[i][0]) and torch.equal(cache.value_cache[i], snap[i][1]), "the original changed under a write to its copy"
+        assert torch.equal(c2.key_cache[i], snap[i][0])
+        assert torch.equal(c1.key_cache[i][: lens[0]], snap[i][0])
+    # the original, extended by the same prompt, arrives at the same rows
+    cache2 = model.forward_cache_update_text(cache, **gi2)
+    for i in range(L):
+        assert torch.equal(cache2.key_cache[i], c1.key_cache[i]) and torch.equal(cache2.value_cache[i], c1.value_cache[i])
+        assert torch.equal(c2.key_cache[i], snap[i][0]), "the remaining sharer changed"
