@@ -183,3 +183,49 @@ def test_whole_model_quantised_load_mode(kind):
     assert torch.equal(ta, tb) or lg < 3e-2, f"decode on the stored codes drifts from the bf16 decode on de-quantised weights: logits rel-L2 {lg:.3g}"
     with pytest.raises(NotImplementedError):
         qm.language_model.engine().refresh()
+
+
+@pytest.mark.parametrize("kind", ["nf4", "int8_rowwise"])
+def test_whole_model_quantised_load_mode_at_7b_width(kind, golden):
+    """The same contract at BAGEL-7B-MoT WIDTH (hidden 3584, intermediate 18944, 28 / 4 heads of 128, 2 MoT layers): the row lengths, the 64-weight
+    NF4 blocks per row (56 / 296) and the scratch-set rotation of ``_StoredLayers`` are the real model's.  Request = the 512^2 text->image of tests/golden/wide7b_options.pt
+    (4 timesteps, CFG 4.0) + 6 greedy tokens."""
+    from oracle.configs import WIDE7B as cfg, NEW_TOKEN_IDS_TINY
+    from tests.test_model_gpu import cfg_kwargs, new_cache
+    from tests.test_wide_gpu import _options_context, _wide_model
+    g = golden("wide7b_options")
+    qm, bm = _wide_model(), _wide_model()
+    o = ops()
+    for L in bm.language_model.model.layers:                      # W <- dequantise(quantise(W)) on every decoder projection
+        mods = [getattr(L.self_attn, n + s) for n in ("q_proj", "k_proj", "v_proj", "o_proj") for s in ("", "_moe_gen")]
+        for s in ("", "_moe_gen"):
+            m = getattr(L, "mlp" + s)
+            mods += [m.gate_proj, m.up_proj, m.down_proj]
+        for m in mods:
+            w = m.weight.data
+            m.weight.data = (o.dequantize_nf4(*o.quantize_nf4(w)) if kind == "nf4" else o.dequantize_rows_i8(*o.quantize_rows_i8(w))).contiguous()
+    bm.language_model.invalidate_packed()
+    resident = qm.quantize_language_model(kind)
+    full = sum(p.numel() * 2 for n, p in bm.language_model.model.layers.named_parameters() if "proj" in n and n.endswith("weight"))
+    assert resident < (0.30 if kind == "nf4" else 0.52) * full
+    with pytest.raises(RuntimeError, match="release_bf16"):
+        qm.state_dict()                                            # (ADVICE r04: no 0-element tensors in a saved state dict)
+    kw, c = g["fp8"]["gen_kwargs"], g["cfg_inputs"]
+    outs = []
+    for model in (qm, bm):
+        cache = _options_context(model, cfg, g)
+        kv = [(cache.key_cache[i].clone(), cache.value_cache[i].clone()) for i in range(cfg["llm"]["num_hidden_layers"])]
+        lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), c), **kw, **g["latent_inputs"])
+        lens, ropes = [cache.seq_lens], [cache.seq_lens]
+        st = model.prepare_start_tokens(lens, ropes, NEW_TOKEN_IDS_TINY)
+        toks = model.generate_text(past_key_values=cache, max_length=6, do_sample=False, end_token_id=None, **st)
+        outs.append((kv, lat, toks, model._last_decode_session))
+    (ka, la, ta, sa), (kb, lb, tb, sb) = outs
+    for (k1, v1), (k2, v2) in zip(ka, kb):
+        assert torch.equal(k1, k2) and torch.equal(v1, v2), "prefill KV differs"
+    for a, b in zip(la, lb):
+        assert torch.isfinite(a).all() and torch.equal(a, b), "latents differ"
+    assert sa.weight_quant == kind and sb.weight_quant is None
+    lg = (sa.logits.float() - sb.logits.float()).norm() / sb.logits.float().norm()
+    assert torch.equal(ta, tb) or lg < 3e-2, f"decode on the stored codes drifts from the bf16 decode on de-quantised weights: logits rel-L2 {lg:.3g}"
+    print(f"whole-model {kind} at 7B width: resident {resident / 1e6:.0f} MB of {full / 1e6:.0f} MB, prefill KV and latents bit-identical, decode logits rel-L2 {lg:.2e}")
