@@ -308,3 +308,70 @@ extern "C" int bagel_argmax_bf16(const void* logits, int64_t ld, int64_t* out, i
     hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, stream, (const bf16_t*)logits, (long)ld, (long*)out, cols);
     return bagel_check_launch("argmax_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Sampling of the next token ON THE DEVICE (bagel.py:980-983: probs = softmax(pred_logits / temperature); curr_tokens = multinomial(probs, 1)).
+// torch.multinomial draws from torch's generator on the host side of the step, which keeps a sampled decode out of the hipGraph (one eager
+// launch sequence per token).  The Gumbel-max form draws from EXACTLY the same categorical distribution with one pass over the logits:
+//     token = argmax_i ( z_i + g_i ),   z_i = bf16(logit_i / temperature)  (the reference divides bf16 logits in bf16),   g_i = -log(-log(u_i)),
+// u_i uniform in (0, 1) from Philox4x32-10 keyed by the call's 64-bit seed with the counter (i / 4, row, step, 0) -- `step` is read from the
+// decode session's device-side step counter, so every replay of the captured step draws fresh numbers.  The RNG STREAM is not torch's (no two
+// devices share one anyway, as the reference's own comment at bagel.py:980 notes); the seed is drawn from torch's generator once per call, so
+// torch.manual_seed still makes a run reproducible.  oracle/sampling.py restates it; tests pin ids and the empirical distribution.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (unsigned)p1; c[2] = n2; c[3] = (unsigned)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float gumbel_of(unsigned x) {
+    const float u = ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-8f;          // (0, 1), every value exact in fp32
+    return -logf(-logf(u));
+}
+
+__global__ __launch_bounds__(1024) void sample_gumbel_kernel(const bf16_t* __restrict__ x, long ld, long* __restrict__ out, int cols, float temperature,
+                                                             unsigned seed_lo, unsigned seed_hi, const int* __restrict__ step_ctr) {
+    const bf16_t* r = x + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    const unsigned step = step_ctr ? (unsigned)step_ctr[0] : 0u;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int q = tid; q * 4 < cols; q += 1024) {                                   // one Philox call = four consecutive columns
+        unsigned c[4] = {(unsigned)q, (unsigned)blockIdx.x, step, 0u};
+        philox4x32_10(c, seed_lo, seed_hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = q * 4 + e;
+            if (i < cols) {
+                const float z = bfround(bf2f(r[i]) / temperature) + gumbel_of(c[e]);
+                if (z > best) { best = z; bi = i; }                                 // indices only grow inside a thread: strict > keeps the lowest
+            }
+        }
+    }
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    sv[tid] = best; si[tid] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float f = sv[tid + s]; const int j = si[tid + s];
+            if (f > sv[tid] || (f == sv[tid] && j < si[tid])) { sv[tid] = f; si[tid] = j; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+
+extern "C" int bagel_sample_gumbel_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows, int32_t cols, float temperature, int64_t seed,
+                                        const int32_t* step_ctr, hipStream_t stream) {
+    BAGEL_REQUIRE(logits && out && cols > 0, "sample_gumbel: bad arguments");
+    BAGEL_REQUIRE(temperature > 0.f, "sample_gumbel: temperature must be positive (got %g)", (double)temperature);
+    if (rows <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(sample_gumbel_kernel, dim3(rows), dim3(1024), 0, stream, (const bf16_t*)logits, (long)ld, (long*)out, cols, temperature,
+                       (unsigned)((uint64_t)seed & 0xffffffffu), (unsigned)((uint64_t)seed >> 32), (const int*)step_ctr);
+    return bagel_check_launch("sample_gumbel_kernel");
+}

@@ -662,19 +662,24 @@ class Bagel(nn.Module):
             weight_quant = getattr(self, "decode_weight_quant", None)    # model-level switch, like the reference's load-time modes (app.py:114-131)
         self._last_decode_session = None      # release the previous call's page pools BEFORE this call allocates its own (16 requests x 5 k tokens: 9 GB;
         #                                       holding both made every call pay a fresh hipMalloc of that size, ~100 ms)
+        # do_sample: the draw happens ON THE DEVICE inside the step (Gumbel-max over Philox numbers: the same categorical distribution as the reference's
+        # multinomial(softmax(logits / temperature)), bagel.py:980-983), seeded once per call from torch's generator -- torch.manual_seed makes a run
+        # reproducible, the decode replays from the hipGraph.  BAGEL_DECODE_SAMPLER=torch keeps torch.multinomial on the logits of every (eager) step.
+        device_sampler = bool(do_sample) and os.environ.get("BAGEL_DECODE_SAMPLER", "device") != "torch"
+        gumbel = ("gumbel", float(temperature), int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())) if device_sampler else None
         sess = DecodeSession(lm.engine(check=True), lm.model.embed_tokens.weight.data, lm.lm_head.weight.data, past_key_values, kv_lens,
-                             packed_start_tokens, packed_query_position_ids, max_length, weight_quant=weight_quant)
+                             packed_start_tokens, packed_query_position_ids, max_length, weight_quant=weight_quant, sampler=gumbel)
         self._last_decode_session = sess
         if use_graph is None:
             use_graph = os.environ.get("BAGEL_DECODE_GRAPH", "1") != "0"
         sampler = None
-        if do_sample:
+        if do_sample and not device_sampler:
             # sampling draws from torch's generator (an RNG stream cannot be matched across devices anyway, bagel.py:980-983)
             sampler = lambda logits: torch.multinomial(torch.softmax(logits.float() / temperature, dim=-1), num_samples=1).squeeze(1)  # noqa: E731
         step = 0
         while step < max_length:
             if step == 1 and use_graph and max_length > 2:
-                sess.capture(include_advance=not do_sample)
+                sess.capture(include_advance=sampler is None)
             sess.step(sampler)
             step += 1
             if end_token_id is not None and sess.last_token(0) == end_token_id:   # only support batch=1 (bagel.py:996)

@@ -89,7 +89,9 @@ class DecodeSession:
     """One ``generate_text`` call: device-resident loop state, the per-token launch sequence, and its hipGraph."""
 
     def __init__(self, engine, embed_table, lm_head_weight, cache, kv_lens, start_tokens, position_ids, max_length,
-                 page_order=None, weight_quant=None):
+                 page_order=None, weight_quant=None, sampler=None):
+        if sampler is not None and (len(sampler) != 3 or sampler[0] != "gumbel" or not float(sampler[1]) > 0.0):
+            raise ValueError(f"DecodeSession: sampler={sampler!r}: expected None or ('gumbel', temperature > 0, seed)")
         self.eng = eng = engine
         dev = eng.device
         self.B = B = len(kv_lens)
@@ -174,6 +176,10 @@ class DecodeSession:
             self.eng_status = torch.zeros((4,), dtype=torch.int32, device=dev)
         # a quantised engine: per-layer views of the small tensors (no scratch copies), built once -- not per eager step
         self._layers = eng.layers.small_views() if getattr(eng, "weight_store", None) is not None else eng.layers
+        # sampler = None: greedy (argmax) | ("gumbel", temperature, seed): the next token is SAMPLED inside the step (bagel_sample_gumbel_bf16: the
+        # categorical distribution of bagel.py:980-983 by Gumbel-max over Philox numbers keyed by seed and the device-side step counter), so a sampled decode
+        # replays from the hipGraph like a greedy one
+        self.sampler = sampler
         self.steps_done = 0
         self.graph = None
         self.graph_error = None
@@ -276,7 +282,7 @@ class DecodeSession:
                     ops.attn_decode_paged(qkv, pg.k[li], pg.v[li], pg.block_table, pg.kv_len, 1, self.max_len, self.part_o,
                                           self.part_ml, att, B, nq, nkv, dp, scale)
                 ops.decode_engine(self._engine_phases(li), eng.eps, self.eng_sync[li], self.eng_status)
-            ops.argmax_into(self.logits, self.next_tok)
+            self._pick_next()
             return
         for li, P in enumerate(self._layers):
             Q = self.w8[li] if self.w8 is not None else None
@@ -294,7 +300,13 @@ class DecodeSession:
             proj(x, Q["wgu"] if Q else P.wgu[0], act, norm_w=P.ln_post[0], epilogue=ops.EPI_SWIGLU16)
             proj(act, Q["wd"] if Q else P.wd[0], x, residual=x)
         proj(x, self.head, self.logits, norm_w=eng.model.norm.weight.data)
-        ops.argmax_into(self.logits, self.next_tok)
+        self._pick_next()
+
+    def _pick_next(self):
+        if self.sampler is None:
+            ops.argmax_into(self.logits, self.next_tok)
+        else:
+            ops.sample_gumbel_into(self.logits, self.next_tok, self.sampler[1], self.sampler[2], self.step_ctr)
 
     def advance_launch(self):
         ops.decode_advance(self.next_tok, self.cur32, self.tokens, self.pos, self.paged.kv_len, self.step_ctr, self.B,

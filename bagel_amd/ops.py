@@ -1225,6 +1225,16 @@ def argmax_into(logits, out):
     return out
 
 
+def sample_gumbel_into(logits, out, temperature, seed, step_ctr=None):
+    """Next-token sampling on the device: out[b] ~ Categorical(softmax(logits[b] / temperature)) by Gumbel-max over Philox uniforms (bagel_sample_gumbel_bf16)."""
+    _req(logits, BF16, "sample_gumbel.logits"); _req(out, torch.int64, "sample_gumbel.out")
+    if step_ctr is not None:
+        _req(step_ctr, torch.int32, "sample_gumbel.step_ctr")
+    check(lib().bagel_sample_gumbel_bf16(_ptr(logits), logits.stride(0), _ptr(out), logits.shape[0], logits.shape[1], float(temperature), int(seed),
+                                         _ptr(step_ctr), _stream()), "bagel_sample_gumbel_bf16")
+    return out
+
+
 def argmax(logits):
     _req(logits, BF16, "argmax.logits")
     out = torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)

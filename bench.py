@@ -802,6 +802,25 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
                     "note": f"weight_quant='{mode}' option (changes results): not the headline metric"}
         except Exception as e:
             return {"error": repr(e)}
+    # do_sample=True (bagel.py:980-983): the draw happens on the device inside the captured step (Gumbel-max, bagel_sample_gumbel_bf16), so the sampled decode replays from
+    # the hipGraph like the greedy one -- reported beside it (round 4: sampling ran torch.multinomial on the host side of every EAGER step and was never measured)
+    sampled = None
+    if UB == 1:
+        try:
+            cs, ls, rs, _ = prefill()
+            ss = model.prepare_start_tokens(ls, rs, ids)
+            torch.manual_seed(0)
+            fence()
+            t4 = time.perf_counter()
+            ts_ = model.generate_text(past_key_values=cs, max_length=n, do_sample=True, temperature=0.7, end_token_id=None, **ss)
+            fence()
+            dts = time.perf_counter() - t4
+            sampled = {"value": n / dts, "unit": "tokens/s", "decode_ms_per_token": dts / n * 1e3, "temperature": 0.7,
+                       "hip_graph": model._last_decode_session.graph is not None, "distinct_tokens": int(torch.unique(ts_).numel()),
+                       "note": "generate_text(do_sample=True): device-side Gumbel-max sampler inside the hipGraph; same categorical distribution as torch.multinomial, its own RNG stream"}
+            del cs
+        except Exception as e:
+            sampled = {"error": repr(e)}
     w8 = w4 = wn = None
     if UB == 1 and not args.no_int8:
         # the reference's OWN 4-bit load mode (app.py:114-125: bitsandbytes NF4, blocks of 64, fp32 absmax, bf16 compute)
@@ -863,7 +882,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
             "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
             "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer", "cpu_baseline": cpu,
-            "int8_rowwise_weights": w8, "mxfp4_weights": w4, "nf4_weights": wn, "batched_decode": bd, "parity_at_full_depth": depth,
+            "int8_rowwise_weights": w8, "mxfp4_weights": w4, "nf4_weights": wn, "batched_decode": bd, "sampled_decode": sampled, "parity_at_full_depth": depth,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_decode_traffic() if (UB == 1 and args.und_image == 980) else None,
                          "kernel": "gemv_kernel (decode step)",

@@ -165,6 +165,12 @@ int bagel_cfg_stage2_euler(float* x_t, const void* v_or_tmp, const float* partia
 /* torch.argmax(logits, -1) (bagel.py:984). */
 int bagel_argmax_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows, int32_t cols, bagel_stream_t stream);
 
+/* Sampled next token on the device (bagel.py:980-983: multinomial(softmax(logits / temperature))): Gumbel-max over Philox4x32-10 uniforms keyed by
+ * `seed` with the counter (column / 4, row, *step_ctr, 0) -- the same categorical distribution as torch.multinomial, drawn inside the captured decode
+ * step (step_ctr = the session's device-side step counter; NULL = step 0).  Not torch's RNG stream; oracle/sampling.py restates it. */
+int bagel_sample_gumbel_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows, int32_t cols, float temperature, int64_t seed,
+                             const int32_t* step_ctr, bagel_stream_t stream);
+
 /* ---- autoregressive text decode (Bagel.generate_text, bagel.py:930-1000) ------------------------------------ */
 /* Skinny GEMM for M <= a few rows (HBM-bound weight streaming): C[M,N] = A[M,K] W[N,K]^T with the epilogues and
  * roundings of bagel_gemm_bf16, plus an optional fused Qwen2RMSNorm of the A rows (norm_w != NULL:

@@ -228,6 +228,14 @@ def argmax(logits):
 
 def argmax_into(logits, out):
     out.copy_(torch.argmax(logits.float(), -1))
+
+
+def sample_gumbel_into(logits, out, temperature, seed, step_ctr=None):
+    """bagel_sample_gumbel_bf16 through its restatement (oracle/sampling.py)."""
+    from oracle import sampling
+    step = 0 if step_ctr is None else int(step_ctr[0])
+    out.copy_(torch.from_numpy(sampling.sample_gumbel(logits.float().numpy(), float(temperature), int(seed), step)))
+    return out
     return out
 
 
@@ -769,7 +777,7 @@ def chw_f32_to_u8(src):
 _NAMES = ["gemm", "gemv", "gemv_mb", "gemm_skinny", "rmsnorm", "layernorm", "rope_table", "qknorm_rope", "v_transpose", "attn_varlen",
           "copy_rows", "f32_to_bf16", "timestep_sinusoid", "flow_add", "add_table_rows", "cfg_stage1", "cfg_stage2_euler",
           "argmax", "require_gpu_bf16", "rope2d", "taylor_update", "taylor_eval", "attn_varlen_ranges", "flow_mix", "flow_add_rows",
-          "mse_rows", "cross_entropy", "argmax_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4", "dequantize_nf4", "quantize_rows_i8", "dequantize_rows_i8", "gemv_w8",
+          "mse_rows", "cross_entropy", "argmax_into", "sample_gumbel_into", "rope_table_into", "decode_qkv_post", "kv_append_paged", "attn_decode_paged", "attn_decode_fused", "quantize_rows_mxfp4", "gemv_w4", "quantize_nf4", "gemv_nf4", "dequantize_nf4", "quantize_rows_i8", "dequantize_rows_i8", "gemv_w8",
           "decode_advance", "require_gpu_f32", "attn_planned", "conv_gemm_f32", "groupnorm_f32", "softmax_rows_f32", "vae_reparam_f32", "conv_gemm_bf16", "groupnorm_bf16", "groupnorm_bf16_workspace_floats", "softmax_rows_bf16", "vae_reparam_bf16", "chw_bf16_to_u8",
           "vae_unscale_f32", "resample_u8", "u8_to_chw_f32", "chw_f32_to_u8", "transpose", "rmsnorm_bwd", "layernorm_bwd", "qknorm_rope_bwd", "swiglu_bwd",
           "act_bwd", "swiglu_fwd", "cross_entropy_bwd", "mse_rows_bwd", "rows_segment_sum", "colsum", "attn_bwd_blockmask"]

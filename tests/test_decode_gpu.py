@@ -492,18 +492,64 @@ def test_generate_text_end_token_and_scattered_pages():
     assert torch.equal(sess.tokens_so_far(), full)
 
 
-def test_generate_text_sampling_runs_and_is_seeded():
+def test_generate_text_sampling_runs_and_is_seeded(monkeypatch):
+    """do_sample=True: the draw happens on the device INSIDE the captured step (Gumbel-max, bagel_sample_gumbel_bf16), so the sampled decode replays from the
+    hipGraph; reproducible under torch.manual_seed, graph == eager, a new seed gives new tokens; BAGEL_DECODE_SAMPLER=torch keeps torch.multinomial (eager steps)."""
     from oracle.configs import TINY as cfg
     from tests.util_models import product_model
     model, _ = product_model(cfg)
     cache, lens, ropes, start = _context(model, cfg, ["sky"])
-    outs = []
+    outs = {}
+    for tag, seed, graph in (("a", 5, True), ("b", 5, True), ("eager", 5, False), ("other", 6, True)):
+        torch.manual_seed(seed)
+        outs[tag] = model.generate_text(past_key_values=copy.deepcopy(cache), max_length=12, do_sample=True, temperature=1.3, end_token_id=None, use_graph=graph, **start)
+        sess = model._last_decode_session
+        assert sess.sampler is not None and (sess.graph is not None) == graph
+        if graph:
+            assert sess._graph_has_advance, "a device-sampled step is captured WITH its bookkeeping"
+    assert outs["a"].shape == (12, 1) and torch.equal(outs["a"], outs["b"]) and torch.equal(outs["a"], outs["eager"])
+    assert not torch.equal(outs["a"], outs["other"])
+    assert (outs["a"] >= 0).all() and (outs["a"] < cfg["llm"]["vocab_size"]).all()
+    monkeypatch.setenv("BAGEL_DECODE_SAMPLER", "torch")
+    t = []
     for _ in range(2):
         torch.manual_seed(5)
-        outs.append(model.generate_text(past_key_values=copy.deepcopy(cache), max_length=6, do_sample=True, temperature=0.7,
-                                        end_token_id=None, **start))
-    assert outs[0].shape == (6, 1) and torch.equal(outs[0], outs[1])
-    assert (outs[0] >= 0).all() and (outs[0] < cfg["llm"]["vocab_size"]).all()
+        t.append(model.generate_text(past_key_values=copy.deepcopy(cache), max_length=6, do_sample=True, temperature=0.7, end_token_id=None, **start))
+    assert model._last_decode_session.sampler is None and torch.equal(t[0], t[1])
+
+
+def test_sample_gumbel_kernel_matches_its_restatement_and_the_softmax_distribution():
+    """bagel_sample_gumbel_bf16 vs oracle/sampling.py (Philox4x32-10 pinned to the Random123 known-answer vectors on the CPU side) at the lm_head width and at ragged widths:
+    identical ids except where the two top perturbed scores are within float rounding of each other; and the empirical distribution of 40 960 draws over a 13-way
+    head within 4.5 sigma of softmax(logits / T) (bagel.py:980-983)."""
+    import numpy as np
+    from oracle import sampling as S
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    for rows, cols, T in ((3, 152064, 0.7), (5, 1001, 1.0), (4, 7, 2.5)):
+        logits = (torch.randn(rows, cols, generator=g) * 3).to(torch.bfloat16)
+        for step in (0, 1, 77):
+            ctr = torch.tensor([step], dtype=torch.int32, device=DEV)
+            out = torch.full((rows,), -1, dtype=torch.int64, device=DEV)
+            o.sample_gumbel_into(logits.to(DEV), out, T, 0x0123456789abcdef & (2 ** 62 - 1), ctr)
+            keys = S.gumbel_keys(logits.float().numpy(), T, 0x0123456789abcdef & (2 ** 62 - 1), step)
+            want = keys.argmax(1)
+            got = out.cpu().numpy()
+            for b in range(rows):
+                if got[b] != want[b]:                           # a float-rounding near tie between the two best perturbed scores (logf differs by an ulp)
+                    assert abs(keys[b, got[b]] - keys[b, want[b]]) <= 1e-5 * max(1.0, abs(keys[b, want[b]])), (rows, cols, step, b)
+    V, T, rows = 13, 0.7, 8192
+    lg = (torch.randn(V, generator=g) * 2).to(torch.bfloat16)
+    counts = np.zeros(V)
+    x = lg.to(DEV).repeat(rows, 1).contiguous()
+    out = torch.empty(rows, dtype=torch.int64, device=DEV)
+    for step in range(5):
+        o.sample_gumbel_into(x, out, T, 99, torch.tensor([step], dtype=torch.int32, device=DEV))
+        counts += np.bincount(out.cpu().numpy(), minlength=V)
+    z = S.bf16_round(lg.float().numpy() / np.float32(T)).astype(np.float64)
+    p = np.exp(z - z.max()); p /= p.sum()
+    n = counts.sum()
+    assert (np.abs(counts - n * p) <= 4.5 * np.sqrt(n * p * (1 - p)) + 1).all(), (counts, n * p)
 
 
 @pytest.mark.parametrize("max_length", [1, 2, 3])
