@@ -747,16 +747,10 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     def prefill(nb=None):
         nb = UB if nb is None else nb
         cache = NaiveCache(L)
-        tp0 = time.perf_counter()
         gi, lens, ropes = model.prepare_vit_images([0] * nb, [0] * nb, [image] * nb, ident, ids)
-        if os.environ.get("BAGEL_BENCH_DEBUG"):
-            torch.cuda.synchronize()
-            sys.stderr.write(f"[prefill] prepare_vit_images {1e3 * (time.perf_counter() - tp0):.1f} ms; reserved {torch.cuda.memory_reserved() / 1e9:.2f} GB\n")
         cache = model.forward_cache_update_vit(cache, **gi)
         torch.cuda.synchronize()
         t_vit = time.perf_counter()
-        if os.environ.get("BAGEL_BENCH_DEBUG"):
-            sys.stderr.write(f"[prefill] through forward_cache_update_vit {1e3 * (t_vit - tp0):.1f} ms; reserved {torch.cuda.memory_reserved() / 1e9:.2f} GB\n")
         gi, lens, ropes = model.prepare_prompts(lens, ropes, ["p"] * nb, tok, ids)
         cache = model.forward_cache_update_text(cache, **gi)
         torch.cuda.synchronize()
