@@ -8,20 +8,24 @@
 // (bagel.py:930-1000).  The attention stays its own two launches: that seam is an all-to-all over keys, the cut the guide prescribes.
 //
 // Structure (MI355X_MICROARCH.md rows ldsdma-fill / nt-weights / engine-vs-launches; cdna_hip_programming.md 5.6, Guideline 16):
-//   * one workgroup per CU, all co-resident (grid == CU count); wave N-1 is the LOADER, waves 0..N-2 are CONSUMERS;
-//   * every workgroup owns a fixed, contiguous share of the weight-row pairs of every phase.  Its loader walks that static list of units
-//     (unit = one row PAIR of K <= 5120, or one K-quarter of a pair for the long rows of the down projection) and streams them with
-//     `global_load_lds_dwordx4 ... nt` into a ring of LDS slots -- it never waits for an activation, so while the consumers sit in the
-//     hand-off between two projections the ring fills with the next projection's weights (the "prefetch credit" that pays for the hop);
-//   * consumer c takes units c, c + NC, c + 2 NC ... of the same list: waits for the slot's `full` word (LDS), runs the lane-FMA body of
-//     gemv_kernel on the slot image and the staged activation vector (same chunk -> lane map, same accumulation order, same wave
-//     reduction, same epilogue roundings: the engine is BIT-IDENTICAL to the chain of bagel_gemv_bf16 launches, tests/test_engine_gpu.py),
-//     hands the slot back (`freed`), and lane 0 writes the outputs write-through (`sc1`: agent-scope relaxed atomic stores);
+//   * one workgroup per CU, all co-resident (grid == CU count); the last `nloaders` waves (2) are LOADERS, the others (6) CONSUMERS;
+//   * every workgroup owns a fixed, contiguous share of the weight-row pairs of every phase.  The loaders walk that static list of units
+//     (unit = one row PAIR of K <= 5120, or one K-quarter of a pair for the long rows of the down projection; loader j takes units j, j + 2, ..
+//     and owns their ring slots) and stream them with `global_load_lds_dwordx4 ... nt` into a ring of LDS slots -- they never wait for an
+//     activation, so while the consumers sit in the hand-off between two projections the ring fills with the next projection's weights (the
+//     "prefetch credit" that is supposed to pay for the hop);
+//   * consumer c takes units c, c + NC, c + 2 NC ... of the same list: waits for the slot's `full` word (LDS), pulls the unit into registers,
+//     hands the slot back (`freed`), runs the lane-FMA body of gemv_kernel on the staged activation vector (same chunk -> lane map, same
+//     accumulation order, same wave reduction, same epilogue roundings: the engine is BIT-IDENTICAL to the chain of bagel_gemv_bf16 launches,
+//     tests/test_engine_gpu.py), and lane 0 writes the outputs write-through (`sc1`: agent-scope relaxed atomic stores);
 //   * hand-off between phases (Guideline 16, form R1): when the last consumer of a workgroup has drained its stores it sets the
 //     workgroup's flag word of that phase (agent-scope relaxed store).  Consumer 0 of every workgroup polls the n_wg flag words with ONE
 //     wave (relaxed `sc1` loads, s_sleep between sweeps), then the activation vector is read with `sc1` loads (no acquire fence: the
-//     payload was stored write-through and the loads bypass L1) and staged in LDS -- with the Qwen2RMSNorm of gemv_kernel fused in.
+//     payload was stored write-through and the loads bypass L1) and staged in LDS -- with the Qwen2RMSNorm of gemv_kernel fused in --
+//     together with the workgroup's bias / residual dwords;
 //   * every spin is bounded: on a timeout the workgroup records a code in `status` and all of its waves leave; the host checks it.
+// MEASURED (profiles/r05_decode_engine.log): 94.4 us per 7B layer against 83.8 us for the four launches -- the launch form stays the default
+// (BAGEL_DECODE_ENGINE=1 selects this kernel); the comments below keep what each step of the way bought.
 //
 // Flags live in caller memory that must be ZERO when the launch starts (one memset per token covers every layer's slice).
 #include "common.h"
