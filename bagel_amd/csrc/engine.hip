@@ -162,7 +162,7 @@ __device__ __forceinline__ void eng_wait_vmcnt(int n) {
 // N x 1 KB of one weight row -> LDS: lane l's 16 bytes of piece i go to lds_dst + 1024 i + 16 l.  Address = wave-uniform 64-bit base (SGPR pair) +
 // the lane's 32-bit byte offset (one VGPR) + the instruction's immediate, and the immediate moves the LDS address as well: ONE base, ONE offset register
 // and ONE M0 value serve four instructions.  M0 is NOT preserved: hipcc has no use for it in this kernel (gfx9 LDS instructions take no M0; checked on
-// the ISA: no m0 outside these statements -- tools/isa_loop_check.py engine).  History (profiles/r05_decode_engine.log): the first version issued every
+// the ISA by tests/test_host_cpu.py::test_decode_engine_isa_invariants: no m0 outside these statements, no scratch).  History (profiles/r05_decode_engine.log): the first version issued every
 // piece from a scalar loop (M0 save / set / restore, 64-bit lane address arithmetic, two branches per instruction): 72 ns per instruction, 2.4 TB/s.
 template <int N, bool NT>
 __device__ __forceinline__ void eng_dma(unsigned voff, const void* sbase_uniform, unsigned lds_dst_uniform) {

@@ -221,3 +221,37 @@ def test_vae_launch_wrappers_match_the_header(monkeypatch):
     ops.gemv_mb(b(4, 128), b(64, 128), b(4, 64), M=4)
     assert calls == ["bagel_conv_gemm_bf16"] * 2 + ["bagel_groupnorm_bf16", "bagel_softmax_rows_bf16", "bagel_vae_reparam_bf16", "bagel_chw_bf16_to_u8",
                      "bagel_gemv_mb_bf16"]
+
+
+def test_decode_engine_isa_invariants():
+    """csrc/engine.hip relies on three things hipcc does not promise: (1) nothing spills to scratch (a scratch reload is a vector-memory load: its wait would drain the
+    loaders' counted LDS-DMA queue), (2) the compiler has no use of M0 of its own in this kernel (the DMA statements set M0 and do NOT restore it), (3) the loaders' only
+    vector-memory waits are the counted ones written in the source.  Checked on the ISA hipcc emits for gfx950 (cross-compiles without a GPU)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from bagel_amd.build import FLAGS
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "engine.s")
+        flags = [f for f in FLAGS if f != "-fPIC"]
+        r = subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", os.path.join(root, "bagel_amd", "csrc", "engine.hip"), "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = open(out).read()
+    meta = asm[asm.index("amdhsa.kernels"):]
+    assert re.search(r"\.private_segment_fixed_size:\s*0\b", meta), "decode_engine_kernel uses scratch"
+    assert re.search(r"\.vgpr_spill_count:\s*0\b", meta)
+    inside = False
+    for line in asm.splitlines():
+        if "#ASMSTART" in line:
+            inside = True
+        elif "#ASMEND" in line:
+            inside = False
+        elif not inside and re.search(r"\bm0\b", line) and not line.lstrip().startswith((";", ".")):
+            raise AssertionError(f"hipcc uses M0 outside the DMA statements: {line.strip()}")
+    assert asm.count("global_load_lds_dwordx4") >= 8
+    assert "buffer_wbl2" not in asm and "buffer_inv" not in asm, "an agent-scope fence crept into the engine (its hand-offs are write-through stores + sc1 loads)"
