@@ -945,3 +945,31 @@ def test_naive_cache_deepcopy_copy_on_write_semantics(monkeypatch):
     for i in range(L):
         assert torch.equal(cache2.key_cache[i], c1.key_cache[i]) and torch.equal(cache2.value_cache[i], c1.value_cache[i])
         assert torch.equal(c2.key_cache[i], snap[i][0]), "the remaining sharer changed"
+
+
+def test_bench_depth_parity_legs_run_on_the_host_path(monkeypatch):
+    """bench.py's two round-5 parity legs -- ``edit_depth_step`` (the 3-forward edit step: cond / CFG-text / CFG-img, text_channel renorm) and the CFG-combine
+    self-consistency gate of ``full_depth_step`` -- exercised end to end on the tiny model with the stand-in operators: the plumbing (contexts, packers, the oracle
+    calls, the gates) is covered without a GPU; the numbers at 7B width are tests/test_full_depth_gpu.py's."""
+    import argparse
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module_depth", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    mock_ops.install(monkeypatch)
+    cfg = TINY_D128
+    model = cpu_model(cfg)
+    ids = NEW_TOKEN_IDS_TINY
+    args = argparse.Namespace(resolution=64)
+    out = bench.edit_depth_step(args, cfg, model, ids, threads=2, ctx_tokens=(20, 6))
+    assert out["contexts"] == [20 + 2 + 6 + 2, 20 + 2, 6 + 2]
+    for k in ("rel_l2_cond_forward", "rel_l2_cfg_text_forward", "rel_l2_cfg_img_forward"):
+        assert out[k] <= 2e-2, (k, out[k])
+    assert out["cfg_combine_self_consistency"]["sequential_forward_flow"] <= bench.FULL_DEPTH_TOL_COMBINE
+    tok = bench.FixedTokenizer(list(range(8, 20)))
+    out2 = bench.full_depth_step(args, cfg, model, tok, ids, threads=2)
+    sc = out2["cfg_combine_self_consistency"]
+    assert sc["sequential_forward_flow"] <= bench.FULL_DEPTH_TOL_COMBINE and sc["generate_image_sequential"] <= bench.FULL_DEPTH_TOL_COMBINE
+    assert out2["rel_l2_cond_forward"] <= 2e-2 and out2["rel_l2_cfg_text_forward"] <= 2e-2
