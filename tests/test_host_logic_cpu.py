@@ -963,6 +963,7 @@ def test_bench_depth_parity_legs_run_on_the_host_path(monkeypatch):
     model = cpu_model(cfg)
     ids = NEW_TOKEN_IDS_TINY
     args = argparse.Namespace(resolution=64)
+    monkeypatch.setattr(torch, "set_num_threads", lambda n: None)      # the legs size torch's thread team for the bench box: other tests' bit-exact golden checks depend on it
     out = bench.edit_depth_step(args, cfg, model, ids, threads=2, ctx_tokens=(20, 6))
     assert out["contexts"] == [20 + 2 + 6 + 2, 20 + 2, 6 + 2]
     for k in ("rel_l2_cond_forward", "rel_l2_cfg_text_forward", "rel_l2_cfg_img_forward"):
