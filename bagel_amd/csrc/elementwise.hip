@@ -329,8 +329,22 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
     }
 }
 __device__ __forceinline__ float gumbel_of(unsigned x) {
-    const float u = ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-8f;          // (0, 1), every value exact in fp32
+    // 23 random bits + 0.5: (2k + 1) / 2 with 2k + 1 < 2^24 is exact in fp32, so u lies in [2^-24, 1 - 2^-24] and both logarithms are finite.
+    // (24 bits + 0.5 is NOT exact: 0xFFFFFF + 0.5 rounds to 2^24, u == 1 and the Gumbel value is +inf -- that column would win regardless of its logit.)
+    const float u = ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-7f;
     return -logf(-logf(u));
+}
+
+// test hook: the uniform -> Gumbel map of the sampler on caller-chosen 32-bit draws (the edge values 0 and 0xFFFFFFFF cannot be reached through a seed)
+__global__ void gumbel_of_kernel(const unsigned* __restrict__ x, float* __restrict__ g, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] = gumbel_of(x[i]);
+}
+extern "C" int bagel_debug_gumbel_of_u32(const uint32_t* x, float* g, int32_t n, hipStream_t stream) {
+    BAGEL_REQUIRE(x && g, "gumbel_of: bad arguments");
+    if (n <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(gumbel_of_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const unsigned*)x, g, n);
+    return bagel_check_launch("gumbel_of_kernel");
 }
 
 __global__ __launch_bounds__(1024) void sample_gumbel_kernel(const bf16_t* __restrict__ x, long ld, long* __restrict__ out, int cols, float temperature,

@@ -658,14 +658,17 @@ static int eng_env(const char* name, int dflt) {
 }
 
 extern "C" int bagel_decode_engine_workgroups(void) {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return bagel_set_error(BAGEL_ERR_LAUNCH, "decode_engine: cannot query the device");
-        n = prop.multiProcessorCount;
-    }
+    // per device (a process may drive several, and a CU-masked device reports its own count); a racing first call computes the same value twice
+    static int n_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return bagel_set_error(BAGEL_ERR_LAUNCH, "decode_engine: cannot query the device");
+    const bool cached = dev >= 0 && dev < 64;
+    if (cached && n_of[dev] > 0) return n_of[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        return bagel_set_error(BAGEL_ERR_LAUNCH, "decode_engine: cannot query the device");
+    if (cached) n_of[dev] = n;
     return n;
 }
 

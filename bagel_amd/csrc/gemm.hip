@@ -1187,13 +1187,10 @@ static int pq_leftover_split(int nblk, int wgs, int nk, size_t ws_bytes, int* n_
     const int n_full = nblk / wgs * wgs, rest = nblk - n_full;
     *n_full_out = n_full;
     if (rest == 0) return 1;
-    static int policy = -1, force = 0;
-    if (policy < 0) {
-        const char* e = getenv("BAGEL_GEMM_SPLIT_POLICY");       // 0 = the round-3 rule (fill the chip ONCE with the leftovers), 1 = the round-5 cost model (A/B knob)
-        policy = e ? atoi(e) : 0;
-        const char* f = getenv("BAGEL_GEMM_SPLIT_FORCE");        // experiment: this many parts for every launch with leftovers
-        force = f ? atoi(f) : 0;
-    }
+    // A/B knobs, READ ONCE PER PROCESS (C++11 thread-safe statics: host threads launching GEMMs concurrently do not race on them; a change of the
+    // environment after the first GEMM has no effect):
+    static const int policy = [] { const char* e = getenv("BAGEL_GEMM_SPLIT_POLICY"); return e ? atoi(e) : 0; }();   // 0 = the round-3 rule (fill the chip ONCE with the leftovers), 1 = the round-5 cost model
+    static const int force = [] { const char* f = getenv("BAGEL_GEMM_SPLIT_FORCE"); return f ? atoi(f) : 0; }();     // experiment: this many parts for every launch with leftovers
     if (force > 1) {
         int sf = force;
         if (sf > nk / 4) sf = nk / 4;

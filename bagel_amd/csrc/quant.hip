@@ -358,11 +358,8 @@ extern "C" int bagel_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int6
     BAGEL_REQUIRE(x && q && scale, "quantize_rows_fp8: null pointer");
     BAGEL_REQUIRE((cols % 8) == 0 && (ldx % 8) == 0 && (ldq_bytes % 8) == 0, "quantize_rows_fp8: cols / leading dims must be multiples of 8");
     if (rows <= 0 || cols <= 0) return BAGEL_OK;
-    static int two_pass = -1;
-    if (two_pass < 0) {
-        const char* e = getenv("BAGEL_FP8_QUANT_TWO_PASS");      // A/B knob: 1 = the two-pass kernel for every row length
-        two_pass = (e && atoi(e) > 0) ? 1 : 0;
-    }
+    // A/B knob, read once per process (thread-safe static): 1 = the two-pass kernel for every row length
+    static const int two_pass = [] { const char* e = getenv("BAGEL_FP8_QUANT_TWO_PASS"); return (e && atoi(e) > 0) ? 1 : 0; }();
     const int nch = cols >> 3;
     if (!two_pass && nch <= 64 * 8)
         hipLaunchKernelGGL(quantize_rows_fp8_reg_kernel<8>, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, (long)ldx,

@@ -165,9 +165,10 @@ class DecodeSession:
             if B > 4:
                 raise NotImplementedError("mxfp4 weights: the projection kernel quantises at most 4 activation rows per launch (batch <= 4)")
         self.w8 = self._quantised_weights() if weight_quant else None
-        # One request on bf16 weights: o_proj -> norm + gate/up -> down -> the next layer's norm + qkv (the last layer: final norm + lm_head) run as
-        # ONE persistent launch per layer on the loader / consumer weight-streaming engine (csrc/engine.hip), bit-identical to the gemv launches it
-        # replaces; 3 launches per layer instead of 6.  BAGEL_DECODE_ENGINE=0 keeps the launch form (also taken for shapes the engine refuses).
+        # OPT-IN (BAGEL_DECODE_ENGINE=1; the default is the launch form, which measured faster: csrc/engine.hip, profiles/r05_decode_engine.log).  One
+        # request on bf16 weights: o_proj -> norm + gate/up -> down -> the next layer's norm + qkv (the last layer: final norm + lm_head) run as ONE
+        # persistent launch per layer on the loader / consumer weight-streaming engine, bit-identical to the gemv launches it replaces; 3 launches per
+        # layer instead of 6.  Shapes the engine refuses (ops.decode_engine_supported mirrors every refusal of eng_launch) take the launch form.
         self.engine_mode = bool(B == 1 and weight_quant is None and os.environ.get("BAGEL_DECODE_ENGINE", "0") == "1"
                                 and self._engine_phases_supported())
         if self.engine_mode:

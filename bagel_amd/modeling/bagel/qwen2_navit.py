@@ -125,6 +125,9 @@ class _LayerView:
         if t is None:
             return None
         c = self._c
+        # READ-ONLY when the layer is shared copy-on-write (after copy.deepcopy / concat): this is a live view of the shared buffer, and torch has no
+        # read-only tensors.  Writers go through store() / ctx_tensors(), which un-share first; a caller that wants to edit a cached tensor in place
+        # through the reference protocol calls cache.unshare() first (the reference's deepcopy gave it private storage).
         return t[: c._total].view(c._total, c._nkv, c._dp)[..., : c._hd]
 
     def items(self):
@@ -197,6 +200,22 @@ class NaiveCache:
                     c._vt[i], c._vt_ok[i], c._vt_own[i] = self._vt[i], True, self._vt_own[i]
                     self._vt_own[i][0] += 1
         return c
+
+    def __copy__(self):
+        # a shallow copy would alias the owner counters themselves (its __del__ would then un-share buffers that are still shared): same as deepcopy
+        return self.__deepcopy__({})
+
+    def unshare(self):
+        """Give this cache private K / V storage for every layer (what the reference's deepcopy does eagerly): call before editing
+        ``key_cache[l]`` / ``value_cache[l]`` IN PLACE on a cache that came out of ``copy.deepcopy`` or ``concat``."""
+        for i in range(self._num_layers):
+            if self._k[i] is not None:
+                self._writable(i)
+                if self._vt_own[i][0] > 1:                 # an edited K / V invalidates a shared V^T image for THIS cache only
+                    self._vt_own[i][0] -= 1
+                    self._vt_own[i] = [1]
+                self._vt[i], self._vt_ok[i] = None, False
+        return self
 
     def _writable(self, layer):
         """Make this cache the only owner of the layer's K / V buffers before they are written."""

@@ -144,7 +144,10 @@ def _gemm_workspace(device):
     key = _ws_key(device)
     ws = _GEMM_WS.get(key)
     if ws is None:
-        ws = _GEMM_WS[key] = torch.empty(512 * 256 * 256, dtype=torch.float32, device=device)      # 512 partial tiles (the 3-way split of 160 leftover tiles needs 480)
+        # 256 partial tiles of 256 x 256 fp32 = 64 MB: the shipped rule cuts `rest` leftover tiles into at most wgs / rest parts.  The round-5 A/B knobs
+        # (multi-pass splits: the 3-way split of 160 leftover tiles needs 480 partial tiles) get twice that.
+        tiles = 512 if (os.environ.get("BAGEL_GEMM_SPLIT_POLICY", "0") != "0" or os.environ.get("BAGEL_GEMM_SPLIT_FORCE")) else 256
+        ws = _GEMM_WS[key] = torch.empty(tiles * 256 * 256, dtype=torch.float32, device=device)
     return ws
 
 
@@ -275,6 +278,10 @@ def decode_engine_supported(phases):
     without a launch, so callers can fall back to the launch form."""
     if not 1 <= len(phases) <= 4:
         return False
+    n_wg = lib().bagel_decode_engine_workgroups()
+    if n_wg <= 0:
+        return False
+    slot = max_k = 0
     for ph in phases:
         N, K = ph["W"].shape
         if K % 8 or N % 2 or ph["W"].stride(0) % 8:
@@ -283,11 +290,22 @@ def decode_engine_supported(phases):
             return False
         split = ph.get("norm_w") is None and K >= 8192 and N // 2 <= 8192
         groups = -(-(K // 8) // 64)
-        if 2 * (-(-groups // 4) if split else groups) > 60:
+        unit_groups = -(-groups // 4) if split else groups
+        if 2 * unit_groups > 60:
+            return False
+        if split and -(-(N // 2) // n_wg) > 32:                                       # ENG_MAX_DPAIRS split-K pairs per workgroup
             return False
         if ph.get("epilogue", EPI_NONE) == EPI_SWIGLU16 and (N % 32 or ph.get("bias") is not None or ph.get("residual") is not None):
             return False
-    return True
+        for key, align in (("A", 16), ("W", 16), ("norm_w", 16), ("C", 4), ("residual", 4)):
+            t = ph.get(key)
+            if t is not None and t.data_ptr() % align:
+                return False
+        slot, max_k = max(slot, 2 * unit_groups * 1024), max(max_k, K)
+    # the LDS ring beside the activation vector and the sync block (ENG_LDS_MAX, ENG_SYNC_BYTES, ENG_MAX_SLOTS; two loaders own alternate slots)
+    nslot = min((160 * 1024 - (max_k * 2 + 1023) // 1024 * 1024 - 2560) // slot, 8)
+    nslot -= nslot % 2
+    return nslot >= 4
 
 
 def decode_engine(phases, eps, sync_ws, status, trace=None):
@@ -1233,6 +1251,14 @@ def sample_gumbel_into(logits, out, temperature, seed, step_ctr=None):
     check(lib().bagel_sample_gumbel_bf16(_ptr(logits), logits.stride(0), _ptr(out), logits.shape[0], logits.shape[1], float(temperature), int(seed),
                                          _ptr(step_ctr), _stream()), "bagel_sample_gumbel_bf16")
     return out
+
+
+def debug_gumbel_of_u32(x):
+    """Test hook: the sampler's uniform -> Gumbel map on caller-chosen uint32 draws (int32 tensor, bit pattern) -> fp32."""
+    _req(x, torch.int32, "gumbel_of.x")
+    g = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().bagel_debug_gumbel_of_u32(_ptr(x), _ptr(g), x.numel(), _stream()), "bagel_debug_gumbel_of_u32")
+    return g
 
 
 def argmax(logits):

@@ -8,7 +8,10 @@
  *   - plain device pointers + explicit sizes/strides (element units) + hipStream_t; no torch types;
  *   - bf16 tensors are raw uint16 bit patterns; "ld*" are row strides in ELEMENTS;
  *   - return 0 on success, <0 on error (bagel_hip_last_error() gives the thread-local message);
- *   - ops never allocate, never synchronise, hold no global mutable state; async on `stream`.
+ *   - ops never allocate, never synchronise, hold no global mutable state; async on `stream`;
+ *   - entry points may be called from several host threads (each on its own stream and workspaces).  The BAGEL_* environment
+ *     variables the launchers consult are A/B tuning knobs for measurements: each is READ ONCE PER PROCESS at the first launch that
+ *     consults it (thread-safe), later changes of the environment have no effect, and the defaults are what bench.py measures.
  */
 #ifndef BAGEL_HIP_H
 #define BAGEL_HIP_H
@@ -170,6 +173,9 @@ int bagel_argmax_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows
  * step (step_ctr = the session's device-side step counter; NULL = step 0).  Not torch's RNG stream; oracle/sampling.py restates it. */
 int bagel_sample_gumbel_bf16(const void* logits, int64_t ld, int64_t* out, int32_t rows, int32_t cols, float temperature, int64_t seed,
                              const int32_t* step_ctr, bagel_stream_t stream);
+/* TEST HOOK (not for integrators): the sampler's uniform -> Gumbel map on caller-chosen 32-bit draws, g[i] = -log(-log(((x[i] >> 9) + 0.5) * 2^-23)):
+ * finite for every x, including the edge draws 0 and 0xFFFFFFFF that no seed can be steered to. */
+int bagel_debug_gumbel_of_u32(const uint32_t* x, float* g, int32_t n, bagel_stream_t stream);
 
 /* ---- autoregressive text decode (Bagel.generate_text, bagel.py:930-1000) ------------------------------------ */
 /* Skinny GEMM for M <= a few rows (HBM-bound weight streaming): C[M,N] = A[M,K] W[N,K]^T with the epilogues and
@@ -300,7 +306,10 @@ int bagel_attn_decode_fused_bf16(const void* qkv, int64_t ld, const void* cos_ta
                                  int32_t head_dim_padded, float eps, int32_t use_norm, float softmax_scale,
                                  bagel_stream_t stream);
 
-/* A CHAIN of 1..4 dependent batch-1 projections as ONE persistent launch (csrc/engine.hip): phase i computes what
+/* EXPERIMENTAL -- do NOT bind these four entry points in an integration: the persistent decode engine is a parity-tested
+ * NEGATIVE result (94.4 us per layer against 83.8 us for the four gemv launches it replaces, profiles/r05_decode_engine.log), off by default
+ * (opt-in BAGEL_DECODE_ENGINE=1), kept for the record; the signatures may change or disappear.
+ * A CHAIN of 1..4 dependent batch-1 projections as ONE persistent launch (csrc/engine.hip): phase i computes what
  * bagel_gemv_bf16(A_i, W_i, bias_i, R_i, C_i, norm_w_i, eps, M = 1, N_i, K_i, epilogue_i) computes, bit for bit, with A_0 written by an
  * earlier launch and A_i == C_{i-1} for i > 0 -- for a decoder layer at Lq = 1 (bagel.py:930-1000): o_proj(+residual)
  * (qwen2_navit.py:591-594) -> post-attention RMSNorm + gate/up with SwiGLU -> down(+residual) (modeling_qwen2.py:200-201, 54-59) -> the

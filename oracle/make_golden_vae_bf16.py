@@ -26,9 +26,10 @@ from oracle import make_golden as MG          # noqa: E402
 from oracle.configs import VAE_FULL           # noqa: E402
 
 
-def main():
+def scenario():
+    """Runs the UNMODIFIED reference VAE under cpu autocast beside the oracle ON THIS HOST and raises unless the "cpu" policy reproduces it bit for bit
+    (the host-independent pin: tests/test_reference_crosscheck.py calls this; nothing is written).  -> the fixture dict."""
     cfg = VAE_FULL
-    t0 = time.time()
     MG.ref_env.activate()
     from modeling.autoencoder import AutoEncoder, AutoEncoderParams
     from oracle.weights import load_synth
@@ -63,6 +64,12 @@ def main():
                            decode_cuda_vs_fp32=rel(out["decoded_cuda"], dec32), encode_cuda_vs_fp32=rel(out["encoded_cuda"], enc32),
                            decode_cpu_vs_fp32=rel(dec, dec32), encode_cpu_vs_fp32=rel(enc, enc32))
     out["host"] = dict(torch=torch.__version__)
+    return out
+
+
+def main():
+    t0 = time.time()
+    out = scenario()
     print("rel-L2 distances:", {k: f"{v:.3e}" for k, v in out["distance"].items()})
     path = os.path.join(MG.GOLD, "vae_full_bf16.pt")
     torch.save(out, path)

@@ -6,7 +6,7 @@ The reference samples with ``probs = softmax(pred_logits / temperature); curr_to
 product draws from the SAME categorical distribution by the Gumbel-max identity, with its own counter-based generator so that the draw can live inside the captured
 decode step:
 
-    token[b] = argmax_i ( bf16(logit[b, i] / T) + g_i ),   g_i = -log(-log(u_i)),   u_i = ((x_i >> 8) + 0.5) * 2^-24,
+    token[b] = argmax_i ( bf16(logit[b, i] / T) + g_i ),   g_i = -log(-log(u_i)),   u_i = ((x_i >> 9) + 0.5) * 2^-23  (23 bits + 0.5 is exact in fp32: u in [2^-24, 1 - 2^-24], the Gumbel value is always finite),
     (x_{4q}, .., x_{4q+3}) = Philox4x32-10(counter = (q, b, step, 0), key = (seed & 0xffffffff, seed >> 32))
 
 (ties -> lowest index).  Philox4x32-10 is Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC'11), the generator curand / torch use as well; the
@@ -39,6 +39,13 @@ def bf16_round(x):
     return u.view(np.float32)
 
 
+def gumbel_of(x_u32):
+    """uint32 draws -> Gumbel(0, 1) values, the device's ``gumbel_of``: 23 bits + 0.5 (exact in fp32), never 0 or 1, so never +-inf."""
+    x = np.asarray(x_u32, dtype=np.uint32)
+    u = ((x >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    return -np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
+
+
 def gumbel_keys(logits_f32, temperature, seed, step):
     """[rows, cols] fp32 (bf16-valued) logits -> the perturbed scores the device maximises."""
     logits_f32 = np.asarray(logits_f32, dtype=np.float32)
@@ -49,8 +56,7 @@ def gumbel_keys(logits_f32, temperature, seed, step):
     for b in range(rows):
         x = philox4x32_10(q, np.full(nq, b, np.uint32), np.full(nq, step, np.uint32), np.zeros(nq, np.uint32), seed & 0xffffffff, (seed >> 32) & 0xffffffff)
         xs = np.stack(x, 1).reshape(-1)
-        u = ((xs >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
-        out[b] = -np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
+        out[b] = gumbel_of(xs)
     z = bf16_round(logits_f32 / np.float32(temperature))
     return z + out[:, :cols]
 

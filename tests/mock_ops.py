@@ -236,7 +236,6 @@ def sample_gumbel_into(logits, out, temperature, seed, step_ctr=None):
     step = 0 if step_ctr is None else int(step_ctr[0])
     out.copy_(torch.from_numpy(sampling.sample_gumbel(logits.float().numpy(), float(temperature), int(seed), step)))
     return out
-    return out
 
 
 def rope_table_into(position_ids, inv_freq, cos, sin):

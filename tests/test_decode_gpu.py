@@ -552,6 +552,18 @@ def test_sample_gumbel_kernel_matches_its_restatement_and_the_softmax_distributi
     assert (np.abs(counts - n * p) <= 4.5 * np.sqrt(n * p * (1 - p)) + 1).all(), (counts, n * p)
 
 
+def test_gumbel_value_on_the_device_is_finite_on_the_edge_draws():
+    """The sampler's uniform -> Gumbel map on the draws no seed can be steered to (bagel_debug_gumbel_of_u32): x = 0xFFFFFFFF used to give u == 1.0 and a
+    Gumbel value of +inf (2^-24 per column = ~0.9 % of the decode steps at the lm_head width picked a uniformly random token).  Also == the restatement."""
+    import numpy as np
+    from oracle import sampling as S
+    xs = np.array([0, 1, 0x1ff, 0x200, 0x7fffffff, 0x80000000, 0xfffffdff, 0xfffffe00, 0xffffffff] + list(range(0xffff0000, 0xffffffff, 0x101)), dtype=np.uint32)
+    g = ops().debug_gumbel_of_u32(torch.from_numpy(xs.view(np.int32)).to(DEV)).cpu().numpy()
+    assert np.isfinite(g).all(), g[:9]
+    np.testing.assert_allclose(g, S.gumbel_of(xs), rtol=3e-6, atol=3e-6)
+    assert (np.diff(g[:9]) >= 0).all()
+
+
 @pytest.mark.parametrize("max_length", [1, 2, 3])
 def test_generate_text_short_runs_and_empty_context(max_length):
     """1-2 steps never reach the graph capture; a decode from an EMPTY cache (no prefill) works and matches the eager path."""
@@ -761,3 +773,13 @@ def test_naive_cache_deepcopy_is_copy_on_write_and_isolated():
     assert all(torch.equal(copies[0].key_cache[i], k0[i]) for i in range(L))
     assert all(torch.equal(cache.key_cache[i], k0[i]) for i in range(L)), "same request, same cache contents"
     del m2
+    # copy.copy == deepcopy (a shallow copy would alias the owner counters), and unshare() gives private storage for in-place edits through the views
+    sh = copy.copy(copies[1])
+    assert sh._own[0] is copies[1]._own[0] and sh._own[0][0] >= 2 and sh._k[0] is copies[1]._k[0]
+    sh.unshare()
+    assert sh._own[0][0] == 1 and sh._k[0] is not copies[1]._k[0]
+    sh.key_cache[0].zero_()
+    assert float(sh.key_cache[0].float().abs().max()) == 0.0
+    assert all(torch.equal(copies[1].key_cache[i], snap_k[i]) for i in range(L)), "an in-place edit after unshare() reached a sharer"
+    del sh
+    assert copies[1]._own[1][0] >= 1

@@ -42,6 +42,23 @@ def test_gumbel_max_draws_from_the_softmax_distribution():
     assert len(set(a.tolist())) > 3
 
 
+def test_gumbel_value_is_finite_on_the_edge_draws():
+    """x = 0xFFFFFFFF must not map to u == 1 (Gumbel +inf: that column would win whatever its logit) and x = 0 not to u == 0 (-inf).  The 24-bit form
+    ((x >> 8) + 0.5) * 2^-24 rounds 0xFFFFFF + 0.5 up to 2^24 in fp32; the 23-bit form is exact."""
+    x = np.array([0, 1, 0x1ff, 0x200, 0x7fffffff, 0x80000000, 0xfffffdff, 0xfffffe00, 0xffffffff], dtype=np.uint32)
+    g = S.gumbel_of(x)
+    assert np.isfinite(g).all(), g
+    assert (np.diff(g) >= 0).all()                                # monotone in the draw
+    u = ((x >> np.uint32(9)).astype(np.float64) + 0.5) * 2.0 ** -23
+    assert (u > 0).all() and (u < 1).all() and u[-1] == 1 - 2.0 ** -24 and u[0] == 2.0 ** -24
+    np.testing.assert_allclose(g, -np.log(-np.log(u)), rtol=2e-6, atol=2e-6)      # the fp32 evaluation agrees with fp64 on exact uniforms
+    # every one of the 2^23 uniforms is exactly representable in fp32 (spot-check the top of the range, where the 24-bit form broke)
+    top = np.arange(2 ** 23 - 4096, 2 ** 23, dtype=np.uint32)
+    uf = (top.astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    assert (uf.astype(np.float64) == (top.astype(np.float64) + 0.5) * 2.0 ** -23).all() and (uf < 1).all()
+    assert abs(float(g[-1]) - 16.6355) < 1e-3 and abs(float(g[0]) + 2.8114) < 1e-3   # -log(-log(1 - 2^-24)) = 24 ln 2, -log(24 ln 2)
+
+
 def test_generate_text_sampling_host_path_is_seeded(monkeypatch):
     from oracle.configs import TINY_D128 as cfg, NEW_TOKEN_IDS_TINY, StubTokenizer
     from tests import mock_ops

@@ -1,11 +1,11 @@
 #!/bin/bash
-# PMC passes (rounds 2-4) (one counter group per rocprofv3 run, --kernel-trace only: gpurun refuses --pmc with the other trace domains),
+# PMC passes (rounds 2-6) (one counter group per rocprofv3 run, --kernel-trace only: gpurun refuses --pmc with the other trace domains),
 # exactly as MI355X_MICROARCH.md prescribes:
 #   (1) denoise: a reduced text->image step (2 layers, 3 timesteps, default execution = stream-batched CFG + marker side path) that
 #       launches the four gen-expert GEMM shapes at M = 32 768 and the attention kernel on 8 x 4098 rows in the proportions of the
 #       full run                                              -> gpurun_out/pmc_denoise_<group>.txt
 #   (2) decode: bench.py --only-understanding, 24 new tokens  -> gpurun_out/pmc_decode_<group>.txt
-# then tools/pmc_make_summary.py folds the per-kernel averages into profiles/r05_pmc_summary.json (stamped with the git commit and the
+# then tools/pmc_make_summary.py folds the per-kernel averages into profiles/r06_pmc_summary.json (stamped with the git commit and the
 # sha1 of the kernel sources, which bench.py checks before quoting `traffic`).
 set -x
 mkdir -p gpurun_out
@@ -32,6 +32,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf /tmp/pmcd_$i
 done
 cd $ROOT
-python tools/pmc_make_summary.py gpurun_out gpurun_out/r05_pmc_summary.json
-head -c 3000 gpurun_out/r05_pmc_summary.json
+python tools/pmc_make_summary.py gpurun_out gpurun_out/r06_pmc_summary.json
+head -c 3000 gpurun_out/r06_pmc_summary.json
 du -sh gpurun_out

@@ -46,8 +46,32 @@ def find(d, prefix):
             yield os.path.join(d, f)
 
 
+def git_commit():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        return ""
+
+
+def stamp(path):
+    """`--stamp <summary.json>`: run in the build container after copying a summary out of gpurun_out/ (the GPU box has no .git, so `commit` is
+    empty there): fills in the commit whose kernel sources match the summary's digests, and refuses when they do not."""
+    d = json.load(open(path))
+    now = {"gemm": digest(["gemm.hip", "common.h"]), "decode": digest(["decode.hip", "skinny.hip", "common.h"]), "attention": digest(["attention2.hip", "common.h"])}
+    stale = [k for k in now if d.get("source_digest", {}).get(k) != now[k]]
+    if stale:
+        sys.exit(f"{path}: kernel sources changed since the PMC run ({stale}): not stamping")
+    d["commit"] = git_commit() + (" (+ uncommitted changes)" if subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "bagel_amd/csrc"], capture_output=True, text=True).stdout.strip() else "")
+    json.dump(d, open(path, "w"), indent=1)
+    print(f"{path}: commit = {d['commit']}")
+
+
 def main():
+    if sys.argv[1] == "--stamp":
+        return stamp(sys.argv[2])
     src, dst = sys.argv[1], sys.argv[2]
+    m = re.match(r"(r\d+)_", os.path.basename(dst))
+    tag = m.group(1) if m else "rNN"                      # the round the raw per-kernel files are committed under (profiles/<tag>_pmc_*.txt)
     den = {}
     for f in find(src, "pmc_denoise_"):
         for k, c in parse(f).items():
@@ -124,12 +148,9 @@ def main():
         algo_step = 2.0 * (L * (2 * Hd * Hd + 2 * Hd * nkv * hd + 3 * Hd * Id) + V * Hd) + 2.0 * nkv * hd * 2 * L * ctx
         decode = {"per_kernel": per, "traffic_bytes_per_step_corrected": int((2 * step_f + step_w) * 1024), "algorithmic_bytes_per_step": int(algo_step),
                   "steps_sampled": steps}
-    try:
-        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
-    except Exception:
-        commit = ""
-    out = {"source": "tools/gpu_pmc.sh (rocprofv3 --kernel-trace --pmc <one group per pass>); raw per-kernel averages in profiles/r04_pmc_denoise_*.txt / "
-                     "profiles/r04_pmc_decode_*.txt",
+    commit = git_commit()                                 # empty on the GPU box (no .git there): `--stamp` fills it in after the copy into profiles/
+    out = {"source": f"tools/gpu_pmc.sh (rocprofv3 --kernel-trace --pmc <one group per pass>); raw per-kernel averages in profiles/{tag}_pmc_denoise_*.txt / "
+                     f"profiles/{tag}_pmc_decode_*.txt",
            "correction": "FETCH_SIZE (KB) doubled for the 16-B/lane streaming patterns (MI355X_MICROARCH.md, HBM section; cross-checked in round 1 against "
                          "TCC_MISS x 128 B and on an in-place kernel); WRITE_SIZE (KB) as reported",
            "commit": commit,
