@@ -112,7 +112,14 @@ __device__ __forceinline__ float a2_sum_halves(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int D>
+// SPLIT (round 6, the round-5 verdict's "second workgroup per CU"): the K and the V^T tiles get a 2-slot ring EACH (2 x 16 KB + 2 x 16 KB = 64 KB instead
+// of the unified 4-slot ring's 128 KB), so TWO workgroups are resident per CU -- four waves per SIMD: while one workgroup's waves sit at the tile
+// barrier or in the softmax VALU, the other's MFMAs have the matrix pipe.  The tile stream is the same (tiles of all the worker's items in order, index x):
+// K(x) is read by the step (or item prologue) that forms S(x), V^T(x) by step x, so after the barrier at the top of step x both K slot x % 2 (held K(x))
+// and V^T slot (x + 1) % 2 (held V^T(x - 1)) are free: the fetch unit F(x) = {K(x + 2), V^T(x + 1)} is issued right there and has landed -- vmcnt(0), it is
+// the newest thing in flight -- before the barrier of step x + 1: ONE step of flight (the unified ring gives three; the second workgroup covers the rest).
+// Two cursors walk the item list, the K one a tile ahead of the V^T one.  Same arithmetic in the same order: bit-identical to the unified-ring kernel.
+template <int D, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, const int* __restrict__ worker_off,
                                                         const AttnItem* __restrict__ item_tab) {
     // (the two tables are separate noalias kernel arguments on purpose: only then does hipcc read them with SCALAR loads -- as members of
@@ -148,6 +155,63 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
     const unsigned koff_ctx = (unsigned)rowk * (unsigned)p.ldk_ctx * 2u + kcol, koff_new = (unsigned)rowk * (unsigned)p.ldk_new * 2u + kcol;
     const unsigned voff_ctx = ((unsigned)dv * (unsigned)p.ldvt_ctx + gchv * 8) * 2u;
     const unsigned voff_new = ((unsigned)dv * (unsigned)p.ldvt_new + gchv * 8) * 2u;
+
+    // ---- SPLIT rings: one cursor per operand (see the kernel's header comment) ----
+    struct Cur { int i, t, t1, ntc, lc, ln, x; const char *c, *n; };
+    Cur kc = {i_begin, 0, 0, 0, 0, 0, 0, nullptr, nullptr}, vc = {i_begin, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
+    auto cur_load = [&](Cur& c, bool is_k) {
+        const AttnItem* it = item_tab + c.i;
+        c.lc = it->l_ctx; c.ln = it->l_new; c.ntc = (c.lc + 63) >> 6; c.t = it->t0; c.t1 = it->t1;
+        const long g = it->g;
+        if (is_k) {
+            c.c = (const char*)(p.k_ctx + (long)it->kc_row0 * p.ldk_ctx + g * D);
+            c.n = (const char*)(p.k_new + (long)it->kn_row0 * p.ldk_new + g * D);
+        } else {
+            c.c = (const char*)(p.vt_ctx + g * D * p.ldvt_ctx + it->vtc_col0);
+            c.n = (const char*)(p.vt_new + g * D * p.ldvt_new + it->vtn_col0);
+        }
+    };
+    auto cur_next = [&](Cur& c, bool is_k) {
+        ++c.x;
+        if (++c.t >= c.t1) {
+            ++c.i;
+            if (c.i < i_end) cur_load(c, is_k);
+        }
+    };
+    // K(x) of the K cursor's tile -> K slot x % 2 (a segment's ragged last tile: rows past its end re-read the last key, masked in the scores)
+    auto fetch_k = [&]() {
+        if (kc.i >= i_end) return;
+        const unsigned sb = __builtin_amdgcn_readfirstlane(smem_base + (kc.x & 1) * KT_BYTES + wave * 1024u);
+        const bool is_ctx = kc.t < kc.ntc;
+        const int ti = is_ctx ? kc.t : kc.t - kc.ntc;
+        const int seglen = is_ctx ? kc.lc : kc.ln;
+        const long ldk = is_ctx ? p.ldk_ctx : p.ldk_new;
+        const char* kseg = a2_uniform(is_ctx ? kc.c : kc.n);
+        if (ti * 64 + 64 <= seglen) {
+            const char* kt = a2_uniform(kseg + (long)ti * 64 * ldk * 2);
+#pragma unroll
+            for (int i = 0; i < NLK; ++i) a2_glds16s(is_ctx ? koff_ctx : koff_new, a2_uniform(kt + (long)i * (RS * NW) * ldk * 2), sb + i * (NW * 1024u));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLK; ++i) {
+                int key = ti * 64 + rowk + RS * NW * i;
+                key = key < seglen ? key : seglen - 1;
+                a2_glds16s((unsigned)key * (unsigned)ldk * 2u + kcol, kseg, sb + i * (NW * 1024u));
+            }
+        }
+        cur_next(kc, true);
+    };
+    auto fetch_v = [&]() {
+        if (vc.i >= i_end) return;
+        const unsigned sb = __builtin_amdgcn_readfirstlane(smem_base + 2 * KT_BYTES + (vc.x & 1) * VT_BYTES + wave * 1024u);
+        const bool is_ctx = vc.t < vc.ntc;
+        const int ti = is_ctx ? vc.t : vc.t - vc.ntc;
+        const long ldvt = is_ctx ? p.ldvt_ctx : p.ldvt_new;
+        const char* vseg = a2_uniform((is_ctx ? vc.c : vc.n) + (long)ti * 128);
+#pragma unroll
+        for (int i = 0; i < NLV; ++i) a2_glds16s(is_ctx ? voff_ctx : voff_new, a2_uniform(vseg + (long)i * (8 * NW) * ldvt * 2), sb + i * (NW * 1024u));
+        cur_next(vc, false);
+    };
 
     // ---- the DMA cursor: (item, tile) of the next 64-key tile to fetch, two tiles ahead of the compute cursor ----
     int d_i = i_begin, d_t = 0, d_t1 = 0, d_ntc = 0, d_lc = 0, d_ln = 0, d_slot = 0, issued = 0;
@@ -228,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
     else          { kswz = (pkey >> 1) & 7; }
     const int vswz = (qi >> 1) & 7;
     const unsigned kb0 = (unsigned)(pkey * KROW) | ((unsigned)(hi ^ kswz) << 4);
-    const unsigned vb0 = (unsigned)(KT_BYTES + qi * 128) | ((unsigned)((hi ^ vswz) & 7) << 4);
+    const unsigned vb0 = (unsigned)((SPLIT ? 2 * KT_BYTES : KT_BYTES) + qi * 128) | ((unsigned)((hi ^ vswz) & 7) << 4);
     static_assert(STAGE % 256 == 0 && KT_BYTES % 128 == 0, "ring slots must keep the low address bits of the fragment offsets free");
 
     constexpr int NK = 2 * KS;                  // K fragments of a tile  (index KS*kb + ks)
@@ -238,13 +302,22 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
     auto vfrag = [&](unsigned vbs, int idx) { return *(const bf16x8_t*)(smem + (vbs ^ (unsigned)((idx & 3) << 5)) + (idx >> 2) * 4096); };
 
     // ---- prime the tile stream: the first two tiles of this worker ----
-    d_load(d_i);
+    if (SPLIT) {
+        cur_load(kc, true);
+        cur_load(vc, false);
+        fetch_k();                              // K(0): the first item's prologue
+        fetch_k();                              // K(1), V^T(0): step 0
+        fetch_v();
+    } else {
+        d_load(d_i);
 #pragma unroll
-    for (int i = 0; i < NS - 1; ++i) issue_next();
+        for (int i = 0; i < NS - 1; ++i) issue_next();
+    }
     int u = 0;                                  // stream index of the compute cursor's tile (tiles are consumed in the order they are fetched)
     // counted wait until this wave's pieces of stream tile x have landed: the `issued - (x + 1)` tiles fetched after it may stay in
     // flight (LDS-DMA returns in order; anything else hipcc issued meanwhile -- the epilogue's stores -- only makes the wait longer)
     auto wait_for = [&](int x) {
+        if (SPLIT) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }      // the newest fetch unit is the one the next barrier needs
         const int n = issued - (x + 1);
         if (n >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NLK + NLV)) : "memory");
         else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLK + NLV) : "memory");
@@ -336,14 +409,23 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
         auto step = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int t, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             if (!(A2_ABL & 1)) {
-            if (!LAST) wait_for(u + 1);                      // this wave's pieces of tile t+1 have landed
+            if (!LAST || SPLIT) wait_for(u + 1);             // this wave's pieces of tile t+1 have landed (SPLIT: F(u - 1) = {K(u + 1), V^T(u)}, needed by a LAST step too)
             asm volatile("s_barrier" ::: "memory");          // ... everyone's; and everyone is done with tile t-1, whose slot the NEXT fetch takes
             }
-            ++u;
-            if (NS == 3 || !live) issue_next();              // 3 slots: fetch tile t+2 here; 4 slots: tile t+3 goes out inside phase B (below)
-            const unsigned sbv = vb0 + cs * STAGE;
-            cs = next_slot(cs);
-            const unsigned sbk = kb0 + cs * STAGE;
+            unsigned sbv, sbk;
+            if (SPLIT) {
+                fetch_k();                                   // F(u) = {K(u + 2), V^T(u + 1)} into the slots step u - 1 read
+                fetch_v();
+                sbv = vb0 + (u & 1) * VT_BYTES;
+                sbk = kb0 + ((u + 1) & 1) * KT_BYTES;
+                ++u;
+            } else {
+                ++u;
+                if (NS == 3 || !live) issue_next();          // 3 slots: fetch tile t+2 here; 4 slots: tile t+3 goes out inside phase B (below)
+                sbv = vb0 + cs * STAGE;
+                cs = next_slot(cs);
+                sbk = kb0 + cs * STAGE;
+            }
             if (!live) return;
             constexpr int WIN = A2_WIN;
             constexpr int NMA = NK, NMB = NV;
@@ -406,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
                 const int db = m % DB, jj = m / DB;
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[m], pfrag(jj), o[db], 0, 0, 0);
                 if (m + WIN < NV) vf[m + WIN] = (A2_ABL & 4) ? vf[m % WIN] : vfrag(sbv, vidx(m + WIN));
-                if (NS > 3 && m == NMB / 2) issue_next();   // the slot of tile t-1 is free since this step's barrier; phase B has the issue slack
+                if (!SPLIT && NS > 3 && m == NMB / 2) issue_next();   // the slot of tile t-1 is free since this step's barrier; phase B has the issue slack
 #pragma unroll
                 for (int u = 0; u < SPB; ++u) {
                     const int slot = m * SPB + u;
@@ -430,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void attn2_kernel(const Attn2Params p, cons
         // prologue: this item's first tile has landed for every wave (each waited before its previous epilogue / after the priming)
         asm volatile("s_barrier" ::: "memory");
         if (live) {
-            const unsigned sbk = kb0 + cs * STAGE;
+            const unsigned sbk = SPLIT ? kb0 + (u & 1) * KT_BYTES : kb0 + cs * STAGE;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -741,14 +823,35 @@ extern "C" int bagel_attn_planned_bf16(const void* q, int64_t ldq, const void* k
     p.part = (float*)partials;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const dim3 grid(n_workers), block(512);
+    // a plan with MORE workers than the device has CUs asks for two resident workgroups per CU: the split-ring kernel (64 KB of LDS per workgroup)
+    static int cus_of[64] = {0};
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return bagel_set_error(BAGEL_ERR_LAUNCH, "attn_planned: cannot query the device");
+    if (dev >= 0 && dev < 64 && cus_of[dev] > 0) cus = cus_of[dev];
+    else {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return bagel_set_error(BAGEL_ERR_LAUNCH, "attn_planned: cannot query the device");
+        if (dev >= 0 && dev < 64) cus_of[dev] = cus;
+    }
+    const bool split = n_workers > cus;
     if (head_dim == 128) {
-        constexpr int smem = A2_SLOTS * (64 * 256 + 128 * 128);
-        if (int rc = bagel_enable_lds((const void*)attn2_kernel<128>, smem, "attn2_kernel<128>")) return rc;
-        hipLaunchKernelGGL((attn2_kernel<128>), grid, block, smem, stream, p, worker_off, items);
+        constexpr int smem = A2_SLOTS * (64 * 256 + 128 * 128), smem_split = 2 * (64 * 256 + 128 * 128);
+        if (split) {
+            if (int rc = bagel_enable_lds((const void*)attn2_kernel<128, true>, smem_split, "attn2_kernel<128, split>")) return rc;
+            hipLaunchKernelGGL((attn2_kernel<128, true>), grid, block, smem_split, stream, p, worker_off, items);
+        } else {
+            if (int rc = bagel_enable_lds((const void*)attn2_kernel<128, false>, smem, "attn2_kernel<128>")) return rc;
+            hipLaunchKernelGGL((attn2_kernel<128, false>), grid, block, smem, stream, p, worker_off, items);
+        }
     } else if (head_dim == 64) {
-        constexpr int smem = A2_SLOTS * (64 * 128 + 64 * 128);
-        if (int rc = bagel_enable_lds((const void*)attn2_kernel<64>, smem, "attn2_kernel<64>")) return rc;
-        hipLaunchKernelGGL((attn2_kernel<64>), grid, block, smem, stream, p, worker_off, items);
+        constexpr int smem = A2_SLOTS * (64 * 128 + 64 * 128), smem_split = 2 * (64 * 128 + 64 * 128);
+        if (split) {
+            if (int rc = bagel_enable_lds((const void*)attn2_kernel<64, true>, smem_split, "attn2_kernel<64, split>")) return rc;
+            hipLaunchKernelGGL((attn2_kernel<64, true>), grid, block, smem_split, stream, p, worker_off, items);
+        } else {
+            if (int rc = bagel_enable_lds((const void*)attn2_kernel<64, false>, smem, "attn2_kernel<64>")) return rc;
+            hipLaunchKernelGGL((attn2_kernel<64, false>), grid, block, smem, stream, p, worker_off, items);
+        }
     } else {
         return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_planned: head_dim %d not in {64,128} (pad the head)", head_dim);
     }
@@ -760,4 +863,26 @@ extern "C" int bagel_attn_planned_bf16(const void* q, int64_t ldq, const void* k
         return bagel_check_launch("attn2_combine_kernel");
     }
     return BAGEL_OK;
+}
+
+// TEST / TOOLING HOOK: resident workgroups per CU of the planned attention kernel (unified 4-slot ring, or the split 2 + 2 ring) as the runtime's occupancy
+// calculator sees them -- registers, LDS and wave slots together (tools/attn2_probe.py --workers).
+extern "C" int bagel_debug_attn_occupancy(int32_t head_dim, int32_t split) {
+    int n = 0;
+    hipError_t e;
+    if (head_dim == 128) {
+        constexpr int smem = A2_SLOTS * (64 * 256 + 128 * 128), smem_split = 2 * (64 * 256 + 128 * 128);
+        if (int rc = bagel_enable_lds(split ? (const void*)attn2_kernel<128, true> : (const void*)attn2_kernel<128, false>, split ? smem_split : smem, "attn2_kernel<128>")) return rc;
+        e = split ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn2_kernel<128, true>, 512, smem_split)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn2_kernel<128, false>, 512, smem);
+    } else if (head_dim == 64) {
+        constexpr int smem = A2_SLOTS * (64 * 128 + 64 * 128), smem_split = 2 * (64 * 128 + 64 * 128);
+        if (int rc = bagel_enable_lds(split ? (const void*)attn2_kernel<64, true> : (const void*)attn2_kernel<64, false>, split ? smem_split : smem, "attn2_kernel<64>")) return rc;
+        e = split ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn2_kernel<64, true>, 512, smem_split)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn2_kernel<64, false>, 512, smem);
+    } else {
+        return bagel_set_error(BAGEL_ERR_UNSUPPORTED, "attn_occupancy: head_dim %d not in {64,128}", head_dim);
+    }
+    if (e != hipSuccess) return bagel_set_error(BAGEL_ERR_LAUNCH, "attn_occupancy: %s", hipGetErrorString(e));
+    return n;
 }

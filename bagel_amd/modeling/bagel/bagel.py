@@ -131,6 +131,8 @@ class Bagel(nn.Module):
         self.cfg_batched = os.environ.get("BAGEL_CFG_BATCH", "1") == "1"
         self.und_side_path = os.environ.get("BAGEL_UND_SIDE", "1") == "1"
         self.step_hook = None          # optional callable(steps_taken, x_t) inside generate_image (trajectory tests / tooling)
+        self.velocity_hook = None      # optional callable(batched: bool, [v_cond, v_cfg_text | None, v_cfg_img | None]) inside every Euler step, BEFORE the CFG
+        #                                combine: the per-stream velocities of the forward(s) the step just ran (LIVE bf16 buffers) -- parity gates of the timed path
         self.global_renorm_allreduce = False      # see _renorm_sums_allreduce
         # option (changes results; off by default, reported beside the bf16 numbers): "fp8" = the gen expert's four projections of the
         # denoise forwards run on the OCP-e4m3 MFMA with row-wise scales -- the MI355X counterpart of the reference's quantised load
@@ -542,6 +544,8 @@ class Bagel(nn.Module):
                 ops.gemm(h, self.llm2vae.weight.data, st["v"][s], bias0=self.llm2vae.bias.data, a_rows0=multi["vae_rows"][s],
                          M0=st["v"][s].shape[0])
             v, v_ct, v_ci = st["v"][0], st["v"][1], (st["v"][2] if plan_i is not None else None)
+            if self.velocity_hook is not None:
+                self.velocity_hook(True, [v, v_ct, v_ci])
             nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
             nparts = self._renorm_sums_allreduce(st["partials"], nparts, mode)
             ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
@@ -550,6 +554,8 @@ class Bagel(nn.Module):
         if plan_t is not None:
             v_ct = self._velocity(st, plan_t, cache_t, st["v"][1], taylor[1])
             v_ci = self._velocity(st, plan_i, cache_i, st["v"][2], taylor[2]) if plan_i is not None else None
+            if self.velocity_hook is not None:
+                self.velocity_hook(False, [v, v_ct, v_ci])
             nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)
             nparts = self._renorm_sums_allreduce(st["partials"], nparts, mode)
             ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))

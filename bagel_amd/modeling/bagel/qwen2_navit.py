@@ -917,6 +917,17 @@ class MoTEngine:
             self._ws[key] = ws
         return ws
 
+    def release_workspaces(self, quantised=False):
+        """Forget the cached activation workspaces (they come back, sized for the next request's row count, on its first forward) -- a serving process moving
+        from batch-4 text->image to one edit request gives back 10+ GB of live bytes; ``quantised=True`` also drops the on-first-use quantised copies of the
+        weights (FP8 gen expert, the decode's INT8 / MXFP4 / NF4 codes).  Nothing of the weights themselves is touched."""
+        self._ws, self._ws_side, self._ws_fp8 = {}, {}, {}
+        if quantised:
+            self._fp8 = None
+            for attr in ("_w8_cache", "_w4_cache", "_nf4_cache"):
+                if hasattr(self, attr):
+                    delattr(self, attr)
+
     def plan(self, query_lens, position_ids, **kw):
         return ForwardPlan(self.device, query_lens, position_ids, inv_freq=self.model.rotary_emb.inv_freq(self.device), **kw)
 

@@ -68,6 +68,16 @@ def parse():
     ap.add_argument("--standins", action="store_true",
                     help="TEST ONLY (tests/test_parallel_cpu.py): run main()'s own one_step() / fence / timing / JSON line on the CPU with the torch "
                          "stand-ins of tests/mock_ops.py in place of the launch wrappers, a tiny model and the gloo backend; the line is flagged invalid")
+    ap.add_argument("--no-oracle-jobs", action="store_true",
+                    help="run the CPU-oracle sides of understanding.parity_at_full_depth and edit.parity_at_depth in this process, after the GPU legs, instead of in "
+                         "worker processes beside the headline loop")
+    ap.add_argument("--oracle-job", choices=["und_depth", "edit_depth"], default=None, help="internal: worker mode (see start_oracle_jobs)")
+    ap.add_argument("--job-dir", default=None, help="internal: worker mode")
+    ap.add_argument("--job-threads", type=int, default=0, help="internal: worker mode")
+    ap.add_argument("--job-node", type=int, default=-1, help="internal: worker mode (NUMA node to pin to, -1 = none)")
+    ap.add_argument("--und-oracle-out", default=None, help="internal: directory of the und_depth worker whose result the understanding child compares with")
+    ap.add_argument("--wall-budget-s", type=float, default=1200.0,
+                    help="the CPU-oracle parity legs are dropped (and the line says so) once the run would pass this many seconds (the driver's limit is 1800)")
     ap.add_argument("--launch-check", action="store_true",
                     help="debug only: rendezvous + barrier + max-over-ranks timing + the JSON line, no model (gloo when there is no GPU)")
     return ap.parse_args()
@@ -129,6 +139,248 @@ def launch_check(args, rank, world, local):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+T_START = time.time()
+EDIT_PARITY_LAYERS = 4      # depth of the model edit.parity_at_depth runs (tests/test_full_depth_gpu.py::test_edit_request_at_full_context uses the same)
+
+
+def numa_nodes():
+    """-> [[cpu ids of node 0], [node 1], ...] from sysfs, or [] when it cannot be read."""
+    import glob
+    import re
+    nodes = []
+    for path in sorted(glob.glob("/sys/devices/system/node/node[0-9]*/cpulist"), key=lambda p: int(re.search(r"node(\d+)", p).group(1))):
+        cpus = []
+        try:
+            for part in open(path).read().strip().split(","):
+                if part:
+                    a, _, b = part.partition("-")
+                    cpus += list(range(int(a), int(b or a) + 1))
+        except (OSError, ValueError):
+            return []
+        nodes.append(cpus)
+    return nodes
+
+
+def oracle_job_main(args):
+    """WORKER MODE (``--oracle-job``): the CPU-oracle side of one parity leg in a process of its own, so that it runs BESIDE the parent's GPU-bound headline loop
+    instead of after it (round-5 verdict, weak 16: the two full-depth oracle legs were 5.5 min of a 15-min run with the GPU idle).  The worker builds the same
+    name-seeded random model on the GPU (bagel_amd/factory.py init_random_: every tensor's generator is seeded by its NAME, so this process, the parent and the
+    understanding child hold identical weights -- the compare phase checks a fingerprint), copies the weights to the host, RELEASES the GPU (``gpu_released`` flag:
+    the parent waits for it before its timed region) and only then starts the oracle on its own share of the host cores.  Checker use of the oracle only."""
+    d = args.job_dir
+    try:
+        nodes = numa_nodes()
+        if 0 <= args.job_node < len(nodes) and len(nodes) > 1:
+            os.sched_setaffinity(0, nodes[args.job_node])
+        threads = args.job_threads or max(1, physical_cores() // 2)
+        torch.set_num_threads(threads)
+        from bagel_amd.factory import BAGEL_7B_MOT as cfg, NEW_TOKEN_IDS_QWEN25 as ids, build_bagel, init_random_
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+        real_edit = args.oracle_job == "edit_depth"
+        L = EDIT_PARITY_LAYERS if real_edit else (args.layers or cfg["llm"]["num_hidden_layers"])
+        model, vae = build_bagel(cfg, device=dev, num_layers=L, with_vae=real_edit)
+        init_random_(model, seed=0)
+        model.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device=dev).manual_seed(1))
+        cfgL = dict(cfg, llm=dict(cfg["llm"], num_hidden_layers=L))
+        VW = None
+        if real_edit:
+            init_random_(vae, seed=0)
+            inp = edit_depth_inputs(args, cfgL, model, ids, real=True)
+            VW = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
+            keep = EDIT_KEEP_REAL
+        else:
+            inp = und_depth_inputs(args, model, ids)
+            keep = UND_KEEP
+        W = {k: v.detach().to("cpu") for k, v in model.state_dict().items() if k.startswith(keep)}
+        del model, vae
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        open(os.path.join(d, "gpu_released"), "w").write(str(time.time()))
+        t0 = time.time()
+        out = edit_depth_oracle(cfgL, W, VW, inp, threads) if real_edit else und_depth_oracle(cfgL, W, inp, threads)
+        out["worker"] = {"seconds": time.time() - t0, "seconds_note": "wall clock, INCLUDING the time this process spent stopped while the parent's timed regions ran", "threads": threads, "numa_node": args.job_node if len(nodes) > 1 else None,
+                         "cpus_allowed": len(os.sched_getaffinity(0)), "started_after_bench_start_s": t0 - float(os.environ.get("BAGEL_BENCH_T0", t0))}
+        torch.save(out, os.path.join(d, "out.pt.tmp"))
+        os.rename(os.path.join(d, "out.pt.tmp"), os.path.join(d, "out.pt"))
+    except BaseException as e:        # the parent falls back to the in-process oracle
+        import traceback
+        open(os.path.join(d, "gpu_released"), "a").write("")
+        open(os.path.join(d, "error.txt"), "w").write(repr(e) + "\n" + traceback.format_exc())
+        raise
+
+
+def start_oracle_jobs(args, local, kinds):
+    """Start one worker per kind (see ``oracle_job_main``); -> {kind: dict(dir, proc)}.  The workers share the host cores between them and leave 1/8 to the
+    parent (its launch thread) -- on a two-socket box each worker is pinned to its own NUMA node."""
+    import subprocess
+    import tempfile
+    jobs = {}
+    if not kinds:
+        return jobs
+    phys, nodes = physical_cores(), numa_nodes()
+    threads = max(4, (phys - max(8, phys // 8)) // len(kinds))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1", BAGEL_BENCH_T0=str(T_START), OMP_NUM_THREADS=str(threads),
+               BAGEL_PAUSE_PIDS="")
+    for i, kind in enumerate(kinds):
+        d = tempfile.mkdtemp(prefix=f"bagel_oracle_{kind}_")
+        cmd = [sys.executable, os.path.abspath(__file__), "--oracle-job", kind, "--job-dir", d, "--job-threads", str(threads),
+               "--job-node", str(i % len(nodes) if len(nodes) > 1 else -1), "--resolution", str(args.resolution), "--und-image", str(args.und_image)]
+        if args.layers is not None:
+            cmd += ["--layers", str(args.layers)]
+        log = open(os.path.join(d, "log.txt"), "w")
+        jobs[kind] = dict(dir=d, proc=subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT), threads=threads)
+        Steady.pause_pids.append(jobs[kind]["proc"].pid)
+
+    def _cleanup():          # a parent that dies inside a timed region must not leave stopped workers behind
+        import signal
+        for j in jobs.values():
+            if j["proc"].poll() is None:
+                try:
+                    os.kill(j["proc"].pid, signal.SIGCONT)
+                    j["proc"].kill()
+                except OSError:
+                    pass
+    import atexit
+    atexit.register(_cleanup)
+    return jobs
+
+
+def wait_gpu_released(jobs, timeout=300.0):
+    """Block until every worker has copied its weights off the GPU (or died): nothing but this process may be on the device inside a timed region."""
+    t0 = time.time()
+    for kind, j in jobs.items():
+        while not os.path.exists(os.path.join(j["dir"], "gpu_released")) and j["proc"].poll() is None and time.time() - t0 < timeout:
+            time.sleep(0.25)
+        j["gpu_released"] = os.path.exists(os.path.join(j["dir"], "gpu_released"))
+        if not j["gpu_released"] and j["proc"].poll() is None:      # still on the GPU after the timeout: stop it, the in-process oracle takes over
+            j["proc"].kill()
+            j["proc"].wait()
+    return time.time() - t0
+
+
+def wait_oracle_job(d, kind, timeout=1500.0, proc=None):
+    """-> the worker's result, or None (failed / timed out: the caller computes the oracle itself)."""
+    t0 = time.time()
+    out = os.path.join(d, "out.pt")
+    while not os.path.exists(out):
+        if os.path.exists(os.path.join(d, "error.txt")) or (proc is not None and proc.poll() not in (None, 0)) or time.time() - t0 > timeout:
+            sys.stderr.write(f"bench.py: oracle worker {kind} gave no result ({d}): falling back to the in-process oracle\n")
+            return None
+        time.sleep(0.5)
+    r = torch.load(out, weights_only=False)
+    r["waited_s"] = time.time() - t0
+    return r
+
+
+def over_budget(args, need_s, what):
+    """The wall-clock guard of the CPU-oracle legs: None, or the reason the leg is dropped."""
+    used = time.time() - T_START
+    if used + need_s > args.wall_budget_s:
+        return {"skipped": f"{what}: {used:.0f} s into the run, the leg needs ~{need_s:.0f} s, --wall-budget-s {args.wall_budget_s:.0f} (the driver stops bench.py at 1800 s)"}
+    return None
+
+
+class Steady:
+    """Memory bracket of ONE timed region: the peak of live tensor bytes inside it (after ``reset_peak_memory_stats``) and what the region asked of the
+    allocator.  A timed region is in the steady state iff the caching allocator served it WITHOUT going to the driver: ``num_device_alloc`` /
+    ``num_device_free`` (hipMalloc / hipFree calls) must not move -- a fresh hipMalloc inside the clock has corrupted two records before (r04 batched decode,
+    r05 prefill: 85 vs 160 ms).  ``cached_block_requests`` (``allocation.all.allocated``: tensors handed out from the cache) is reported, not gated: the host
+    code allocates its per-step tensors from the cache by design.  No GPU (the --standins test mode): every figure is None and the region counts as steady."""
+
+    # worker processes of this run (start_oracle_jobs) that are STOPPED for the duration of every timed region: measured on MI355X (round 6, first visit), two
+    # CPU-oracle workers beside the GPU legs cost the one-request edit leg 15 % (10.09 vs 8.77 s/image), TaylorSeer 10 %, the FP8 leg 5 % and the headline step
+    # 4 % -- the launch thread shares cores, caches and the host memory system with them.  SIGSTOP / SIGCONT: the workers only run beside UNTIMED work (model
+    # builds, warm-ups, the checker's own product-side runs); the understanding child inherits the pids through BAGEL_PAUSE_PIDS.
+    pause_pids = [int(x) for x in os.environ.get("BAGEL_PAUSE_PIDS", "").split(",") if x]
+
+    @classmethod
+    def _signal_workers(cls, sig):
+        for pid in list(cls.pause_pids):
+            try:
+                os.kill(pid, sig)
+            except (ProcessLookupError, PermissionError):
+                cls.pause_pids.remove(pid)
+
+    def __init__(self, dev=None):
+        self.cuda = torch.cuda.is_available() and (dev is None or torch.device(dev).type == "cuda")
+        self.dev = dev
+
+    def __enter__(self):
+        import signal
+        self._signal_workers(signal.SIGSTOP)
+        if self.cuda:
+            torch.cuda.synchronize(self.dev)
+            torch.cuda.reset_peak_memory_stats(self.dev)
+            self._s0 = torch.cuda.memory_stats(self.dev)
+        return self
+
+    def __exit__(self, *exc):
+        if self.cuda:
+            torch.cuda.synchronize(self.dev)
+            s0, s1 = self._s0, torch.cuda.memory_stats(self.dev)
+            d = lambda k: int(s1.get(k, 0) - s0.get(k, 0))  # noqa: E731
+            self.report = {"peak_mem_gb": torch.cuda.max_memory_allocated(self.dev) / 2 ** 30, "peak_reserved_gb": torch.cuda.max_memory_reserved(self.dev) / 2 ** 30,
+                           "device_allocs_in_timed_region": d("num_device_alloc"), "device_frees_in_timed_region": d("num_device_free"),
+                           "segments_delta": d("segment.all.current"), "cached_block_requests": d("allocation.all.allocated"),
+                           "alloc_retries": d("num_alloc_retries")}
+            self.report["steady"] = self.report["device_allocs_in_timed_region"] == 0 and self.report["device_frees_in_timed_region"] == 0
+        else:
+            self.report = {"peak_mem_gb": None, "steady": True}
+        import signal
+        self._signal_workers(signal.SIGCONT)
+        return False
+
+
+def timed_steady(fn, dev, fence, attempts=2):
+    """One timed region, fenced on both sides, under the ``Steady`` bracket; a region that made the allocator go to the driver is run again (the first pass was
+    its warm-up) -- and a leg that is STILL not steady is failed by its caller (``steady`` False in the report) rather than quoted.  -> (fn's result, seconds, report)"""
+    for attempt in range(attempts):
+        fence()
+        with Steady(dev) as m:
+            t1 = time.perf_counter()
+            r = fn()
+            fence()
+            dt = time.perf_counter() - t1
+        if m.report["steady"]:
+            break
+    return r, dt, dict(m.report, attempts=attempt + 1)
+
+
+def unsteady(leg, mem):
+    """Fail a leg whose timed region allocated from the driver even on its second pass (round-5 verdict, weak 17)."""
+    if leg is not None and not mem.get("steady", True):
+        leg["error"] = (f"{mem['device_allocs_in_timed_region']} hipMalloc / {mem['device_frees_in_timed_region']} hipFree call(s) inside the timed region on "
+                        f"pass {mem['attempts']}: not a steady-state measurement, value not to be quoted")
+    return leg
+
+
+def resident_weight_bytes(model, vae=None):
+    """What the model keeps resident, itemised: the reference-layout nn.Parameters / buffers (what a checkpoint holds) and the MI355X-layout packed copies the
+    engines keep BESIDE them (modeling/packed.py: fused Wqkv, 16-row interleaved gate/up, padded heads; tensors that merely alias a parameter are not counted)."""
+    seen = set()
+
+    def nbytes(ts):
+        n = 0
+        for t in ts:
+            if torch.is_tensor(t) and t.numel() and t.untyped_storage().data_ptr() not in seen:
+                seen.add(t.untyped_storage().data_ptr())
+                n += t.untyped_storage().nbytes()
+        return n
+    out = {"parameters_and_buffers_gb": nbytes(list(model.parameters()) + list(model.buffers())) / 2 ** 30}
+    if vae is not None:
+        out["vae_parameters_gb"] = nbytes(list(vae.parameters()) + list(vae.buffers())) / 2 ** 30
+    packed = {}
+    try:
+        eng = model.language_model.engine()
+        for name in ("wqkv", "bqkv", "wo", "wgu", "wd"):
+            packed["llm." + name] = nbytes([t for P in eng.layers for t in getattr(P, name)]) / 2 ** 30
+    except Exception as e:        # a quantised store has another layout: reported as such
+        packed["llm"] = repr(e)
+    out["packed_copies_gb"] = packed
+    out["packed_copies_total_gb"] = sum(v for v in packed.values() if isinstance(v, float))
+    return out
 
 
 class FixedTokenizer:
@@ -385,10 +637,23 @@ def full_depth_step(args, cfg, model, tok, ids, threads, layers=None):
                                   cfg_renorm_type="global", **lkw2)
         out["rel_l2_cfg_text_forward"] = rel(v_u.float().cpu(), parts["v_cfg_text"].float())
         out["tolerance_forward"] = FULL_DEPTH_TOL_FORWARD
-        lat = model.generate_image(past_key_values=cache, num_timesteps=2, cfg_text_scale=4.0, cfg_interval=[0, 1.0], cfg_renorm_min=0.0,
-                                   cfg_renorm_type="global", timestep_shift=3.0, **ckw, **li)
+        # THE TIMED PATH: the default stream-batched generate_image; its per-stream velocities are taken BEFORE the combine (model.velocity_hook) and each is
+        # gated like a single forward (round-5 verdict: a defect confined to the batched work list must not hide in the CFG-combined band)
+        got = {}
+        model.velocity_hook = lambda batched, vs: got.update(batched=batched, vs=[None if v is None else v.float().cpu() for v in vs])  # noqa: E731
+        try:
+            lat = model.generate_image(past_key_values=cache, num_timesteps=2, cfg_text_scale=4.0, cfg_interval=[0, 1.0], cfg_renorm_min=0.0,
+                                       cfg_renorm_type="global", timestep_shift=3.0, **ckw, **li)
+        finally:
+            model.velocity_hook = None
         v_gpu = x0 - torch.cat([t.float().cpu() for t in lat])
         out["rel_l2"] = rel(v_gpu, v_cpu)
+        out["stream_batched"] = {"ran_batched": bool(got.get("batched")),
+                                 "rel_l2_cond_forward": rel(got["vs"][0], parts["v_cond"].float()), "rel_l2_cfg_text_forward": rel(got["vs"][1], parts["v_cfg_text"].float()),
+                                 "vs_own_sequential_forwards": [rel(got["vs"][0], v_c.float().cpu()), rel(got["vs"][1], v_u.float().cpu())],
+                                 "tolerance_forward": FULL_DEPTH_TOL_FORWARD,
+                                 "what": "per-stream velocities of the ONE stream-batched forward inside generate_image (the timed path), taken before the CFG combine, "
+                                         "each against the oracle's single forward"}
         # the CFG combine / renorm / stream-batching path on its OWN inputs: the oracle's combine of the product's two single-forward velocities
         # against what the product's combined paths returned -- no forward noise in this comparison, so it is gated tightly
         v_self = O.cfg_combine(v_c.cpu(), v_u.cpu(), None, 4.0, 1.0, 0.0, "global").float()
@@ -411,71 +676,190 @@ def full_depth_step(args, cfg, model, tok, ids, threads, layers=None):
         raise NotImplementedError("full_depth_step compares whole-model velocities: build the model with the depth to test")
     # THE GATE is the per-forward bound (round-3 verdict): the CFG-combined figure amplifies the difference of two forwards ~5x on random-init
     # weights and a 12 % band would pass a real bug of that size -- it is reported (with whether it sits inside its own noise band), not gated on
-    sc = out["cfg_combine_self_consistency"]
+    sc, sb = out["cfg_combine_self_consistency"], out["stream_batched"]
     out["within_tolerance"] = bool(out["rel_l2_cond_forward"] <= FULL_DEPTH_TOL_FORWARD and out["rel_l2_cfg_text_forward"] <= FULL_DEPTH_TOL_FORWARD
+                                   and sb["ran_batched"] and sb["rel_l2_cond_forward"] <= FULL_DEPTH_TOL_FORWARD and sb["rel_l2_cfg_text_forward"] <= FULL_DEPTH_TOL_FORWARD
                                    and sc["sequential_forward_flow"] <= FULL_DEPTH_TOL_COMBINE and sc["generate_image_sequential"] <= FULL_DEPTH_TOL_COMBINE
                                    and sc["generate_image_stream_batched"] <= FULL_DEPTH_TOL)
-    out["gate"] = (f"rel_l2_cond_forward and rel_l2_cfg_text_forward <= {FULL_DEPTH_TOL_FORWARD} (1.5 x the reference's own single-forward accumulation-order "
-                   f"noise) AND the combine step on the product's own two forwards <= {FULL_DEPTH_TOL_COMBINE}; the CFG-combined rel_l2 vs the oracle is information only")
+    out["gate"] = (f"every single forward <= {FULL_DEPTH_TOL_FORWARD} (1.5 x the reference's own single-forward accumulation-order noise): the two sequential forwards AND "
+                   f"the two per-stream velocities of the stream-batched forward that generate_image (the timed path) runs; AND the combine step on the product's own two "
+                   f"forwards <= {FULL_DEPTH_TOL_COMBINE}; the CFG-combined rel_l2 vs the oracle is information only")
     out["cfg_combined_inside_noise_band"] = bool(out["rel_l2"] <= FULL_DEPTH_TOL and out["rel_l2_sequential_forward_flow"] <= FULL_DEPTH_TOL)
     out["noise_floor"] = {"cfg_combined_velocity": 0.080, "single_forward_velocity": 0.016, "source": "profiles/r03_full_depth_noise_floor.log"}
     return out
 
 
 EDIT_DEPTH_TOL_BATCHED = 0.25     # three forwards, CFG 4.0 x 2.0: the single-forward noise is amplified ~2x further than in the two-forward step
+EDIT_CONTEXT_TOL_KV = 0.0226      # per-layer K / V of a prefilled context: the understanding leg's bound (1.5 x the reference's own noise at depth 28: UND_DEPTH_TOL_KV)
 
 
-def edit_depth_step(args, cfg, model, ids, threads, ctx_tokens=(576, 30)):
+def _cpu_tree(x):
+    """Host copies of every tensor in a (nested) packer output."""
+    if torch.is_tensor(x):
+        return x.detach().cpu()
+    if isinstance(x, dict):
+        return {k: _cpu_tree(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_cpu_tree(v) for v in x)
+    return x
+
+
+def edit_depth_inputs(args, cfg, model, ids, ctx_tokens=(576, 30), real=False, prompt_tokens=30, vit_side=980):
+    """PHASE 1 (host only): every input of the edit-request parity step -- the packer outputs that build the three contexts (the product's packers are bit-exact
+    with the reference's, so one set feeds product and oracle), the denoise step's index tensors, the seeded noise.
+    ``real=False``: the image context is STOOD IN FOR by ``ctx_tokens[0]`` text tokens.  ``real=True``: the request chain of configs[4] itself
+    (inferencer.py:62-97 update_context_image(vae=True, vit=True), :40-60 update_context_text; bagel.py:417-550,299-415): the R x R source image for the VAE
+    (seeded reparameterisation draw), its ``vit_side``^2 view for the SigLIP tower, then the prompt => 9 032 / 9 000 / 32-key contexts at R = 1024."""
+    R = args.resolution
+    inp = {"real": bool(real), "R": R}
+    if not real:
+        g = torch.Generator().manual_seed(11)
+        V = cfg["llm"]["vocab_size"]
+        tok_img = FixedTokenizer(torch.randint(8, V - 8, (ctx_tokens[0],), generator=g).tolist())
+        tok_txt = FixedTokenizer(torch.randint(8, V - 8, (ctx_tokens[1],), generator=g).tolist())
+        gi1, l1, r1 = model.prepare_prompts([0], [0], ["image"], tok_img, ids)
+        gi2, l2, r2 = model.prepare_prompts(l1, r1, ["prompt"], tok_txt, ids)
+        gi3, l3, r3 = model.prepare_prompts([0], [0], ["prompt"], tok_txt, ids)
+        inp.update(image_text=gi1, prompt=gi2, prompt_alone=gi3, cond=(l2, r2), text=(l1, r1), img=(l3, r3), chain="text stand-in for the image context")
+    else:
+        gsrc = torch.Generator().manual_seed(3)
+        src_vae = torch.rand(3, R, R, generator=gsrc) * 2 - 1                   # vae_transform(image) stand-in
+        src_vit = torch.rand(3, vit_side, vit_side, generator=gsrc) * 2 - 1     # vit_transform(image) stand-in
+        inp["enc_noise"] = torch.randn(1, cfg["vae"]["z_channels"], R // 8, R // 8, generator=torch.Generator().manual_seed(43))
+        tok = FixedTokenizer(torch.randint(8, min(151643, cfg["llm"]["vocab_size"] - 8), (prompt_tokens,), generator=torch.Generator().manual_seed(1)).tolist())
+        ident = lambda t: t  # noqa: E731
+        vi, l1, r1 = model.prepare_vae_images([0], [0], [src_vae], ident, ids)
+        ti, l2, r2 = model.prepare_vit_images(l1, r1, [src_vit], ident, ids)
+        pi, l3, r3 = model.prepare_prompts(l2, r2, ["p"], tok, ids)
+        pi2, l4, r4 = model.prepare_prompts([0], [0], ["p"], tok, ids)
+        inp.update(vae_image=vi, vit_image=ti, prompt=pi, prompt_alone=pi2, cond=(l3, r3), text=(l2, r2), img=(l4, r4),
+                   chain=f"{R}^2 VAE-encode (bf16 autocast, seeded draw) -> gen-mode prefill -> {vit_side}^2 SigLIP + connector -> und-mode prefill -> "
+                         f"{prompt_tokens}+2 prompt tokens")
+    (l2, r2), (l1, r1), (l3, r3) = inp["cond"], inp["text"], inp["img"]
+    li = model.prepare_vae_latent(l2, r2, [(R, R)], ids)
+    li["packed_init_noises"] = torch.randn(li["packed_init_noises"].shape, generator=torch.Generator().manual_seed(4343))
+    inp.update(latent=li, cfg_text=model.prepare_vae_latent_cfg(l1, r1, [(R, R)]), cfg_img=model.prepare_vae_latent_cfg(l3, r3, [(R, R)]))
+    return _cpu_tree(inp)
+
+
+EDIT_KEEP = ("language_model.model.", "time_embedder.", "vae2llm.", "llm2vae.", "latent_pos_embed.")
+EDIT_KEEP_REAL = EDIT_KEEP + ("vit_model.", "connector.", "vit_pos_embed.")
+
+
+def weight_fingerprint(W):
+    """A few numbers that identify a set of weights (the oracle may run in ANOTHER process than the product it is compared with: both sides must hold the same
+    name-seeded random initialisation, bagel_amd/factory.py init_random_)."""
+    names = sorted(W)
+    pick = [names[0], names[len(names) // 2], names[-1]] + [n for n in names if n.endswith("llm2vae.weight") or n.endswith("layers.0.mlp_moe_gen.down_proj.weight")]
+    return {n: float(W[n].float().double().sum()) for n in pick}
+
+
+def check_fingerprint(model, ora, L, who):
+    """The oracle worker's weights == this model's (fp64 sums of the fingerprinted tensors; the summation order differs between host and device)."""
+    sd = model.state_dict()
+    mine = {n: float(sd[n].float().double().sum()) for n in ora["weights"]}
+    bad = [n for n, v in ora["weights"].items() if abs(mine[n] - v) > 1e-6 * max(1.0, abs(v))]
+    if bad or ora["layers"] != L:
+        raise RuntimeError(f"{who}: the oracle worker ran on other weights than this model's (layers {ora['layers']} vs {L}; {[(n, ora['weights'][n], mine[n]) for n in bad]})")
+
+
+def edit_depth_oracle(cfg, W, VW, inp, threads):
+    """PHASE 2 (CPU only, checker): the three contexts and the 3-forward step of ``inp`` through the oracle; may run in a worker process beside the GPU legs
+    (``--oracle-job``).  -> the per-layer K / V of the three contexts, the three single-forward velocities and the combined one."""
+    import copy
+    from oracle import bagel_oracle as O
+    torch.set_num_threads(threads)
+    L = cfg["llm"]["num_hidden_layers"]
+    tt = {}
+    t0 = t1 = time.time()
+    if not inp["real"]:
+        ocache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **inp["image_text"])
+    else:
+        try:
+            O.VAE_AUTOCAST = "cuda"      # the policy of the device the reference runs on (group_norm in fp32): what the MI355X bf16 VAE implements
+            ocache = O.forward_cache_update_vae(W, cfg, VW, O.OracleCache(L), sample_noise=inp["enc_noise"].to(torch.bfloat16), **inp["vae_image"])
+        finally:
+            O.VAE_AUTOCAST = None
+        tt["vae_encode_plus_prefill"] = time.time() - t1
+        t1 = time.time()
+        ocache = O.forward_cache_update_vit(W, cfg, ocache, **inp["vit_image"])
+        tt["siglip_plus_prefill"] = time.time() - t1
+    octext = copy.deepcopy(ocache)
+    t1 = time.time()
+    ocache = O.forward_cache_update_text(W, cfg, ocache, **inp["prompt"])
+    ocimg = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **inp["prompt_alone"])
+    tt["text_prefills"] = time.time() - t1
+    li, ct, cim = inp["latent"], inp["cfg_text"], inp["cfg_img"]
+    x0 = li["packed_init_noises"]
+    ts = torch.tensor([1.0] * x0.shape[0])
+    od = lambda c, d: dict(cache=c, position_ids=d["cfg_packed_position_ids"], query_indexes=d["cfg_packed_query_indexes"],  # noqa: E731
+                           key_values_lens=d["cfg_key_values_lens"], key_value_indexes=d["cfg_packed_key_value_indexes"])
+    lis = lambda d: dict(li, packed_position_ids=d["cfg_packed_position_ids"], packed_indexes=d["cfg_packed_query_indexes"],  # noqa: E731
+                         key_values_lens=d["cfg_key_values_lens"], packed_key_value_indexes=d["cfg_packed_key_value_indexes"])
+    t1 = time.time()
+    out = {"v_cpu": O.forward_flow(W, cfg, x0, ts, li, ocache, od(octext, ct), od(ocimg, cim), 4.0, 2.0, 0.0, "text_channel").float(),
+           # the three single forwards of the oracle (scale 1.0 = no combine), each on its own context
+           "o_c": O.forward_flow(W, cfg, x0, ts, li, ocache, None, None, 1.0, 1.0, 0.0, "global").float(),
+           "o_t": O.forward_flow(W, cfg, x0, ts, lis(ct), octext, None, None, 1.0, 1.0, 0.0, "global").float(),
+           "o_i": O.forward_flow(W, cfg, x0, ts, lis(cim), ocimg, None, None, 1.0, 1.0, 0.0, "global").float()}
+    tt["denoise_step_x4"] = time.time() - t1
+    out["kv"] = {n: [(c.key_cache[i], c.value_cache[i]) for i in range(L)] for n, c in (("cond", ocache), ("cfg_text", octext), ("cfg_img", ocimg))}
+    out.update(cpu_seconds=time.time() - t0, cpu_seconds_by_phase=tt, threads=threads, weights=weight_fingerprint(W), layers=L)
+    return out
+
+
+def edit_depth_step(args, cfg, model, ids, threads, ctx_tokens=(576, 30), vae=None, oracle_out=None):
     """The THREE-forward Euler step of an image-edit request (app.py:224-228 defaults; bagel.py:854-905): cond forward on [image context | prompt], CFG-text
     forward on [image context] (a prefix of the cond context, as ``copy.deepcopy(gen_context)`` before the prompt makes it, inferencer.py:230-253), CFG-img
     forward on [prompt] alone, cfg_text_scale 4.0, cfg_img_scale 2.0, ``text_channel`` renorm -- through the oracle on this box's host cores WITH THE GPU MODEL'S
-    OWN WEIGHTS and through the HIP engine (sequential ``_forward_flow`` and the stream-batched three-forward batch inside ``generate_image``).  The image context
-    is stood in for by ``ctx_tokens[0]`` text tokens (the contexts may be shortened; what is under test is the denoise step on three different contexts, not the
-    encoders that filled them).  Gates like ``full_depth_step``: every single forward within FULL_DEPTH_TOL_FORWARD of the oracle, and the combine step on the
-    product's own three velocities within FULL_DEPTH_TOL_COMBINE.  Checker use of the oracle only."""
+    OWN WEIGHTS and through the HIP engine (sequential ``_forward_flow`` and the stream-batched three-forward batch inside ``generate_image``).
+    ``vae=None``: the image context is stood in for by ``ctx_tokens[0]`` text tokens (what is under test is the denoise step on three different contexts).
+    ``vae=<AutoEncoder>``: the REAL request chain at its own context lengths (round-5 verdict: VAE-encode -> gen-mode prefill -> SigLIP -> und-mode prefill -> prompt
+    => 9 032 / 9 000 / 32-key contexts at 1024^2), see ``edit_depth_inputs``.  ``oracle_out``: the result of ``edit_depth_oracle`` computed elsewhere (a worker
+    process of this bench run, ``--oracle-job``, on a model with the same name-seeded weights -- checked by fingerprint); None = computed here.
+    Gates like ``full_depth_step``: every single forward -- the three sequential ones AND the three per-stream velocities of the stream-batched forward, the timed
+    path -- within FULL_DEPTH_TOL_FORWARD of the oracle, the per-layer K / V of the three contexts within EDIT_CONTEXT_TOL_KV, and the combine step on the product's
+    own three velocities within FULL_DEPTH_TOL_COMBINE.  Checker use of the oracle only."""
     import copy
     from oracle import bagel_oracle as O
     from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
     L = model.config.llm_config.num_hidden_layers
-    R = args.resolution
-    torch.set_num_threads(threads)
-    keep = ("language_model.model.", "time_embedder.", "vae2llm.", "llm2vae.", "latent_pos_embed.")
-    W = {k: v.detach().to("cpu") for k, v in model.state_dict().items() if k.startswith(keep)}
+    real = vae is not None
     cfg = dict(cfg, llm=dict(cfg["llm"], num_hidden_layers=L))          # (a depth-reduced model in the tests: the oracle walks the layers the model has)
-    g = torch.Generator().manual_seed(11)
-    V = cfg["llm"]["vocab_size"]
-    tok_img = FixedTokenizer(torch.randint(8, V - 8, (ctx_tokens[0],), generator=g).tolist())
-    tok_txt = FixedTokenizer(torch.randint(8, V - 8, (ctx_tokens[1],), generator=g).tolist())
-    # contexts: product and oracle side by side (the packers are bit-exact, so one set of inputs feeds both)
-    gi1, l1, r1 = model.prepare_prompts([0], [0], ["image"], tok_img, ids)
-    gi2, l2, r2 = model.prepare_prompts(l1, r1, ["prompt"], tok_txt, ids)
-    gi3, l3, r3 = model.prepare_prompts([0], [0], ["prompt"], tok_txt, ids)
-    cache = model.forward_cache_update_text(NaiveCache(L), **gi1)
+    inp = edit_depth_inputs(args, cfg, model, ids, ctx_tokens, real)
+    keep = EDIT_KEEP_REAL if real else EDIT_KEEP
+    if oracle_out is None:
+        W = {k: v.detach().to("cpu") for k, v in model.state_dict().items() if k.startswith(keep)}
+        VW = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()} if real else None
+        ora = edit_depth_oracle(cfg, W, VW, inp, threads)
+        del W, VW
+    else:
+        ora = oracle_out
+        check_fingerprint(model, ora, L, "edit_depth_step")
+    # ---- product: the same chain
+    if not real:
+        cache = model.forward_cache_update_text(NaiveCache(L), **inp["image_text"])
+    else:
+        enc_noise = inp["enc_noise"]
+
+        class _FixedNoiseVae:      # the reference draws randn_like inside encode; both sides get the same seeded CPU draw (SURVEY.md 8d config 5)
+            def encode(self, x):
+                return vae.encode(x.to(model.device), sample_noise=enc_noise, precision="bf16")
+        cache = model.forward_cache_update_vae(_FixedNoiseVae(), NaiveCache(L), **inp["vae_image"])
+        cache = model.forward_cache_update_vit(cache, **inp["vit_image"])
     cfg_text_cache = copy.deepcopy(cache)
-    cache = model.forward_cache_update_text(cache, **gi2)
-    cfg_img_cache = model.forward_cache_update_text(NaiveCache(L), **gi3)
-    t1 = time.time()
-    ocache = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi1)
-    octext = copy.deepcopy(ocache)
-    ocache = O.forward_cache_update_text(W, cfg, ocache, **gi2)
-    ocimg = O.forward_cache_update_text(W, cfg, O.OracleCache(L), **gi3)
-    li = model.prepare_vae_latent(l2, r2, [(R, R)], ids)
-    x0 = torch.randn(li["packed_init_noises"].shape, generator=torch.Generator().manual_seed(4343))
-    li["packed_init_noises"] = x0
-    ct = model.prepare_vae_latent_cfg(l1, r1, [(R, R)])
-    cim = model.prepare_vae_latent_cfg(l3, r3, [(R, R)])
+    cache = model.forward_cache_update_text(cache, **inp["prompt"])
+    cfg_img_cache = model.forward_cache_update_text(NaiveCache(L), **inp["prompt_alone"])
+    (l2, r2), (l1, r1), (l3, r3) = inp["cond"], inp["text"], inp["img"]
+    relk = lambda a, b: float((a.float().cpu().reshape(b.shape) - b.float()).norm() / b.float().norm())  # noqa: E731
+    kv_err = {n: max(max(relk(c.key_cache[i], ora["kv"][n][i][0]), relk(c.value_cache[i], ora["kv"][n][i][1])) for i in range(L))
+              for n, c in (("cond", cache), ("cfg_text", cfg_text_cache), ("cfg_img", cfg_img_cache))}
+    li, ct, cim = inp["latent"], inp["cfg_text"], inp["cfg_img"]
+    x0 = li["packed_init_noises"]
     ts = torch.tensor([1.0] * x0.shape[0])
-    od = lambda c, d: dict(cache=c, position_ids=d["cfg_packed_position_ids"], query_indexes=d["cfg_packed_query_indexes"],  # noqa: E731
-                           key_values_lens=d["cfg_key_values_lens"], key_value_indexes=d["cfg_packed_key_value_indexes"])
-    v_cpu = O.forward_flow(W, cfg, x0, ts, li, ocache, od(octext, ct), od(ocimg, cim), 4.0, 2.0, 0.0, "text_channel").float()
-    # the three single forwards of the oracle (scale 1.0 = no combine), each on its own context
-    o_c = O.forward_flow(W, cfg, x0, ts, li, ocache, None, None, 1.0, 1.0, 0.0, "global").float()
+    v_cpu, o_c, o_t, o_i = ora["v_cpu"], ora["o_c"], ora["o_t"], ora["o_i"]
     lis = lambda d: dict(li, packed_position_ids=d["cfg_packed_position_ids"], packed_indexes=d["cfg_packed_query_indexes"],  # noqa: E731
                          key_values_lens=d["cfg_key_values_lens"], packed_key_value_indexes=d["cfg_packed_key_value_indexes"])
-    o_t = O.forward_flow(W, cfg, x0, ts, lis(ct), octext, None, None, 1.0, 1.0, 0.0, "global").float()
-    o_i = O.forward_flow(W, cfg, x0, ts, lis(cim), ocimg, None, None, 1.0, 1.0, 0.0, "global").float()
-    t_cpu = time.time() - t1
-    del W
     rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())  # noqa: E731
     kw = {}
     for tag, c, d in (("cfg_text", cfg_text_cache, ct), ("cfg_img", cfg_img_cache, cim)):
@@ -488,21 +872,39 @@ def edit_depth_step(args, cfg, model, ids, threads, ctx_tokens=(576, 30)):
         one(cfg_img_cache, {k: v for k, v in lis(cim).items() if k != "packed_init_noises"})
     v_seq = model._forward_flow(x_t=x0, timestep=ts, past_key_values=cache, cfg_text_scale=4.0, cfg_img_scale=2.0, cfg_renorm_min=0.0,
                                 cfg_renorm_type="text_channel", **kw, **lkw)
-    lat = model.generate_image(past_key_values=cache, num_timesteps=2, cfg_text_scale=4.0, cfg_img_scale=2.0, cfg_interval=[0, 1.0], cfg_renorm_min=0.0,
-                               cfg_renorm_type="text_channel", timestep_shift=3.0, **kw, **li)
+    got = {}
+    model.velocity_hook = lambda batched, vs: got.update(batched=batched, vs=[None if v is None else v.float().cpu() for v in vs])  # noqa: E731
+    try:
+        lat = model.generate_image(past_key_values=cache, num_timesteps=2, cfg_text_scale=4.0, cfg_img_scale=2.0, cfg_interval=[0, 1.0], cfg_renorm_min=0.0,
+                                   cfg_renorm_type="text_channel", timestep_shift=3.0, **kw, **li)
+    finally:
+        model.velocity_hook = None
     v_gpu = x0 - torch.cat([t.float().cpu() for t in lat])
     v_self = O.cfg_combine(v_c.cpu(), v_t.cpu(), v_i.cpu(), 4.0, 2.0, 0.0, "text_channel").float()
     out = {"what": f"one Euler step (t = 1) of an image-edit request: cond / CFG-text / CFG-img forwards of {L} MoT layers over {x0.shape[0] + 2} tokens on "
                    f"{int(l2[0])} / {int(l1[0])} / {int(l3[0])}-token contexts, CFG 4.0 / 2.0, text_channel renorm, 7B shapes, identical weights and inputs",
-           "layers": L, "contexts": [int(l2[0]), int(l1[0]), int(l3[0])], "cpu_seconds": t_cpu, "threads": threads,
+           "contexts_from": inp["chain"], "layers": L, "contexts": [int(l2[0]), int(l1[0]), int(l3[0])], "cpu_seconds": ora["cpu_seconds"],
+           "cpu_seconds_by_phase": ora["cpu_seconds_by_phase"], "threads": ora["threads"],
+           "oracle_ran": "in this process" if oracle_out is None else "in a worker process of this run, beside the GPU legs (same name-seeded weights: fingerprint checked)",
+           "context_kv_rel_l2_max": kv_err,
            "rel_l2_cond_forward": rel(v_c, o_c), "rel_l2_cfg_text_forward": rel(v_t, o_t), "rel_l2_cfg_img_forward": rel(v_i, o_i),
            "rel_l2_combined_sequential": rel(v_seq, v_cpu), "rel_l2_combined_stream_batched": float((v_gpu - v_cpu).norm() / v_cpu.norm()),
            "cfg_combine_self_consistency": {"sequential_forward_flow": rel(v_seq, v_self), "generate_image_stream_batched": float((v_gpu - v_self).norm() / v_self.norm())},
-           "tolerance_forward": FULL_DEPTH_TOL_FORWARD, "tolerance_combine": FULL_DEPTH_TOL_COMBINE, "tolerance_stream_batched": EDIT_DEPTH_TOL_BATCHED}
-    sc = out["cfg_combine_self_consistency"]
+           "stream_batched": {"ran_batched": bool(got.get("batched")), "rel_l2_cond_forward": float((got["vs"][0] - o_c).norm() / o_c.norm()),
+                              "rel_l2_cfg_text_forward": float((got["vs"][1] - o_t).norm() / o_t.norm()), "rel_l2_cfg_img_forward": float((got["vs"][2] - o_i).norm() / o_i.norm()),
+                              "what": "per-stream velocities of the ONE three-stream forward inside generate_image (the timed path), before the combine, vs the oracle's"},
+           "tolerance_forward": FULL_DEPTH_TOL_FORWARD, "tolerance_combine": FULL_DEPTH_TOL_COMBINE, "tolerance_stream_batched": EDIT_DEPTH_TOL_BATCHED,
+           "tolerance_context_kv": EDIT_CONTEXT_TOL_KV}
+    sc, sb = out["cfg_combine_self_consistency"], out["stream_batched"]
     out["within_tolerance"] = bool(max(out["rel_l2_cond_forward"], out["rel_l2_cfg_text_forward"], out["rel_l2_cfg_img_forward"]) <= FULL_DEPTH_TOL_FORWARD
+                                   and sb["ran_batched"] and max(sb["rel_l2_cond_forward"], sb["rel_l2_cfg_text_forward"], sb["rel_l2_cfg_img_forward"]) <= FULL_DEPTH_TOL_FORWARD
+                                   and max(kv_err.values()) <= EDIT_CONTEXT_TOL_KV
                                    and sc["sequential_forward_flow"] <= FULL_DEPTH_TOL_COMBINE and sc["generate_image_stream_batched"] <= EDIT_DEPTH_TOL_BATCHED)
     return out
+
+
+PORT_OVER_REFERENCE = "1.03 +- 0.05"          # seconds per layer-forward, oracle port / unmodified reference classes, measured in the build container (round 6)
+PORT_OVER_REFERENCE_LOG = os.path.join(ROOT, "profiles", "r06_cpu_baseline_build_container.log")
 
 
 def cpu_baseline(args, cfg, gpu=None):
@@ -541,8 +943,10 @@ def cpu_baseline(args, cfg, gpu=None):
     full = None
     if gpu is not None and torch.cuda.is_available() and not args.no_full_depth:
         try:
-            full = full_depth_step(args, cfg, gpu["model"], gpu["tok"], gpu["ids"], threads)
-            sec_per_image = steps * full["cpu_seconds_per_euler_step"]          # measured: a whole Euler step at full depth (cond + CFG)
+            full = over_budget(args, 240, "cpu_baseline.parity_at_full_depth (one Euler step of the 28-layer model through the oracle)")
+            if full is None:
+                full = full_depth_step(args, cfg, gpu["model"], gpu["tok"], gpu["ids"], threads)
+                sec_per_image = steps * full["cpu_seconds_per_euler_step"]          # measured: a whole Euler step at full depth (cond + CFG)
         except Exception as e:
             import traceback
             full = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
@@ -552,7 +956,7 @@ def cpu_baseline(args, cfg, gpu=None):
         config0 = {"error": repr(e)}
     out = dict(value=1.0 / sec_per_image, unit="images/s", cores=threads, threads=threads, logical_cpus=os.cpu_count(), kind=kind, warmup=1,
                cpu_tflops=fl / dt / 1e12, seconds_per_layer_forward=dt, parity_at_full_size=parity, parity_at_full_depth=full, config0=config0,
-               value_from=("one MEASURED Euler step at full depth (cond + CFG forward of all layers, B = 1) x Euler steps" if full and "error" not in full
+               value_from=("one MEASURED Euler step at full depth (cond + CFG forward of all layers, B = 1) x Euler steps" if full and "error" not in full and "skipped" not in full
                            else "one measured layer-forward x layers x 2 forwards x Euler steps"),
                sample=f"{'unmodified reference (generate_image, 1 Euler step = 2 forwards' if kind == 'reference' else 'oracle MoT decoder layer (gen mode'}, "
                       f"{Lq} query tokens on a {C}-token context, 7B shapes, {nl} layer(s)), after one warm-up pass: {dt:.2f} s per layer-forward on "
@@ -560,7 +964,12 @@ def cpu_baseline(args, cfg, gpu=None):
                       f"steps (glue, prefill and VAE excluded)"
                       + (f"; and ONE MEASURED Euler step at full depth through the oracle with the GPU model's weights (cond + CFG-text forward of "
                          f"{full['layers']} layers, B = 1): {full['cpu_seconds_per_euler_step']:.1f} s -> value = 1 / ({steps} x that)"
-                         if full and "error" not in full else ""))
+                         if full and "error" not in full and "skipped" not in full else "")
+                      + ("" if kind == "reference" else f"; port / unmodified-reference time on the same cores = {PORT_OVER_REFERENCE} "
+                         f"({os.path.relpath(PORT_OVER_REFERENCE_LOG, ROOT)}: three alternating pairs of this same one-layer sample in the build container, where "
+                         "/root/reference exists)"))
+    if kind != "reference":
+        out["port_over_reference_time_ratio"] = {"value": 1.03, "spread": 0.05, "source": os.path.relpath(PORT_OVER_REFERENCE_LOG, ROOT)}
     if "reference_error" in keep:
         out["reference_error"] = keep["reference_error"]
     return out
@@ -663,37 +1072,72 @@ UND_DEPTH_TOL_KV = 1.5 * UND_DEPTH_NOISE["kv"]
 UND_DEPTH_TOL_LOGITS = 1.5 * UND_DEPTH_NOISE["logits"]
 
 
-def understanding_full_depth(args, cfg, model, ids, image, tok, threads, n_tokens=6):
-    """configs[1] at the DEPTH it is measured at (VERDICT r04 missing-2): the 26-layer SigLIP encoder + connector + the 28-layer non-causal prefill of the
-    ViT block + the causal text prefill + ``n_tokens`` greedy decode steps through the oracle on this box's host cores WITH THE GPU MODEL'S OWN WEIGHTS, against
-    the product on the same inputs: per-layer K / V of the whole context (max rel-L2), the first decode step's logits (rel-L2), and the greedy ids up to the
-    first reference near-tie (the rule of tests/test_und_shapes_gpu.py: a differing id must sit within 2^-6 max|logit| of the reference's top-1).
-    Reference: bagel.py:362-415 (forward_cache_update_vit), :321-360 (text), :930-1000 (generate_text); siglip_navit.py:389-402.  Checker use of the oracle only."""
-    import copy
-    from oracle import bagel_oracle as O
-    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
-    L = model.config.llm_config.num_hidden_layers
-    torch.set_num_threads(threads)
-    t0 = time.time()
-    keep = ("language_model.", "vit_model.", "connector.", "vit_pos_embed.")
-    W = {k: v.detach().to("cpu") for k, v in model.state_dict().items() if k.startswith(keep)}
-    t_copy = time.time() - t0
+UND_KEEP = ("language_model.", "vit_model.", "connector.", "vit_pos_embed.")
+
+
+def und_request(args):
+    """The synthetic understanding request of configs[1]: a seeded U(-1, 1) image and 32 random prompt ids."""
+    g = torch.Generator().manual_seed(2)
+    image = torch.rand(3, args.und_image, args.und_image, generator=g) * 2 - 1
+    prompt_ids = torch.randint(0, 151643, (32,), generator=torch.Generator().manual_seed(1)).tolist()
+    return image, FixedTokenizer(prompt_ids)
+
+
+def und_depth_inputs(args, model, ids):
+    """PHASE 1 (host only): the packer outputs of the understanding request (ViT image block, prompt, start tokens)."""
+    image, tok = und_request(args)
     ident = lambda t: t  # noqa: E731
     ti, l1, r1 = model.prepare_vit_images([0], [0], [image], ident, ids)
     pi, l2, r2 = model.prepare_prompts(l1, r1, ["p"], tok, ids)
     st = model.prepare_start_tokens(l2, r2, ids)
-    # ---- oracle
+    return _cpu_tree(dict(vit_image=ti, prompt=pi, start=st, context_tokens=int(l2[0])))
+
+
+def und_depth_oracle(cfg, W, inp, threads, n_tokens=6):
+    """PHASE 2 (CPU only, checker): SigLIP + connector + the non-causal prefill of the ViT block + the causal text prefill + ``n_tokens`` greedy steps through the
+    oracle; may run in a worker process beside the GPU legs (``--oracle-job``)."""
+    from oracle import bagel_oracle as O
+    torch.set_num_threads(threads)
+    L = cfg["llm"]["num_hidden_layers"]
     t1 = time.time()
-    ocache = O.forward_cache_update_vit(W, cfg, O.OracleCache(L), **ti)
+    ocache = O.forward_cache_update_vit(W, cfg, O.OracleCache(L), **inp["vit_image"])
     t_vit = time.time() - t1
-    ocache = O.forward_cache_update_text(W, cfg, ocache, **pi)
+    ocache = O.forward_cache_update_text(W, cfg, ocache, **inp["prompt"])
     t_prefill = time.time() - t1
     okv = [(ocache.key_cache[i].clone(), ocache.value_cache[i].clone()) for i in range(L)]
     t1 = time.time()
+    st = inp["start"]
     otoks, ologits = O.generate_text(W, cfg, ocache, st["packed_key_value_indexes"], st["key_values_lens"], st["packed_start_tokens"],
                                      st["packed_query_position_ids"], n_tokens, return_logits=True)
     t_decode = time.time() - t1
-    del W
+    return dict(kv=okv, tokens=otoks, logits=[x.clone() for x in ologits], n_tokens=n_tokens, layers=L, threads=threads, weights=weight_fingerprint(W),
+                cpu_seconds={"vit_prefill": t_vit, "vit_plus_text_prefill": t_prefill, "decode": t_decode})
+
+
+def understanding_full_depth(args, cfg, model, ids, threads, n_tokens=6, oracle_out=None):
+    """configs[1] at the DEPTH it is measured at (VERDICT r04 missing-2): the 26-layer SigLIP encoder + connector + the 28-layer non-causal prefill of the
+    ViT block + the causal text prefill + ``n_tokens`` greedy decode steps through the oracle on this box's host cores WITH THE GPU MODEL'S OWN WEIGHTS, against
+    the product on the same inputs: per-layer K / V of the whole context (max rel-L2), the first decode step's logits (rel-L2), and the greedy ids up to the
+    first reference near-tie (the rule of tests/test_und_shapes_gpu.py: a differing id must sit within 2^-6 max|logit| of the reference's top-1).
+    ``oracle_out``: ``und_depth_oracle``'s result from a worker process of this run (same name-seeded weights, fingerprint checked); None = computed here.
+    Reference: bagel.py:362-415 (forward_cache_update_vit), :321-360 (text), :930-1000 (generate_text); siglip_navit.py:389-402.  Checker use of the oracle only."""
+    import copy
+    from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
+    L = model.config.llm_config.num_hidden_layers
+    inp = und_depth_inputs(args, model, ids)
+    t_copy = None
+    if oracle_out is None:
+        t0 = time.time()
+        W = {k: v.detach().to("cpu") for k, v in model.state_dict().items() if k.startswith(UND_KEEP)}
+        t_copy = time.time() - t0
+        ora = und_depth_oracle(dict(cfg, llm=dict(cfg["llm"], num_hidden_layers=L)), W, inp, threads, n_tokens)
+        del W
+    else:
+        ora = oracle_out
+        n_tokens = ora["n_tokens"]
+        check_fingerprint(model, ora, L, "understanding_full_depth")
+    okv, otoks, ologits = ora["kv"], ora["tokens"], ora["logits"]
+    ti, pi, st = inp["vit_image"], inp["prompt"], inp["start"]
     # ---- product
     cache = model.forward_cache_update_vit(NaiveCache(L), **ti)
     cache = model.forward_cache_update_text(cache, **pi)
@@ -714,14 +1158,15 @@ def understanding_full_depth(args, cfg, model, ids, image, tok, threads, n_token
         tie = {"step": s_, "logit_gap": gap, "near_tie_bound": float(2 ** -6 * lg.abs().max()), "is_near_tie": bool(gap <= 2 ** -6 * lg.abs().max())}
         break
     lg0 = ologits[0][0].float()
-    out = {"what": f"{cfg['vit']['num_hidden_layers']}-layer SigLIP + connector + {L}-layer prefill of a {int(l2[0])}-token context + {n_tokens} greedy decode steps, 7B shapes, "
+    out = {"what": f"{cfg['vit']['num_hidden_layers']}-layer SigLIP + connector + {L}-layer prefill of a {inp['context_tokens']}-token context + {n_tokens} greedy decode steps, 7B shapes, "
                    "identical weights and inputs: HIP engines vs oracle",
-           "layers": L, "context_tokens": int(l2[0]), "kv_rel_l2_max": max(ek + ev), "k_rel_l2_by_layer": [round(e, 5) for e in ek],
+           "layers": L, "context_tokens": inp["context_tokens"], "kv_rel_l2_max": max(ek + ev), "k_rel_l2_by_layer": [round(e, 5) for e in ek],
            "v_rel_l2_by_layer": [round(e, 5) for e in ev], "first_step_logits_rel_l2": e_logits,
            "first_step_top1_margin_over_max_logit": float((lg0.max() - lg0.topk(2).values[1]) / lg0.abs().max()),
            "greedy_ids_agree_until_step": agree + 1 if tie is None else tie["step"], "greedy_steps_compared": n_tokens - 1, "first_mismatch": tie,
            "tokens_gpu": [int(x) for x in toks[:, 0]], "tokens_oracle": [int(x) for x in otoks[:, 0]],
-           "cpu_seconds": {"weights_copy": t_copy, "vit_prefill": t_vit, "vit_plus_text_prefill": t_prefill, "decode": t_decode}, "threads": threads,
+           "cpu_seconds": dict(ora["cpu_seconds"], weights_copy=t_copy), "threads": ora["threads"],
+           "oracle_ran": "in this process" if oracle_out is None else "in a worker process of this run, beside the GPU legs (same name-seeded weights: fingerprint checked)",
            "tolerance_kv": UND_DEPTH_TOL_KV, "tolerance_logits": UND_DEPTH_TOL_LOGITS, "noise_floor": UND_DEPTH_NOISE}
     out["within_tolerance"] = bool(out["kv_rel_l2_max"] <= UND_DEPTH_TOL_KV and e_logits <= UND_DEPTH_TOL_LOGITS and (tie is None or tie["is_near_tie"]))
     out["gate"] = (f"max per-layer K/V rel-L2 <= {UND_DEPTH_TOL_KV:.3g}, first-step logits rel-L2 <= {UND_DEPTH_TOL_LOGITS:.3g} (1.5 x the reference's own "
@@ -736,10 +1181,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
     L = model.config.llm_config.num_hidden_layers
     llm = cfg["llm"]
-    g = torch.Generator().manual_seed(2)
-    image = torch.rand(3, args.und_image, args.und_image, generator=g) * 2 - 1
-    prompt_ids = torch.randint(0, 151643, (32,), generator=torch.Generator().manual_seed(1)).tolist()
-    tok = FixedTokenizer(prompt_ids)
+    image, tok = und_request(args)
     ident = lambda t: t  # noqa: E731
 
     UB = args.und_batch
@@ -766,16 +1208,20 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     # this call they came from hipMalloc inside the timed region, which took anything from 0 to 75 ms depending on what else held device memory (the parent bench
     # process: 160 ms instead of 85 on two visits of round 5) -- a serving process is past its first two requests
     cache, lens, ropes, _ = prefill()
-    fence()
-    t0 = time.perf_counter()
-    cache, lens, ropes, t_vit = prefill()
-    t1 = time.perf_counter()
-    fence()
     n = args.und_new_tokens
-    t2 = time.perf_counter()
-    toks = decode(cache, lens, ropes, n)
+    decode(cache, lens, ropes, n)              # the timed decode's own length once (session buffers, page pools and the merged cache it leaves behind)
+    cache, lens, ropes, _ = prefill()
     fence()
-    t3 = time.perf_counter()
+    with Steady(dev) as mem_prefill:
+        t0 = time.perf_counter()
+        cache, lens, ropes, t_vit = prefill()
+        t1 = time.perf_counter()
+        fence()
+    with Steady(dev) as mem_decode:
+        t2 = time.perf_counter()
+        toks = decode(cache, lens, ropes, n)
+        fence()
+        t3 = time.perf_counter()
     sess = model._last_decode_session
     dt = t3 - t2
     # option: row-wise INT8 layer weights (the analogue of the reference's quantised load modes; changes results) -- reported
@@ -788,11 +1234,12 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             c8, l8, r8, _ = prefill()
             s8 = model.prepare_start_tokens(l8, r8, ids)
             fence()
-            t4 = time.perf_counter()
-            model.generate_text(past_key_values=c8, max_length=n, do_sample=False, end_token_id=None, weight_quant=mode, **s8)
-            fence()
-            dt8 = time.perf_counter() - t4
-            return {"value": n / dt8, "unit": "tokens/s", "decode_ms_per_token": dt8 / n * 1e3, "weights": weights,
+            with Steady(dev) as m8:
+                t4 = time.perf_counter()
+                model.generate_text(past_key_values=c8, max_length=n, do_sample=False, end_token_id=None, weight_quant=mode, **s8)
+                fence()
+                dt8 = time.perf_counter() - t4
+            return {"value": n / dt8, "unit": "tokens/s", "decode_ms_per_token": dt8 / n * 1e3, "weights": weights, "peak_mem_gb": m8.report["peak_mem_gb"],
                     "note": f"weight_quant='{mode}' option (changes results): not the headline metric"}
         except Exception as e:
             return {"error": repr(e)}
@@ -805,10 +1252,11 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             ss = model.prepare_start_tokens(ls, rs, ids)
             torch.manual_seed(0)
             fence()
-            t4 = time.perf_counter()
-            ts_ = model.generate_text(past_key_values=cs, max_length=n, do_sample=True, temperature=0.7, end_token_id=None, **ss)
-            fence()
-            dts = time.perf_counter() - t4
+            with Steady(dev):
+                t4 = time.perf_counter()
+                ts_ = model.generate_text(past_key_values=cs, max_length=n, do_sample=True, temperature=0.7, end_token_id=None, **ss)
+                fence()
+                dts = time.perf_counter() - t4
             sampled = {"value": n / dts, "unit": "tokens/s", "decode_ms_per_token": dts / n * 1e3, "temperature": 0.7,
                        "hip_graph": model._last_decode_session.graph is not None, "distinct_tokens": int(torch.unique(ts_).numel()),
                        "note": "generate_text(do_sample=True): device-side Gumbel-max sampler inside the hipGraph; same categorical distribution as torch.multinomial, its own RNG stream"}
@@ -836,13 +1284,15 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             cb, lb, rb, _ = prefill(nb)
             sb = model.prepare_start_tokens(lb, rb, ids)
             fence()
-            t4 = time.perf_counter()
-            tb = model.generate_text(past_key_values=cb, max_length=nn, do_sample=False, end_token_id=None, **sb)
-            fence()
-            dtb = time.perf_counter() - t4
+            with Steady(dev) as mem_bd:
+                t4 = time.perf_counter()
+                tb = model.generate_text(past_key_values=cb, max_length=nn, do_sample=False, end_token_id=None, **sb)
+                fence()
+                dtb = time.perf_counter() - t4
             bd = {"value": nb * nn / dtb, "unit": "tokens/s", "batch": nb, "new_tokens": nn, "decode_ms_per_step": dtb / nn * 1e3,
-                  "context_tokens": int(lb[0]), "outputs_ok": bool(tb.shape == (nn, nb)),
+                  "context_tokens": int(lb[0]), "outputs_ok": bool(tb.shape == (nn, nb)), "memory": mem_bd.report,
                   "note": "batched multi-request decode (SURVEY 8f.4b): beside the batch-1 headline, never as it"}
+            unsteady(bd, dict(mem_bd.report, attempts=1))
             del cb
         except Exception as e:
             bd = {"error": repr(e)}
@@ -863,9 +1313,17 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     if UB == 1 and not args.no_cpu_baseline and not args.no_full_depth and int(os.environ.get("RANK", 0)) == 0:
         try:
             del cache
-            depth = understanding_full_depth(args, cfg, model, ids, image, tok, physical_cores())
+            ora = wait_oracle_job(args.und_oracle_out, "und_depth", timeout=max(60.0, args.wall_budget_s - (time.time() - T_START))) if args.und_oracle_out else None
+            skip = None if ora is not None else over_budget(args, 230, "understanding.parity_at_full_depth with the oracle in this process")
+            if skip is None:
+                depth = understanding_full_depth(args, cfg, model, ids, physical_cores(), oracle_out=ora)
+                if ora is not None:
+                    depth["worker"] = dict(ora.get("worker", {}), child_waited_s=ora.get("waited_s"))
+            else:
+                depth = skip
         except Exception as e:
-            depth = {"error": repr(e)}
+            import traceback
+            depth = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
     w_bytes = 2.0 * (L * (2 * H * H + 2 * H * nkv * hd + 3 * H * I) + V * H)
     ctx = lens[0]
     kv_bytes = 2.0 * nkv * hd * 2 * L * (ctx + n / 2.0)          # average context over the decoded span
@@ -876,6 +1334,9 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "prefill_ms": {"vit_encoder_plus_llm_prefill": (t_vit - t0) * 1e3, "text_prefill": (t1 - t_vit) * 1e3},
             "decode_ms_per_step": dt / n * 1e3, "decode_ms_per_token": dt / n / UB * 1e3, "hip_graph": sess.graph is not None, "hip_graph_error": sess.graph_error,
             "kv_cache": f"paged, {sess.paged.PAGE}-token pages, {sess.paged.num_pages} pages/layer", "cpu_baseline": cpu,
+            "memory": {"prefill_timed_region": mem_prefill.report, "decode_timed_region": mem_decode.report, "resident": resident_weight_bytes(model),
+                       "what": f"a process that holds the model (no VAE) and serves understanding requests at batch {UB}: peak of live tensor bytes inside each timed region"},
+            "steady_state": bool(mem_prefill.report["steady"] and mem_decode.report["steady"]),
             "int8_rowwise_weights": w8, "mxfp4_weights": w4, "nf4_weights": wn, "batched_decode": bd, "sampled_decode": sampled, "parity_at_full_depth": depth,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_decode_traffic() if (UB == 1 and args.und_image == 980) else None,
@@ -957,17 +1418,20 @@ def pmc_decode_traffic():
         return None
 
 
-def understanding_subprocess(args, local):
+def understanding_subprocess(args, local, job=None):
     """Run the configs[1] leg in a child process on the same GPU (a replica per rank): a fault or hang there can never
     take the text->image number down with it."""
     import subprocess
     env = dict(os.environ)
-    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1")
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local), LOCAL_WORLD_SIZE="1", BAGEL_PAUSE_PIDS=",".join(str(x) for x in Steady.pause_pids))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--only-understanding"] + (["--no-cpu-baseline"] if args.no_cpu_baseline or int(os.environ.get("WORLD_SIZE", 1)) != 1 else []) + [
            "--und-new-tokens", str(args.und_new_tokens), "--und-image", str(args.und_image), "--und-batch", str(args.und_batch)] + (
            ["--no-int8"] if args.no_int8 else []) + (["--no-batched-decode"] if args.no_batched_decode else []) + (["--no-full-depth"] if args.no_full_depth else [])
     if args.layers is not None:
         cmd += ["--layers", str(args.layers)]
+    if job is not None:
+        cmd += ["--und-oracle-out", job["dir"]]
+    cmd += ["--wall-budget-s", str(args.wall_budget_s - (time.time() - T_START) - 250.0)]      # what is left of this run's budget, less the parent's own full-depth leg
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
     except subprocess.TimeoutExpired:
@@ -986,6 +1450,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.oracle_job:
+        return oracle_job_main(args)
     if args.cpu_baseline_only:
         from bagel_amd.factory import BAGEL_7B_MOT
         print(json.dumps({"cpu_baseline": cpu_baseline(args, BAGEL_7B_MOT)}), flush=True)
@@ -1016,6 +1482,11 @@ def main():
     from bagel_amd.modeling.bagel.qwen2_navit import NaiveCache
     from bagel_amd.parallel import broadcast_cache
 
+    # the CPU-oracle sides of the two parity legs that do not time the CPU start NOW, in worker processes, and run beside the GPU-bound headline loop
+    jobs = {}
+    if (cuda and world == 1 and not args.standins and not args.no_oracle_jobs and not args.no_cpu_baseline and not args.no_full_depth and args.workload == "t2i"
+            and not args.only_understanding and args.layers is None and not args.weight_store):
+        jobs = start_oracle_jobs(args, local, ([] if args.no_understanding or args.und_batch != 1 else ["und_depth"]) + ([] if args.no_edit else ["edit_depth"]))
     cfg = BAGEL_7B_MOT
     if args.standins:
         # TEST ONLY: the launch wrappers become the torch stand-ins of tests/mock_ops.py and the model a 2-layer toy, so that THIS
@@ -1068,7 +1539,7 @@ def main():
 
     bcast = []          # (start, end, bytes) of every conditioning-KV broadcast
 
-    def one_step(taylorseer=False):
+    def one_step(taylorseer=False, B=B, T=T):
         # conditioning context: computed once (rank 0) and broadcast; every sample shares the prompt (gen_images_mp.py:43)
         gi, newlens, newrope = model.prepare_prompts([0] * B, [0] * B, ["p"] * B, tok, ids)
         if rank == 0:
@@ -1090,7 +1561,7 @@ def main():
                 cache = broadcast_cache(cache, src=0, stats=st)
                 bcast.append((t_b, time.perf_counter(), st.get("bytes", 0)))
         li = model.prepare_vae_latent(newlens, newrope, [(R, R)] * B, ids)
-        li["packed_init_noises"] = my_noise
+        li["packed_init_noises"] = my_noise[: B * n_img]
         ci = model.prepare_vae_latent_cfg([0] * B, [0] * B, [(R, R)] * B)
         latents = model.generate_image(
             past_key_values=cache, num_timesteps=T, cfg_text_scale=4.0, cfg_interval=[0, 1.0], cfg_renorm_min=0.0,
@@ -1110,34 +1581,44 @@ def main():
     #      the 3-forward sampler (cond + cfg-text + cfg-img, text_channel renorm; app.py:224-228), one request per GPU
     edit_state = {}
 
-    def edit_step(taylorseer=False, timesteps=None):
+    def edit_request(i):
+        """Inputs of edit request ``i`` of this rank (seeded; request 0 is the one the one-request latency is quoted on)."""
+        if i not in edit_state:
+            gsrc = torch.Generator().manual_seed(3 + 100 * i)
+            edit_state[i] = dict(src_vae=(torch.rand(3, R, R, generator=gsrc) * 2 - 1).to(dev),        # vae_transform(image) stand-in
+                                 src_vit=(torch.rand(3, 980, 980, generator=gsrc) * 2 - 1).to(dev),    # vit_transform(image) stand-in
+                                 enc_noise=torch.randn(1, 16, R // 8, R // 8, generator=torch.Generator().manual_seed(43 + 100 * i)),
+                                 noise=(all_noise[rank * n_img:(rank + 1) * n_img] if i == 0 else
+                                        torch.randn(n_img, pdim, generator=torch.Generator().manual_seed(4242 + 100 * i + rank))).to(dev))
+        return edit_state[i]
+
+    def edit_step(taylorseer=False, timesteps=None, reqs=(0,)):
+        """``reqs``: the edit requests served TOGETHER as one NaViT batch (the packers and the engines take batches; every sample keeps its own contexts, its own
+        per-token text_channel renorm and its own noise, so a request's result does not depend on its batch mates beyond fp32 summation order in split tiles)."""
         import copy
-        if not edit_state:
-            gsrc = torch.Generator().manual_seed(3)
-            edit_state["src_vae"] = (torch.rand(3, R, R, generator=gsrc) * 2 - 1).to(dev)        # vae_transform(image) stand-in
-            edit_state["src_vit"] = (torch.rand(3, 980, 980, generator=gsrc) * 2 - 1).to(dev)    # vit_transform(image) stand-in
-            edit_state["enc_noise"] = torch.randn(1, 16, R // 8, R // 8, generator=torch.Generator().manual_seed(43))
-            edit_state["noise"] = all_noise[rank * n_img:(rank + 1) * n_img].to(dev)
+        rq = [edit_request(i) for i in reqs]
+        nb = len(rq)
         ident = lambda t: t  # noqa: E731
+        enc_noise = torch.cat([r_["enc_noise"] for r_ in rq], 0)
 
         class _FixedNoiseVae:      # the reference draws randn_like inside encode; feed a seeded CPU draw (SURVEY.md 8d config 5)
             def encode(self, x):       # the edit request is the app's / inferencer's path: its VAE runs inside torch.autocast(bf16) (inferencer.py:233)
-                return vae.encode(x, sample_noise=edit_state["enc_noise"], **({} if args.standins else {"precision": "bf16"}))
+                return vae.encode(x, sample_noise=enc_noise, **({} if args.standins else {"precision": "bf16"}))
 
-        ctx = dict(kv_lens=[0], ropes=[0], past_key_values=NaiveCache(L))
-        vi, l1, r1 = model.prepare_vae_images(ctx["kv_lens"], ctx["ropes"], [edit_state["src_vae"]], ident, ids)
-        cache = model.forward_cache_update_vae(_FixedNoiseVae(), ctx["past_key_values"], **vi)
-        ti, l2, r2 = model.prepare_vit_images(l1, r1, [edit_state["src_vit"]], ident, ids)
+        z = [0] * nb
+        vi, l1, r1 = model.prepare_vae_images(z, z, [r_["src_vae"] for r_ in rq], ident, ids)
+        cache = model.forward_cache_update_vae(_FixedNoiseVae(), NaiveCache(L), **vi)
+        ti, l2, r2 = model.prepare_vit_images(l1, r1, [r_["src_vit"] for r_ in rq], ident, ids)
         cache = model.forward_cache_update_vit(cache, **ti)
         cfg_text_cache = copy.deepcopy(cache)
-        pi, l3, r3 = model.prepare_prompts(l2, r2, ["p"], tok, ids)
+        pi, l3, r3 = model.prepare_prompts(l2, r2, ["p"] * nb, tok, ids)
         cache = model.forward_cache_update_text(cache, **pi)
-        pi2, l4, r4 = model.prepare_prompts([0], [0], ["p"], tok, ids)
+        pi2, l4, r4 = model.prepare_prompts(z, z, ["p"] * nb, tok, ids)
         cimg_cache = model.forward_cache_update_text(NaiveCache(L), **pi2)
-        li = model.prepare_vae_latent(l3, r3, [(R, R)], ids)
-        li["packed_init_noises"] = edit_state["noise"]
-        ct = model.prepare_vae_latent_cfg(l2, r2, [(R, R)])
-        cim = model.prepare_vae_latent_cfg(l4, r4, [(R, R)])
+        li = model.prepare_vae_latent(l3, r3, [(R, R)] * nb, ids)
+        li["packed_init_noises"] = torch.cat([r_["noise"] for r_ in rq], 0)
+        ct = model.prepare_vae_latent_cfg(l2, r2, [(R, R)] * nb)
+        cim = model.prepare_vae_latent_cfg(l4, r4, [(R, R)] * nb)
         kw = {}
         for tag, c, d in (("cfg_text", cfg_text_cache, ct), ("cfg_img", cimg_cache, cim)):
             kw.update({f"{tag}_past_key_values": c, f"{tag}_packed_position_ids": d["cfg_packed_position_ids"],
@@ -1180,8 +1661,24 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    # ---- memory, the reference's only published figure for this path ("80 GiB is sufficient": app.py:77 max_memory, README.md:139-151): ONE text->image request
+    #      (B = 1, full resolution, VAE decode included; 3 timesteps reach the same peak as 50) in a process that holds nothing but the model -- before any B = 4 workspace exists
+    mem_b1 = None
+    if cuda and args.workload == "t2i" and not args.standins and world == 1:
+        try:
+            one_step(B=1, T=3)
+            one_step(B=1, T=3)
+            with Steady(dev) as m1:
+                one_step(B=1, T=3)
+            mem_b1 = dict(m1.report, what="bf16 model (parameters + packed copies" + (" + VAE" if vae is not None else "") + ") + one 1024^2 text->image request, B = 1, "
+                          "cond + CFG forward stream-batched, fp32 VAE decode included: peak of live tensor bytes in a process that holds nothing else",
+                          fits_80gb=bool(m1.report["peak_mem_gb"] <= 80.0))
+            model.language_model.engine().release_workspaces()
+        except Exception as e:
+            mem_b1 = {"error": repr(e)}
     for _ in range(args.warmup):
         one_step()
+    jobs_wait_s = wait_gpu_released(jobs) if jobs else 0.0          # the workers' model builds overlap the warm-up; nothing else is on the GPU from here on
     records, orig_gemm = [], ops.gemm
     arecords, orig_attn = [], ops.attn_planned
     if cuda:
@@ -1191,11 +1688,12 @@ def main():
         ops.attn_planned = timed_attn
     del bcast[:]
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        latents, imgs = one_step()
-    fence()
-    dt = time.perf_counter() - t0
+    with Steady(dev) as mem_head:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            latents, imgs = one_step()
+        fence()
+        dt = time.perf_counter() - t0
     ops.gemm = orig_gemm
     ops.attn_planned = orig_attn
     bcast_timed = list(bcast)
@@ -1214,19 +1712,17 @@ def main():
         # the reference's own accelerator option (generate_image(enable_taylorseer=True), bagel.py:678-689): same workload,
         # 19 instead of 49 full backbone forwards per stream.  It CHANGES the samples, so it is reported beside the headline
         # number, never as it.
-        fence()
-        t1 = time.perf_counter()
-        lat_ts, _ = one_step(taylorseer=True)
-        fence()
-        dt_ts = time.perf_counter() - t1
+        one_step(taylorseer=True, T=8)              # warm-up: the per-layer Taylor state buffers (two full steps + extrapolated ones)
+        (lat_ts, _), dt_ts, mem_ts = timed_steady(lambda: one_step(taylorseer=True), dev, fence)
         if world > 1:
             tt = torch.tensor([dt_ts], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ts = float(tt.item())
         st = model._last_taylor_states[0]
         ts = {"value": world * B / dt_ts, "unit": "images/s", "ms_per_step": dt_ts * 1e3, "full_forwards_per_stream": st.full_steps,
-              "extrapolated_forwards_per_stream": st.taylor_steps, "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_ts),
+              "extrapolated_forwards_per_stream": st.taylor_steps, "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_ts), "memory": mem_ts,
               "note": "enable_taylorseer=True (reference option, changes the samples): not the headline metric"}
+        unsteady(ts, mem_ts)
     fp8 = None
     if args.workload == "t2i" and not args.no_fp8 and not args.only_understanding:
         # option model.gen_weight_quant = "fp8": the gen expert's projections on the OCP-e4m3 MFMA with row-wise scales (SURVEY.md 8f.4;
@@ -1234,21 +1730,18 @@ def main():
         # reported beside the headline number, never as it.
         try:
             model.gen_weight_quant = "fp8"
-            one_step()                                  # warm-up: quantises the 28 x 4 gen-expert matrices once
-            fence()
-            t1 = time.perf_counter()
-            lat_8, _ = one_step()
-            fence()
-            dt_8 = time.perf_counter() - t1
+            one_step(T=3)                               # warm-up: quantises the 28 x 4 gen-expert matrices once, allocates the fp8 workspaces
+            (lat_8, _), dt_8, mem_8 = timed_steady(one_step, dev, fence)
             if world > 1:
                 tt = torch.tensor([dt_8], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt_8 = float(tt.item())
             dev_l2 = max(float(((a.float() - b.float()).norm() / b.float().norm()).item()) for a, b in zip(lat_8, latents))
             fp8 = {"value": world * B / dt_8, "unit": "images/s", "ms_per_step": dt_8 * 1e3, "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_8),
-                   "latents_rel_l2_vs_bf16_run": dev_l2, "weights": "gen expert q/k/v/o/gate/up/down in OCP e4m3, row-wise absmax scales; activations "
+                   "latents_rel_l2_vs_bf16_run": dev_l2, "memory": mem_8, "weights": "gen expert q/k/v/o/gate/up/down in OCP e4m3, row-wise absmax scales; activations "
                    "quantised per row on the fly; und expert, attention, norms, residual stream bf16",
                    "note": "gen_weight_quant='fp8' option (changes results): not the headline metric"}
+            unsteady(fp8, mem_8)
         except Exception as e:
             import traceback
             fp8 = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
@@ -1259,12 +1752,11 @@ def main():
         # BASELINE configs[4] beside the headline: ONE image-edit request per GPU (VAE-encode + SigLIP + prompt -> ~9 k-token
         # context, 49 Euler steps x 3 forwards, text_channel renorm, VAE decode), after a 2-step warm-up of its shapes
         try:
+            if cuda and not args.standins:
+                model.language_model.engine().release_workspaces(quantised=True)      # the peak reported below is the model + THIS request's working set
             edit_step(timesteps=3)
-            fence()
-            t1 = time.perf_counter()
-            lat_e, _ = edit_step()
-            fence()
-            dt_e = time.perf_counter() - t1
+            edit_step(timesteps=3)          # twice: the second request is set up while the first one's caches are still referenced (cf. the understanding prefill)
+            (lat_e, _), dt_e, mem_e = timed_steady(edit_step, dev, fence)
             if world > 1:
                 tt = torch.tensor([dt_e], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -1278,13 +1770,67 @@ def main():
                     "whole_path_roofline": {"bound": "mfma", "achieved": pf / dt_e / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                             "frac": pf / dt_e / 1e12 / PEAK_BF16_TFLOPS,
                                             "note": "denoise FLOPs only (linear + attention of the 147 forwards) over the WHOLE request time incl. VAE encode, ViT, prefill and VAE decode"},
-                    "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_e),
+                    "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_e), "memory": mem_e,
                     "vae_precision": "bf16 convolutions, fp32 GroupNorm (the VAE inside the inferencer's autocast region, inferencer.py:233), encode and decode",
                     "workload": f"BASELINE configs[4]: VAE-encode + SigLIP(980^2) + {args.prompt_tokens}+2 prompt tokens, {T} timesteps x [cond + CFG-text 4.0 + "
                                 f"CFG-img 2.0], text_channel renorm, VAE decode included, 1 request/GPU"}
+            unsteady(edit, mem_e)
+            # THROUGHPUT form, beside the one-request latency and never as it: TWO requests per GPU in one NaViT batch (96 row tiles instead of 48: the
+            # o / down projections run 5.25 rounds of the 256 persistent workgroups instead of 2.63, qkv 6.75 instead of 3.375 -- the partial last rounds that
+            # idle 12-16 % of the chip at one request).  The batch driver of the reference serves one image per rank at a time (gen_images_mp_imgedit.py:278-303).
+            try:
+                def same_as_single(nt=3):
+                    """Each sample of the two-request batch against its own single-request run (``nt`` timesteps): identical up to fp32 summation order where
+                    a GEMM tile or an attention item is split differently in the two launches."""
+                    both, _ = edit_step(timesteps=nt, reqs=(0, 1))
+                    res = []
+                    for i in (0, 1):
+                        one, _ = edit_step(timesteps=nt, reqs=(i,))
+                        a, b_ = both[i].float(), one[0].float()
+                        res.append({"bit_identical": bool(torch.equal(a, b_)), "rel_l2": float((a - b_).norm() / b_.norm()), "elements_differing": int((a != b_).sum())})
+                    return res
+                same = same_as_single()
+                edit_step(timesteps=3, reqs=(0, 1))
+                (lat_b, _), dt_b, mem_b = timed_steady(lambda: edit_step(reqs=(0, 1)), dev, fence)
+                if world > 1:
+                    tt = torch.tensor([dt_b], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt_b = float(tt.item())
+                edit["batched"] = unsteady({"value": 2 * world / dt_b, "unit": "images/s", "requests_per_gpu": 2, "seconds_per_batch": dt_b, "seconds_per_image": dt_b / 2,
+                                            "speedup_over_one_request_per_gpu": (2 / dt_b) / (1 / dt_e), "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_b),
+                                            "each_sample_vs_its_single_request_run": same, "memory": mem_b,
+                                            "whole_path_roofline_frac": 2 * pf / dt_b / 1e12 / PEAK_BF16_TFLOPS,
+                                            "note": "two independent edit requests (own images, prompts' contexts, noise) served as one batch: THROUGHPUT, beside the "
+                                                    "one-request latency above, never as it"}, mem_b)
+            except Exception as e:
+                import traceback
+                edit["batched"] = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
         except Exception as e:
             import traceback
             edit = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
+        if cuda and rank == 0 and world == 1 and not args.standins and not args.no_cpu_baseline and not args.no_full_depth and args.layers is None:
+            # configs[4] against the oracle AT THE CONTEXT LENGTHS IT IS TIMED AT, on a depth-reduced model (the oracle's 9 032-token chain at depth 28 is ~10 min of
+            # host time): the real request chain, the three contexts' K / V, every single forward incl. the stream-batched ones (edit_depth_step)
+            try:
+                job = jobs.get("edit_depth")
+                ora = wait_oracle_job(job["dir"], "edit_depth", proc=job["proc"]) if job else None
+                skip = None if ora is not None else over_budget(args, 330 + 240, "edit.parity_at_depth with the oracle in this process")
+                if skip is None:
+                    m4, _ = build_bagel(cfg, device=dev, num_layers=EDIT_PARITY_LAYERS, with_vae=False)
+                    init_random_(m4, seed=0)
+                    m4.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device=dev).manual_seed(1))
+                    par = edit_depth_step(args, cfg, m4, ids, physical_cores(), vae=vae, oracle_out=ora)
+                    if ora is not None:
+                        par["worker"] = dict(ora.get("worker", {}), parent_waited_s=ora.get("waited_s"))
+                    del m4
+                    torch.cuda.empty_cache()
+                else:
+                    par = skip
+            except Exception as e:
+                import traceback
+                par = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
+            if isinstance(edit, dict):
+                edit["parity_at_depth"] = par
     trainf = None
     if args.workload == "t2i" and not args.no_train_forward and (args.layers is None or args.standins):
         # SURVEY 8f.2 beside the headline: Bagel.forward (training forward, per-token CE / MSE losses, no backward) on a packed 7B batch of
@@ -1299,14 +1845,15 @@ def main():
                 tn = torch.randn(len(tb["packed_vae_token_indexes"]), 64, generator=torch.Generator().manual_seed(1)).to(dev)
             o_ = model(noise=tn, **tb)
             fence()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                o_ = model(noise=tn, **tb)
-            fence()
-            dtt = (time.perf_counter() - t1) / 3
+            with Steady(dev) as mem_tf:
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    o_ = model(noise=tn, **tb)
+                fence()
+                dtt = (time.perf_counter() - t1) / 3
             ntok = tb["sequence_length"]
             trainf = {"value": world * ntok / dtt, "unit": "tokens/s", "tokens_per_forward": ntok, "ms_per_forward": dtt * 1e3,
-                      "linear_tflops": 13.0506e-3 * ntok / dtt, "outputs_finite": bool(torch.isfinite(o_["ce"]).all() and torch.isfinite(o_["mse"]).all()),
+                      "linear_tflops": 13.0506e-3 * ntok / dtt, "outputs_finite": bool(torch.isfinite(o_["ce"]).all() and torch.isfinite(o_["mse"]).all()), "memory": mem_tf.report,
                       "note": "training FORWARD only (losses, no tape): beside the headline, never as it"}
             if not args.no_train_step:
                 # the whole step of train/pretrain_unified_navit.py:683-735 minus the optimizer: forward with a tape + loss.backward() through
@@ -1340,7 +1887,8 @@ def main():
                         return float(loss.detach()), a1 - a0, a2 - a1, a3 - a2
                     one_train_step()
                     one_train_step()
-                    rs = [one_train_step() for _ in range(2)]
+                    with Steady(dev):                    # (the step's own peak is read below from max_memory_allocated: this bracket resets the counter and stops the workers)
+                        rs = [one_train_step() for _ in range(2)]
                     tf_, tb_, to_ = sum(r[1] for r in rs) / 2, sum(r[2] for r in rs) / 2, sum(r[3] for r in rs) / 2
                     gn = sum(float(p_.grad.float().norm()) ** 2 for p_ in model.parameters() if p_.grad is not None) ** 0.5
                     lin = 13.0506e-3 * ntok                                   # TFLOP of the decoder's linears in one forward
@@ -1369,7 +1917,7 @@ def main():
             trainf = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
     und = None
     if not args.no_understanding:
-        und = understanding_subprocess(args, local)
+        und = understanding_subprocess(args, local, jobs.get("und_depth"))
         if world > 1:   # replicas: aggregate tokens/s = sum over ranks
             v = und.get("per_gpu_tokens_per_s", 0.0) if isinstance(und, dict) else 0.0
             tt = torch.tensor([v], dtype=torch.float64, device=dev)
@@ -1421,6 +1969,17 @@ def main():
                 "calls": len(bcast_timed), "bytes_per_call": bcast_timed[0][2],
                 "ms_per_call": (sum(a.elapsed_time(b) for a, b, _ in bcast_timed) if cuda else sum((b - a) * 1e3 for a, b, _ in bcast_timed)) / len(bcast_timed),
                 "what": "conditioning KV of the shared prompt: rank 0 prefills, one flat bf16 buffer [L][2][rows][nkv*D] + an int64 header to every rank"},
+            "memory": {"resident": resident_weight_bytes(model, vae) if cuda and not args.standins else None,
+                       "t2i_b1_request": mem_b1,
+                       "headline_timed_region": dict(mem_head.report, what=f"the {args.steps} timed steps at B = {B}/GPU (fp32 VAE decode included)"),
+                       "note": "peak_mem_gb = torch.cuda.max_memory_allocated after reset_peak_memory_stats (live tensor bytes: weights + packed copies + the leg's "
+                               "working set); every leg's own figure sits in its object (edit.memory, understanding.memory, taylorseer.memory, fp8_gen_expert.memory, "
+                               "training_forward.training_step.peak_mem_gb); steady = no hipMalloc / hipFree inside the timed region"},
+            "oracle_workers": None if not jobs else {
+                "what": "the CPU-oracle sides of understanding.parity_at_full_depth and edit.parity_at_depth ran in worker processes beside the GPU legs (bench.py "
+                        "--oracle-job: same name-seeded weights, fingerprint-checked by the compare phase); the parent waited for them to leave the GPU before its "
+                        "timed region and STOPS them (SIGSTOP / SIGCONT) for the duration of every timed region of every leg", "kinds": sorted(jobs), "threads_each": next(iter(jobs.values()))["threads"], "parent_waited_for_gpu_release_s": jobs_wait_s,
+                "gpu_released_before_timed_region": all(j.get("gpu_released") for j in jobs.values())},
             "understanding": und,
             "edit": edit,
             "taylorseer": ts,
@@ -1450,10 +2009,16 @@ def main():
             out["cpu_baseline"] = None      # timed on rank 0 at N=1 only: the host cores are shared by N ranks here
         elif not args.no_cpu_baseline:
             try:
+                for j in jobs.values():                    # the CPU baseline is TIMED: no worker may still be on the host cores
+                    try:
+                        j["proc"].wait(timeout=600)
+                    except Exception:
+                        j["proc"].kill()
                 gpu = None if (args.layers is not None or args.workload != "t2i") else dict(model=model, tok=tok, ids=ids)
                 out["cpu_baseline"] = cpu_baseline(args, cfg, gpu)
             except Exception as e:   # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
+        out["wall_seconds"] = time.time() - T_START
         if ranks_seen != args.gpus or ranks_seen != world:
             # a job that did not run on the N ranks it was asked for has no line: a throughput quoted for N GPUs over fewer (or more) ranks
             # would be read as a scaling point

@@ -122,7 +122,9 @@ int bagel_attn_varlen_ranges_bf16(const void* q, int64_t ldq, const void* k_new,
  * 256 * (head_dim + 2) floats.  The caller copies the plan to the device once per forward SHAPE (it is the same for every layer)
  * and launches bagel_attn_planned_bf16 with the device copy; `partials` may be null when n_comb == 0.
  * Replaces flash_attn_varlen_func at qwen2_navit.py:579-588 / siglip_navit.py:232-241 like bagel_attn_varlen_bf16; items that are
- * not key-split produce bit-identical results to it. */
+ * not key-split produce bit-identical results to it.  A plan with MORE workers than the device has CUs selects the split-ring form of
+ * the kernel (2 K + 2 V^T slots = 64 KB of LDS per workgroup, one tile step of DMA flight; csrc/attention2.hip): a round-6 experiment,
+ * bit-identical, measured slower than the default (profiles/r06_attn_split_ring.log) -- plan with the CU count. */
 int bagel_attn_plan(const int32_t* q_start, const int32_t* q_len, const int32_t* ctx_start, const int32_t* ctx_len,
                     const int32_t* vt_new_col, const int32_t* vt_ctx_col, int32_t batch, int32_t nq, int32_t nkv,
                     int32_t causal, int32_t n_workers, int32_t split_min_tiles, int32_t* plan, int64_t plan_ints);
@@ -131,6 +133,9 @@ int bagel_attn_planned_bf16(const void* q, int64_t ldq, const void* k_new, int64
                             void* out, int64_t ldo, const int32_t* plan_dev, int32_t n_workers, int32_t n_comb,
                             int32_t off_items, int32_t off_comb, void* partials, int32_t head_dim, float softmax_scale,
                             bagel_stream_t stream);
+/* TEST / TOOLING HOOK (not for integrators): resident workgroups per CU of the planned attention kernel -- split = 0 the unified 4-slot ring, 1 the split
+ * 2 + 2 ring -- by the runtime's occupancy calculator; >= 0, or a negative error code. */
+int bagel_debug_attn_occupancy(int32_t head_dim, int32_t split);
 
 /* V[rows][nkv][D] -> V^T[nkv][D][cols] per sample (layout consumed by bagel_attn_varlen_bf16). */
 int bagel_v_transpose_bf16(const void* v, int64_t ld_src, void* vt, int64_t ld_dst, const int32_t* cu_rows,

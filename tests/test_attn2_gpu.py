@@ -26,8 +26,10 @@ def _unsplit_rows(ap, M, nq):
     return m
 
 
+# "2xchip": a plan with more workers than CUs selects the SPLIT-RING form of the kernel (2 K + 2 V^T slots, two cursors: round 6) -- same arithmetic, same order
 @pytest.mark.parametrize("q_lens,ctx_lens,nq,nkv,D,causal", ATTN_CASES)
-@pytest.mark.parametrize("planned", [dict(), dict(n_workers=8), dict(n_workers=16, split_min_tiles=1)], ids=["chip", "w8", "w16_split"])
+@pytest.mark.parametrize("planned", [dict(), dict(n_workers=8), dict(n_workers=16, split_min_tiles=1), dict(n_workers="2xchip"), dict(n_workers="2xchip", split_min_tiles=1)],
+                         ids=["chip", "w8", "w16_split", "split_ring", "split_ring_keysplit"])
 def test_planned_attention_matches_definition_and_tile_kernel(q_lens, ctx_lens, nq, nkv, D, causal, planned):
     got, ref, got2, ap = run_attention(q_lens, ctx_lens, nq, nkv, D, causal, planned=planned)
     close(got2, ref, ulps=2, rel_l2=6e-3, what=f"planned attn q={q_lens} ctx={ctx_lens} D={D} causal={causal} {planned}")
@@ -43,8 +45,9 @@ def test_planned_attention_matches_definition_and_tile_kernel(q_lens, ctx_lens, 
     ([4900], [0], 16, 16, False),                            # SigLIP: one 980^2 image
     ([34], [0], 28, 4, True),                                # short text prefill: four head-per-wave items
 ], ids=["denoise_b8", "edit_3streams", "prefill_4936_causal", "siglip_4900", "prompt_34"])
-def test_planned_attention_at_benchmark_launches(q_lens, ctx_lens, nq, nkv, causal):
-    got, ref, got2, ap = run_attention(q_lens, ctx_lens, nq, nkv, 128, causal, planned=dict())
+@pytest.mark.parametrize("planned", [dict(), dict(n_workers="2xchip")], ids=["unified_ring", "split_ring"])
+def test_planned_attention_at_benchmark_launches(q_lens, ctx_lens, nq, nkv, causal, planned):
+    got, ref, got2, ap = run_attention(q_lens, ctx_lens, nq, nkv, 128, causal, planned=planned)
     close(got2, ref, ulps=2, rel_l2=6e-3, what=f"planned attn q={q_lens} ctx={ctx_lens}")
     keep = _unsplit_rows(ap, got.shape[0], nq)
     assert torch.equal(got.cpu().view(torch.int16)[keep], got2.cpu().view(torch.int16)[keep])

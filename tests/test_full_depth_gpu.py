@@ -29,6 +29,8 @@ def test_euler_step_matches_oracle_at_7b_width_depth_4():
     assert out["prefill_kv_rel_l2_max"] <= 2e-2          # 1.0e-2 at 4 layers, 2.05e-2 at 28 (bench): the tiny models' 1e-2 grows with depth
     assert out["rel_l2"] <= bench.FULL_DEPTH_TOL and out["rel_l2_sequential_forward_flow"] <= bench.FULL_DEPTH_TOL, out
     assert out["rel_l2_cond_forward"] <= bench.FULL_DEPTH_TOL_FORWARD and out["rel_l2_cfg_text_forward"] <= bench.FULL_DEPTH_TOL_FORWARD, out
+    sb = out["stream_batched"]       # the timed path: per-stream velocities of the stream-batched forward, before the combine
+    assert sb["ran_batched"] and sb["rel_l2_cond_forward"] <= bench.FULL_DEPTH_TOL_FORWARD and sb["rel_l2_cfg_text_forward"] <= bench.FULL_DEPTH_TOL_FORWARD, sb
     assert out["within_tolerance"] is True
 
 
@@ -49,6 +51,35 @@ def test_edit_step_three_forwards_match_oracle_at_7b_width_depth_4():
     assert out["layers"] == 4 and out["contexts"] == [576 + 2 + 30 + 2, 576 + 2, 30 + 2]
     for k in ("rel_l2_cond_forward", "rel_l2_cfg_text_forward", "rel_l2_cfg_img_forward"):
         assert out[k] <= bench.FULL_DEPTH_TOL_FORWARD, (k, out[k])
-    sc = out["cfg_combine_self_consistency"]
+    sc, sb = out["cfg_combine_self_consistency"], out["stream_batched"]
+    assert sc["sequential_forward_flow"] <= bench.FULL_DEPTH_TOL_COMBINE and sc["generate_image_stream_batched"] <= bench.EDIT_DEPTH_TOL_BATCHED, sc
+    # the timed path: the per-stream velocities of the ONE three-stream forward inside generate_image, each held to the single-forward bound
+    assert sb["ran_batched"] and max(sb[k] for k in ("rel_l2_cond_forward", "rel_l2_cfg_text_forward", "rel_l2_cfg_img_forward")) <= bench.FULL_DEPTH_TOL_FORWARD, sb
+    assert out["within_tolerance"] is True
+
+
+def test_edit_request_at_full_context():
+    """configs[4] at the context lengths it is TIMED at (round-5 verdict, missing-3): a depth-4 7B-width model with the full SigLIP tower (26 layers, so400m width) and
+    the real VAE (ch 128) runs the REAL request chain -- 1024^2 VAE-encode (seeded draw, bf16 autocast) -> ``forward_cache_update_vae`` (gen mode, t = 0) -> 980^2
+    SigLIP + connector -> ``forward_cache_update_vit`` -> prompt => 9 032 / 9 000 / 32-key contexts -- and one 3-forward ``text_channel`` Euler step on them, against
+    the oracle on this box's host cores (inferencer.py:62-172, bagel.py:491-550,757-907, autoencoder.py:315-322).  Gated: per-layer K / V of all three contexts, the
+    three sequential single forwards, the three per-stream velocities of the stream-batched forward (the timed path), and the combine on the product's own forwards."""
+    import bench
+    from bagel_amd.factory import BAGEL_7B_MOT, build_bagel, init_random_
+    cfg = dict(BAGEL_7B_MOT, llm=dict(BAGEL_7B_MOT["llm"], vocab_size=512))
+    model, vae = build_bagel(cfg, device="cuda", num_layers=4, with_vae=True)
+    init_random_(model, seed=0)
+    init_random_(vae, seed=0)
+    model.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device="cuda").manual_seed(1))
+    ids = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
+    args = argparse.Namespace(resolution=1024)
+    out = bench.edit_depth_step(args, cfg, model, ids, threads=bench.physical_cores(), vae=vae)
+    print("depth-4 edit REQUEST parity at full context:", {k: v for k, v in out.items() if k != "what"})
+    assert out["layers"] == 4 and out["contexts"] == [4098 + 4902 + 32, 4098 + 4902, 32], out["contexts"]
+    assert max(out["context_kv_rel_l2_max"].values()) <= bench.EDIT_CONTEXT_TOL_KV, out["context_kv_rel_l2_max"]
+    for k in ("rel_l2_cond_forward", "rel_l2_cfg_text_forward", "rel_l2_cfg_img_forward"):
+        assert out[k] <= bench.FULL_DEPTH_TOL_FORWARD, (k, out[k])
+    sc, sb = out["cfg_combine_self_consistency"], out["stream_batched"]
+    assert sb["ran_batched"] and max(sb[k] for k in ("rel_l2_cond_forward", "rel_l2_cfg_text_forward", "rel_l2_cfg_img_forward")) <= bench.FULL_DEPTH_TOL_FORWARD, sb
     assert sc["sequential_forward_flow"] <= bench.FULL_DEPTH_TOL_COMBINE and sc["generate_image_stream_batched"] <= bench.EDIT_DEPTH_TOL_BATCHED, sc
     assert out["within_tolerance"] is True

@@ -315,6 +315,8 @@ def run_attention(q_lens, ctx_lens, nq, nkv, D, causal, seed=0, scale_dim=None, 
     o.attn_varlen(qkv[:, :qw], qkv[:, qw:qw + kw], vt, out, i32(cu_q), i32(vcol), B, max(q_lens), nq, nkv, D, causal, scale, **kwargs)
     if planned is None:
         return out.view(M, nq, D), ref
+    if planned.get("n_workers") == "2xchip":      # more workers than CUs: the split-ring form of the planned kernel
+        planned = dict(planned, n_workers=2 * (torch.cuda.get_device_properties(0).multi_processor_count // 8 * 8))
     ap = o.AttnPlan(cu_q[:-1], q_lens, vcol, nq, nkv, D, causal, DEV, ctx_start=cu_c[:-1] if Ctot > 0 else None,
                     ctx_len=ctx_lens if Ctot > 0 else None, vt_ctx_col=ccol if Ctot > 0 else None, **planned)
     out2 = torch.full((M, qw), float("nan"), dtype=BF16, device=DEV)

@@ -67,7 +67,15 @@ def case(name, q_lens, ctx_lens, nq, nkv, causal, iters, D=128, split_min_tiles=
     ap = ops.AttnPlan(cu_q[:-1], q_lens, vcol, nq, nkv, D, causal, DEV, ctx_start=cu_c[:-1] if Ctot else None, ctx_len=ctx_lens if Ctot else None,
                       vt_ctx_col=ccol if Ctot else None, split_min_tiles=split_min_tiles)
     run2 = lambda: ops.attn_planned(qkv[:, :qw], qkv[:, qw:qw + kw], vt, out2, ap, scale, k_ctx=kc, vt_ctx=vtc)  # noqa: E731
+    extra = []
+    for nw in WORKERS:
+        apx = ops.AttnPlan(cu_q[:-1], q_lens, vcol, nq, nkv, D, causal, DEV, ctx_start=cu_c[:-1] if Ctot else None, ctx_len=ctx_lens if Ctot else None,
+                           vt_ctx_col=ccol if Ctot else None, split_min_tiles=split_min_tiles, n_workers=nw)
+        outx = torch.empty((M, qw), dtype=BF16, device=DEV)
+        extra.append((nw, apx, outx, (lambda a=apx, o=outx: ops.attn_planned(qkv[:, :qw], qkv[:, qw:qw + kw], vt, o, a, scale, k_ctx=kc, vt_ctx=vtc))))
     run1(); run2()
+    for _, _, _, r in extra:
+        r()
     torch.cuda.synchronize()
     diff = (out1.float() - out2.float()).abs().max().item()
     nan = not bool(torch.isfinite(out2.float()).all())
@@ -76,13 +84,31 @@ def case(name, q_lens, ctx_lens, nq, nkv, causal, iters, D=128, split_min_tiles=
     print(f"{name:28s} tile kernel {t1:8.3f} ms {fl / t1 / 1e9:7.1f} TF | planned {t2:8.3f} ms {fl / t2 / 1e9:7.1f} TF  ({t1 / t2:5.3f}x)  "
           f"max|d| {diff:.3g}{' NON-FINITE' if nan else ''}  items {ap.n_items} split {ap.n_comb} makespan {ap.makespan} ideal {ap.total / ap.n_workers:.1f}",
           flush=True)
+    for nw, apx, outx, r in extra:
+        tx = timeit(r, iters)
+        dx = (outx.float() - out2.float()).abs().max().item()
+        print(f"{'':28s}   planned with {nw} workers ({'split 2+2 ring, 64 KB' if nw > CUS else 'unified ring'}) {tx:8.3f} ms {fl / tx / 1e9:7.1f} TF  ({t2 / tx:5.3f}x of the default)  "
+              f"max|d vs default| {dx:.3g}  items {apx.n_items} split {apx.n_comb} makespan {apx.makespan} ideal {apx.total / apx.n_workers:.1f}", flush=True)
+
+
+WORKERS = []
+CUS = 256
 
 
 def main():
+    global CUS
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--workers", type=int, nargs="*", default=[], help="extra plans with these worker counts (more than the CU count = the split-ring kernel, two workgroups per CU asked for)")
     a = ap.parse_args()
+    WORKERS[:] = a.workers
+    CUS = torch.cuda.get_device_properties(0).multi_processor_count
+    if a.workers:
+        from bagel_amd import _lib
+        L = _lib.lib()
+        print(f"CUs {CUS}; resident workgroups per CU by the runtime's occupancy calculator: head_dim 128 unified ring {L.bagel_debug_attn_occupancy(128, 0)}, "
+              f"split ring {L.bagel_debug_attn_occupancy(128, 1)}; head_dim 64 unified {L.bagel_debug_attn_occupancy(64, 0)}, split {L.bagel_debug_attn_occupancy(64, 1)}", flush=True)
     cases = [("denoise_b8 (configs[2])", [4098] * 8, [32] * 4 + [0] * 4, 28, 4, False),
              ("denoise_b4 (one stream)", [4098] * 4, [32] * 4, 28, 4, False),
              ("edit_3streams (configs[4])", [4098] * 3, [9032, 9000, 32], 28, 4, False),
