@@ -79,6 +79,10 @@ __device__ __forceinline__ void a2_glds16s(unsigned voff, const void* sbase_unif
                  : "memory");
 }
 
+// Measured and removed in round 6 (profiles/r06_attn_split_ring.log, "DMA path A/B"): an incremental-pointer fast path for the regular tiles of the LDS-DMA stream
+// (all pieces of a tile in one asm statement off ONE uniform base per operand, m0 saved once per tile, the cursor arithmetic reduced to two 64-bit adds): 1 018-1 024
+// TFLOP/s against 1 035-1 037 for the general path below on the same box -- the second code path cost 114 spilled SGPRs -- while switching the DMA OFF altogether
+// (A2_ABL = 8) bounds everything on that side at +5.8 %.  The softmax VALU (A2_ABL = 2: +26 %) is what this loop waits for, not its scalar address work.
 #define ATTN2_DEFER_LOG2 8.0f
 
 // Measured and removed in round 3 (profiles/r03_attn_planned_vs_tile.log; the machinery was a table of softmax slices / LDS-DMA pieces per

@@ -48,6 +48,12 @@ struct GemmParams {
     // FP8 operands (gemm_pq_kernel<MODE, true>): A / W are e4m3 bytes, sa[physical A row] and sw[n] the fp32 de-quantisation scales
     const float* sa;
     const float* sw;
+    // QOUT (gemm_pq_kernel<0, true, false, true>): the SwiGLU result leaves the kernel as e4m3 bytes quantised with a scale the CALLER supplies per physical C row
+    // (delayed scaling: it comes from the previous denoise step's row maxima), and the row maxima of THIS step's values are collected for the next one
+    unsigned char* Cq;       // [physical row][ldcq bytes]
+    long ldcq;
+    const float* cs;         // scale in use, per physical C row (the consumer GEMM's `sa`)
+    unsigned* cmax;          // per physical C row: max |value| seen (fp32 bit pattern, atomicMax; non-negative floats order like unsigned integers)
     // split launches of the persistent kernel (launch_gemm_pq): this launch covers the tile indices [w_begin, w_begin + w_count) of the
     // XCD-aware walk; ksplit > 1 cuts every one of them into ksplit work items along K that leave fp32 partial tiles in `part`
     // (gemm_pq_kernel<4>) for gemm_splitk_reduce_kernel
@@ -635,8 +641,18 @@ __device__ __forceinline__ i32x8_t cat_frag(const bf16x8_t& lo, const bf16x8_t& 
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int MODE, bool FP8 = false, bool SADDR = false>
+// max over the 16 lanes of a DPP row (all 16 end up with it): quads, half-row mirror, row mirror
+__device__ __forceinline__ float pq_rowmax16(float x) {
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)));     // quad_perm [1, 0, 3, 2]
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)));     // quad_perm [2, 3, 0, 1]
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true)));    // row_half_mirror
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true)));    // row_mirror
+    return x;
+}
+
+template <int MODE, bool FP8 = false, bool SADDR = false, bool QOUT = false>
 __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
+    static_assert(!QOUT || (MODE == 0 && FP8), "the fp8 output exists for the SwiGLU epilogue of the fp8 kernel");
     constexpr bool SWIGLU = MODE == 0, HAS_R = MODE == 1, HAS_BIAS = MODE == 2, PARTIAL = MODE == 4;
     constexpr int BM = 256, BN = 256;
     constexpr int PIECE = 128 * 128;
@@ -954,6 +970,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+v"(sw_c[nb][jn]));
             }
+            float cinv[8];                         // QOUT: 1 / (the scale in use) of this lane's 8 store rows -- loaded with the other epilogue operands
+            if constexpr (QOUT) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) cinv[it] = p.cs[crow[it]];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) { asm volatile("" : "+v"(cinv[it])); cinv[it] = 1.0f / cinv[it]; }
+            }
             start_next();
 #pragma unroll
             for (int ma = 0; ma < 2; ++ma)
@@ -992,7 +1015,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 #if BAGEL_PQ_ABL & 2                 /* timing-only ablation (wrong results): no global stores; the staged tile is kept live */
                     asm volatile("" ::"v"(v));
 #else
-                    if (col_ok && m0 + it * 32 + rb < Mg) *(u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc) = v;
+                    if constexpr (QOUT) {
+                        // 8 bf16 of one row -> 8 e4m3 bytes with the caller's scale (clamped to the format's range: a row that grew past the delayed scale's
+                        // headroom saturates instead of turning into NaN codes), and this row's max |value| for the next step's scale
+                        const bool ok = col_ok && m0 + it * 32 + rb < Mg;
+                        float f[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(v[e] << 16); f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+                        float am = fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3])));
+                        am = fmaxf(am, fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
+                        am = pq_rowmax16(ok ? am : 0.f);                       // the 16 lanes of a DPP row hold the 128 columns of one tile row
+                        const float inv = cinv[it];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e] * inv, -448.f), 448.f);
+                        int w0 = 0, w1 = 0;
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+                        if (ok) *(u32x2_t*)(p.Cq + (long)crow[it] * p.ldcq + oc) = (u32x2_t){(unsigned)w0, (unsigned)w1};
+                        if (qs == 0 && m0 + it * 32 + rb < Mg) atomicMax(p.cmax + crow[it], __float_as_uint(am));
+                    } else {
+                        if (col_ok && m0 + it * 32 + rb < Mg) *(u32x4_t*)(p.C + (long)crow[it] * p.ldc + oc) = v;
+                    }
 #endif
                 }
             }
@@ -1227,7 +1272,7 @@ static int pq_leftover_split(int nblk, int wgs, int nk, size_t ws_bytes, int* n_
     return best;
 }
 
-template <int MODE, bool FP8 = false, bool SADDR = false>
+template <int MODE, bool FP8 = false, bool SADDR = false, bool QOUT = false>
 static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream, void* ws = nullptr, size_t ws_bytes = 0) {
     GemmParams p = p0;
     int t = 0;
@@ -1256,7 +1301,7 @@ static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream, void* ws = n
     const int wgs = wgs_of_dev[dev];
     p.gm = gm;
     constexpr int smem = 2 * 4 * 128 * 128 + 3 * 2048;   // two k-tile stages + the three-deep row-table ring
-    if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<MODE, FP8, SADDR>, smem, "gemm_pq_kernel")) return rc;
+    if (int rc = bagel_enable_lds((const void*)gemm_pq_kernel<MODE, FP8, SADDR, QOUT>, smem, "gemm_pq_kernel")) return rc;
     const int nblk = p.tiles_m * p.tiles_n;
     p.w_begin = 0; p.w_count = nblk; p.ksplit = 1; p.part = nullptr;
     if constexpr (!FP8 && MODE != 0) {
@@ -1278,7 +1323,7 @@ static int launch_gemm_pq(const GemmParams& p0, hipStream_t stream, void* ws = n
             return bagel_check_launch("gemm_splitk_reduce_kernel");
         }
     }
-    hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8, SADDR>), dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
+    hipLaunchKernelGGL((gemm_pq_kernel<MODE, FP8, SADDR, QOUT>), dim3(nblk < wgs ? nblk : wgs), dim3(512), smem, stream, p);
     return bagel_check_launch("gemm_pq_kernel");
 }
 
@@ -1420,4 +1465,29 @@ extern "C" int bagel_gemm_fp8_bf16(const void* Aq, int64_t lda_bytes, const floa
     if (R) return launch_gemm_pq<1, true>(p, stream);
     if (bias) return launch_gemm_pq<2, true>(p, stream);
     return launch_gemm_pq<3, true>(p, stream);
+}
+
+// The gate/up projection of the FP8 gen expert with the SwiGLU result written as e4m3 bytes (no bf16 round trip, no stand-alone quantiser pass in front of the
+// down projection): Cq[c_rows[i], :N/2] = e4m3(clamp(swiglu(...) / cs[c_rows[i]], +-448)), cmax[c_rows[i]] = max(cmax[..], max_n |swiglu(...)|) (fp32 bits,
+// atomicMax).  DELAYED scaling: `cs` is chosen by the caller before the values exist (bagel_fp8_delayed_scales: from the previous denoise step's row maxima,
+// with headroom), `cmax` collects this step's maxima for the next one.  oracle/fp8.py restates the scheme.
+extern "C" int bagel_gemm_fp8_swiglu_q8(const void* Aq, int64_t lda_bytes, const float* sa, const void* Wq, int64_t ldw_bytes, const float* sw,
+                                        const int32_t* a_rows, const int32_t* c_rows, int32_t M, void* Cq, int64_t ldcq_bytes, const float* cs,
+                                        void* cmax, int32_t N, int32_t K, hipStream_t stream) {
+    BAGEL_REQUIRE(Aq && Wq && sa && sw && Cq && cs && cmax, "gemm_fp8_swiglu_q8: null pointer");
+    BAGEL_REQUIRE(K >= 256 && (K % 128) == 0, "gemm_fp8_swiglu_q8: K=%d must be a multiple of 128 (>= 256)", K);
+    BAGEL_REQUIRE(N > 0 && (N % 32) == 0, "gemm_fp8_swiglu_q8: N=%d must be a multiple of 32", N);
+    BAGEL_REQUIRE((lda_bytes % 16) == 0 && (ldw_bytes % 16) == 0 && (ldcq_bytes % 8) == 0 && (((uintptr_t)Cq) & 7) == 0,
+                  "gemm_fp8_swiglu_q8: leading dims must keep rows aligned (operands 16 bytes, the fp8 output 8)");
+    if (M <= 0) return BAGEL_OK;
+    GemmParams p;
+    p.A = (const bf16_t*)Aq; p.R = nullptr; p.C = nullptr;
+    p.lda = lda_bytes / 2; p.ldw = ldw_bytes / 2; p.ldr = 0; p.ldc = 0;
+    p.N = N; p.K = K / 2; p.epi = EPI_SWIGLU16;
+    p.sa = sa; p.sw = sw;
+    p.Cq = (unsigned char*)Cq; p.ldcq = ldcq_bytes; p.cs = cs; p.cmax = (unsigned*)cmax;
+    p.ngroups = 1;
+    p.g[0] = GemmGroup{(const bf16_t*)Wq, nullptr, a_rows, c_rows, M, 0};
+    p.g[1] = p.g[0];
+    return launch_gemm_pq<0, true, false, true>(p, stream);
 }

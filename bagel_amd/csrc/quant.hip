@@ -353,6 +353,25 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_reg_kernel(const bf16_t
     }
 }
 
+// Delayed scaling of the FP8 gen expert's SwiGLU output (bagel_gemm_fp8_swiglu_q8): turn the row maxima one denoise step collected into the scales the next
+// step quantises with -- scale = margin * amax / 448 (margin 2: one binade of headroom for a row that grows between two steps; 1.0 where nothing was seen) --
+// and clear the maxima for the step that follows.  `rows`: the physical rows in use (NULL = 0..n-1).
+__global__ __launch_bounds__(256) void fp8_delayed_scales_kernel(unsigned* __restrict__ amax, float* __restrict__ scale, const int* __restrict__ rows, int n, float k) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = rows ? rows[i] : i;
+    const float a = __uint_as_float(amax[r]);
+    scale[r] = a > 0.f ? a * k : 1.0f;
+    amax[r] = 0u;
+}
+extern "C" int bagel_fp8_delayed_scales(void* amax, float* scale, const int32_t* rows, int32_t n, float margin, hipStream_t stream) {
+    BAGEL_REQUIRE(amax && scale, "fp8_delayed_scales: null pointer");
+    BAGEL_REQUIRE(margin >= 1.0f, "fp8_delayed_scales: margin %g < 1 would clip the values the scale was measured on", (double)margin);
+    if (n <= 0) return BAGEL_OK;
+    hipLaunchKernelGGL(fp8_delayed_scales_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, (unsigned*)amax, scale, (const int*)rows, n, margin / 448.0f);
+    return bagel_check_launch("fp8_delayed_scales_kernel");
+}
+
 extern "C" int bagel_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq_bytes, float* scale, int32_t rows, int32_t cols,
                                        hipStream_t stream) {
     BAGEL_REQUIRE(x && q && scale, "quantize_rows_fp8: null pointer");

@@ -18,7 +18,7 @@ from ... import ops
 from ...data.data_utils import (get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
 from .modeling_utils import MLPconnector, PositionEmbedding, TimestepEmbedder
 from ..cache_utils.taylorseer import TaylorSeerState
-from .qwen2_navit import NaiveCache, _Linear, concat_plans
+from .qwen2_navit import Fp8DelayedScales, NaiveCache, _Linear, concat_plans
 
 BF16 = torch.bfloat16
 
@@ -131,6 +131,7 @@ class Bagel(nn.Module):
         self.cfg_batched = os.environ.get("BAGEL_CFG_BATCH", "1") == "1"
         self.und_side_path = os.environ.get("BAGEL_UND_SIDE", "1") == "1"
         self.step_hook = None          # optional callable(steps_taken, x_t) inside generate_image (trajectory tests / tooling)
+        self.fp8_delayed_scaling = os.environ.get("BAGEL_FP8_DELAYED", "1") != "0"   # gen_weight_quant = "fp8": delayed row scales for the SwiGLU output (qwen2_navit.Fp8DelayedScales)
         self.velocity_hook = None      # optional callable(batched: bool, [v_cond, v_cfg_text | None, v_cfg_img | None]) inside every Euler step, BEFORE the CFG
         #                                combine: the per-stream velocities of the forward(s) the step just ran (LIVE bf16 buffers) -- parity gates of the timed path
         self.global_renorm_allreduce = False      # see _renorm_sums_allreduce
@@ -423,6 +424,8 @@ class Bagel(nn.Module):
         self.language_model.engine(check=True)                  # re-pack if the parameters changed since the last call
         taylor = [TaylorSeerState(num_timesteps) for _ in range(3)] if enable_taylorseer else [None, None, None]
         self._last_taylor_states = taylor
+        # FP8 gen expert: one delayed-scale state per forward stream (sequential steps) + one for the stream-batched forward (its rows are all the streams')
+        f8 = [Fp8DelayedScales() for _ in range(4)] if (self.gen_weight_quant == "fp8" and self.fp8_delayed_scaling) else [None] * 4
         if cfg_renorm_type not in ops.RENORM_MODES:
             raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
         st = self._flow_state(packed_text_ids, packed_text_indexes, packed_vae_position_ids, packed_vae_token_indexes,
@@ -462,7 +465,7 @@ class Bagel(nn.Module):
             self._flow_step(st, x_t, float(t), float(dts[i]), plan, past_key_values,
                             plan_t if s_t > 1.0 else None, cfg_text_past_key_values,
                             plan_i if (s_t > 1.0 and s_i > 1.0) else None, cfg_img_past_key_values,
-                            s_t, s_i, cfg_renorm_min, mode, taylor, multi)
+                            s_t, s_i, cfg_renorm_min, mode, taylor, multi, f8)
             if self.step_hook is not None:     # test / tooling aid (trajectory parity): called with (Euler steps taken, x_t) -- x_t is the LIVE buffer
                 self.step_hook(i + 1, x_t)
         return x_t.split([int(n) - 2 for n in packed_seqlens.tolist()])
@@ -517,15 +520,15 @@ class Bagel(nn.Module):
             tmp=torch.empty((nv, self.patch_latent_dim), dtype=BF16, device=dev),
             partials=torch.empty((2 * 256,), dtype=torch.float32, device=dev), embedded=False)
 
-    def _velocity(self, st, plan, cache, out, taylor=None):
+    def _velocity(self, st, plan, cache, out, taylor=None, fp8_state=None):
         """llm2vae(backbone(seq))[latent rows] -> out (bagel.py:820-833)."""
         h = self.language_model.engine().forward(st["seq"], plan, "gen" if self.use_moe else "und", cache, update=False,
-                                                 causal=False, taylor=taylor, gen_quant=self.gen_weight_quant)
+                                                 causal=False, taylor=taylor, gen_quant=self.gen_weight_quant, fp8_state=fp8_state)
         ops.gemm(h, self.llm2vae.weight.data, out, bias0=self.llm2vae.bias.data, a_rows0=st["vae_rows"], M0=out.shape[0])
         return out
 
     def _flow_step(self, st, x_t, t, dt, plan, cache, plan_t, cache_t, plan_i, cache_i, s_t, s_i, renorm_min, mode,
-                   taylor=(None, None, None), multi=None):
+                   taylor=(None, None, None), multi=None, f8=(None, None, None, None)):
         """One Euler step of bagel.py:698-746 (= _forward_flow + the update), all on the current stream."""
         seq = st["seq"]
         if not st["embedded"]:      # marker-token rows never change across steps
@@ -539,7 +542,7 @@ class Bagel(nn.Module):
                 multi["seq"][s * M:(s + 1) * M].copy_(seq)
             h = self.language_model.engine().forward(multi["seq"], multi["plan"], "gen" if self.use_moe else "und", multi["cache"],
                                                      update=False, causal=False, taylor=list(taylor[:S]) if taylor[0] is not None else None,
-                                                     gen_quant=self.gen_weight_quant)
+                                                     gen_quant=self.gen_weight_quant, fp8_state=f8[3])
             for s in range(S):
                 ops.gemm(h, self.llm2vae.weight.data, st["v"][s], bias0=self.llm2vae.bias.data, a_rows0=multi["vae_rows"][s],
                          M0=st["v"][s].shape[0])
@@ -550,10 +553,10 @@ class Bagel(nn.Module):
             nparts = self._renorm_sums_allreduce(st["partials"], nparts, mode)
             ops.cfg_stage2_euler(x_t, st["tmp"], st["partials"], nparts, renorm_min, dt, use_global_scale=(mode == 0))
             return
-        v = self._velocity(st, plan, cache, st["v"][0], taylor[0])
+        v = self._velocity(st, plan, cache, st["v"][0], taylor[0], f8[0])
         if plan_t is not None:
-            v_ct = self._velocity(st, plan_t, cache_t, st["v"][1], taylor[1])
-            v_ci = self._velocity(st, plan_i, cache_i, st["v"][2], taylor[2]) if plan_i is not None else None
+            v_ct = self._velocity(st, plan_t, cache_t, st["v"][1], taylor[1], f8[1])
+            v_ci = self._velocity(st, plan_i, cache_i, st["v"][2], taylor[2], f8[2]) if plan_i is not None else None
             if self.velocity_hook is not None:
                 self.velocity_hook(False, [v, v_ct, v_ci])
             nparts = ops.cfg_stage1(v, v_ct, v_ci, st["tmp"], st["partials"], s_t, s_i, renorm_min, mode)

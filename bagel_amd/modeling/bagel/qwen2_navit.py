@@ -793,6 +793,24 @@ class _StoredLayers:
         return sum(q.numel() * q.element_size() + sc.numel() * sc.element_size() for st in self.stored for ms in st.values() for q, sc in ms)
 
 
+class Fp8DelayedScales:
+    """State of the DELAYED row scales of the FP8 gen expert's SwiGLU output across the forwards of ONE stream set of a denoise loop (the same latent rows at
+    consecutive timesteps): per layer and physical row the max |value| the last forward saw (collected by the gate/up GEMM's epilogue with atomicMax) and the
+    scale in use.  ``margin`` = headroom factor between what was seen and what fits the e4m3 range (2.0: a row may double between two steps before it
+    saturates -- saturates, not overflows: the epilogue clamps).  ``oracle/fp8.py::DelayedScales`` restates the scheme."""
+
+    def __init__(self, margin=2.0):
+        self.margin = float(margin)
+        self.amax = self.scale = None
+        self.primed = False
+
+    def fit(self, layers, rows, device):
+        if self.amax is None or self.amax.shape != (layers, rows) or self.amax.device != torch.device(device):
+            self.amax = torch.zeros((layers, rows), dtype=torch.float32, device=device)
+            self.scale = torch.ones((layers, rows), dtype=torch.float32, device=device)
+            self.primed = False
+
+
 class MoTEngine:
     """Owns the MI355X-layout copies of a Qwen2Model's weights and runs forward_inference on them."""
 
@@ -947,7 +965,7 @@ class MoTEngine:
         return self._fp8
 
     def forward(self, seq, plan: ForwardPlan, mode="und", cache: NaiveCache = None, update=True, causal=True,
-                num_layers=None, taylor=None, final_norm=True, gen_quant=None):
+                num_layers=None, taylor=None, final_norm=True, gen_quant=None, fp8_state=None):
         """Qwen2Model.forward_inference (qwen2_navit.py:1018-1092).  ``seq`` is not modified.
         ``taylor``: a TaylorSeerState (cache_utils/taylorseer.py) -> the TaylorSeer hooks of :1034-1037,1057-1061,
         1086-1087 are active: a 'full' step runs the layers and refreshes the feature cache, a 'Taylor' step replaces
@@ -1000,7 +1018,7 @@ class MoTEngine:
         # row tiles), so the marker rows travel beside it as a small dense matrix [n_text, H]: their projections are weight-streaming
         # skinny GEMMs, their q/k/v rows are scattered into the fused projection buffer before the attention and their attention
         # rows gathered after it.  Same operators, same rounding points; only the GEMM kernel that serves those rows differs.
-        fp8 = None
+        fp8 = delayed = None
         if gen_quant is not None and nl > 0 and gen:
             if gen_quant != "fp8":
                 raise NotImplementedError(f"gen_weight_quant={gen_quant!r}: only 'fp8' (OCP e4m3, row-wise scales) is built")
@@ -1014,6 +1032,13 @@ class MoTEngine:
                 if len(self._ws_fp8) > 3:
                     self._ws_fp8.pop(next(iter(self._ws_fp8)))
                 fw = self._ws_fp8[plan.M] = dict(hq=u8(plan.M, self.H), sh=f32(), aq=u8(plan.M, nq * dp), sa=f32(), cq=u8(plan.M, self.I), sc=f32())
+            # DELAYED scaling of the SwiGLU output (Fp8DelayedScales: a denoise loop hands the same state to every step of one forward stream set): from the
+            # second forward on the gate/up GEMM writes e4m3 bytes itself, scaled by what the previous step's rows reached -- no bf16 round trip of the
+            # [M, I] activation and no quantiser pass in front of the down projection.  The first forward (no history) and callers without a state take the
+            # exact path and, with a state, leave their row maxima behind.
+            if fp8_state is not None:
+                fp8_state.fit(nl, plan.M, self.device)
+                delayed = fp8_state
         side = bool(gen_attn and (plan.und_side or fp8 is not None) and nl > 0 and 2 <= plan.n_text <= ops.SKINNY_MAX_ROWS)
         if side:
             nt = plan.n_text
@@ -1076,9 +1101,17 @@ class MoTEngine:
                     ops.rmsnorm(xu, P.ln_post[0], hu, self.eps)
                     ops.rmsnorm_fp8(x, P.ln_post[1], fw["hq"], fw["sh"], self.eps)
                     ops.gemm(hu, P.wgu[0], actu, epilogue=ops.EPI_SWIGLU16)
+                    if delayed is not None and delayed.primed:
+                        ops.fp8_delayed_scales(delayed.amax[li], delayed.scale[li], rows=plan.vae_idx, n=plan.n_vae, margin=delayed.margin)
+                        ops.gemm_fp8_swiglu_q8(fw["hq"], fw["sh"], Q["wgu"][0], Q["wgu"][1], fw["cq"], delayed.scale[li], delayed.amax[li], rows=plan.vae_idx, M=plan.n_vae)
+                        ops.gemm(actu, P.wd[0], xu, residual=xu)
+                        ops.gemm_fp8(fw["cq"], delayed.scale[li], Q["wd"][0], Q["wd"][1], x, rows=plan.vae_idx, M=plan.n_vae, residual=x)
+                        continue
                     ops.gemm_fp8(fw["hq"], fw["sh"], Q["wgu"][0], Q["wgu"][1], act, rows=plan.vae_idx, M=plan.n_vae, epilogue=ops.EPI_SWIGLU16)
                     ops.gemm(actu, P.wd[0], xu, residual=xu)
                     ops.quantize_rows_fp8(act, fw["cq"], fw["sc"])
+                    if delayed is not None:          # the exact scale is rowmax / 448: leave the row maxima for the next forward
+                        torch.mul(fw["sc"], 448.0, out=delayed.amax[li])
                     ops.gemm_fp8(fw["cq"], fw["sc"], Q["wd"][0], Q["wd"][1], x, rows=plan.vae_idx, M=plan.n_vae, residual=x)
                     continue
                 ops.gemm(att, C=x, residual=x, **gen_only(P.wo))
@@ -1095,6 +1128,8 @@ class MoTEngine:
             ops.gemm(act, C=x, residual=x, **groups(P.wd, None, gen))
         if side:
             ops.copy_rows(xu, x, nt, self.H, dst_rows=plan.text_idx)
+        if delayed is not None:
+            delayed.primed = True            # every layer has left its rows' maxima behind: the next forward of this stream set quantises with them
         if taylor is not None:
             if not skip_layers:
                 taylor.update(x)

@@ -397,6 +397,37 @@ def gemm_fp8(Aq, sa, Wq, sw, C, *, bias=None, rows=None, M=None, residual=None, 
     return C
 
 
+def gemm_fp8_swiglu_q8(Aq, sa, Wq, sw, Cq, cs, cmax, *, rows=None, M=None):
+    """The FP8 gen expert's gate/up projection with the SwiGLU result written as e4m3 bytes under a DELAYED row scale: Cq[rows] =
+    e4m3(clamp(swiglu(sa[rows] * sw * (Aq[rows] @ Wq^T)) / cs[rows], +-448)), cmax[rows] = max(cmax[rows], rowmax |swiglu(..)|) (fp32 bit patterns);
+    see bagel_gemm_fp8_swiglu_q8 / fp8_delayed_scales."""
+    _req(Aq, torch.uint8, "gemm_fp8_swiglu_q8.Aq"); _req(Wq, torch.uint8, "gemm_fp8_swiglu_q8.Wq"); _req(Cq, torch.uint8, "gemm_fp8_swiglu_q8.Cq")
+    for t, n in ((sa, "sa"), (sw, "sw"), (cs, "cs"), (cmax, "cmax")):
+        _req(t, torch.float32, "gemm_fp8_swiglu_q8." + n)
+    N, K = Wq.shape
+    if Aq.shape[-1] != K or sw.numel() != N or Cq.shape[-1] < N // 2 or min(sa.numel(), cs.numel(), cmax.numel()) < Aq.shape[0] or Cq.shape[0] < Aq.shape[0]:
+        raise BagelHipError("gemm_fp8_swiglu_q8: shape mismatch")
+    if rows is not None:
+        _req(rows, torch.int32, "gemm_fp8_swiglu_q8.rows")
+    if M is None:
+        M = rows.numel() if rows is not None else Aq.shape[0]
+    check(lib().bagel_gemm_fp8_swiglu_q8(_ptr(Aq), Aq.stride(0), _ptr(sa), _ptr(Wq), Wq.stride(0), _ptr(sw), _ptr(rows), _ptr(rows), M,
+                                         _ptr(Cq), Cq.stride(0), _ptr(cs), _ptr(cmax), N, K, _stream()), "bagel_gemm_fp8_swiglu_q8")
+    return Cq
+
+
+def fp8_delayed_scales(amax, scale, *, rows=None, n=None, margin=2.0):
+    """scale[r] = margin * amax[r] / 448 (1.0 where amax is 0) and amax[r] = 0 for the rows in use: the step between two denoise forwards of the delayed
+    scaling (bagel_fp8_delayed_scales); ``amax`` holds non-negative fp32 values collected by atomicMax on their bit patterns."""
+    _req(amax, torch.float32, "fp8_delayed_scales.amax"); _req(scale, torch.float32, "fp8_delayed_scales.scale")
+    if rows is not None:
+        _req(rows, torch.int32, "fp8_delayed_scales.rows")
+    if n is None:
+        n = rows.numel() if rows is not None else amax.numel()
+    check(lib().bagel_fp8_delayed_scales(_ptr(amax), _ptr(scale), _ptr(rows), n, float(margin), _stream()), "bagel_fp8_delayed_scales")
+    return scale
+
+
 def gemv_w8(A, Wq, scale, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0):
     """``gemv`` on row-wise INT8 weights (u8 + fp32 scales), activations bf16; see bagel_gemv_w8_bf16."""
     _req(A, BF16, "gemv_w8.A"); _req(Wq, torch.uint8, "gemv_w8.Wq"); _req(scale, torch.float32, "gemv_w8.scale"); _req(C, BF16, "gemv_w8.C")

@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--no-int8", action="store_true", help="understanding leg: skip the extra weight_quant='int8_rowwise' / 'mxfp4' decodes")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra gen_weight_quant='fp8' measurement")
     ap.add_argument("--no-edit", action="store_true", help="skip the extra configs[4] measurement (one image-edit request per GPU)")
+    ap.add_argument("--edit-batch", type=int, default=2, help="edit.batched: this many edit requests per GPU served as one batch (beside the one-request latency)")
     ap.add_argument("--weight-store", choices=["nf4", "int8_rowwise"], default=None,
                     help="option that changes results (line flagged invalid): the reference's quantised load modes (app.py:114-131) over the WHOLE forward "
                          "path -- Bagel.quantize_language_model before the timed region; skips the fp8 / training / understanding legs")
@@ -378,6 +379,15 @@ def resident_weight_bytes(model, vae=None):
             packed["llm." + name] = nbytes([t for P in eng.layers for t in getattr(P, name)]) / 2 ** 30
     except Exception as e:        # a quantised store has another layout: reported as such
         packed["llm"] = repr(e)
+    try:                          # the SigLIP tower's packed copies exist once it has run (heads padded 72 -> 128, MLP width padded to the k-tile)
+        vp = getattr(model.vit_model, "_packed", None)
+        if vp:
+            for name in ("wqkv", "bqkv", "wo"):
+                packed["vit." + name] = nbytes([L[name] for L in vp["layers"]]) / 2 ** 30
+            packed["vit.fc1p"] = nbytes([L["fc1p"][0] for L in vp["layers"]] + [L["fc1p"][1] for L in vp["layers"]]) / 2 ** 30
+            packed["vit.fc2p"] = nbytes([L["fc2p"][0] for L in vp["layers"]]) / 2 ** 30
+    except Exception as e:
+        packed["vit"] = repr(e)
     out["packed_copies_gb"] = packed
     out["packed_copies_total_gb"] = sum(v for v in packed.values() if isinstance(v, float))
     return out
@@ -1346,7 +1356,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
                         f"prompt tokens prefill, greedy decode of {n} tokens, bf16, batch {UB}/GPU"}
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
 
 
 def _source_digest(names):
@@ -1396,10 +1406,11 @@ def attention_object(arecords, args, R):
     fl = sum(r[0] for r in big)
     ms = sum(r[1].elapsed_time(r[2]) for r in big)
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    out = {"kernel": "attn2_kernel<128> (+ attn2_combine_kernel<128>)", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+    out = {"kernel": "attn2_kernel<128, false> (+ attn2_combine_kernel<128>)", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
            "frac": ach / PEAK_BF16_TFLOPS, "launches": len(big), "avg_launch_ms": ms / len(big), "samples_per_launch": big[0][3]}
     d = _pmc_entry("attention", None, ["attention2.hip", "common.h"]) if (args.workload == "t2i" and args.batch == 4 and R == 1024) else None
-    k = (d or {}).get("kernels", {}).get("attn2_kernel<128>")
+    ks = (d or {}).get("kernels", {})
+    k = ks.get("attn2_kernel<128, false>") or ks.get("attn2_kernel<128>")          # (round 6: a second template argument; "false" = the unified ring the product launches)
     if k:
         out["traffic"] = k.get("traffic_bytes_per_launch_corrected")
         out["pmc"] = {x: k.get(x) for x in ("mfma_busy_frac", "l2_hit_rate", "wave_cycles_split", "algorithmic_bytes_per_launch")}
@@ -1664,7 +1675,7 @@ def main():
     # ---- memory, the reference's only published figure for this path ("80 GiB is sufficient": app.py:77 max_memory, README.md:139-151): ONE text->image request
     #      (B = 1, full resolution, VAE decode included; 3 timesteps reach the same peak as 50) in a process that holds nothing but the model -- before any B = 4 workspace exists
     mem_b1 = None
-    if cuda and args.workload == "t2i" and not args.standins and world == 1:
+    if cuda and args.workload == "t2i" and not args.standins and world == 1 and args.layers is None:      # (not under the debug flags of the PMC passes: its B = 1 launches would dilute their per-kernel averages)
         try:
             one_step(B=1, T=3)
             one_step(B=1, T=3)
@@ -1779,28 +1790,47 @@ def main():
             # o / down projections run 5.25 rounds of the 256 persistent workgroups instead of 2.63, qkv 6.75 instead of 3.375 -- the partial last rounds that
             # idle 12-16 % of the chip at one request).  The batch driver of the reference serves one image per rank at a time (gen_images_mp_imgedit.py:278-303).
             try:
+                NB = args.edit_batch
+                breqs = tuple(range(NB))
+
                 def same_as_single(nt=3):
-                    """Each sample of the two-request batch against its own single-request run (``nt`` timesteps): identical up to fp32 summation order where
-                    a GEMM tile or an attention item is split differently in the two launches."""
-                    both, _ = edit_step(timesteps=nt, reqs=(0, 1))
+                    """Each sample of the batch against its own single-request run (``nt`` timesteps).  The launches of the two runs cut their work differently
+                    (another row count: other GEMM tiles are K-split, the attention planner splits other items along the key axis), so a sample's arithmetic
+                    differs in fp32 summation ORDER only: its three per-stream velocities of the FIRST Euler step -- before any CFG amplification -- are compared
+                    (a single forward's accumulation-order noise is ~1e-2 at this depth, bench.FULL_DEPTH_TOL_FORWARD = 2.4e-2), and the latents after ``nt - 1``
+                    steps, where CFG 4.0 x 2.0 has amplified that noise like it does between any two execution orders of the same request."""
+                    got = {}
+
+                    def hook(batched, vs):
+                        if "vs" not in got:
+                            got["vs"] = [None if v is None else v.float().clone() for v in vs]
                     res = []
-                    for i in (0, 1):
-                        one, _ = edit_step(timesteps=nt, reqs=(i,))
-                        a, b_ = both[i].float(), one[0].float()
-                        res.append({"bit_identical": bool(torch.equal(a, b_)), "rel_l2": float((a - b_).norm() / b_.norm()), "elements_differing": int((a != b_).sum())})
+                    try:
+                        model.velocity_hook = hook
+                        both, _ = edit_step(timesteps=nt, reqs=breqs)
+                        vb = got.pop("vs")
+                        for i in breqs:
+                            one, _ = edit_step(timesteps=nt, reqs=(i,))
+                            v1 = got.pop("vs")
+                            a, b_ = both[i].float(), one[0].float()
+                            n1 = v1[0].shape[0]
+                            res.append({"first_step_velocity_rel_l2_per_stream": [float((vb[s_][i * n1:(i + 1) * n1] - v1[s_]).norm() / v1[s_].norm()) for s_ in range(3)],
+                                        "latents_bit_identical": bool(torch.equal(a, b_)), "latents_rel_l2": float((a - b_).norm() / b_.norm())})
+                    finally:
+                        model.velocity_hook = None
                     return res
                 same = same_as_single()
-                edit_step(timesteps=3, reqs=(0, 1))
-                (lat_b, _), dt_b, mem_b = timed_steady(lambda: edit_step(reqs=(0, 1)), dev, fence)
+                edit_step(timesteps=3, reqs=breqs)
+                (lat_b, _), dt_b, mem_b = timed_steady(lambda: edit_step(reqs=breqs), dev, fence)
                 if world > 1:
                     tt = torch.tensor([dt_b], dtype=torch.float64, device=dev)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     dt_b = float(tt.item())
-                edit["batched"] = unsteady({"value": 2 * world / dt_b, "unit": "images/s", "requests_per_gpu": 2, "seconds_per_batch": dt_b, "seconds_per_image": dt_b / 2,
-                                            "speedup_over_one_request_per_gpu": (2 / dt_b) / (1 / dt_e), "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_b),
+                edit["batched"] = unsteady({"value": NB * world / dt_b, "unit": "images/s", "requests_per_gpu": NB, "seconds_per_batch": dt_b, "seconds_per_image": dt_b / NB,
+                                            "speedup_over_one_request_per_gpu": (NB / dt_b) / (1 / dt_e), "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_b),
                                             "each_sample_vs_its_single_request_run": same, "memory": mem_b,
-                                            "whole_path_roofline_frac": 2 * pf / dt_b / 1e12 / PEAK_BF16_TFLOPS,
-                                            "note": "two independent edit requests (own images, prompts' contexts, noise) served as one batch: THROUGHPUT, beside the "
+                                            "whole_path_roofline_frac": NB * pf / dt_b / 1e12 / PEAK_BF16_TFLOPS,
+                                            "note": f"{NB} independent edit requests (own images, contexts, noise) served as one NaViT batch: THROUGHPUT, beside the "
                                                     "one-request latency above, never as it"}, mem_b)
             except Exception as e:
                 import traceback

@@ -275,6 +275,16 @@ int bagel_rmsnorm_fp8(const void* x, int64_t ldx, const void* w, void* q, int64_
 int bagel_gemm_fp8_bf16(const void* Aq, int64_t lda_bytes, const float* sa, const void* Wq, int64_t ldw_bytes, const float* sw,
                         const void* bias, const int32_t* a_rows, const int32_t* c_rows, int32_t M, const void* R, int64_t ldr,
                         void* C, int64_t ldc, int32_t N, int32_t K, int32_t epilogue, bagel_stream_t stream);
+/* The FP8 gen expert's gate/up projection with the SwiGLU result written as e4m3 bytes -- no bf16 round trip and no quantiser pass in front of the down
+ * projection (modeling_qwen2.py:200-201 on the gen expert, option gen_weight_quant = "fp8"): Cq[c_rows[i], n] = e4m3(clamp(swiglu(..)[i, n] / cs[c_rows[i]], +-448)),
+ * n < N / 2, and cmax[c_rows[i]] = max(cmax[c_rows[i]], max_n |swiglu(..)[i, n]|) as fp32 bit patterns (atomicMax on uint32: non-negative floats order like
+ * integers).  DELAYED scaling: the scale of a row is chosen BEFORE its values exist -- bagel_fp8_delayed_scales derives it from the row maxima the previous
+ * denoise step collected (scale = margin * amax / 448; 1.0 where nothing was seen) and clears the maxima for the step that follows; the first step of a
+ * request has no history and takes the exact path (bagel_gemm_fp8_bf16 + bagel_quantize_rows_fp8).  oracle/fp8.py restates the scheme. */
+int bagel_gemm_fp8_swiglu_q8(const void* Aq, int64_t lda_bytes, const float* sa, const void* Wq, int64_t ldw_bytes, const float* sw,
+                             const int32_t* a_rows, const int32_t* c_rows, int32_t M, void* Cq, int64_t ldcq_bytes, const float* cs,
+                             void* cmax, int32_t N, int32_t K, bagel_stream_t stream);
+int bagel_fp8_delayed_scales(void* amax, float* scale, const int32_t* rows, int32_t n, float margin, bagel_stream_t stream);
 
 /* Paged KV cache (64-token pages; token j of sample b at pool row block_table[b*bt_stride + j/64]*64 + j%64).
  * Appends this step's K/V row of every sample at slot kv_len[b] (device memory) -- the in-place form of the

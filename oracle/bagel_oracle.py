@@ -61,6 +61,8 @@ LINEAR_FP32_ACCUM = False
 # FP8 option of the product (model.gen_weight_quant = "fp8", oracle/fp8.py): data_ptr()s of the weight tensors whose linear runs on
 # e4m3 operands with row-wise scales (the gen expert's q/k/v/o/gate/up/down projections).  Empty = the reference's arithmetic.
 FP8_WEIGHT_PTRS = set()
+# ... and, inside a denoise loop, the DELAYED row scales of the SwiGLU output (oracle/fp8.py DelayedScales; None = every input gets its exact row-wise scale)
+FP8_DELAYED = None
 
 
 def fp8_gen_weight_ptrs(W):
@@ -107,7 +109,10 @@ def linear(x, w, b=None):
     if FP8_WEIGHT_PTRS and w.data_ptr() in FP8_WEIGHT_PTRS:
         from oracle import fp8 as F8
         x2 = x.to(w.dtype).reshape(-1, x.shape[-1])
-        qa, sa = F8.quantize_rows_fp8(x2)
+        if FP8_DELAYED is not None and w.data_ptr() in FP8_DELAYED.ptrs:
+            qa, sa = FP8_DELAYED.quantize(w.data_ptr(), x2)
+        else:
+            qa, sa = F8.quantize_rows_fp8(x2)
         qw, sw = F8.quantize_rows_fp8(w)
         return F8.gemm_fp8(qa, sa, qw, sw, bias=None if b is None else b.to(w.dtype)).reshape(*x.shape[:-1], w.shape[0])
     if LINEAR_FP32_ACCUM:
@@ -578,6 +583,8 @@ def generate_image(W, cfg, gi, cache, cfg_text=None, cfg_img=None, num_timesteps
         if max_steps is not None and i >= max_steps:
             break
         timestep = torch.tensor([t] * x_t.shape[0])
+        if FP8_DELAYED is not None:
+            FP8_DELAYED.begin_step()
         if t > cfg_interval[0] and t <= cfg_interval[1]:
             s_t, s_i = cfg_text_scale, cfg_img_scale
         else:

@@ -7,6 +7,15 @@ scheme the kernels implement so the tests can check them bit for bit (quantiser)
     scale[r]  = max_k |x[r, k]| / 448                    (448 = largest finite e4m3fn value)
     q[r, k]   = e4m3fn(round-to-nearest-even(x[r, k] * (1 / scale[r])))
     C[m, n]   = epilogue( (sa[m] * sw[n]) * sum_k q_a[m, k] * q_w[n, k] )        fp32 accumulation, epilogues of the bf16 GEMM
+
+DELAYED scaling of the SwiGLU output (round 6; the down projection's input inside a denoise loop -- ``DelayedScales`` below): from the second forward of a stream
+on, the gate/up GEMM's epilogue writes the e4m3 bytes itself, so a row's scale has to exist before its values do:
+
+    scale_t[r] = margin * amax_{t-1}[r] / 448     (margin = 2; 1.0 where amax_{t-1}[r] = 0),    amax_t[r] = max_k |x_t[r, k]|
+    q_t[r, k]  = e4m3fn(rne(clamp(x_t[r, k] * (1 / scale_t[r]), -448, 448)))
+
+with amax_{t-1} the row maxima of the SAME rows in the previous forward of the same stream; the first forward (no history) uses the exact row-wise scale above and
+leaves amax_0 = (max|row| / 448) * 448 (what the product reconstructs from the exact scale).
 """
 import torch
 
@@ -41,3 +50,37 @@ def gemm_fp8(qa, sa, qw, sw, bias=None, residual=None, swiglu=False):
     if residual is not None:
         c = residual + c
     return c
+
+
+class DelayedScales:
+    """Restates bagel_amd.modeling.bagel.qwen2_navit.Fp8DelayedScales + the fp8-output epilogue of bagel_gemm_fp8_swiglu_q8 + bagel_fp8_delayed_scales for the
+    oracle's sequential forwards: the history of a (weight, call index within the Euler step) pair is the history of one forward stream's rows at one layer.
+    ``ptrs``: data_ptr()s of the weights whose INPUT is quantised this way (the gen expert's down projections); ``begin_step()`` once per Euler step."""
+
+    def __init__(self, ptrs, margin=2.0):
+        self.ptrs, self.margin = set(ptrs), float(margin)
+        self.hist, self.calls = {}, {}
+
+    def begin_step(self):
+        self.calls = {}
+
+    def quantize(self, key, x):
+        i = self.calls.get(key, 0)
+        self.calls[key] = i + 1
+        prev = self.hist.get((key, i))
+        xf = x.float()
+        if prev is None:                                   # no history: the exact scheme; the product keeps scale * 448 as the rows' maxima
+            q, scale = quantize_rows_fp8(x)
+            self.hist[(key, i)] = scale * torch.tensor(448.0)
+            return q, scale
+        k = torch.tensor(self.margin, dtype=torch.float32) / torch.tensor(448.0, dtype=torch.float32)
+        scale = torch.where(prev > 0, prev * k, torch.ones_like(prev))
+        inv = 1.0 / scale
+        q = (xf * inv[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+        self.hist[(key, i)] = xf.abs().amax(dim=1)
+        return q.view(torch.uint8), scale
+
+
+def down_proj_gen_ptrs(W):
+    """The weights whose input the product quantises with DELAYED scales: the gen expert's down projections."""
+    return {v.data_ptr() for k, v in W.items() if "language_model.model.layers." in k and k.endswith("mlp_moe_gen.down_proj.weight")}

@@ -55,6 +55,53 @@ def test_gemm_fp8_matches_dequantised_product(M, N, K, mode):
         assert e < 6e-2, e
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (2500, 1024, 3584), (4096 + 77, 37888 // 8, 3584), (32768, 512, 3584)])
+def test_gemm_fp8_swiglu_with_fp8_output_and_delayed_scales(M, N, K):
+    """bagel_gemm_fp8_swiglu_q8 + bagel_fp8_delayed_scales against the restatement (oracle/fp8.py DelayedScales): given the previous step's row maxima, the scale
+    kernel's output bit for bit; the e4m3 codes of the SwiGLU result equal to the restatement's applied to the bf16 SwiGLU result of bagel_gemm_fp8_bf16 (the SAME
+    kernel's bf16 output: an exact per-element statement of the epilogue) except where that bf16 value sits on a rounding boundary of the code; the collected row
+    maxima exact; rows outside the row list untouched; values past the delayed scale's headroom SATURATE at +-448 (no NaN codes)."""
+    g = torch.Generator().manual_seed(M + N + 1)
+    A = torch.randn(M + 6, K, generator=g).to(BF16)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(BF16)
+    rows = torch.tensor([i for i in range(M + 6) if i not in (0, 7, 100, 101, 255, 256)][:M], dtype=torch.int32)
+    r = rows.long()
+    qa, sa = F8.quantize_rows_fp8(A)
+    qw, sw = F8.quantize_rows_fp8(W)
+    o = ops()
+    # the kernel's own bf16 SwiGLU output = what the fp8-output epilogue quantises
+    act = torch.zeros((M + 6, N // 2), dtype=BF16, device=DEV)
+    o.gemm_fp8(qa.to(DEV), sa.to(DEV), qw.to(DEV), sw.to(DEV), act, rows=rows.to(DEV), epilogue=o.EPI_SWIGLU16)
+    act = act.cpu()
+    true_amax = act.float().abs().amax(1)
+    # "previous step": maxima off by random factors in [0.3, 1.6] -> some rows exceed the 2x headroom (saturation), row 3 of the list has no history (0 -> scale 1)
+    prev = true_amax * (0.3 + 1.3 * torch.rand(M + 6, generator=g))
+    prev[r[3]] = 0.0
+    amax = prev.clone().to(DEV)
+    scale = torch.full((M + 6,), -1.0, device=DEV)
+    o.fp8_delayed_scales(amax, scale, rows=rows.to(DEV), margin=2.0)
+    k = torch.tensor(2.0) / torch.tensor(448.0)
+    want_scale = torch.where(prev > 0, prev * k, torch.ones_like(prev))
+    assert torch.equal(scale.cpu()[r], want_scale[r]) and (scale.cpu()[[0, 7]] == -1.0).all() and (amax.cpu()[r] == 0).all() and torch.equal(amax.cpu()[[0, 7]], prev[[0, 7]])
+    Cq = torch.full((M + 6, N // 2), 0x7f, dtype=torch.uint8, device=DEV)           # 0x7f = an e4m3 NaN code: must disappear from every listed row
+    o.gemm_fp8_swiglu_q8(qa.to(DEV), sa.to(DEV), qw.to(DEV), sw.to(DEV), Cq, scale, amax, rows=rows.to(DEV))
+    torch.cuda.synchronize()
+    got = Cq.cpu()
+    inv = 1.0 / want_scale
+    y = (act.float() * inv[:, None]).clamp(-448.0, 448.0)
+    want = y.to(torch.float8_e4m3fn)
+    gv, wv = got.view(torch.float8_e4m3fn).float()[r], want.float()[r]
+    assert torch.isfinite(gv).all(), "NaN codes in the fp8 output"
+    assert torch.equal(gv, wv), f"{int((gv != wv).sum())} of {gv.numel()} codes differ from the restatement (max |d| {float((gv - wv).abs().max())})"
+    assert torch.equal(amax.cpu()[r], true_amax[r]), "collected row maxima"
+    assert (got[[0, 7, 100]] == 0x7f).all(), "rows outside the row list were written"
+    sat = (act.float()[r].abs() * inv[r][:, None] > 448.0)
+    assert sat.any() and (gv[sat].abs() == 448.0).all(), "values past the headroom must saturate"
+    # and a second pass of the scale kernel turns the collected maxima into the next scales
+    o.fp8_delayed_scales(amax, scale, rows=rows.to(DEV), margin=2.0)
+    assert torch.equal(scale.cpu()[r], torch.where(true_amax > 0, true_amax * k, torch.ones_like(true_amax))[r])
+
+
 @pytest.mark.parametrize("rows,cols", [(7, 128), (257, 3584)])
 def test_rmsnorm_fp8_equals_rmsnorm_then_quantise(rows, cols):
     g = torch.Generator().manual_seed(cols)
@@ -70,7 +117,7 @@ def test_rmsnorm_fp8_equals_rmsnorm_then_quantise(rows, cols):
     assert torch.equal(s, s_ref) and torch.equal(q, q_ref)
 
 
-def _fp8_oracle_latents(cfg, W, g, kw):
+def _fp8_oracle_latents(cfg, W, g, kw, delayed=False):
     from oracle import bagel_oracle as O
     from oracle import packers as P
     from oracle.configs import NEW_TOKEN_IDS_TINY, StubTokenizer
@@ -85,10 +132,15 @@ def _fp8_oracle_latents(cfg, W, g, kw):
                 key_values_lens=ci["cfg_key_values_lens"], key_value_indexes=ci["cfg_packed_key_value_indexes"])
     O.FP8_WEIGHT_PTRS = O.fp8_gen_weight_ptrs(W)
     assert len(O.FP8_WEIGHT_PTRS) == 7 * L
+    if delayed:
+        from oracle import fp8 as F8o
+        O.FP8_DELAYED = F8o.DelayedScales(F8o.down_proj_gen_ptrs(W))
+        assert len(O.FP8_DELAYED.ptrs) == L
     try:
         return O.generate_image(W, cfg, g["latent_inputs"], cache, cfg_text=cfgd, **kw)
     finally:
         O.FP8_WEIGHT_PTRS = set()
+        O.FP8_DELAYED = None
 
 
 def test_model_fp8_gen_expert_matches_its_restatement(golden):
@@ -104,20 +156,23 @@ def test_model_fp8_gen_expert_matches_its_restatement(golden):
     g = golden("tiny_d128_t2i")
     W, _ = oracle_weights(cfg)
     kw = g["gen_kwargs"]
-    ref8 = _fp8_oracle_latents(cfg, W, g, kw)
+    ref8 = {False: _fp8_oracle_latents(cfg, W, g, kw), True: _fp8_oracle_latents(cfg, W, g, kw, delayed=True)}
+    print("restatement: delayed scales vs exact row scales", [f"{rel_l2(a, b):.3e}" for a, b in zip(ref8[True], ref8[False])])
     model, _ = product_model(cfg)
     tok = StubTokenizer(cfg["llm"]["vocab_size"])
     gi, _, _ = model.prepare_prompts([0, 0], [0, 0], g["prompts"], tok, NEW_TOKEN_IDS_TINY)
     cache = model.forward_cache_update_text(new_cache(cfg), **gi)
     try:
-        for batched in (True, False):
-            model.gen_weight_quant, model.cfg_batched = "fp8", batched
-            lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **kw, **g["latent_inputs"])
-            for a, b, c in zip(lat, ref8, g["latents"]):
-                assert torch.isfinite(a).all()
-                e8, e16 = rel_l2(a, b), rel_l2(a, c)
-                print(f"fp8 gen expert (cfg_batched={batched}): vs its CPU restatement {e8:.3e}; vs the bf16 reference {e16:.3e}")
-                assert e8 <= 8e-2, e8
-                assert 1e-3 < e16 < 0.5, e16            # it IS a different result, and not a wild one
+        # both schemes of the SwiGLU output's row scales -- delayed (the default inside a denoise loop, round 6) and exact -- each against ITS restatement
+        for delayed in (True, False):
+            for batched in (True, False):
+                model.gen_weight_quant, model.cfg_batched, model.fp8_delayed_scaling = "fp8", batched, delayed
+                lat = model.generate_image(past_key_values=cache, **cfg_kwargs("cfg_text", new_cache(cfg), g["cfg_inputs"]), **kw, **g["latent_inputs"])
+                for a, b, c in zip(lat, ref8[delayed], g["latents"]):
+                    assert torch.isfinite(a).all()
+                    e8, e16 = rel_l2(a, b), rel_l2(a, c)
+                    print(f"fp8 gen expert (delayed_scales={delayed}, cfg_batched={batched}): vs its CPU restatement {e8:.3e}; vs the bf16 reference {e16:.3e}")
+                    assert e8 <= 8e-2, e8
+                    assert 1e-3 < e16 < 0.5, e16            # it IS a different result, and not a wild one
     finally:
-        model.gen_weight_quant, model.cfg_batched = None, True
+        model.gen_weight_quant, model.cfg_batched, model.fp8_delayed_scaling = None, True, True

@@ -974,3 +974,85 @@ def test_bench_depth_parity_legs_run_on_the_host_path(monkeypatch):
     sc = out2["cfg_combine_self_consistency"]
     assert sc["sequential_forward_flow"] <= bench.FULL_DEPTH_TOL_COMBINE and sc["generate_image_sequential"] <= bench.FULL_DEPTH_TOL_COMBINE
     assert out2["rel_l2_cond_forward"] <= 2e-2 and out2["rel_l2_cfg_text_forward"] <= 2e-2
+    # round 6: the per-stream velocities of the stream-batched forward (the timed path) are taken out before the combine and gated like single forwards
+    for o_ in (out, out2):
+        sb = o_["stream_batched"]
+        assert sb["ran_batched"] and max(v for k, v in sb.items() if k.startswith("rel_l2_")) <= 2e-2, sb
+    assert max(out["context_kv_rel_l2_max"].values()) <= 2e-2
+    assert model.velocity_hook is None
+
+
+def test_bench_edit_request_parity_leg_runs_the_real_chain_on_the_host_path(monkeypatch):
+    """``bench.edit_depth_step(vae=...)`` -- the REAL request chain of configs[4] (VAE-encode -> gen-mode prefill -> SigLIP -> und-mode prefill -> prompt, then the
+    3-forward step) -- on the tiny model with the stand-in operators, in its three phases: inputs (host), oracle (here computed separately, as the bench's worker
+    process does, and handed in as ``oracle_out``), product + compare; and the weight fingerprint refuses an oracle that ran on other weights."""
+    import argparse
+    import importlib.util
+    import os
+    from bagel_amd.factory import build_bagel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module_edit_request", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    mock_ops.install(monkeypatch)
+    cfg = TINY_D128
+    W, VW = oracle_weights(cfg)
+    model, vae = build_bagel(cfg, device="cpu", with_vae=True)
+    model.load_state_dict(W, strict=True)
+    vae.load_state_dict(VW, strict=True)
+    model = model.to(torch.bfloat16).eval()
+    ids = NEW_TOKEN_IDS_TINY
+    args = argparse.Namespace(resolution=64)
+    monkeypatch.setattr(torch, "set_num_threads", lambda n: None)
+    side = cfg["vit"]["patch_size"] * 3
+    monkeypatch.setattr(bench.edit_depth_inputs, "__defaults__", ((576, 30), False, 5, side))     # ctx_tokens, real, prompt_tokens, vit_side: the tiny tower's image
+    inp = bench.edit_depth_inputs(args, cfg, model, ids, real=True)
+    n_vae, n_vit = (64 // 16) ** 2 + 2, 9 + 2
+    assert [int(inp[k][0][0]) for k in ("cond", "text", "img")] == [n_vae + n_vit + 7, n_vae + n_vit, 7]
+    Wk = {k: v for k, v in model.state_dict().items() if k.startswith(bench.EDIT_KEEP_REAL)}
+    ora = bench.edit_depth_oracle(cfg, Wk, {k: v.float() for k, v in vae.state_dict().items()}, inp, threads=2)
+    out = bench.edit_depth_step(args, cfg, model, ids, threads=2, vae=vae, oracle_out=ora)
+    assert out["contexts"] == [n_vae + n_vit + 7, n_vae + n_vit, 7] and "worker process" in out["oracle_ran"]
+    assert max(out["context_kv_rel_l2_max"].values()) <= 3e-2, out["context_kv_rel_l2_max"]
+    for k in ("rel_l2_cond_forward", "rel_l2_cfg_text_forward", "rel_l2_cfg_img_forward"):
+        assert out[k] <= 3e-2 and out["stream_batched"][k] <= 3e-2, (k, out[k], out["stream_batched"][k])
+    assert out["cfg_combine_self_consistency"]["sequential_forward_flow"] <= bench.FULL_DEPTH_TOL_COMBINE
+    # an oracle result from OTHER weights is refused
+    bad = dict(ora, weights={k: v + 1.0 for k, v in ora["weights"].items()})
+    with pytest.raises(RuntimeError, match="other weights"):
+        bench.edit_depth_step(args, cfg, model, ids, threads=2, vae=vae, oracle_out=bad)
+    # the understanding leg's three phases the same way
+    uargs = argparse.Namespace(und_image=side)
+    monkeypatch.setattr(bench, "und_request", lambda a: (torch.rand(3, side, side, generator=torch.Generator().manual_seed(2)) * 2 - 1,      # (the bench's prompt ids are drawn from the 7B vocabulary)
+                                                          bench.FixedTokenizer(torch.randint(8, 500, (32,), generator=torch.Generator().manual_seed(1)).tolist())))
+    uin = bench.und_depth_inputs(uargs, model, ids)
+    uW = {k: v for k, v in model.state_dict().items() if k.startswith(bench.UND_KEEP)}
+    uora = bench.und_depth_oracle(cfg, uW, uin, threads=2, n_tokens=3)
+    monkeypatch.setattr(bench, "UND_DEPTH_TOL_KV", 3e-2)
+    monkeypatch.setattr(bench, "UND_DEPTH_TOL_LOGITS", 3e-2)
+    gt = model.generate_text
+    monkeypatch.setattr(model, "generate_text", lambda **kw: gt(use_graph=False, **kw))           # no hipGraph on the host path
+    uout = bench.understanding_full_depth(uargs, cfg, model, ids, threads=2, oracle_out=uora)
+    assert uout["kv_rel_l2_max"] <= 3e-2 and uout["first_step_logits_rel_l2"] <= 3e-2 and uout["context_tokens"] == 9 + 2 + 34, uout
+
+
+def test_bench_steady_bracket_and_budget_guard_without_a_gpu():
+    import argparse
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module_steady", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with bench.Steady("cpu") as m:
+        pass
+    assert m.report["steady"] is True and m.report["peak_mem_gb"] is None
+    r, dt, rep = bench.timed_steady(lambda: 7, "cpu", lambda: None)
+    assert r == 7 and dt >= 0 and rep["attempts"] == 1
+    leg = bench.unsteady({"value": 1.0}, {"steady": False, "device_allocs_in_timed_region": 2, "device_frees_in_timed_region": 0, "attempts": 2})
+    assert "error" in leg and "hipMalloc" in leg["error"]
+    a = argparse.Namespace(wall_budget_s=10.0)
+    assert bench.over_budget(a, 1e9, "x")["skipped"].startswith("x:") and bench.over_budget(argparse.Namespace(wall_budget_s=1e9), 5, "x") is None
+    nodes = bench.numa_nodes()
+    assert isinstance(nodes, list) and all(isinstance(n, list) for n in nodes)
+    assert bench._cpu_tree({"a": (torch.ones(2), [1, 2]), "b": 3})["a"][1] == [1, 2]

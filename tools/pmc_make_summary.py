@@ -82,7 +82,8 @@ def main():
             "gemm_pq_kernel<2, false": 2.0 * (M * H + 4608 * H) + 2.0 * M * 4608,                     # qkv   (keys = name prefixes: the SGPR-base-DMA
                                                                                                       #        instantiations carry a third argument)
             # the stream-batched denoise launch: Q read + O written (8 x 4098 rows x 28 heads x 128) + K and V^T of every sample once
-            "attn2_kernel<128>": 2.0 * 2 * (8 * 4098) * 3584 + 2.0 * 2 * (8 * 4098 + 4 * 32) * 512}
+            # (prefix "attn2_kernel<128": round 6 gave the kernel a second template argument -- "<128, false>" is the unified-ring form the product launches)
+            "attn2_kernel<128": 2.0 * 2 * (8 * 4098) * 3584 + 2.0 * 2 * (8 * 4098 + 4 * 32) * 512}
     for k, c in den.items():
         if not (k.startswith("gemm_p") or k.startswith("attn") or k.startswith("rmsnorm") or k.startswith("qknorm")):
             continue
@@ -132,14 +133,16 @@ def main():
     step_f = step_w = 0.0
     per = {}
     for k, c in dec.items():
-        if not (k.startswith("gemv_kernel") or k.startswith("attn_decode") or k.startswith("decode_") or k.startswith("argmax")):
+        if not (k.startswith("gemv_kernel") or k.startswith("attn_decode") or k.startswith("decode_") or k.startswith("argmax") or k.startswith("sample_gumbel")):
             continue
         f, w = c.get("FETCH_SIZE", (0, 0)), c.get("WRITE_SIZE", (0, 0))
         n = max(f[1], w[1])
         per[k] = {"fetch_kb_raw": f[0], "write_kb": w[0], "launches_sampled": n}
     if per:
         # launches per decode step: the sampled run has 8 warm-up + 24 timed tokens in two prefill+decode rounds; per-step counts from the launch sequence
-        steps = max(1, max(v["launches_sampled"] for k, v in per.items() if k.startswith("argmax")) if any(k.startswith("argmax") for k in per) else 32)
+        # (one token-selection launch per decode step: argmax on the greedy legs, the Gumbel sampler on the sampled one)
+        sel = [v["launches_sampled"] for k, v in per.items() if k.startswith("argmax") or k.startswith("sample_gumbel")]
+        steps = max(1, sum(sel)) if sel else 32
         for k, v in per.items():
             v["launches_per_step"] = round(v["launches_sampled"] / steps, 2)
             step_f += v["fetch_kb_raw"] * v["launches_sampled"] / steps
