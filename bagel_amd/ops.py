@@ -73,6 +73,11 @@ def default_gemm_variant(M, N, K):
         # every M, so neighbouring prompt lengths share one kernel and one accumulation order.
         if -(-M // 256) * -(-N // 256) <= 128 and K >= 2048 and K % 64 != 0:
             return 0
+        # ... and a SHORT K on fewer than half a round of tiles: SigLIP's out projection at a 980^2 image (100 tiles, K = 1152) -- 29.3 us on the 128x128 kernel
+        # against 37.7 us on the persistent one, whose pipeline fill and K-split reduce pass weigh on an 18-k-tile loop (round 6, tools/gemm_prefill_shapes.py).
+        # (The MLP width of that tower is padded to the k-tile in its packed weights, siglip_navit.py: fc2 at K = 4352 stays on variant 4, 66 vs 91 us.)
+        if -(-M // 256) * -(-N // 256) <= 128 and K <= 1536:
+            return 0
         return 4
     return 0
 

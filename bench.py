@@ -296,9 +296,24 @@ class Steady:
     # builds, warm-ups, the checker's own product-side runs); the understanding child inherits the pids through BAGEL_PAUSE_PIDS.
     pause_pids = [int(x) for x in os.environ.get("BAGEL_PAUSE_PIDS", "").split(",") if x]
 
+    @staticmethod
+    def _is_worker(pid):
+        """Still one of OUR oracle workers?  (A finished worker's pid may be recycled by the system: never signal a process that is not `bench.py --oracle-job`.)"""
+        try:
+            with open(f"/proc/{pid}/cmdline", "rb") as f:
+                cmd = f.read()
+            with open(f"/proc/{pid}/stat") as f:
+                zombie = f.read().rsplit(")", 1)[1].split()[0] == "Z"
+            return b"--oracle-job" in cmd and not zombie
+        except (OSError, IndexError):
+            return False
+
     @classmethod
     def _signal_workers(cls, sig):
         for pid in list(cls.pause_pids):
+            if not cls._is_worker(pid):
+                cls.pause_pids.remove(pid)
+                continue
             try:
                 os.kill(pid, sig)
             except (ProcessLookupError, PermissionError):

@@ -1056,3 +1056,24 @@ def test_bench_steady_bracket_and_budget_guard_without_a_gpu():
     nodes = bench.numa_nodes()
     assert isinstance(nodes, list) and all(isinstance(n, list) for n in nodes)
     assert bench._cpu_tree({"a": (torch.ones(2), [1, 2]), "b": 3})["a"][1] == [1, 2]
+    # a worker process (anything whose command line carries --oracle-job) is STOPPED for the duration of a timed region and resumed after it; a pid that is not
+    # (or no longer) a worker is never signalled (a finished worker's pid may have been recycled)
+    import subprocess
+    import sys
+    import time
+    p = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(60)", "--oracle-job"])
+    state = lambda: open(f"/proc/{p.pid}/stat").read().rsplit(")", 1)[1].split()[0]  # noqa: E731
+    try:
+        time.sleep(0.3)
+        bench.Steady.pause_pids[:] = [p.pid, os.getpid()]
+        with bench.Steady("cpu"):
+            time.sleep(0.1)
+            assert state() == "T" and bench.Steady.pause_pids == [p.pid]        # (this test process was dropped from the list, not stopped)
+        time.sleep(0.1)
+        assert state() in "SR"
+    finally:
+        p.kill()
+        p.wait()
+    with bench.Steady("cpu"):
+        pass
+    assert bench.Steady.pause_pids == []
