@@ -1853,29 +1853,6 @@ def main():
         except Exception as e:
             import traceback
             edit = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
-        if cuda and rank == 0 and world == 1 and not args.standins and not args.no_cpu_baseline and not args.no_full_depth and args.layers is None:
-            # configs[4] against the oracle AT THE CONTEXT LENGTHS IT IS TIMED AT, on a depth-reduced model (the oracle's 9 032-token chain at depth 28 is ~10 min of
-            # host time): the real request chain, the three contexts' K / V, every single forward incl. the stream-batched ones (edit_depth_step)
-            try:
-                job = jobs.get("edit_depth")
-                ora = wait_oracle_job(job["dir"], "edit_depth", proc=job["proc"]) if job else None
-                skip = None if ora is not None else over_budget(args, 330 + 240, "edit.parity_at_depth with the oracle in this process")
-                if skip is None:
-                    m4, _ = build_bagel(cfg, device=dev, num_layers=EDIT_PARITY_LAYERS, with_vae=False)
-                    init_random_(m4, seed=0)
-                    m4.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device=dev).manual_seed(1))
-                    par = edit_depth_step(args, cfg, m4, ids, physical_cores(), vae=vae, oracle_out=ora)
-                    if ora is not None:
-                        par["worker"] = dict(ora.get("worker", {}), parent_waited_s=ora.get("waited_s"))
-                    del m4
-                    torch.cuda.empty_cache()
-                else:
-                    par = skip
-            except Exception as e:
-                import traceback
-                par = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
-            if isinstance(edit, dict):
-                edit["parity_at_depth"] = par
     trainf = None
     if args.workload == "t2i" and not args.no_train_forward and (args.layers is None or args.standins):
         # SURVEY 8f.2 beside the headline: Bagel.forward (training forward, per-token CE / MSE losses, no backward) on a packed 7B batch of
@@ -1970,6 +1947,31 @@ def main():
             if isinstance(und, dict) and "value" in und:
                 und["value"] = float(tt.item())
                 und["replicas"] = world
+
+    if (isinstance(edit, dict) and cuda and rank == 0 and world == 1 and not args.standins and not args.no_cpu_baseline and not args.no_full_depth
+            and args.layers is None):   # (after the understanding child: its start-up is untimed time in which the worker advances)
+        # configs[4] against the oracle AT THE CONTEXT LENGTHS IT IS TIMED AT, on a depth-reduced model (the oracle's 9 032-token chain at depth 28 is ~10 min of
+        # host time): the real request chain, the three contexts' K / V, every single forward incl. the stream-batched ones (edit_depth_step)
+        try:
+            job = jobs.get("edit_depth")
+            ora = wait_oracle_job(job["dir"], "edit_depth", proc=job["proc"]) if job else None
+            skip = None if ora is not None else over_budget(args, 330 + 240, "edit.parity_at_depth with the oracle in this process")
+            if skip is None:
+                m4, _ = build_bagel(cfg, device=dev, num_layers=EDIT_PARITY_LAYERS, with_vae=False)
+                init_random_(m4, seed=0)
+                m4.llm2vae.weight.data.normal_(0, cfg["llm"]["hidden_size"] ** -0.5, generator=torch.Generator(device=dev).manual_seed(1))
+                par = edit_depth_step(args, cfg, m4, ids, physical_cores(), vae=vae, oracle_out=ora)
+                if ora is not None:
+                    par["worker"] = dict(ora.get("worker", {}), parent_waited_s=ora.get("waited_s"))
+                del m4
+                torch.cuda.empty_cache()
+            else:
+                par = skip
+        except Exception as e:
+            import traceback
+            par = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
+        if isinstance(edit, dict):
+            edit["parity_at_depth"] = par
 
     if rank == 0:
         # the dominant kernel = the GEMM variant that carries the most FLOPs in the timed region
