@@ -17,7 +17,7 @@ fi
 grep "^{" gpurun_out/bench.log | cut -c1-400
 if [ -z "$SKIP_PROF" ]; then
   cd /tmp
-  ( timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-understanding --no-taylorseer --no-edit --no-fp8 --no-train-forward ) > $ROOT/gpurun_out/bench_prof.log 2>&1
+  ( timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof -o bench -- python $ROOT/bench.py --steps 1 --warmup 0 --no-memory-leg --no-cpu-baseline --no-understanding --no-taylorseer --no-edit --no-fp8 --no-train-forward ) > $ROOT/gpurun_out/bench_prof.log 2>&1
   cd $ROOT
   DB=$(find gpurun_out/prof -name "*.db" | head -1)
   [ -n "$DB" ] && python tools/rocprof_summary.py $DB > gpurun_out/bench_kernel_stats.csv 2>gpurun_out/kernel_stats.err
