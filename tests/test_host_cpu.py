@@ -255,3 +255,13 @@ def test_decode_engine_isa_invariants():
             raise AssertionError(f"hipcc uses M0 outside the DMA statements: {line.strip()}")
     assert asm.count("global_load_lds_dwordx4") >= 8
     assert "buffer_wbl2" not in asm and "buffer_inv" not in asm, "an agent-scope fence crept into the engine (its hand-offs are write-through stores + sc1 loads)"
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md's table ("entry point | replaces") is the reader's map of the C ABI: every prototype of include/bagel_hip.h must appear in it (the header
+    and the library are compared symbol for symbol by the build check; this keeps the document in step with both)."""
+    from bagel_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [n for n in sorted(_lib.parse_header()) if n not in doc]
+    assert not missing, f"INTEGRATION.md does not mention {missing}"
