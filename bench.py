@@ -1943,6 +1943,18 @@ def main():
             trainf = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
     und = None
     if not args.no_understanding:
+        # the understanding child has SHORT timed regions (an 85 ms prefill): it starts once the workers are gone -- at the driver's flags that is a wait of ~25 s.
+        # (Measured, round 6: with two workers alive -- stopped during the child's timed regions like during the parent's -- the child's prefill read 177 ms instead
+        # of 84; the parent's own legs, seconds long each, were unaffected.  Not waiting is not worth finding out why.)
+        jobs_wait_end_s = 0.0
+        if jobs:
+            t_w = time.time()
+            for j in jobs.values():
+                try:
+                    j["proc"].wait(timeout=max(30.0, args.wall_budget_s - (time.time() - T_START) - 500.0))
+                except Exception:
+                    pass
+            jobs_wait_end_s = time.time() - t_w
         und = understanding_subprocess(args, local, jobs.get("und_depth"))
         if world > 1:   # replicas: aggregate tokens/s = sum over ranks
             v = und.get("per_gpu_tokens_per_s", 0.0) if isinstance(und, dict) else 0.0
@@ -2030,6 +2042,7 @@ def main():
                 "what": "the CPU-oracle sides of understanding.parity_at_full_depth and edit.parity_at_depth ran in worker processes beside the GPU legs (bench.py "
                         "--oracle-job: same name-seeded weights, fingerprint-checked by the compare phase); the parent waited for them to leave the GPU before its "
                         "timed region and STOPS them (SIGSTOP / SIGCONT) for the duration of every timed region of every leg", "kinds": sorted(jobs), "threads_each": next(iter(jobs.values()))["threads"], "parent_waited_for_gpu_release_s": jobs_wait_s,
+                "parent_waited_for_the_workers_to_end_s": jobs_wait_end_s if not args.no_understanding else None,
                 "gpu_released_before_timed_region": all(j.get("gpu_released") for j in jobs.values())},
             "understanding": und,
             "edit": edit,
