@@ -58,7 +58,9 @@ def parse():
     ap.add_argument("--no-int8", action="store_true", help="understanding leg: skip the extra weight_quant='int8_rowwise' / 'mxfp4' decodes")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra gen_weight_quant='fp8' measurement")
     ap.add_argument("--no-edit", action="store_true", help="skip the extra configs[4] measurement (one image-edit request per GPU)")
-    ap.add_argument("--edit-batch", type=int, default=2, help="edit.batched: this many edit requests per GPU served as one batch (beside the one-request latency)")
+    ap.add_argument("--edit-batch", type=lambda v: [int(x) for x in v.split(",") if x], default=[2, 4],
+                    help="edit.batched (the first value) / edit.batched_<n> (the others): this many edit requests per GPU served as ONE batch, beside the one-request "
+                         "latency; every sample of the first size is also checked against its own single-request run")
     ap.add_argument("--weight-store", choices=["nf4", "int8_rowwise"], default=None,
                     help="option that changes results (line flagged invalid): the reference's quantised load modes (app.py:114-131) over the WHOLE forward "
                          "path -- Bagel.quantize_language_model before the timed region; skips the fp8 / training / understanding legs")
@@ -253,7 +255,7 @@ def start_oracle_jobs(args, local, kinds):
 def wait_gpu_released(jobs, timeout=300.0):
     """Block until every worker has copied its weights off the GPU (or died): nothing but this process may be on the device inside a timed region."""
     t0 = time.time()
-    for kind, j in jobs.items():
+    for j in jobs.values():
         while not os.path.exists(os.path.join(j["dir"], "gpu_released")) and j["proc"].poll() is None and time.time() - t0 < timeout:
             time.sleep(0.25)
         j["gpu_released"] = os.path.exists(os.path.join(j["dir"], "gpu_released"))
@@ -1808,8 +1810,7 @@ def main():
             # THROUGHPUT form, beside the one-request latency and never as it: TWO requests per GPU in one NaViT batch (96 row tiles instead of 48: the
             # o / down projections run 5.25 rounds of the 256 persistent workgroups instead of 2.63, qkv 6.75 instead of 3.375 -- the partial last rounds that
             # idle 12-16 % of the chip at one request).  The batch driver of the reference serves one image per rank at a time (gen_images_mp_imgedit.py:278-303).
-            try:
-                NB = args.edit_batch
+            def edit_batched(NB, check):
                 breqs = tuple(range(NB))
 
                 def same_as_single(nt=3):
@@ -1838,22 +1839,27 @@ def main():
                     finally:
                         model.velocity_hook = None
                     return res
-                same = same_as_single()
+                same = same_as_single() if check else None
+                edit_step(timesteps=3, reqs=breqs)
                 edit_step(timesteps=3, reqs=breqs)
                 (lat_b, _), dt_b, mem_b = timed_steady(lambda: edit_step(reqs=breqs), dev, fence, attempts=tries)
                 if world > 1:
                     tt = torch.tensor([dt_b], dtype=torch.float64, device=dev)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     dt_b = float(tt.item())
-                edit["batched"] = unsteady({"value": NB * world / dt_b, "unit": "images/s", "requests_per_gpu": NB, "seconds_per_batch": dt_b, "seconds_per_image": dt_b / NB,
-                                            "speedup_over_one_request_per_gpu": (NB / dt_b) / (1 / dt_e), "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_b),
-                                            "each_sample_vs_its_single_request_run": same, "memory": mem_b,
-                                            "whole_path_roofline_frac": NB * pf / dt_b / 1e12 / PEAK_BF16_TFLOPS,
-                                            "note": f"{NB} independent edit requests (own images, contexts, noise) served as one NaViT batch: THROUGHPUT, beside the "
-                                                    "one-request latency above, never as it"}, mem_b)
-            except Exception as e:
-                import traceback
-                edit["batched"] = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
+                return unsteady({"value": NB * world / dt_b, "unit": "images/s", "requests_per_gpu": NB, "seconds_per_batch": dt_b, "seconds_per_image": dt_b / NB,
+                                 "speedup_over_one_request_per_gpu": (NB / dt_b) / (1 / dt_e), "outputs_finite": all(torch.isfinite(x).all().item() for x in lat_b),
+                                 "each_sample_vs_its_single_request_run": same, "memory": mem_b,
+                                 "whole_path_roofline_frac": NB * pf / dt_b / 1e12 / PEAK_BF16_TFLOPS,
+                                 "note": f"{NB} independent edit requests (own images, contexts, noise) served as one NaViT batch: THROUGHPUT, beside the "
+                                         "one-request latency above, never as it"}, mem_b)
+            for bi, NB in enumerate(args.edit_batch):
+                key = "batched" if bi == 0 else f"batched_{NB}"
+                try:
+                    edit[key] = edit_batched(NB, check=bi == 0)
+                except Exception as e:
+                    import traceback
+                    edit[key] = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
         except Exception as e:
             import traceback
             edit = {"error": repr(e), "trace": traceback.format_exc()[-1200:]}
