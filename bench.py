@@ -823,15 +823,11 @@ def edit_depth_oracle(cfg, W, VW, inp, threads):
     ts = torch.tensor([1.0] * x0.shape[0])
     od = lambda c, d: dict(cache=c, position_ids=d["cfg_packed_position_ids"], query_indexes=d["cfg_packed_query_indexes"],  # noqa: E731
                            key_values_lens=d["cfg_key_values_lens"], key_value_indexes=d["cfg_packed_key_value_indexes"])
-    lis = lambda d: dict(li, packed_position_ids=d["cfg_packed_position_ids"], packed_indexes=d["cfg_packed_query_indexes"],  # noqa: E731
-                         key_values_lens=d["cfg_key_values_lens"], packed_key_value_indexes=d["cfg_packed_key_value_indexes"])
     t1 = time.time()
-    out = {"v_cpu": O.forward_flow(W, cfg, x0, ts, li, ocache, od(octext, ct), od(ocimg, cim), 4.0, 2.0, 0.0, "text_channel").float(),
-           # the three single forwards of the oracle (scale 1.0 = no combine), each on its own context
-           "o_c": O.forward_flow(W, cfg, x0, ts, li, ocache, None, None, 1.0, 1.0, 0.0, "global").float(),
-           "o_t": O.forward_flow(W, cfg, x0, ts, lis(ct), octext, None, None, 1.0, 1.0, 0.0, "global").float(),
-           "o_i": O.forward_flow(W, cfg, x0, ts, lis(cim), ocimg, None, None, 1.0, 1.0, 0.0, "global").float()}
-    tt["denoise_step_x4"] = time.time() - t1
+    parts = {}        # the three single-forward velocities of the SAME pass, before the combine (the oracle is deterministic: a stand-alone forward on one context gives these bits)
+    out = {"v_cpu": O.forward_flow(W, cfg, x0, ts, li, ocache, od(octext, ct), od(ocimg, cim), 4.0, 2.0, 0.0, "text_channel", parts=parts).float()}
+    out.update(o_c=parts["v_cond"].float(), o_t=parts["v_cfg_text"].float(), o_i=parts["v_cfg_img"].float())
+    tt["denoise_step_3_forwards"] = time.time() - t1
     out["kv"] = {n: [(c.key_cache[i], c.value_cache[i]) for i in range(L)] for n, c in (("cond", ocache), ("cfg_text", octext), ("cfg_img", ocimg))}
     out.update(cpu_seconds=time.time() - t0, cpu_seconds_by_phase=tt, threads=threads, weights=weight_fingerprint(W), layers=L)
     return out

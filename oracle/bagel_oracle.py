@@ -566,6 +566,8 @@ def forward_flow(W, cfg, x_t, timestep, gi, cache, cfg_text=None, cfg_img=None, 
         parts["v_cond"] = v_t
         if cfg_text_scale > 1.0:
             parts["v_cfg_text"] = v_ct
+        if cfg_img_scale > 1.0:
+            parts["v_cfg_img"] = v_ci
     if cfg_text_scale > 1.0:
         v_t = cfg_combine(v_t, v_ct, v_ci if cfg_img_scale > 1.0 else None, cfg_text_scale, cfg_img_scale, cfg_renorm_min, cfg_renorm_type)
     return v_t

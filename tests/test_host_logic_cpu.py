@@ -1013,6 +1013,17 @@ def test_bench_edit_request_parity_leg_runs_the_real_chain_on_the_host_path(monk
     ora = bench.edit_depth_oracle(cfg, Wk, {k: v.float() for k, v in vae.state_dict().items()}, inp, threads=2)
     out = bench.edit_depth_step(args, cfg, model, ids, threads=2, vae=vae, oracle_out=ora)
     assert out["contexts"] == [n_vae + n_vit + 7, n_vae + n_vit, 7] and "worker process" in out["oracle_ran"]
+    # the oracle phase takes its three single-forward velocities out of ONE 3-forward pass (forward_flow's `parts`): the same bits as a stand-alone forward on that context
+    from oracle import bagel_oracle as O
+    li, ct = inp["latent"], inp["cfg_text"]
+    x0 = li["packed_init_noises"]
+    lis = dict(li, packed_position_ids=ct["cfg_packed_position_ids"], packed_indexes=ct["cfg_packed_query_indexes"], key_values_lens=ct["cfg_key_values_lens"],
+               packed_key_value_indexes=ct["cfg_packed_key_value_indexes"])
+    octext = O.OracleCache(cfg["llm"]["num_hidden_layers"])
+    for i, (k_, v_) in enumerate(ora["kv"]["cfg_text"]):
+        octext.key_cache[i], octext.value_cache[i] = k_, v_
+    alone = O.forward_flow(Wk, cfg, x0, torch.tensor([1.0] * x0.shape[0]), lis, octext, None, None, 1.0, 1.0, 0.0, "global").float()
+    assert torch.equal(alone, ora["o_t"])
     assert max(out["context_kv_rel_l2_max"].values()) <= 3e-2, out["context_kv_rel_l2_max"]
     for k in ("rel_l2_cond_forward", "rel_l2_cfg_text_forward", "rel_l2_cfg_img_forward"):
         assert out[k] <= 3e-2 and out["stream_batched"][k] <= 3e-2, (k, out[k], out["stream_batched"][k])
