@@ -117,6 +117,11 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
         return gemv(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if variant is None:
         variant = default_gemm_variant(M0 + M1, N, K)
+        # bias AND residual in one epilogue is not instantiated in the persistent kernel (the library falls back to the one-tile-per-workgroup ping-pong kernel,
+        # variant 3, WITHOUT the K-split of leftover tiles): on fewer than half a round of 256 x 256 tiles the 128 x 128 kernel covers the chip instead -- SigLIP's
+        # fc2 at a 980^2 image (100 tiles, K = 4352 after the k-tile padding): 71 us against ~97 us (round 6, tools/gemm_prefill_shapes.py + the prefill's rocprof)
+        if variant == 4 and bias0 is not None and residual is not None and W1 is None and -(-(M0 + M1) // 256) * -(-N // 256) <= 128:
+            variant = 0
         # variant 5 = variant 4 with SGPR-base DMA addresses (one address register per LDS-DMA instruction: the persistent kernel is
         # DMA-issue bound, gate+up 1 304 -> 1 411 TFLOP/s at M = 32 768): legal when every operand row lies within 4 GiB of the operand's
         # base pointer, which the tensors' extents tell here (gathered rows index into A, so A's extent bounds them).  Same arithmetic,

@@ -29,16 +29,18 @@ for name, M, N, K, mode in (("vit qkv", 4900, 3456, 1152, "bias"), ("vit out", 4
                             ("vit fc2", 4900, 1152, 4304, "bias"),
                             # round 6: the MLP width padded to the 64-deep k-tile (siglip_navit.py _pack): fc1 writes 4352 columns (48 exact zeros), fc2 contracts over them
                             ("vit fc1 pad", 4900, 4352, 1152, "gelu"), ("vit fc2 pad", 4900, 1152, 4352, "bias"),
+                            # ... as the model calls them: bias AND residual in one epilogue (not instantiated in the persistent kernel: variant 4 falls back to 3)
+                            ("vit out +res", 4900, 1152, 1152, "bias+residual"), ("vit fc2 pad +res", 4900, 1152, 4352, "bias+residual"),
                             ("llm qkv", 4902, 4608, 3584, "bias"), ("llm o", 4902, 3584, 3584, "residual"),
                             ("llm gate_up", 4902, 37888, 3584, "swiglu"), ("llm down", 4902, 3584, 18944, "residual"),
                             ("edit o", 12288, 3584, 3584, "residual"), ("edit down", 12288, 3584, 18944, "residual")):
     A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
-    bias = torch.zeros(N, dtype=torch.bfloat16, device=dev) if mode in ("bias", "gelu") else None
+    bias = torch.zeros(N, dtype=torch.bfloat16, device=dev) if mode in ("bias", "gelu", "bias+residual") else None
     Nout = N // 2 if mode == "swiglu" else N
     C = torch.zeros((M, Nout), dtype=torch.bfloat16, device=dev)
     epi = {"swiglu": ops.EPI_SWIGLU16, "gelu": ops.EPI_GELU_TANH}.get(mode, ops.EPI_NONE)
-    res = C if mode == "residual" else None
+    res = C if mode in ("residual", "bias+residual") else None
     out = []
     for v in (0, 2, 4, None):           # None = what ops.gemm picks (variant 5 = 4 with SGPR-base DMA where legal, + the K-split of leftover tiles)
         try:
