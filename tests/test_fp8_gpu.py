@@ -176,3 +176,61 @@ def test_model_fp8_gen_expert_matches_its_restatement(golden):
                     assert 1e-3 < e16 < 0.5, e16            # it IS a different result, and not a wild one
     finally:
         model.gen_weight_quant, model.cfg_batched, model.fp8_delayed_scaling = None, True, True
+
+
+def test_fp8_single_layer_at_7b_shapes_matches_its_restatement_tightly():
+    """ONE MoT decoder layer at BAGEL-7B shapes (hidden 3584, 28 / 4 heads of 128, MLP 18 944), 1 026 query tokens on a 32-token context, gen mode: the UPDATE the layer
+    adds to the residual stream (y - x: nothing of the input hides a defect) through the HIP engine with ``gen_quant="fp8"`` against the oracle layer with the same
+    scheme in its gen-expert linears -- before any depth, CFG or sampler amplifies the e4m3 code flips, so the gate can be an order of magnitude tighter than the
+    end-to-end ones (round-5 verdict, weak 4: a 5 % scheme bug passed those).  Both schemes of the SwiGLU output's scale: exact row scales, and the DELAYED scales on
+    the second forward of a stream (state carried over from the first, as inside ``generate_image``).  The bf16 layer on the same inputs is the yardstick."""
+    import argparse
+    import bench
+    from bagel_amd.factory import BAGEL_7B_MOT as cfg, build_bagel
+    from bagel_amd.modeling.bagel.qwen2_navit import Fp8DelayedScales, NaiveCache
+    from oracle import bagel_oracle as O
+    llm = cfg["llm"]
+    nkv, hd = llm["num_key_value_heads"], llm["hidden_size"] // llm["num_attention_heads"]
+    k = {}
+    bench.cpu_port_layer(argparse.Namespace(cpu_layers=1, resolution=512, prompt_tokens=30), cfg, bench.physical_cores(), k)      # the bf16 oracle layer: k["x"]
+    W, x0, Lq, C = k["W"], k["x0"], k["Lq"], k["C"]
+    cos_sin = O.rope_tables(torch.full((Lq,), C, dtype=torch.long), hd, llm["rope_theta"], torch.bfloat16)
+    qlens, kvlens = torch.tensor([Lq], dtype=torch.int), torch.tensor([C], dtype=torch.int)
+    layer = lambda x: O.mot_layer(W, llm, 0, x, qlens, cos_sin, k["q_idx"], k["cache"], kvlens, k["kv_idx"], False, False, "gen", k["vae_idx"], k["text_idx"])  # noqa: E731
+    # a second input = the first moved a little, as a latent row is between two Euler steps (the delayed scale of step 2 comes from step 1's row maxima)
+    x1 = (x0.float() * 1.05 + 0.02 * torch.randn(x0.shape, generator=torch.Generator().manual_seed(5))).to(torch.bfloat16)
+    O.FP8_WEIGHT_PTRS = O.fp8_gen_weight_ptrs(W)
+    try:
+        assert len(O.FP8_WEIGHT_PTRS) == 7
+        o8_exact = [layer(x0), layer(x1)]
+        O.FP8_DELAYED = F8.DelayedScales(F8.down_proj_gen_ptrs(W))
+        O.FP8_DELAYED.begin_step(); layer(x0)
+        O.FP8_DELAYED.begin_step(); o8_delayed = layer(x1)
+    finally:
+        O.FP8_WEIGHT_PTRS, O.FP8_DELAYED = set(), None
+    o16 = layer(x1)
+    m1, _ = build_bagel(cfg, device=DEV, num_layers=1, with_vae=False)
+    m1.load_state_dict(dict(W), strict=False)
+    eng = m1.language_model.engine()
+    c1 = NaiveCache(1)
+    c1.store(0, k["cache"].key_cache[0].reshape(C, nkv * hd).to(DEV), k["cache"].value_cache[0].reshape(C, nkv * hd).to(DEV), [C], [0], nkv, hd, eng.dp)
+    plan = eng.plan([Lq], torch.full((Lq,), C, dtype=torch.long), packed_query_indexes=k["q_idx"], key_values_lens=[C], packed_key_value_indexes=k["kv_idx"],
+                    text_indexes=k["text_idx"], vae_indexes=k["vae_idx"])
+    fwd = lambda x, **kw: eng.forward(x.to(DEV), plan, "gen", c1, update=False, causal=False, num_layers=1, final_norm=False, **kw).float().cpu()  # noqa: E731
+    upd = lambda y, x, ry: float(((y - x.float()) - (ry.float() - x.float())).norm() / (ry.float() - x.float()).norm())  # noqa: E731
+    e16 = upd(fwd(x1), x1, o16)
+    e8 = [upd(fwd(x, gen_quant="fp8"), x, r) for x, r in ((x0, o8_exact[0]), (x1, o8_exact[1]))]
+    st = Fp8DelayedScales()
+    fwd(x0, gen_quant="fp8", fp8_state=st)
+    assert st.primed and float(st.amax[0].max()) > 0
+    y8d = fwd(x1, gen_quant="fp8", fp8_state=st)
+    e8d = upd(y8d, x1, o8_delayed)
+    moved = upd(o8_exact[1], x1, o16)                 # how far the option moves the layer's update from bf16: the scale of what a scheme bug would do
+    print(f"7B-shape layer update, product vs restatement: bf16 {e16:.3e}; fp8 exact scales {e8[0]:.3e} / {e8[1]:.3e}; fp8 delayed scales (2nd forward) {e8d:.3e}; "
+          f"the option itself moves the update {moved:.3e} from bf16; delayed vs exact restatement {upd(o8_delayed, x1, o8_exact[1]):.3e}")
+    # measured on MI355X (round 6): bf16 4.9e-3; fp8 2.68e-2 / 2.63e-2 (exact scales) and 2.67e-2 (delayed) -- e4m3 codes next to a rounding boundary flip on the
+    # bf16-level differences between the two sides' activations, the noise floor of ANY two executions of this scheme -- while the option moves the update 6.6e-2 from
+    # bf16 and a wrong or missing scale moves it by O(1).  Frozen at 1.5 x the measured floor: 4e-2 (the end-to-end gates of this option sit at 8e-2 / 0.11).
+    assert e16 <= 1e-2, e16
+    assert max(e8) <= 4e-2 and e8d <= 4e-2, (e8, e8d)
+    assert 2e-2 < moved < 0.2
