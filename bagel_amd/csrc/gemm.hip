@@ -627,7 +627,8 @@ __device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_dst_uni
                  : "memory");
 }
 
-// MODE fixes the epilogue at compile time (0 SwiGLU pairing, 1 residual add, 2 bias, 3 plain) so that no load of hipcc's sits
+// MODE fixes the epilogue at compile time (0 SwiGLU pairing, 1 residual add, 2 bias, 3 plain, 4 fp32 partials of a K part, 5 bias + residual, 6 bias + GELU-tanh:
+// the SigLIP out / fc2 and fc1 projections, siglip_navit.py:216-258) so that no load of hipcc's sits
 // behind a run-time branch: after such a join its wait counting turns conservative and drains the DMA pipe.
 // FP8 = true: the operands are OCP e4m3 bytes with per-row fp32 scales (A: per activation row, W: per output column).  The LDS
 // image, the DMA and the whole pipeline are byte-for-byte those of the bf16 kernel -- a 128-byte LDS row is 128 fp8 values instead of
@@ -653,7 +654,7 @@ __device__ __forceinline__ float pq_rowmax16(float x) {
 template <int MODE, bool FP8 = false, bool SADDR = false, bool QOUT = false>
 __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
     static_assert(!QOUT || (MODE == 0 && FP8), "the fp8 output exists for the SwiGLU epilogue of the fp8 kernel");
-    constexpr bool SWIGLU = MODE == 0, HAS_R = MODE == 1, HAS_BIAS = MODE == 2, PARTIAL = MODE == 4;
+    constexpr bool SWIGLU = MODE == 0, HAS_R = MODE == 1 || MODE == 5, HAS_BIAS = MODE == 2 || MODE == 5 || MODE == 6, PARTIAL = MODE == 4, GELU = MODE == 6;
     constexpr int BM = 256, BN = 256;
     constexpr int PIECE = 128 * 128;
     constexpr int STAGE = 4 * PIECE;
@@ -1128,6 +1129,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
                                 o[0] += lo2f(bv[nb][jn][0]); o[1] += hi2f(bv[nb][jn][0]);
                                 o[2] += lo2f(bv[nb][jn][1]); o[3] += hi2f(bv[nb][jn][1]);
                             }
+                            if constexpr (GELU) {      // the rounding points of the one-tile kernels: act(bf16(acc + bias))
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bfround(o[e]));
+                            }
                             u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                             *(u32x2_t*)(rowp + (((c >> 2) ^ efr) << 3)) = v;
                         }
@@ -1173,7 +1178,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pq_kernel(const GemmParams p) {
 // bf16(that + residual).
 template <int MODE>
 __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(const GemmParams p) {
-    constexpr bool HAS_R = MODE == 1, HAS_BIAS = MODE == 2;
+    constexpr bool HAS_R = MODE == 1 || MODE == 5, HAS_BIAS = MODE == 2 || MODE == 5 || MODE == 6, GELU = MODE == 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = p.tiles_m * p.tiles_n;
     const int t = blockIdx.x >> 3, mi = blockIdx.x & 7;           // leftover tile, fragment row group ma * 4 + i
@@ -1213,6 +1218,9 @@ __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(const GemmParam
             if constexpr (HAS_BIAS) {
                 const u32x2_t bv = *(const u32x2_t*)(bias + n);
                 o[0] += lo2f(bv[0]); o[1] += hi2f(bv[0]); o[2] += lo2f(bv[1]); o[3] += hi2f(bv[1]);
+            }
+            if constexpr (GELU) {
+                for (int e = 0; e < 4; ++e) o[e] = gelu_tanh_f(bfround(o[e]));
             }
             u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
             if constexpr (HAS_R) {
@@ -1415,10 +1423,16 @@ static int gemm_bf16_impl(const void* A, int64_t lda,
             if ((K & 63) != 0) return launch_gemm<256, 256, 2, 4>(p, stream);
             const bool has_bias = p.g[0].bias != nullptr || p.g[1].bias != nullptr;
             const bool all_bias = p.g[0].bias != nullptr && p.g[1].bias != nullptr;
-            if (K < 128 || epilogue == EPI_GELU_TANH || epilogue == EPI_SILU || (has_bias && (R || !all_bias))) return launch_gemm_pp<0>(p, stream);
             bool saddr = variant == 5 && (uint64_t)N * (uint64_t)ldw * 2 < (1ull << 32);
             for (int g = 0; g < p.ngroups && saddr; ++g)
                 if (!p.g[g].a_rows && (uint64_t)p.g[g].M * (uint64_t)lda * 2 >= (1ull << 32)) saddr = false;
+            // round 6: the ViT's epilogues (bias + residual: out / fc2; bias + GELU-tanh: fc1) on the persistent kernel, SGPR-base form only
+            const bool vit_epi = saddr && all_bias && K >= 128 && ((epilogue == EPI_NONE && R) || (epilogue == EPI_GELU_TANH && !R));
+            if (!vit_epi && (K < 128 || epilogue == EPI_GELU_TANH || epilogue == EPI_SILU || (has_bias && (R || !all_bias)))) return launch_gemm_pp<0>(p, stream);
+            if (vit_epi) {
+                if (epilogue == EPI_GELU_TANH) return launch_gemm_pq<6, false, true>(p, stream, ws, ws_bytes);
+                return launch_gemm_pq<5, false, true>(p, stream, ws, ws_bytes);
+            }
             if (saddr) {
                 if (epilogue == EPI_SWIGLU16) return launch_gemm_pq<0, false, true>(p, stream);
                 if (R) return launch_gemm_pq<1, false, true>(p, stream, ws, ws_bytes);

@@ -23,7 +23,7 @@ int bagel_check_launch(const char* what) {
 }
 
 int bagel_enable_lds(const void* func, int bytes, const char* what) {
-    constexpr int MAXF = 128, MAXDEV = 16;
+    constexpr int MAXF = 256, MAXDEV = 16;
     static std::mutex mu;
     static const void* funcs[MAXF];
     static int enabled[MAXF][MAXDEV];      // largest size enabled for (kernel, device); 0 = never

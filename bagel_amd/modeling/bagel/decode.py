@@ -246,7 +246,7 @@ class DecodeSession:
         scale = hd ** -0.5
         ops.rope_table_into(self.pos, self.inv_freq, self.cos, self.sin)
         ops.copy_rows(self.table, x, B, eng.H, src_rows=self.cur32)
-        fused = B == 1      # one request: lane-FMA kernel with the RMSNorm fused in; 2..16: the register-resident MFMA stream (gemv_mb); more: RMSNorm kernel + skinny MFMA GEMM
+        fused = B == 1      # one request: lane-FMA kernel with the RMSNorm fused in; 2..32: the register-resident MFMA stream (gemv_mb); more: RMSNorm kernel + skinny MFMA GEMM
         h = self.h
 
         def proj(inp, w, out, norm_w=None, **kw):
@@ -259,8 +259,8 @@ class DecodeSession:
             if fused:
                 return ops.gemv(inp, w, out, norm_w=norm_w, eps=eng.eps, **kw)
             if B <= ops.MB_MAX_ROWS and ops.gemv_mb_supported(inp, w, out, kw.get("bias"), kw.get("residual"), kw.get("epilogue", ops.EPI_NONE),
-                                                              norm_w is not None):
-                # 2..16 requests: the weight stream with the activations in registers and the RMSNorm fused (csrc/gemv_mb.hip); the K-slice
+                                                              norm_w is not None, M=B):
+                # 2..32 requests: the weight stream with the activations in registers and the RMSNorm fused (csrc/gemv_mb.hip); the K-slice
                 # workspace of the long rows is the session's own, so the captured graph keeps a stable pointer
                 return ops.gemv_mb(inp, w, out, norm_w=norm_w, eps=eng.eps, M=B, workspace=self.mb_ws, **kw)
             if norm_w is not None:

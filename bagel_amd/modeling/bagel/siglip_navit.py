@@ -157,7 +157,7 @@ class SiglipVisionModel(PackedWeights):
             w = torch.cat([w, w.new_zeros((D, kpad - kin))], 1).contiguous()
         # the MLP width padded to the GEMM's 64-deep k-tile (so400m: 4304 -> 4352): fc1 gets zero rows + zero bias (tanh-GELU(0) = 0: the extra columns of the
         # activation are exact zeros), fc2 zero columns -- the same sums with zeros added; fc2 at K = 4352 takes the K % 64 == 0 path of whichever kernel serves it
-        # (the 128 x 128 kernel: 92 -> 75 us with its bias + residual epilogue; ops.gemm routes it there: round-5 verdict, item 8)
+        # (92 -> 75 us on the 128 x 128 kernel with its bias + residual epilogue, 66 us on the persistent kernel's bias + residual mode since round 6; ops.gemm routes it: round-5 verdict, item 8)
         I = cfg.intermediate_size
         ipad = _ceil_to(I, 64)
 

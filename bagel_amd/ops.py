@@ -100,8 +100,8 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
     if residual is not None:
         _req(residual, BF16, "gemm.residual")
     dense1 = variant is None and W1 is None and M1 == 0 and a_rows0 is None and c_rows0 is None
-    if dense1 and 2 <= M0 <= MB_MAX_ROWS and gemv_mb_supported(A, W0, C, bias0, residual, epilogue, False):
-        # 2..16 rows (batched decode steps, the marker rows of a denoise forward): weight stream with the activations in registers
+    if dense1 and 2 <= M0 <= MB_MAX_ROWS and gemv_mb_supported(A, W0, C, bias0, residual, epilogue, False, M=M0):
+        # 2..32 rows (batched decode steps, the marker rows of a denoise forward, a short text prefill): weight stream with the activations in registers
         return gemv_mb(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if (dense1 and 2 <= M0 <= SKINNY_MAX_ROWS and K % 32 == 0 and N % (32 if epilogue == EPI_SWIGLU16 else 16) == 0
             and A.data_ptr() % 16 == 0 and W0.data_ptr() % 16 == 0 and C.data_ptr() % 8 == 0 and _ld(C) % 4 == 0
@@ -117,11 +117,16 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
         return gemv(A, W0, C, bias=bias0, residual=residual, epilogue=epilogue, M=M0)
     if variant is None:
         variant = default_gemm_variant(M0 + M1, N, K)
-        # bias AND residual in one epilogue is not instantiated in the persistent kernel (the library falls back to the one-tile-per-workgroup ping-pong kernel,
-        # variant 3, WITHOUT the K-split of leftover tiles): on fewer than half a round of 256 x 256 tiles the 128 x 128 kernel covers the chip instead -- SigLIP's
-        # fc2 at a 980^2 image (100 tiles, K = 4352 after the k-tile padding): 71 us against ~97 us (round 6, tools/gemm_prefill_shapes.py + the prefill's rocprof)
-        if variant == 4 and bias0 is not None and residual is not None and W1 is None and -(-(M0 + M1) // 256) * -(-N // 256) <= 128:
+        # The ViT's epilogues -- bias + residual (out / fc2), bias + GELU-tanh (fc1) -- exist in the persistent kernel's SGPR-base form since round 6 (variant 5 below,
+        # with the K-split of leftover tiles): fc1 at a 980^2 image 101 -> 87 us, fc2 (100 tiles, K = 4352) 72 (128 x 128 kernel) -> 66 us.  On fewer than half a
+        # round of tiles with a SHORT K the 128 x 128 kernel still covers the chip better than two half-length parts per tile + a reduce pass: the out projection
+        # (K = 2048 with the padded heads) 44.6 vs 47.2 us (tools/gemm_prefill_shapes.py, profiles/r06_vit_epilogues.log).
+        # BAGEL_GEMM_VIT_EPI=0 restores the earlier routing for a same-box A/B (bias + residual on few tiles -> 128 x 128, the rest -> the library's fallback, variant 3).
+        vit_few = variant == 4 and bias0 is not None and residual is not None and W1 is None and -(-(M0 + M1) // 256) * -(-N // 256) <= 128
+        if vit_few and (K <= 3072 or not GEMM_VIT_EPI):
             variant = 0
+        elif variant == 4 and not GEMM_VIT_EPI and bias0 is not None and W1 is None and (residual is not None or epilogue == EPI_GELU_TANH):
+            variant = 3
         # variant 5 = variant 4 with SGPR-base DMA addresses (one address register per LDS-DMA instruction: the persistent kernel is
         # DMA-issue bound, gate+up 1 304 -> 1 411 TFLOP/s at M = 32 768): legal when every operand row lies within 4 GiB of the operand's
         # base pointer, which the tensors' extents tell here (gathered rows index into A, so A's extent bounds them).  Same arithmetic,
@@ -140,6 +145,7 @@ def gemm(A, W0, C, *, bias0=None, a_rows0=None, c_rows0=None, M0=None, W1=None, 
 # tiles of 256 x 256 (every leftover tile cut into at most 256 / leftover parts).  BAGEL_GEMM_SPLITK=0 switches it off (same-box A/B).
 GEMM_SPLITK = os.environ.get("BAGEL_GEMM_SPLITK", "1") != "0"
 GEMM_SADDR = os.environ.get("BAGEL_GEMM_SADDR", "1") != "0"
+GEMM_VIT_EPI = os.environ.get("BAGEL_GEMM_VIT_EPI", "1") != "0"
 _GEMM_WS = {}
 
 
@@ -164,35 +170,43 @@ def _gemm_workspace(device):
 GEMV_MAX_ROWS = 8
 GEMV_MAX_K_BYTES = 144 * 1024
 SKINNY_MAX_ROWS = 64
-MB_MAX_ROWS = 16
-# BAGEL_GEMV_MB=0: 2..16 rows go back to rmsnorm + skinny.hip (same-box A/B of the batched decode step)
+MB_MAX_ROWS = 32
+# BAGEL_GEMV_MB=0: 2..32 rows go back to rmsnorm + skinny.hip (same-box A/B of the batched decode step); BAGEL_GEMV_MB_ROWS=16: only 17..32 rows do
+# (the round-5 routing: A/B of the two-block form)
 GEMV_MB = os.environ.get("BAGEL_GEMV_MB", "1") != "0"
+MB_MAX_ROWS = min(MB_MAX_ROWS, int(os.environ.get("BAGEL_GEMV_MB_ROWS", MB_MAX_ROWS)))
 _MB_WS = {}
 
 
-def _mb_slices(K):
+def _mb_slices(K, M=1):
     """(steps per wave if the row runs as ONE K slice else None, minimum K slices) of bagel_gemv_mb_bf16 -- mirrors mb_geometry in
     csrc/gemv_mb.hip (rows of more than 8 x 19 steps of 32 are cut over workgroups; the launcher picks the slice count between the
-    minimum and 4 x the minimum so that the column blocks divide evenly over the CUs)."""
+    minimum and 4 x the minimum so that the column blocks divide evenly over the CUs).  M > 16 (two blocks of 16 request rows per wave): the
+    longest instantiation is 14 steps, so one slice holds 8 x 14 steps (K = 3584)."""
     nsteps = K // 32
-    if nsteps <= 8 * 19:
+    nsm = 14 if M > 16 else 19
+    if nsteps <= 8 * nsm:
         return -(-nsteps // 8), 1
-    return None, -(-nsteps // (8 * 19))
+    return None, -(-nsteps // (8 * nsm))
 
 
 def mb_workspace_floats(N, K):
-    """fp32 elements of the K-slice workspace bagel_gemv_mb_bf16 may need for an [N, K] weight (0: the row runs in one slice)."""
-    per, ks = _mb_slices(K)
-    return 0 if per is not None else 4 * ks * 16 * N
+    """fp32 elements of the K-slice workspace bagel_gemv_mb_bf16 may need for an [N, K] weight at ANY row count (bagel_gemv_mb_workspace_bytes: the bound
+    of the 32-row form -- shorter slices, 32-row slabs); 0: the row runs in one slice whatever M is."""
+    per, ks = _mb_slices(K, 32)
+    return 0 if per is not None else 4 * ks * 32 * N
 
 
-def gemv_mb_supported(A, W, C, bias, residual, epilogue, has_norm):
+def gemv_mb_supported(A, W, C, bias, residual, epilogue, has_norm, M=None):
     if not GEMV_MB:
         return False
     N, K = W.shape
     if K % 32 or N % (32 if epilogue == EPI_SWIGLU16 else 16):
         return False
-    per, ks = _mb_slices(K)
+    M = A.shape[0] if M is None else M
+    if not 1 <= M <= MB_MAX_ROWS:
+        return False
+    per, ks = _mb_slices(K, M)
     if per is not None:
         ns = next(n for n in (4, 10, 14, 19) if per <= n)
         if K // 32 < ns:
@@ -207,9 +221,9 @@ def gemv_mb_supported(A, W, C, bias, residual, epilogue, has_norm):
 
 
 def gemv_mb(A, W, C, *, bias=None, residual=None, epilogue=EPI_NONE, M=None, norm_w=None, eps=0.0, workspace=None):
-    """C[M <= 16, N] = norm(A) W^T with the epilogues of ``gemm``: the batched-decode weight stream (bagel_gemv_mb_bf16): the waves of a
-    workgroup partition K and hold their activation fragments in registers, optional fused RMSNorm.  Long rows (K > 3584 at 7B: the down
-    projection) run as K slices through an fp32 workspace (``workspace`` or a per-(device, stream) one) and a second, tiny launch."""
+    """C[M <= 32, N] = norm(A) W^T with the epilogues of ``gemm``: the batched-decode weight stream (bagel_gemv_mb_bf16): the waves of a
+    workgroup partition K and hold their activation fragments in registers (one or two blocks of 16 rows), optional fused RMSNorm.  Long rows
+    (K > 3584 at 7B: the down projection) run as K slices through an fp32 workspace (``workspace`` or a per-(device, stream) one) and a second, tiny launch."""
     _req(A, BF16, "gemv_mb.A"); _req(W, BF16, "gemv_mb.W"); _req(C, BF16, "gemv_mb.C")
     N, K = W.shape
     if A.shape[-1] != K:

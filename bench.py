@@ -1297,13 +1297,11 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
         w4 = quantised_decode("mxfp4", "OCP-MX FP4 E2M1 blocks of 32 with E8M0 scales (W4A8 on v_mfma_scale_f32_16x16x128_f8f6f4), lm_head bf16")
     # SURVEY 8f.4b beside the batch-1 number: 16 requests decoded together (one weight pass serves the batch; the reference decodes
     # batch 1 only, bagel.py:996) -- 160 new tokens each on their own 4936-token contexts
-    bd = None
-    if UB == 1 and not args.no_batched_decode:
+    def batched_decode(nb, nn=160):      # (step 0 runs eagerly and the hipGraph capture follows it: amortised over the run)
         try:
-            nb, nn = 16, 160         # (step 0 runs eagerly and the hipGraph capture follows it: amortised over the run)
             cb, lb, rb, _ = prefill(nb)
             sb = model.prepare_start_tokens(lb, rb, ids)
-            # warm-up with the SAME length: the call re-allocates the merged caches on the way out (16 x (4936 + 160) rows x 28 layers), and a warm-up
+            # warm-up with the SAME length: the call re-allocates the merged caches on the way out (nb x (4936 + 160) rows x 28 layers), and a warm-up
             # of another length left the timed call ~80 ms of first-time hipMalloc (0.5 ms per step of 160) -- a serving process is past that
             model.generate_text(past_key_values=cb, max_length=nn, do_sample=False, end_token_id=None, **sb)
             cb, lb, rb, _ = prefill(nb)
@@ -1314,13 +1312,19 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
                 tb = model.generate_text(past_key_values=cb, max_length=nn, do_sample=False, end_token_id=None, **sb)
                 fence()
                 dtb = time.perf_counter() - t4
-            bd = {"value": nb * nn / dtb, "unit": "tokens/s", "batch": nb, "new_tokens": nn, "decode_ms_per_step": dtb / nn * 1e3,
-                  "context_tokens": int(lb[0]), "outputs_ok": bool(tb.shape == (nn, nb)), "memory": mem_bd.report,
-                  "note": "batched multi-request decode (SURVEY 8f.4b): beside the batch-1 headline, never as it"}
-            unsteady(bd, dict(mem_bd.report, attempts=1))
+            out = {"value": nb * nn / dtb, "unit": "tokens/s", "batch": nb, "new_tokens": nn, "decode_ms_per_step": dtb / nn * 1e3,
+                   "context_tokens": int(lb[0]), "outputs_ok": bool(tb.shape == (nn, nb)), "memory": mem_bd.report,
+                   "note": "batched multi-request decode (SURVEY 8f.4b): beside the batch-1 headline, never as it"}
+            unsteady(out, dict(mem_bd.report, attempts=1))
             del cb
+            return out
         except Exception as e:
-            bd = {"error": repr(e)}
+            return {"error": repr(e)}
+    bd = bd32 = None
+    if UB == 1 and not args.no_batched_decode:
+        bd = batched_decode(16)
+        # round 6: two blocks of 16 request rows share every weight fragment (csrc/gemv_mb.hip MB = 2): 32 requests per weight pass
+        bd32 = batched_decode(32)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -1362,7 +1366,7 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             "memory": {"prefill_timed_region": mem_prefill.report, "decode_timed_region": mem_decode.report, "resident": resident_weight_bytes(model),
                        "what": f"a process that holds the model (no VAE) and serves understanding requests at batch {UB}: peak of live tensor bytes inside each timed region"},
             "steady_state": bool(mem_prefill.report["steady"] and mem_decode.report["steady"]),
-            "int8_rowwise_weights": w8, "mxfp4_weights": w4, "nf4_weights": wn, "batched_decode": bd, "sampled_decode": sampled, "parity_at_full_depth": depth,
+            "int8_rowwise_weights": w8, "mxfp4_weights": w4, "nf4_weights": wn, "batched_decode": bd, "batched_decode_32": bd32, "sampled_decode": sampled, "parity_at_full_depth": depth,
             "roofline": {"bound": "hbm", "achieved": bpt * (tps / UB) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bpt * (tps / UB) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_decode_traffic() if (UB == 1 and args.und_image == 980) else None,
                          "kernel": "gemv_kernel (decode step)",

@@ -200,15 +200,19 @@ int bagel_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ld
                            int64_t ldr, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                            bagel_stream_t stream);
 
-/* Batched-decode projection: C[M <= 16, N] = norm(A) W^T with the epilogues and rounding points of bagel_gemm_bf16 (bias, activation,
- * SwiGLU16 pairing, residual; R == C allowed) and an optional fused Qwen2RMSNorm of the A rows (norm_w != NULL).  Replaces, for 2..16
+/* Batched-decode projection: C[M <= 32, N] = norm(A) W^T with the epilogues and rounding points of bagel_gemm_bf16 (bias, activation,
+ * SwiGLU16 pairing, residual; R == C allowed) and an optional fused Qwen2RMSNorm of the A rows (norm_w != NULL).  Replaces, for 2..32
  * concurrent requests, the F.linear call sites of a decode step (modeling/bagel/qwen2_navit.py:515-517,591-594;
- * modeling/qwen2/modeling_qwen2.py:54-59,200-201; modeling/bagel/bagel.py:978) and serves the und marker rows of a denoise forward.
+ * modeling/qwen2/modeling_qwen2.py:54-59,200-201; modeling/bagel/bagel.py:978), serves the und marker rows of a denoise forward and the
+ * 17..32 rows of a short text prefill (modeling/bagel/bagel.py:267-297).
  * A pure weight stream through the MFMA: the 8 waves of a persistent workgroup (one per CU) partition K and keep their activation
- * fragments in registers, every weight byte is loaded once, straight into the matrix-core operand layout.  K % 32 == 0, N % 16 == 0
- * (SwiGLU16: N % 32 == 0, no bias / residual).  Rows longer than 4864 elements run as K slices over workgroups through a caller-owned
- * fp32 workspace (bagel_gemv_mb_workspace_bytes; 16-byte aligned; only touched by this call) and a second small launch; such rows
- * take neither the fused norm nor SwiGLU16 (BAGEL_ERR_UNSUPPORTED).  Deterministic: fixed summation order, no atomics. */
+ * fragments in registers (one block of 16 rows, or two: every weight fragment then feeds two MFMAs), every weight byte is loaded once,
+ * straight into the matrix-core operand layout.  K % 32 == 0, N % 16 == 0 (SwiGLU16: N % 32 == 0, no bias / residual).  Rows longer than
+ * 4864 elements (M <= 16) resp. 3584 elements (M > 16: the second block of activation fragments takes the registers of the longest
+ * instantiation) run as K slices over workgroups through a caller-owned fp32 workspace (bagel_gemv_mb_workspace_bytes: an upper bound for
+ * every M; 16-byte aligned; only touched by this call) and a second small launch; such rows take neither the fused norm nor SwiGLU16
+ * (BAGEL_ERR_UNSUPPORTED).  Deterministic: fixed summation order, no atomics; a row's result does not depend on M within one block
+ * count (M <= 16 / M > 16) -- across the two the K partition may differ (fp32 summation order), like the K-split tiles of bagel_gemm_bf16. */
 int bagel_gemv_mb_workspace_bytes(int32_t N, int32_t K, int64_t* bytes);
 int bagel_gemv_mb_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr,
                        void* C, int64_t ldc, const void* norm_w, float eps, int32_t M, int32_t N, int32_t K, int32_t epilogue,

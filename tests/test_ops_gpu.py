@@ -89,6 +89,23 @@ def test_gemm_activation_and_residual(epi):
     close(X, ref_gemm(A, W, b, 0, R), ulps=2, what="gemm residual in place")
 
 
+@pytest.mark.parametrize("variant", [3, 5, None])
+@pytest.mark.parametrize("N,K,mode", [(1152, 4352, "res"), (1152, 2048, "res"), (4352, 1152, "gelu"), (1152, 1152, "res")])
+def test_gemm_vit_epilogues_at_the_tower_shapes(N, K, mode, variant):
+    """SigLIP's out / fc2 (bias + residual, in place) and fc1 (bias + GELU-tanh) at a 980^2 image (M = 4900; siglip_navit.py:216-258) against fp32: on the
+    one-tile ping-pong kernel (3), on the persistent kernel's round-6 epilogue modes 5 / 6 incl. the K-split of its leftover tiles (5) and as ops.gemm routes them."""
+    M = 4900
+    A, W, b, R = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1), rnd(M, N, seed=4)
+    if mode == "res":
+        C = R.to(DEV).clone()
+        ops().gemm(A.to(DEV), W.to(DEV), C, bias0=b.to(DEV), residual=C, variant=variant)
+        close(C, ref_gemm(A, W, b, 0, R), ulps=2, what=f"gemm bias + residual {M}x{N}x{K} v{variant}")
+    else:
+        C = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+        ops().gemm(A.to(DEV), W.to(DEV), C, bias0=b.to(DEV), epilogue=1, variant=variant)
+        close(C, ref_gemm(A, W, b, 1), ulps=2, what=f"gemm bias + gelu {M}x{N}x{K} v{variant}")
+
+
 @pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
 def test_gemm_swiglu(variant):
     from bagel_amd.modeling.bagel.qwen2_navit import interleave_gate_up

@@ -31,6 +31,8 @@ for name, M, N, K, mode in (("vit qkv", 4900, 3456, 1152, "bias"), ("vit out", 4
                             ("vit fc1 pad", 4900, 4352, 1152, "gelu"), ("vit fc2 pad", 4900, 1152, 4352, "bias"),
                             # ... as the model calls them: bias AND residual in one epilogue (not instantiated in the persistent kernel: variant 4 falls back to 3)
                             ("vit out +res", 4900, 1152, 1152, "bias+residual"), ("vit fc2 pad +res", 4900, 1152, 4352, "bias+residual"),
+                            # the packed tower's real shapes: heads padded 72 -> 128 (qkv writes 3 x 16 x 128 columns, the out projection contracts over 16 x 128)
+                            ("vit qkv padded", 4900, 6144, 1152, "bias"), ("vit out padded +res", 4900, 1152, 2048, "bias+residual"),
                             ("llm qkv", 4902, 4608, 3584, "bias"), ("llm o", 4902, 3584, 3584, "residual"),
                             ("llm gate_up", 4902, 37888, 3584, "swiglu"), ("llm down", 4902, 3584, 18944, "residual"),
                             ("edit o", 12288, 3584, 3584, "residual"), ("edit down", 12288, 3584, 18944, "residual")):
@@ -42,7 +44,7 @@ for name, M, N, K, mode in (("vit qkv", 4900, 3456, 1152, "bias"), ("vit out", 4
     epi = {"swiglu": ops.EPI_SWIGLU16, "gelu": ops.EPI_GELU_TANH}.get(mode, ops.EPI_NONE)
     res = C if mode in ("residual", "bias+residual") else None
     out = []
-    for v in (0, 2, 4, None):           # None = what ops.gemm picks (variant 5 = 4 with SGPR-base DMA where legal, + the K-split of leftover tiles)
+    for v in (0, 3, 4, 5, None):        # None = what ops.gemm picks; 3 = one tile per workgroup; 4 = persistent; 5 = 4 with SGPR-base DMA (+ the ViT epilogues, round 6)
         try:
             t = timeit(lambda: ops.gemm(A, W, C, bias0=bias, residual=res, epilogue=epi, variant=v))
             out.append(f"{'auto' if v is None else 'v' + str(v)} {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.0f} TF")
