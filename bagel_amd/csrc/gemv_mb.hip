@@ -244,10 +244,11 @@ __global__ __launch_bounds__(512) void gemv_mb_kernel(const MbParams p) {
         }
         __syncthreads();
         const int nout = swiglu ? cb >> 1 : cb;
-        if (wave < nout) {
-            const int j = wave;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
+        // (output j, request block mb) pairs dealt over the 8 waves: with two request blocks a chunk of up to four outputs still finishes in ONE pass (the
+        // residual / store latency of an epilogue is paid once, not once per request block)
+        for (int t = wave; t < nout * MB; t += 8) {
+            const int j = t % nout, mb = t / nout;
+            {
                 const int m = 16 * mb + r;
                 if (swiglu) {
                     f32x4_t ag = part[(((2 * j) * 8) * MB + mb) * 64 + lane], au = part[(((2 * j + 1) * 8) * MB + mb) * 64 + lane];

@@ -20,6 +20,7 @@ import torch
 from ... import ops
 
 BF16 = torch.bfloat16
+MB2_FUSED_NORM = os.environ.get("BAGEL_MB2_FUSED_NORM", "0") == "1"
 
 
 def _ceil_to(x, m):
@@ -262,6 +263,11 @@ class DecodeSession:
                                                               norm_w is not None, M=B):
                 # 2..32 requests: the weight stream with the activations in registers and the RMSNorm fused (csrc/gemv_mb.hip); the K-slice
                 # workspace of the long rows is the session's own, so the captured graph keeps a stable pointer
+                if norm_w is not None and B > 16 and not MB2_FUSED_NORM:
+                    # two request blocks: every one of the 256 workgroups normalises all 32 rows in its prologue (~8 us of VALU in front of the stream against
+                    # ~4.5 at 16 rows); one RMSNorm launch in front of the un-fused stream is shorter (BAGEL_MB2_FUSED_NORM=1 keeps the fused form: same-box A/B)
+                    ops.rmsnorm(inp, norm_w, h, eng.eps)
+                    return ops.gemv_mb(h, w, out, M=B, workspace=self.mb_ws, **kw)
                 return ops.gemv_mb(inp, w, out, norm_w=norm_w, eps=eng.eps, M=B, workspace=self.mb_ws, **kw)
             if norm_w is not None:
                 ops.rmsnorm(inp, norm_w, h, eng.eps)
