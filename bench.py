@@ -1324,6 +1324,8 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
     if UB == 1 and not args.no_batched_decode:
         bd = batched_decode(16)
         # round 6: two blocks of 16 request rows share every weight fragment (csrc/gemv_mb.hip MB = 2): 32 requests per weight pass
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()         # (this leg peaks at 96 GB allocated / 122 GB reserved; the parent bench process lives on the same GPU)
         bd32 = batched_decode(32)
     if world > 1:
         import torch.distributed as dist
@@ -1941,6 +1943,16 @@ def main():
                     for p_ in model.parameters():
                         p_.requires_grad_(False)
                         p_.grad = None
+                    # what a training loop keeps RESIDENT between its steps -- the tape-buffer pool (35-75 GB at 7B) and the transposed weight images of
+                    # dX = dY W (2 bytes per parameter) -- goes back to the device before the understanding child starts on the same GPU: with it in
+                    # place the child's 32-request decode leg (96 GB peak) met 156 MB of free memory (visit 15 of round 6)
+                    lm_ = model.language_model
+                    if hasattr(lm_.model, "release_train_buffers"):
+                        lm_.model.release_train_buffers()
+                    eng_ = getattr(lm_, "_engine", None)
+                    for P_ in (getattr(eng_, "layers", None) or []):
+                        if hasattr(P_, "wt"):
+                            P_.wt = {}
                     if cuda:
                         torch.cuda.empty_cache()
             del tb, tn, o_

@@ -223,6 +223,24 @@ def test_vae_launch_wrappers_match_the_header(monkeypatch):
                      "bagel_gemv_mb_bf16"]
 
 
+def test_gemv_mb_workspace_mirror_matches_the_library():
+    """``ops.mb_workspace_floats`` / ``ops._mb_slices`` mirror csrc/gemv_mb.hip's geometry (the decode session sizes its K-slice workspace with the Python side,
+    the launcher checks it against its own arithmetic): the library's ``bagel_gemv_mb_workspace_bytes`` is a host-only function -- no GPU needed -- and must
+    agree for every row length the models use, incl. the round-6 bound of the two-block (17..32 rows) form: slices of at most 8 x 14 steps, 32-row slabs."""
+    import ctypes
+    from bagel_amd import _lib, ops
+    L = _lib.lib()
+    for N, K in [(3584, 18944), (3584, 3584), (4608, 3584), (37888, 3584), (152064, 3584), (64, 128), (528, 4864), (160, 4896), (1024, 8192), (256, 7168)]:
+        out = ctypes.c_int64(-1)
+        assert L.bagel_gemv_mb_workspace_bytes(N, K, ctypes.byref(out)) == 0
+        assert out.value == ops.mb_workspace_floats(N, K) * 4, (N, K, out.value)
+    # one slice up to 8 x 19 steps at <= 16 rows, up to 8 x 14 steps (K = 3584) at 17..32 rows; beyond that the minimum slice count
+    assert ops._mb_slices(3584, 16) == (14, 1) and ops._mb_slices(3584, 32) == (14, 1)
+    assert ops._mb_slices(4864, 16) == (19, 1) and ops._mb_slices(4864, 17) == (None, 2)
+    assert ops._mb_slices(18944, 16) == (None, 4) and ops._mb_slices(18944, 32) == (None, 6)
+    assert ops.MB_MAX_ROWS == 32
+
+
 def test_decode_engine_isa_invariants():
     """csrc/engine.hip relies on three things hipcc does not promise: (1) nothing spills to scratch (a scratch reload is a vector-memory load: its wait would drain the
     loaders' counted LDS-DMA queue), (2) the compiler has no use of M0 of its own in this kernel (the DMA statements set M0 and do NOT restore it), (3) the loaders' only
