@@ -432,7 +432,10 @@ def _prefill_engine_decode(model, cache, start, lens, tokens_in):
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_d128"])
-@pytest.mark.parametrize("prompts", [["a small red cube"], ["sky", "a much longer prompt about nothing in particular"]])
+@pytest.mark.parametrize("prompts", [["a small red cube"], ["sky", "a much longer prompt about nothing in particular"],
+                                     # 20 requests: the two-block (17..32 rows) form of the batched projection + one RMSNorm launch in front of it (round 6)
+                                     [("word " * (1 + i % 7)).strip() + f" {i}" for i in range(20)]],
+                         ids=["one", "two", "twenty"])
 def test_generate_text_graph_eager_and_prefill_engine(name, prompts):
     from oracle.configs import TINY, TINY_D128
     from tests.util_models import product_model
