@@ -960,7 +960,8 @@ static int attn_decode_common(const void* q, int64_t ldq, const void* kpool, con
     }
     const int nchunks = ceil_div(max_len, DEC_CH);
     int cpw = cpw_env ? cpw_env : ceil_div((long)nchunks * nkv * batch, 512);     // two resident workgroups per CU, one round
-    if (cpw > 8) cpw = 8;
+    if (cpw > 5 && !cpw_env) cpw = 5;           // 32 requests x 4 936 keys: 4-5 chunks per workgroup (1 024-1 280 workgroups) 72.7 us per layer, 8 (the former cap) 79.2 -- profiles/r06_gemv_mb_32rows.log
+    if (cpw > 16) cpw = 16;
     if (cpw > nchunks) cpw = nchunks;
     if (cpw < 1) cpw = 1;
     const int ch = DEC_CH * cpw;                   // keys per workgroup = per partial slot
