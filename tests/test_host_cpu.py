@@ -223,6 +223,56 @@ def test_vae_launch_wrappers_match_the_header(monkeypatch):
                      "bagel_gemv_mb_bf16"]
 
 
+def test_ops_gemm_routing_of_the_vit_epilogues_and_small_row_counts(monkeypatch):
+    """Which kernel ``ops.gemm`` hands a launch to, pinned without a GPU (the library is swapped for a recorder): the ViT's epilogues on the persistent kernel's
+    SGPR-base form (variant 5) since round 6 -- except bias + residual on fewer than half a round of tiles with a short K, which stays on the 128 x 128 kernel
+    (measured: profiles/r06_vit_epilogues.log) --, 2..32 dense rows on the register-resident weight stream, 33..64 on the skinny MFMA kernel."""
+    from bagel_amd import ops
+    seen = []
+
+    class Recorder:
+        def __getattr__(self, name):
+            def fn(*args):
+                seen.append((name, args))
+                return 0
+            return fn
+    monkeypatch.setattr(ops, "lib", lambda: Recorder())
+    monkeypatch.setattr(ops, "_ptr", lambda t: None if t is None else 4096)
+    monkeypatch.setattr(ops, "_stream", lambda: 0)
+    monkeypatch.setattr(ops, "_req", lambda t, dtype, name: None)
+    monkeypatch.setattr(ops, "_gemm_workspace", lambda device: torch.zeros(16))
+    monkeypatch.setattr(ops, "_ws_key", lambda device: ("cpu", 0))
+    monkeypatch.setattr(torch.Tensor, "data_ptr", lambda self: 4096, raising=False)
+    b = lambda *s: torch.empty(*s, dtype=torch.bfloat16)  # noqa: E731
+
+    def variant_of(M, N, K, **kw):
+        del seen[:]
+        ops.gemm(b(M, K), b(N, K), b(M, N), **kw)
+        name, args = seen[-1]
+        return name, (args[20] if name == "bagel_gemm_bf16_ws" else None)
+    bias = lambda N: dict(bias0=b(N))  # noqa: E731
+    # SigLIP at a 980^2 image (M = 4900): fc1 (bias + GELU) and fc2 (bias + residual, K = 4352) -> variant 5; the out projection (K = 2048 / 1152) -> 128 x 128
+    assert variant_of(4900, 4352, 1152, epilogue=ops.EPI_GELU_TANH, **bias(4352)) == ("bagel_gemm_bf16_ws", 5)
+    assert variant_of(4900, 1152, 4352, residual=b(4900, 1152), **bias(1152)) == ("bagel_gemm_bf16_ws", 5)
+    assert variant_of(4900, 1152, 2048, residual=b(4900, 1152), **bias(1152)) == ("bagel_gemm_bf16_ws", 0)
+    assert variant_of(4900, 1152, 1152, residual=b(4900, 1152), **bias(1152)) == ("bagel_gemm_bf16_ws", 0)
+    # the earlier routing behind the A/B knob: few-tile bias + residual -> 128 x 128, GELU -> the one-tile ping-pong kernel
+    monkeypatch.setattr(ops, "GEMM_VIT_EPI", False)
+    assert variant_of(4900, 1152, 4352, residual=b(4900, 1152), **bias(1152)) == ("bagel_gemm_bf16_ws", 0)
+    assert variant_of(4900, 4352, 1152, epilogue=ops.EPI_GELU_TANH, **bias(4352)) == ("bagel_gemm_bf16_ws", 3)
+    monkeypatch.setattr(ops, "GEMM_VIT_EPI", True)
+    # the LLM's projections keep the persistent kernel at every M >= 2048
+    assert variant_of(4902, 3584, 18944, residual=b(4902, 3584)) == ("bagel_gemm_bf16_ws", 5)
+    assert variant_of(32784, 4608, 3584, **bias(4608)) == ("bagel_gemm_bf16_ws", 5)
+    # row counts: 2..32 -> gemv_mb (one or two blocks of request rows), 33..64 -> skinny, 1 -> the lane-FMA gemv
+    assert variant_of(16, 4608, 3584, **bias(4608))[0] == "bagel_gemv_mb_bf16"
+    assert variant_of(32, 4608, 3584, **bias(4608))[0] == "bagel_gemv_mb_bf16"
+    assert variant_of(34, 4608, 3584, **bias(4608))[0] == "bagel_gemm_skinny_bf16"
+    assert variant_of(1, 4608, 3584, **bias(4608))[0] == "bagel_gemv_bf16"
+    monkeypatch.setattr(ops, "MB_MAX_ROWS", 16)
+    assert variant_of(32, 4608, 3584, **bias(4608))[0] == "bagel_gemm_skinny_bf16"
+
+
 def test_gemv_mb_workspace_mirror_matches_the_library():
     """``ops.mb_workspace_floats`` / ``ops._mb_slices`` mirror csrc/gemv_mb.hip's geometry (the decode session sizes its K-slice workspace with the Python side,
     the launcher checks it against its own arithmetic): the library's ``bagel_gemv_mb_workspace_bytes`` is a host-only function -- no GPU needed -- and must
