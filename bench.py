@@ -1318,7 +1318,13 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
                 tb = model.generate_text(past_key_values=cb, max_length=nn, do_sample=False, end_token_id=None, **sb)
                 fence()
                 dtb = time.perf_counter() - t4
+            # algorithmic bytes of a step: ONE pass over the und expert + lm_head serves the batch, every request reads its own KV (average context of the span)
+            H_, I_, nkv_, V_ = llm["hidden_size"], llm["intermediate_size"], llm["num_key_value_heads"], llm["vocab_size"]
+            hd_ = H_ // llm["num_attention_heads"]
+            b_step = 2.0 * (L * (2 * H_ * H_ + 2 * H_ * nkv_ * hd_ + 3 * H_ * I_) + V_ * H_) + nb * 2.0 * nkv_ * hd_ * 2 * L * (int(lb[0]) + nn / 2.0)
             out = {"value": nb * nn / dtb, "unit": "tokens/s", "batch": nb, "new_tokens": nn, "decode_ms_per_step": dtb / nn * 1e3,
+                   "roofline": {"bound": "hbm", "achieved": b_step / (dtb / nn) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_step / (dtb / nn) / 1e9 / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_step": b_step},
                    "context_tokens": int(lb[0]), "outputs_ok": bool(tb.shape == (nn, nb)), "memory": mem_bd.report,
                    "note": "batched multi-request decode (SURVEY 8f.4b): beside the batch-1 headline, never as it"}
             unsteady(out, dict(mem_bd.report, attempts=1))
