@@ -1325,7 +1325,12 @@ def understanding_leg(args, model, cfg, ids, dev, world, fence):
             out = {"value": nb * nn / dtb, "unit": "tokens/s", "batch": nb, "new_tokens": nn, "decode_ms_per_step": dtb / nn * 1e3,
                    "roofline": {"bound": "hbm", "achieved": b_step / (dtb / nn) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_step / (dtb / nn) / 1e9 / HBM_PEAK_GBS,
                                 "algorithmic_bytes_per_step": b_step},
-                   "context_tokens": int(lb[0]), "outputs_ok": bool(tb.shape == (nn, nb)), "memory": mem_bd.report,
+                   "context_tokens": int(lb[0]), "outputs_ok": bool(tb.shape == (nn, nb)),
+                   # the nb requests are the SAME request (one image, one prompt): every column must carry the same ids, and they must be the batch-1 run's ids up to
+                   # the first near-tie flip (other kernels, other fp32 summation orders; tests/test_wide_gpu.py::test_wide_model_batched_decode_is_batch_invariant)
+                   "all_requests_agree": bool((tb == tb[:, :1]).all()),
+                   "ids_equal_to_the_batch1_run_for_steps": int(next((i for i in range(min(nn, int(toks.shape[0]))) if int(tb[i, 0]) != int(toks[i, 0])), min(nn, int(toks.shape[0])))),
+                   "memory": mem_bd.report,
                    "note": "batched multi-request decode (SURVEY 8f.4b): beside the batch-1 headline, never as it"}
             unsteady(out, dict(mem_bd.report, attempts=1))
             del cb
